@@ -1,0 +1,270 @@
+"""ctypes binding of the CPU ORACLE (oracle/liboracle.so) -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (camera_calibration_amd) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "cba_oracle.c")
+    hdr = os.path.join(_HERE, "cba_oracle.h")
+    if (force or not os.path.exists(_LIB_PATH)
+            or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _LIB_PATH
+
+
+class OrcCamera(C.Structure):
+    _fields_ = [("model_type", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("calib_min_x", C.c_int32), ("calib_min_y", C.c_int32),
+                ("calib_max_x", C.c_int32), ("calib_max_y", C.c_int32),
+                ("grid_w", C.c_int32), ("grid_h", C.c_int32)]
+
+
+class OrcProblem(C.Structure):
+    _fields_ = [("n_cameras", C.c_int32), ("n_images", C.c_int32), ("n_points", C.c_int32),
+                ("n_obs", C.c_int64), ("cams", C.POINTER(OrcCamera)),
+                ("obs_xy", C.POINTER(C.c_float)), ("obs_point", C.POINTER(C.c_int32)),
+                ("obs_image", C.POINTER(C.c_int32)), ("obs_camera", C.POINTER(C.c_int32)),
+                ("last_projection", C.POINTER(C.c_double)), ("fd_delta", C.c_double),
+                ("localize_only", C.c_int32), ("eliminate_points", C.c_int32)]
+
+
+class OrcState(C.Structure):
+    _fields_ = [("rig_tr_global", C.POINTER(C.c_double)), ("camera_tr_rig", C.POINTER(C.c_double)),
+                ("points", C.POINTER(C.c_double)), ("grids", C.POINTER(C.POINTER(C.c_double)))]
+
+
+class OrcSystem(C.Structure):
+    _fields_ = [("block_size", C.c_int32), ("n_blocks", C.c_int32), ("dense_dof", C.c_int32),
+                ("block_diag_H", C.POINTER(C.c_double)), ("off_diag_H", C.POINTER(C.c_double)),
+                ("dense_H", C.POINTER(C.c_double)), ("block_diag_b", C.POINTER(C.c_double)),
+                ("dense_b", C.POINTER(C.c_double))]
+
+
+class OrcObsRecord(C.Structure):
+    _fields_ = [("valid", C.c_int32), ("has_jacobian", C.c_int32),
+                ("pixel", C.c_double * 2), ("residual", C.c_double * 2),
+                ("cost", C.c_double), ("weight", C.c_double),
+                ("pose_jac", C.c_double * 12), ("rig_jac", C.c_double * 12), ("point_jac", C.c_double * 6),
+                ("grid_indices", C.c_int32 * 80), ("grid_jac", C.c_double * 160)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        L.orc_bspline_surface.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, dp]
+        L.orc_bspline_surface_slow.argtypes = L.orc_bspline_surface.argtypes
+        L.orc_unproject.argtypes = [C.POINTER(OrcCamera), dp, C.c_double, C.c_double, dp]
+        L.orc_unproject.restype = C.c_int
+        L.orc_unproject_with_jacobian.argtypes = [C.POINTER(OrcCamera), dp, C.c_double, C.c_double, dp, dp]
+        L.orc_unproject_with_jacobian.restype = C.c_int
+        L.orc_project_with_initial_estimate.argtypes = [C.POINTER(OrcCamera), dp, dp, dp]
+        L.orc_project_with_initial_estimate.restype = C.c_int
+        L.orc_project.argtypes = [C.POINTER(OrcCamera), dp, dp, dp]
+        L.orc_project.restype = C.c_int
+        L.orc_grid_point_to_pixel.argtypes = [C.POINTER(OrcCamera), C.c_double, C.c_double, dp]
+        L.orc_pixel_to_grid_point.argtypes = [C.POINTER(OrcCamera), C.c_double, C.c_double, dp]
+        L.orc_tangents.argtypes = [dp, dp, dp]
+        L.orc_apply_quaternion_update.argtypes = [dp, dp, dp]
+        L.orc_se3_mul.argtypes = [dp, dp, dp]
+        L.orc_se3_exp.argtypes = [dp, dp]
+        L.orc_huber_cost_sq.argtypes = [C.c_double, C.c_double]
+        L.orc_huber_cost_sq.restype = C.c_double
+        L.orc_huber_weight_sq.argtypes = [C.c_double, C.c_double]
+        L.orc_huber_weight_sq.restype = C.c_double
+        L.orc_compute_jacobian.argtypes = [dp, dp, dp]
+        L.orc_compute_rig_jacobian.argtypes = [dp, dp, dp, dp, dp]
+        L.orc_dense_dof.argtypes = [C.POINTER(OrcProblem)]
+        L.orc_dense_dof.restype = C.c_int32
+        L.orc_total_dof.argtypes = [C.POINTER(OrcProblem)]
+        L.orc_total_dof.restype = C.c_int32
+        L.orc_cost_pass.argtypes = [C.POINTER(OrcProblem), C.POINTER(OrcState), dp]
+        L.orc_cost_pass.restype = C.c_double
+        L.orc_jacobian_pass.argtypes = [C.POINTER(OrcProblem), C.POINTER(OrcState), C.POINTER(OrcSystem), dp,
+                                        C.POINTER(OrcObsRecord), C.c_int32, C.c_int32]
+        L.orc_jacobian_pass.restype = C.c_double
+        L.orc_schur_solve.argtypes = [C.POINTER(OrcSystem), dp]
+        L.orc_ldlt_solve_upper.argtypes = [dp, C.c_int, dp, dp]
+        L.orc_apply_update.argtypes = [C.POINTER(OrcProblem), C.POINTER(OrcState), dp, C.POINTER(OrcState)]
+        L.orc_optimize_jointly.argtypes = [C.POINTER(OrcProblem), C.POINTER(OrcState), C.c_int, C.c_double,
+                                           dp, ip, dp, ip]
+        L.orc_optimize_jointly.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def _dp(a: np.ndarray):
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a: np.ndarray):
+    assert a.dtype == np.int32 and a.flags.c_contiguous
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def camera_struct(cam) -> OrcCamera:
+    return OrcCamera(cam.model_type, cam.width, cam.height, cam.calib_min_x, cam.calib_min_y,
+                     cam.calib_max_x, cam.calib_max_y, cam.grid_w, cam.grid_h)
+
+
+class System:
+    """Dense normal equations in the reference's layout (libvis lm_optimizer.h:660-685)."""
+
+    def __init__(self, block_size: int, n_blocks: int, dense_dof: int):
+        self.block_size, self.n_blocks, self.dense_dof = block_size, n_blocks, dense_dof
+        self.block_diag_H = np.zeros((n_blocks, block_size, block_size))
+        self.off_diag_H = np.zeros((n_blocks * block_size, dense_dof))
+        self.dense_H = np.zeros((dense_dof, dense_dof))
+        self.block_diag_b = np.zeros(n_blocks * block_size)
+        self.dense_b = np.zeros(dense_dof)
+
+    def struct(self) -> OrcSystem:
+        return OrcSystem(self.block_size, self.n_blocks, self.dense_dof, _dp(self.block_diag_H),
+                         _dp(self.off_diag_H), _dp(self.dense_H), _dp(self.block_diag_b), _dp(self.dense_b))
+
+    def add_lambda(self, lam: float) -> None:
+        i = np.arange(self.block_size)
+        self.block_diag_H[:, i, i] += lam
+        j = np.arange(self.dense_dof)
+        self.dense_H[j, j] += lam
+
+
+class OracleProblem:
+    """Holds the ctypes views of a camera_calibration_amd.problem.Problem (keeps arrays alive)."""
+
+    def __init__(self, problem, last_projection: Optional[np.ndarray] = None):
+        self.p = problem
+        self.cams = (OrcCamera * problem.n_cameras)(*[camera_struct(c) for c in problem.cameras])
+        self.last_projection = (np.zeros((problem.n_obs, 2)) if last_projection is None
+                                else np.ascontiguousarray(last_projection, dtype=np.float64))
+        self.c = OrcProblem(problem.n_cameras, problem.n_images, problem.n_points, problem.n_obs, self.cams,
+                            problem.obs_xy.ctypes.data_as(C.POINTER(C.c_float)), _ip(problem.obs_point),
+                            _ip(problem.obs_image), _ip(problem.obs_camera), _dp(self.last_projection),
+                            problem.fd_delta, int(problem.localize_only), int(problem.eliminate_points))
+
+    # -- helpers -------------------------------------------------------------------------------
+    def _state(self, st):
+        grids = (C.POINTER(C.c_double) * len(st.grids))(*[_dp(g) for g in st.grids])
+        s = OrcState(_dp(st.rig_tr_global), _dp(st.camera_tr_rig), _dp(st.points), grids)
+        s._keep = (grids, st)
+        return s
+
+    def new_system(self) -> System:
+        return System(self.p.block_size, self.p.n_blocks, self.p.dense_dof)
+
+    # -- passes --------------------------------------------------------------------------------
+    def cost_pass(self, st):
+        cost_vec = np.zeros(self.p.n_obs)
+        cost = lib().orc_cost_pass(C.byref(self.c), C.byref(self._state(st)), _dp(cost_vec))
+        return cost, cost_vec
+
+    def jacobian_pass(self, st, system: Optional[System] = None, want_records: bool = False,
+                      img_begin: int = 0, img_end: Optional[int] = None):
+        cost_vec = np.zeros(self.p.n_obs)
+        recs = (OrcObsRecord * self.p.n_obs)() if want_records else None
+        sysc = system.struct() if system is not None else None
+        cost = lib().orc_jacobian_pass(C.byref(self.c), C.byref(self._state(st)),
+                                       C.byref(sysc) if sysc is not None else None, _dp(cost_vec), recs,
+                                       img_begin, self.p.n_images if img_end is None else img_end)
+        return cost, cost_vec, recs
+
+    def apply_update(self, st, x: np.ndarray):
+        out = st.copy()
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        lib().orc_apply_update(C.byref(self.c), C.byref(self._state(st)), _dp(x), C.byref(self._state(out)))
+        return out
+
+    def optimize_jointly(self, st, max_iteration_count: int = 1, init_lambda: float = -1.0):
+        """In-place on st. Returns dict(cost, lambda, performed, timings, lm_attempts)."""
+        lam = C.c_double(0)
+        performed = C.c_int32(0)
+        attempts = C.c_int32(0)
+        timings = np.zeros(3)
+        cost = lib().orc_optimize_jointly(C.byref(self.c), C.byref(self._state(st)), max_iteration_count,
+                                          init_lambda, C.byref(lam), C.byref(performed), _dp(timings),
+                                          C.byref(attempts))
+        return dict(cost=cost, final_lambda=lam.value, performed=bool(performed.value),
+                    t_jac=timings[0], t_solve=timings[1], t_cost=timings[2], lm_attempts=attempts.value)
+
+
+def schur_solve(system: System) -> np.ndarray:
+    x = np.zeros(system.n_blocks * system.block_size + system.dense_dof)
+    lib().orc_schur_solve(C.byref(system.struct()), _dp(x))
+    return x
+
+
+def ldlt_solve_upper(A: np.ndarray, b: np.ndarray) -> np.ndarray:
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros_like(b)
+    lib().orc_ldlt_solve_upper(_dp(A), A.shape[0], _dp(b), _dp(x))
+    return x
+
+
+# ---- model-level convenience wrappers (operate on one camera + its grid array) ---------------
+def project(cam, grid: np.ndarray, local_points: np.ndarray, init: Optional[np.ndarray] = None):
+    """CameraModel::Project (from the centre) or ProjectWithInitialEstimate for a batch of points."""
+    cs = camera_struct(cam)
+    g = np.ascontiguousarray(grid, dtype=np.float64)
+    pts = np.ascontiguousarray(local_points, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros((pts.shape[0], 2))
+    ok = np.zeros(pts.shape[0], dtype=bool)
+    L = lib()
+    px = np.zeros(2)
+    for i in range(pts.shape[0]):
+        if init is None:
+            ok[i] = bool(L.orc_project(C.byref(cs), _dp(g), _dp(pts[i].copy()), _dp(px)))
+        else:
+            px[:] = init[i]
+            ok[i] = bool(L.orc_project_with_initial_estimate(C.byref(cs), _dp(g), _dp(pts[i].copy()), _dp(px)))
+        out[i] = px
+    return out, ok
+
+
+def unproject(cam, grid: np.ndarray, pixels: np.ndarray, with_jacobian: bool = False):
+    cs = camera_struct(cam)
+    g = np.ascontiguousarray(grid, dtype=np.float64)
+    px = np.asarray(pixels, dtype=np.float64).reshape(-1, 2)
+    lines = np.zeros((px.shape[0], 6))
+    jac = np.zeros((px.shape[0], 6, 2))
+    ok = np.zeros(px.shape[0], dtype=bool)
+    L = lib()
+    for i in range(px.shape[0]):
+        if with_jacobian:
+            ok[i] = bool(L.orc_unproject_with_jacobian(C.byref(cs), _dp(g), px[i, 0], px[i, 1], _dp(lines[i]), _dp(jac[i])))
+        else:
+            ok[i] = bool(L.orc_unproject(C.byref(cs), _dp(g), px[i, 0], px[i, 1], _dp(lines[i])))
+    return (lines, jac, ok) if with_jacobian else (lines, ok)
+
+
+def se3_mul(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+    o = np.zeros(7)
+    lib().orc_se3_mul(_dp(a), _dp(b), _dp(o))
+    return o
+
+
+def se3_exp(t):
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    o = np.zeros(7)
+    lib().orc_se3_exp(_dp(t), _dp(o))
+    return o
