@@ -1,0 +1,768 @@
+// C-ABI implementation (include/cba.h): device-resident problem, LM control flow
+// (LMOptimizer::OptimizeImpl, libvis/src/libvis/lm_optimizer.h:629-991 in the reference tree) and the
+// stateless model / solver entry points.  Everything numerical runs in the HIP kernels of
+// kernels_obs.hip / kernels_linalg.hip; there is no CPU fallback.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "cba_internal.h"
+
+namespace cba {
+
+static thread_local std::string g_error;
+void set_error(const std::string& msg) { g_error = msg; }
+
+// implemented in kernels_linalg.hip
+int launch_dinv_times_B_ld(const double* Dinv, const double* B, int bs, int nb, int dd, int ld, double* W, hipStream_t s);
+int launch_gemv_t_strided(const double* M, int K, int n, int ld, const double* v, const double* base, double* y,
+                          int ystride, hipStream_t s);
+int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const double* Cin, double* C, int n_pad, int ld,
+               int n_real, int add_diag, double lambda, hipStream_t s);
+int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWorkspace& w, double* x, hipStream_t s);
+int launch_finish_diag(double* S, int ld, int n_real, int n_pad, double lambda, hipStream_t s);
+int launch_diag_sum(const double* Dblk, int bs, int nb, const double* Hdd, int ld, int dd, double* out, hipStream_t s);
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static void make_layout(const cba_config& cfg, Layout& L) {
+  L.n_cameras = cfg.n_cameras; L.n_images = cfg.n_images; L.n_points = cfg.n_points;
+  L.localize_only = cfg.localize_only ? 1 : 0;
+  L.eliminate_points = cfg.eliminate_points ? 1 : 0;
+  const int N = cfg.n_images, C = cfg.n_cameras, P = cfg.n_points;
+  L.rig_in_state = C > 1;
+  const int rig_dof = L.rig_in_state ? 6 * C : 0;
+  L.first_rig_tr_global = L.eliminate_points ? 3 * P : 0;
+  L.first_camera_tr_rig = L.first_rig_tr_global + 6 * N;
+  L.first_points = L.eliminate_points ? 0 : L.first_camera_tr_rig + rig_dof;
+  L.first_intrinsics = L.eliminate_points ? (L.first_camera_tr_rig + rig_dof) : (L.first_points + 3 * P);
+  if (L.eliminate_points) { L.block_size = 3; L.n_blocks = P; } else { L.block_size = 6; L.n_blocks = N; }
+  L.block_dof = L.block_size * L.n_blocks;
+  int off = L.first_intrinsics;
+  for (int c = 0; c < C; ++c) {
+    L.intr_offset[c] = off - L.block_dof;  // dense column
+    off += (cfg.cameras[c].model_type == CBA_CENTRAL_GENERIC ? 2 : 5) * cfg.cameras[c].grid_w * cfg.cameras[c].grid_h;
+  }
+  L.total_dof = L.localize_only ? L.first_intrinsics : off;
+  L.dense_dof = L.total_dof - L.block_dof;
+}
+
+static void padded_dims(int dd, int* n_pad, int* n_fact) {
+  int nf = round_up(dd, 64);
+  int np = round_up(dd + 1, 128);
+  if (nf >= np) np += 128;  // keep the right-hand-side column (n_pad - 1) outside the factored rows
+  *n_pad = np; *n_fact = nf;
+}
+
+static CamDev make_camdev(const cba_camera& c, const double* grid, const double* tangents, int intr_offset) {
+  CamDev d;
+  d.model_type = c.model_type;
+  d.gw = c.grid_w; d.gh = c.grid_h;
+  d.min_x = c.calib_min_x; d.min_y = c.calib_min_y; d.max_x = c.calib_max_x; d.max_y = c.calib_max_y;
+  d.gsx = (double)((float)c.grid_w - 3.f); d.gsy = (double)((float)c.grid_h - 3.f);
+  d.span_x = (double)(c.calib_max_x + 1 - c.calib_min_x);
+  d.span_y = (double)(c.calib_max_y + 1 - c.calib_min_y);
+  d.jscale_x = (double)(((float)c.grid_w - 3.f) / (float)(c.calib_max_x + 1 - c.calib_min_x));
+  d.jscale_y = (double)(((float)c.grid_h - 3.f) / (float)(c.calib_max_y + 1 - c.calib_min_y));
+  d.grid = grid; d.tangents = tangents; d.intr_offset = intr_offset;
+  d.params_per_point = c.model_type == CBA_CENTRAL_GENERIC ? 2 : 5;
+  return d;
+}
+
+static bool camera_ok(const cba_camera& c) {
+  return (c.model_type == CBA_CENTRAL_GENERIC || c.model_type == CBA_NONCENTRAL_GENERIC) && c.grid_w >= 4 && c.grid_h >= 4 &&
+         c.calib_max_x >= c.calib_min_x && c.calib_max_y >= c.calib_min_y;
+}
+
+}  // namespace cba
+
+using namespace cba;
+
+struct KernelTimer {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  double seconds = 0, flops = 0, bytes = 0;
+  int launches = 0;
+  bool pending = false;
+};
+
+struct cba_problem {
+  cba_config cfg{};
+  std::vector<cba_camera> cams;
+  Layout L{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int64_t n_obs = 0;
+  bool have_obs = false, have_state = false, have_system = false;
+  int model_mask = 0;
+  int tasks_per_obs = 0, rec_doubles = 0;
+  // observations
+  float* obs_xy = nullptr; int* obs_point = nullptr; int* obs_image = nullptr; int* obs_camera = nullptr;
+  double* last_projection = nullptr;
+  // state (double buffered)
+  DevState st[2];
+  int cur = 0;
+  double* itg = nullptr;
+  double* tangents[kMaxCameras] = {};
+  CamDev* cams_dev[2] = {nullptr, nullptr};
+  // pass outputs
+  double* cost_ref = nullptr; double* cost_test = nullptr; double* pixels = nullptr; uint8_t* flags = nullptr;
+  double* fd_out = nullptr; uint8_t* fd_ok = nullptr; double* jrec = nullptr; int* cells = nullptr;
+  uint32_t* pair_tables = nullptr; int* pair_counts = nullptr;
+  double* red_partials = nullptr; double* red8 = nullptr;
+  // system
+  int n_pad = 0, n_fact = 0, Kpad = 0;
+  double* Dblk = nullptr; double* bblk = nullptr; double* B = nullptr; double* Hdd = nullptr; double* bd = nullptr;
+  double* Dinv = nullptr; double* dinvb = nullptr; double* W = nullptr; double* S = nullptr; bool S_owned = true;
+  double* x = nullptr; double* scal = nullptr;
+  int* status = nullptr;
+  LdltWorkspace ldlt;
+  KernelTimer timers[4];
+  double last_lambda = 0;
+};
+
+namespace cba {
+
+static int timer_begin(cba_problem* p, int which) {
+  KernelTimer& t = p->timers[which];
+  if (!t.e0) { CBA_HIP(hipEventCreate(&t.e0)); CBA_HIP(hipEventCreate(&t.e1)); }
+  CBA_HIP(hipEventRecord(t.e0, p->stream));
+  return CBA_OK;
+}
+static int timer_end(cba_problem* p, int which, double flops, double bytes, int launches) {
+  KernelTimer& t = p->timers[which];
+  CBA_HIP(hipEventRecord(t.e1, p->stream));
+  CBA_HIP(hipEventSynchronize(t.e1));
+  float ms = 0;
+  CBA_HIP(hipEventElapsedTime(&ms, t.e0, t.e1));
+  t.seconds += ms * 1e-3; t.flops += flops; t.bytes += bytes; t.launches += launches;
+  return CBA_OK;
+}
+
+template <typename T>
+static int dev_alloc(T** p, size_t n) {
+  *p = nullptr;
+  if (n == 0) n = 1;
+  CBA_HIP(hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+  return CBA_OK;
+}
+#define CBA_TRY(expr) do { int _rc = (expr); if (_rc != CBA_OK) return _rc; } while (0)
+
+static int alloc_state(cba_problem* p, DevState& s) {
+  CBA_TRY(dev_alloc(&s.rig_tr_global, 7 * (size_t)p->L.n_images));
+  CBA_TRY(dev_alloc(&s.camera_tr_rig, 7 * (size_t)p->L.n_cameras));
+  CBA_TRY(dev_alloc(&s.points, 3 * (size_t)p->L.n_points));
+  for (int c = 0; c < p->L.n_cameras; ++c) {
+    size_t G = (size_t)p->cams[c].grid_w * p->cams[c].grid_h;
+    CBA_TRY(dev_alloc(&s.grids[c], (p->cams[c].model_type == CBA_CENTRAL_GENERIC ? 3 : 6) * G));
+  }
+  return CBA_OK;
+}
+
+static int upload_camdevs(cba_problem* p, int which) {
+  std::vector<CamDev> h(p->L.n_cameras);
+  for (int c = 0; c < p->L.n_cameras; ++c)
+    h[c] = make_camdev(p->cams[c], p->st[which].grids[c], p->tangents[c], p->L.intr_offset[c]);
+  CBA_HIP(hipMemcpyAsync(p->cams_dev[which], h.data(), sizeof(CamDev) * h.size(), hipMemcpyHostToDevice, p->stream));
+  CBA_HIP(hipStreamSynchronize(p->stream));
+  return CBA_OK;
+}
+
+static PassArgs pass_args(cba_problem* p, int which) {
+  PassArgs a;
+  a.n_obs = p->n_obs; a.n_cameras = p->L.n_cameras;
+  a.obs_xy = p->obs_xy; a.obs_point = p->obs_point; a.obs_image = p->obs_image; a.obs_camera = p->obs_camera;
+  a.last_projection = p->last_projection;
+  a.points = p->st[which].points; a.itg = p->itg; a.cams = p->cams_dev[which];
+  a.fd_delta = p->cfg.numerical_diff_delta;
+  return a;
+}
+
+static int read_scalars(cba_problem* p, const double* dev, double* host, int n) {
+  CBA_HIP(hipMemcpyAsync(host, dev, sizeof(double) * n, hipMemcpyDeviceToHost, p->stream));
+  CBA_HIP(hipStreamSynchronize(p->stream));
+  return CBA_OK;
+}
+
+static int allreduce(cba_problem* p, double* dev, int64_t count) {
+  if (!p->cfg.allreduce) return CBA_OK;
+  CBA_HIP(hipStreamSynchronize(p->stream));
+  int rc = p->cfg.allreduce(dev, count, p->cfg.allreduce_user);
+  if (rc != 0) { set_error("allreduce callback failed"); return CBA_ERR_STATE; }
+  return CBA_OK;
+}
+
+// residual pass on state `which`; fills cost vector `cost_vec` and reduces to out8 (host)
+static int residual_pass(cba_problem* p, int which, double* cost_vec) {
+  CBA_TRY(launch_compose_poses(p->st[which], p->L.n_images, p->L.n_cameras, p->itg, p->stream));
+  PassArgs a = pass_args(p, which);
+  CBA_TRY(launch_base_project(a, p->model_mask, cost_vec, p->pixels, p->flags, p->stream));
+  return CBA_OK;
+}
+
+static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
+  const Layout& L = p->L;
+  const int w = p->cur;
+  for (int c = 0; c < L.n_cameras; ++c)
+    CBA_TRY(launch_tangents(p->st[w].grids[c], p->tangents[c], p->cams[c].grid_w * p->cams[c].grid_h, p->stream));
+  CBA_TRY(residual_pass(p, w, p->cost_ref));
+  PassArgs a = pass_args(p, w);
+  CBA_TRY(timer_begin(p, 3));
+  CBA_TRY(launch_fd_tasks(a, p->model_mask, p->tasks_per_obs, L.localize_only, p->pixels, p->flags, p->fd_out, p->fd_ok, p->stream));
+  CBA_TRY(timer_end(p, 3, 0, 0, 1));
+  CBA_TRY(launch_assemble(a, L, p->st[w], p->tasks_per_obs, p->rec_doubles, p->pixels, p->flags, p->fd_out, p->fd_ok,
+                          p->jrec, p->cells, p->stream));
+  const size_t bs = L.block_size, nb = L.n_blocks;
+  CBA_HIP(hipMemsetAsync(p->Dblk, 0, sizeof(double) * nb * bs * bs, p->stream));
+  CBA_HIP(hipMemsetAsync(p->bblk, 0, sizeof(double) * nb * bs, p->stream));
+  CBA_HIP(hipMemsetAsync(p->B, 0, sizeof(double) * (size_t)p->Kpad * p->n_pad, p->stream));
+  CBA_HIP(hipMemsetAsync(p->Hdd, 0, sizeof(double) * (size_t)p->n_pad * p->n_pad, p->stream));
+  CBA_HIP(hipMemsetAsync(p->bd, 0, sizeof(double) * (size_t)p->n_pad, p->stream));
+  double t0 = now_s();
+  CBA_TRY(timer_begin(p, 2));
+  AccumTargets T{p->Dblk, p->bblk, p->B, p->Hdd, p->bd};
+  // Hdd/B use the padded leading dimension
+  Layout Lp = L;
+  Lp.dense_dof = p->n_pad;  // row stride used by the kernel
+  CBA_TRY(launch_accumulate(a, Lp, p->rec_doubles, p->flags, p->jrec, p->cells, p->pair_tables, p->pair_counts, T, p->stream));
+  CBA_TRY(timer_end(p, 2, 0, 0, 1));
+  if (t_acc) *t_acc += now_s() - t0;
+  p->have_system = true;
+  return CBA_OK;
+}
+
+// Builds S (+ right-hand side in its last column) for `lambda`, factors and solves; x (device) = full update.
+static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
+  const Layout& L = p->L;
+  const int bs = L.block_size, nb = L.n_blocks, dd = L.dense_dof, ld = p->n_pad;
+  const bool multi = p->cfg.allreduce != nullptr;
+  CBA_HIP(hipMemsetAsync(p->status, 0, sizeof(int), p->stream));
+  CBA_HIP(hipMemsetAsync(p->ldlt.status, 0, sizeof(int), p->stream));
+  CBA_TRY(launch_block_inverse(p->Dblk, p->bblk, lambda, bs, nb, p->Dinv, p->dinvb, p->status, p->stream));
+  CBA_TRY(launch_dinv_times_B_ld(p->Dinv, p->B, bs, nb, dd, ld, p->W, p->stream));
+  double t0 = now_s();
+  CBA_TRY(timer_begin(p, 0));
+  CBA_TRY(schur_gemm(p->B, p->W, p->Kpad, ld, p->Hdd, p->S, p->n_pad, ld, dd, multi ? 0 : 1, lambda, p->stream));
+  {
+    double nt = p->n_pad / 128.0;
+    double tiles = nt * (nt + 1) / 2;
+    CBA_TRY(timer_end(p, 0, tiles * 2.0 * 128 * 128 * p->Kpad, tiles * (2.0 * 128 * 128 * 8 + 2.0 * p->Kpad * 128 * 8), 1));
+  }
+  if (rep) rep->t_gemm += now_s() - t0;
+  // right-hand side: S[j][n_pad-1] = bd[j] - sum_k B[k][j] dinvb[k]
+  CBA_TRY(launch_gemv_t_strided(p->B, L.block_dof, dd, ld, p->dinvb, p->bd, p->S + (ld - 1), ld, p->stream));
+  if (multi) {
+    CBA_TRY(allreduce(p, p->S, (int64_t)ld * ld));
+    CBA_TRY(launch_finish_diag(p->S, ld, dd, p->n_pad, lambda, p->stream));
+  }
+  t0 = now_s();
+  GemmStats gs;
+  CBA_TRY(timer_begin(p, 1));
+  CBA_TRY(ldlt_factor(p->S, p->n_fact, ld, p->ldlt, p->stream, &gs));
+  CBA_TRY(timer_end(p, 1, gs.flops, 0, gs.launches));
+  CBA_TRY(ldlt_back_solve(p->S, p->n_fact, ld, ld - 1, p->ldlt, p->x + L.block_dof, p->stream));
+  if (rep) rep->t_factor += now_s() - t0;
+  // block part: x_b = D^-1 b - W x_d      (lm_optimizer.h:1366-1367)
+  CBA_TRY(launch_gemv_n(p->W, L.block_dof, dd, ld, p->x + L.block_dof, p->dinvb, p->x, p->stream));
+  int st[2] = {0, 0};
+  CBA_HIP(hipMemcpyAsync(&st[0], p->status, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+  CBA_HIP(hipMemcpyAsync(&st[1], p->ldlt.status, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+  CBA_HIP(hipStreamSynchronize(p->stream));
+  if (st[0] || st[1]) return CBA_ERR_NUMERIC;
+  return CBA_OK;
+}
+
+}  // namespace cba
+
+// =================================================================================================
+// C-ABI
+// =================================================================================================
+extern "C" {
+
+const char* cba_last_error(void) { return g_error.c_str(); }
+const char* cba_version(void) { return "camera_calibration_amd 0.1 (gfx950)"; }
+
+int32_t cba_total_dof(const cba_problem* p) { return p ? p->L.total_dof : 0; }
+int32_t cba_dense_dof(const cba_problem* p) { return p ? p->L.dense_dof : 0; }
+int32_t cba_jacobian_record_doubles(const cba_problem* p) { return p ? p->rec_doubles : 0; }
+
+int64_t cba_reduce_buffer_doubles(const cba_config* config) {
+  if (!config || !config->cameras) return 0;
+  Layout L; make_layout(*config, L);
+  int n_pad, n_fact; padded_dims(L.dense_dof, &n_pad, &n_fact);
+  return (int64_t)n_pad * n_pad;
+}
+
+int cba_create(const cba_config* config, cba_problem** out) {
+  if (!config || !out || !config->cameras || config->n_cameras < 1 || config->n_cameras > kMaxCameras ||
+      config->n_images < 0 || config->n_points < 0 || !(config->numerical_diff_delta > 0)) {
+    set_error("cba_create: bad config"); return CBA_ERR_ARG;
+  }
+  for (int c = 0; c < config->n_cameras; ++c)
+    if (!camera_ok(config->cameras[c])) { set_error("cba_create: bad camera"); return CBA_ERR_ARG; }
+  if (config->allreduce && config->eliminate_points) { set_error("image sharding requires eliminate_points = 0"); return CBA_ERR_UNSUPPORTED; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device available (the engine has no CPU fallback)"); return CBA_ERR_HIP; }
+  if (config->device < 0 || config->device >= ndev) { set_error("cba_create: bad device ordinal"); return CBA_ERR_ARG; }
+  CBA_HIP(hipSetDevice(config->device));
+  cba_problem* p = new cba_problem();
+  p->cfg = *config;
+  p->cams.assign(config->cameras, config->cameras + config->n_cameras);
+  p->cfg.cameras = p->cams.data();
+  p->device = config->device;
+  make_layout(p->cfg, p->L);
+  const Layout& L = p->L;
+  if (L.total_dof <= 0) { delete p; set_error("empty problem"); return CBA_ERR_ARG; }
+  CBA_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  for (int c = 0; c < L.n_cameras; ++c) p->model_mask |= (p->cams[c].model_type == CBA_CENTRAL_GENERIC) ? 1 : 2;
+  const int maxKg = L.localize_only ? 0 : ((p->model_mask & 2) ? 80 : 32);
+  p->tasks_per_obs = 3 + maxKg;
+  p->rec_doubles = kRecHeader + 2 * maxKg;
+  CBA_TRY(alloc_state(p, p->st[0]));
+  CBA_TRY(alloc_state(p, p->st[1]));
+  CBA_TRY(dev_alloc(&p->itg, 16 * (size_t)L.n_images * L.n_cameras));
+  for (int c = 0; c < L.n_cameras; ++c) CBA_TRY(dev_alloc(&p->tangents[c], 6 * (size_t)p->cams[c].grid_w * p->cams[c].grid_h));
+  CBA_TRY(dev_alloc(&p->cams_dev[0], L.n_cameras));
+  CBA_TRY(dev_alloc(&p->cams_dev[1], L.n_cameras));
+  CBA_TRY(upload_camdevs(p, 0));
+  CBA_TRY(upload_camdevs(p, 1));
+  // pair tables (upper-triangle (row,col) pairs) for the two column-count classes
+  {
+    const size_t stride = (size_t)kMaxCols * (kMaxCols + 1) / 2;
+    std::vector<uint32_t> tab(2 * stride, 0);
+    int counts[2] = {0, 0};
+    for (int slot = 0; slot < 2; ++slot) {
+      int Kg = L.localize_only ? 0 : (slot == 0 ? 32 : 80);
+      int K = 6 + (L.rig_in_state ? 6 : 0) + 3 + Kg;
+      int e = 0;
+      for (int i = 0; i < K; ++i)
+        for (int k = i; k < K; ++k) tab[slot * stride + e++] = ((uint32_t)i << 16) | (uint32_t)k;
+      counts[slot] = e;
+    }
+    CBA_TRY(dev_alloc(&p->pair_tables, tab.size()));
+    CBA_TRY(dev_alloc(&p->pair_counts, 2));
+    CBA_HIP(hipMemcpy(p->pair_tables, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    CBA_HIP(hipMemcpy(p->pair_counts, counts, sizeof(counts), hipMemcpyHostToDevice));
+  }
+  CBA_TRY(dev_alloc(&p->red_partials, 256 * 8));
+  CBA_TRY(dev_alloc(&p->red8, 16));
+  // normal equations
+  padded_dims(L.dense_dof, &p->n_pad, &p->n_fact);
+  p->Kpad = round_up(L.block_dof > 0 ? L.block_dof : 1, 16);
+  const size_t bs = L.block_size, nb = L.n_blocks;
+  CBA_TRY(dev_alloc(&p->Dblk, nb * bs * bs));
+  CBA_TRY(dev_alloc(&p->bblk, nb * bs));
+  CBA_TRY(dev_alloc(&p->Dinv, nb * bs * bs));
+  CBA_TRY(dev_alloc(&p->dinvb, (size_t)p->Kpad));
+  CBA_TRY(dev_alloc(&p->B, (size_t)p->Kpad * p->n_pad));
+  CBA_TRY(dev_alloc(&p->W, (size_t)p->Kpad * p->n_pad));
+  CBA_TRY(dev_alloc(&p->Hdd, (size_t)p->n_pad * p->n_pad));
+  CBA_TRY(dev_alloc(&p->bd, (size_t)p->n_pad));
+  if (config->reduce_buffer) {
+    if (config->reduce_buffer_doubles < (int64_t)p->n_pad * p->n_pad) { set_error("reduce_buffer too small"); return CBA_ERR_ARG; }
+    p->S = static_cast<double*>(config->reduce_buffer); p->S_owned = false;
+  } else {
+    CBA_TRY(dev_alloc(&p->S, (size_t)p->n_pad * p->n_pad));
+  }
+  CBA_HIP(hipMemset(p->S, 0, sizeof(double) * (size_t)p->n_pad * p->n_pad));
+  CBA_HIP(hipMemset(p->W, 0, sizeof(double) * (size_t)p->Kpad * p->n_pad));
+  CBA_HIP(hipMemset(p->dinvb, 0, sizeof(double) * (size_t)p->Kpad));
+  CBA_TRY(dev_alloc(&p->x, (size_t)L.block_dof + p->n_pad));
+  CBA_HIP(hipMemset(p->x, 0, sizeof(double) * ((size_t)L.block_dof + p->n_pad)));
+  CBA_TRY(dev_alloc(&p->scal, 16));
+  CBA_TRY(dev_alloc(&p->status, 1));
+  CBA_TRY(ldlt_workspace_alloc(p->ldlt, p->n_pad));
+  *out = p;
+  return CBA_OK;
+}
+
+void cba_destroy(cba_problem* p) {
+  if (!p) return;
+  hipSetDevice(p->device);
+  if (p->stream) hipStreamSynchronize(p->stream);
+  auto F = [](void* q) { if (q) hipFree(q); };
+  F(p->obs_xy); F(p->obs_point); F(p->obs_image); F(p->obs_camera); F(p->last_projection);
+  for (int s = 0; s < 2; ++s) {
+    F(p->st[s].rig_tr_global); F(p->st[s].camera_tr_rig); F(p->st[s].points);
+    for (int c = 0; c < kMaxCameras; ++c) F(p->st[s].grids[c]);
+    F(p->cams_dev[s]);
+  }
+  F(p->itg);
+  for (int c = 0; c < kMaxCameras; ++c) F(p->tangents[c]);
+  F(p->cost_ref); F(p->cost_test); F(p->pixels); F(p->flags); F(p->fd_out); F(p->fd_ok); F(p->jrec); F(p->cells);
+  F(p->pair_tables); F(p->pair_counts); F(p->red_partials); F(p->red8);
+  F(p->Dblk); F(p->bblk); F(p->B); F(p->Hdd); F(p->bd); F(p->Dinv); F(p->dinvb); F(p->W);
+  if (p->S_owned) F(p->S);
+  F(p->x); F(p->scal); F(p->status);
+  ldlt_workspace_free(p->ldlt);
+  for (auto& t : p->timers) { if (t.e0) hipEventDestroy(t.e0); if (t.e1) hipEventDestroy(t.e1); }
+  if (p->stream) hipStreamDestroy(p->stream);
+  delete p;
+}
+
+int cba_set_observations(cba_problem* p, int64_t n, const float* xy, const int32_t* point_index,
+                         const int32_t* image_index, const int32_t* camera_index, const double* last_projection) {
+  if (!p || n < 0 || (n > 0 && (!xy || !point_index || !image_index || !camera_index))) { set_error("cba_set_observations: bad argument"); return CBA_ERR_ARG; }
+  const Layout& L = p->L;
+  int64_t prev = -1;
+  for (int64_t i = 0; i < n; ++i) {
+    if (point_index[i] < 0 || point_index[i] >= L.n_points || image_index[i] < 0 || image_index[i] >= L.n_images ||
+        camera_index[i] < 0 || camera_index[i] >= L.n_cameras) { set_error("cba_set_observations: index out of range"); return CBA_ERR_ARG; }
+    int64_t key = (int64_t)image_index[i] * L.n_cameras + camera_index[i];
+    if (key < prev) { set_error("cba_set_observations: observations must be sorted image-major, then camera"); return CBA_ERR_ARG; }
+    prev = key;
+  }
+  CBA_HIP(hipSetDevice(p->device));
+  auto F = [](void* q) { if (q) hipFree(q); };
+  F(p->obs_xy); F(p->obs_point); F(p->obs_image); F(p->obs_camera); F(p->last_projection);
+  F(p->cost_ref); F(p->cost_test); F(p->pixels); F(p->flags); F(p->fd_out); F(p->fd_ok); F(p->jrec); F(p->cells);
+  p->n_obs = n;
+  CBA_TRY(dev_alloc(&p->obs_xy, 2 * (size_t)n)); CBA_TRY(dev_alloc(&p->obs_point, (size_t)n));
+  CBA_TRY(dev_alloc(&p->obs_image, (size_t)n)); CBA_TRY(dev_alloc(&p->obs_camera, (size_t)n));
+  CBA_TRY(dev_alloc(&p->last_projection, 2 * (size_t)n));
+  CBA_TRY(dev_alloc(&p->cost_ref, (size_t)n)); CBA_TRY(dev_alloc(&p->cost_test, (size_t)n));
+  CBA_TRY(dev_alloc(&p->pixels, 2 * (size_t)n)); CBA_TRY(dev_alloc(&p->flags, (size_t)n));
+  CBA_TRY(dev_alloc(&p->fd_out, 2 * (size_t)n * p->tasks_per_obs)); CBA_TRY(dev_alloc(&p->fd_ok, (size_t)n * p->tasks_per_obs));
+  CBA_TRY(dev_alloc(&p->jrec, (size_t)n * p->rec_doubles)); CBA_TRY(dev_alloc(&p->cells, 2 * (size_t)n));
+  if (n > 0) {
+    CBA_HIP(hipMemcpy(p->obs_xy, xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice));
+    CBA_HIP(hipMemcpy(p->obs_point, point_index, sizeof(int) * n, hipMemcpyHostToDevice));
+    CBA_HIP(hipMemcpy(p->obs_image, image_index, sizeof(int) * n, hipMemcpyHostToDevice));
+    CBA_HIP(hipMemcpy(p->obs_camera, camera_index, sizeof(int) * n, hipMemcpyHostToDevice));
+    if (last_projection) CBA_HIP(hipMemcpy(p->last_projection, last_projection, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+    else CBA_HIP(hipMemset(p->last_projection, 0, sizeof(double) * 2 * n));
+    CBA_HIP(hipMemset(p->flags, 0, (size_t)n));
+  }
+  p->have_obs = true; p->have_system = false;
+  return CBA_OK;
+}
+
+int cba_set_state(cba_problem* p, const double* rig_tr_global, const double* camera_tr_rig, const double* points,
+                  const double* const* grids) {
+  if (!p || !camera_tr_rig || !grids || (p->L.n_images > 0 && !rig_tr_global) || (p->L.n_points > 0 && !points)) { set_error("cba_set_state: bad argument"); return CBA_ERR_ARG; }
+  CBA_HIP(hipSetDevice(p->device));
+  DevState& s = p->st[p->cur];
+  const Layout& L = p->L;
+  if (L.n_images) CBA_HIP(hipMemcpy(s.rig_tr_global, rig_tr_global, sizeof(double) * 7 * L.n_images, hipMemcpyHostToDevice));
+  CBA_HIP(hipMemcpy(s.camera_tr_rig, camera_tr_rig, sizeof(double) * 7 * L.n_cameras, hipMemcpyHostToDevice));
+  if (L.n_points) CBA_HIP(hipMemcpy(s.points, points, sizeof(double) * 3 * L.n_points, hipMemcpyHostToDevice));
+  for (int c = 0; c < L.n_cameras; ++c) {
+    if (!grids[c]) { set_error("cba_set_state: null grid"); return CBA_ERR_ARG; }
+    size_t G = (size_t)p->cams[c].grid_w * p->cams[c].grid_h;
+    CBA_HIP(hipMemcpy(s.grids[c], grids[c], sizeof(double) * (p->cams[c].model_type == CBA_CENTRAL_GENERIC ? 3 : 6) * G, hipMemcpyHostToDevice));
+  }
+  p->have_state = true; p->have_system = false;
+  return CBA_OK;
+}
+
+int cba_get_state(cba_problem* p, double* rig_tr_global, double* camera_tr_rig, double* points, double* const* grids) {
+  if (!p || !p->have_state) { set_error("cba_get_state: no state"); return CBA_ERR_STATE; }
+  CBA_HIP(hipSetDevice(p->device));
+  CBA_HIP(hipStreamSynchronize(p->stream));
+  const DevState& s = p->st[p->cur];
+  const Layout& L = p->L;
+  if (rig_tr_global && L.n_images) CBA_HIP(hipMemcpy(rig_tr_global, s.rig_tr_global, sizeof(double) * 7 * L.n_images, hipMemcpyDeviceToHost));
+  if (camera_tr_rig) CBA_HIP(hipMemcpy(camera_tr_rig, s.camera_tr_rig, sizeof(double) * 7 * L.n_cameras, hipMemcpyDeviceToHost));
+  if (points && L.n_points) CBA_HIP(hipMemcpy(points, s.points, sizeof(double) * 3 * L.n_points, hipMemcpyDeviceToHost));
+  if (grids)
+    for (int c = 0; c < L.n_cameras; ++c) {
+      if (!grids[c]) continue;
+      size_t G = (size_t)p->cams[c].grid_w * p->cams[c].grid_h;
+      CBA_HIP(hipMemcpy(grids[c], s.grids[c], sizeof(double) * (p->cams[c].model_type == CBA_CENTRAL_GENERIC ? 3 : 6) * G, hipMemcpyDeviceToHost));
+    }
+  return CBA_OK;
+}
+
+int cba_get_last_projection(cba_problem* p, double* out) {
+  if (!p || !out || !p->have_obs) { set_error("cba_get_last_projection: bad argument"); return CBA_ERR_ARG; }
+  CBA_HIP(hipSetDevice(p->device));
+  CBA_HIP(hipStreamSynchronize(p->stream));
+  if (p->n_obs) CBA_HIP(hipMemcpy(out, p->last_projection, sizeof(double) * 2 * p->n_obs, hipMemcpyDeviceToHost));
+  return CBA_OK;
+}
+
+int cba_cost(cba_problem* p, double* cost, int64_t* n_valid, double* cost_vector) {
+  if (!p || !p->have_obs || !p->have_state) { set_error("cba_cost: observations/state missing"); return CBA_ERR_STATE; }
+  CBA_HIP(hipSetDevice(p->device));
+  CBA_TRY(upload_camdevs(p, p->cur));
+  CBA_TRY(residual_pass(p, p->cur, p->cost_test));
+  CBA_TRY(launch_reduce_costs(nullptr, p->cost_test, nullptr, p->n_obs, p->red_partials, p->red8, p->stream));
+  CBA_TRY(allreduce(p, p->red8, 8));
+  double h[8];
+  CBA_TRY(read_scalars(p, p->red8, h, 8));
+  if (cost) *cost = h[1];
+  if (n_valid) *n_valid = (int64_t)h[6];
+  if (cost_vector && p->n_obs) CBA_HIP(hipMemcpy(cost_vector, p->cost_test, sizeof(double) * p->n_obs, hipMemcpyDeviceToHost));
+  return CBA_OK;
+}
+
+int cba_debug_accumulate(cba_problem* p, double* cost) {
+  if (!p || !p->have_obs || !p->have_state) { set_error("cba_debug_accumulate: observations/state missing"); return CBA_ERR_STATE; }
+  CBA_HIP(hipSetDevice(p->device));
+  CBA_TRY(upload_camdevs(p, p->cur));
+  CBA_TRY(jacobian_pass_and_accumulate(p, nullptr));
+  CBA_TRY(launch_reduce_costs(p->cost_ref, nullptr, p->flags, p->n_obs, p->red_partials, p->red8, p->stream));
+  double h[8];
+  CBA_TRY(read_scalars(p, p->red8, h, 8));
+  if (cost) *cost = h[0];
+  return CBA_OK;
+}
+
+int cba_debug_solve(cba_problem* p, double lambda) {
+  if (!p || !p->have_system) { set_error("cba_debug_solve: no accumulated system"); return CBA_ERR_STATE; }
+  CBA_HIP(hipSetDevice(p->device));
+  return solve_system(p, lambda, nullptr);
+}
+
+int cba_debug_apply_update(cba_problem* p, const double* x) {
+  if (!p || !x || !p->have_state) { set_error("cba_debug_apply_update: bad argument"); return CBA_ERR_STATE; }
+  CBA_HIP(hipSetDevice(p->device));
+  CBA_HIP(hipMemcpy(p->x, x, sizeof(double) * p->L.total_dof, hipMemcpyHostToDevice));
+  CBA_TRY(launch_apply_update(p->L, p->cams, p->st[p->cur], p->x, p->st[p->cur ^ 1], p->stream));
+  CBA_HIP(hipStreamSynchronize(p->stream));
+  p->cur ^= 1;
+  p->have_system = false;
+  return CBA_OK;
+}
+
+int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double init_lambda_factor, cba_report* report) {
+  if (!p || !report || max_lm_attempts < 1 || init_lambda_factor < 0) { set_error("cba_step: bad argument"); return CBA_ERR_ARG; }
+  if (!p->have_obs || !p->have_state) { set_error("cba_step: observations/state missing"); return CBA_ERR_STATE; }
+  CBA_HIP(hipSetDevice(p->device));
+  std::memset(report, 0, sizeof(*report));
+  for (auto& t : p->timers) { t.seconds = t.flops = t.bytes = 0; t.launches = 0; }
+  const Layout& L = p->L;
+  const bool multi = p->cfg.allreduce != nullptr;
+  double h[8];
+  // ---- residual + Jacobian pass, accumulation (lm_optimizer.h:706-720) ----
+  double t0 = now_s();
+  CBA_TRY(upload_camdevs(p, p->cur));
+  CBA_TRY(jacobian_pass_and_accumulate(p, &report->t_accumulate));
+  CBA_TRY(launch_reduce_costs(p->cost_ref, nullptr, p->flags, p->n_obs, p->red_partials, p->red8, p->stream));
+  CBA_TRY(allreduce(p, p->red8, 8));
+  CBA_TRY(read_scalars(p, p->red8, h, 8));
+  report->t_jac = now_s() - t0;
+  double last_cost = h[0];
+  report->initial_cost = last_cost;
+  report->n_residuals_valid = (int64_t)h[5];
+  report->n_jacobians_dropped = (int64_t)h[7];
+  report->final_cost = last_cost;
+  double lambda = p->last_lambda;
+  if (last_cost == 0) { report->lambda = lambda; return CBA_OK; }   // lm_optimizer.h:755-760
+  if (init_lambda >= 0) {
+    lambda = init_lambda;
+  } else {  // lm_optimizer.h:766-781
+    CBA_TRY(launch_diag_sum(p->Dblk, L.block_size, L.n_blocks, p->Hdd, p->n_pad, L.dense_dof, p->scal, p->stream));
+    CBA_TRY(allreduce(p, p->scal, 1));
+    double sum;
+    CBA_TRY(read_scalars(p, p->scal, &sum, 1));
+    const int n_img_global = (multi && p->cfg.n_images_global > 0) ? p->cfg.n_images_global : L.n_images;
+    const double dof_global = (double)L.total_dof + 6.0 * (n_img_global - L.n_images);
+    lambda = init_lambda_factor * sum / dof_global;
+  }
+  // ---- LM attempts (lm_optimizer.h:802-965) ----
+  for (int lm = 0; lm < max_lm_attempts; ++lm) {
+    report->lm_attempts += 1;
+    t0 = now_s();
+    int rc = solve_system(p, lambda, report);
+    report->t_solve += now_s() - t0;
+    if (rc != CBA_OK && rc != CBA_ERR_NUMERIC) return rc;
+    double x0 = NAN;
+    if (rc == CBA_OK) CBA_TRY(read_scalars(p, p->x, &x0, 1));
+    if (rc == CBA_ERR_NUMERIC || std::isnan(x0)) {   // NaN update -> lambda *= 2 (lm_optimizer.h:905-913)
+      lambda = 2.f * lambda;
+      continue;
+    }
+    t0 = now_s();
+    const int cand = p->cur ^ 1;
+    CBA_TRY(launch_apply_update(L, p->cams, p->st[p->cur], p->x, p->st[cand], p->stream));
+    CBA_TRY(upload_camdevs(p, cand));
+    CBA_TRY(residual_pass(p, cand, p->cost_test));
+    CBA_TRY(launch_reduce_costs(p->cost_ref, p->cost_test, nullptr, p->n_obs, p->red_partials, p->red8, p->stream));
+    CBA_TRY(allreduce(p, p->red8, 8));
+    CBA_TRY(read_scalars(p, p->red8, h, 8));
+    report->t_cost += now_s() - t0;
+    // CostIsSmallerThan (lm_optimizer.h:993-1011): only residuals valid in both passes
+    const bool smaller = h[4] > 0 && h[3] < h[2];
+    if (smaller) {
+      p->cur = cand;
+      lambda = 0.5f * lambda;
+      report->accepted = 1;
+      last_cost = h[1];
+      break;
+    } else {
+      lambda = 2.f * lambda;
+    }
+  }
+  report->final_cost = last_cost;
+  report->lambda = lambda;
+  p->last_lambda = lambda;
+  p->have_system = true;
+  return CBA_OK;
+}
+
+int cba_kernel_stats(cba_problem* p, int32_t which, double* seconds, double* flops, double* bytes, int32_t* launches) {
+  if (!p || which < 0 || which > 3) { set_error("cba_kernel_stats: bad argument"); return CBA_ERR_ARG; }
+  const KernelTimer& t = p->timers[which];
+  if (seconds) *seconds = t.seconds;
+  if (flops) *flops = t.flops;
+  if (bytes) *bytes = t.bytes;
+  if (launches) *launches = t.launches;
+  return CBA_OK;
+}
+
+int cba_debug_dump(cba_problem* p, int32_t what, void* out, size_t bytes) {
+  if (!p || !out) { set_error("cba_debug_dump: bad argument"); return CBA_ERR_ARG; }
+  CBA_HIP(hipSetDevice(p->device));
+  CBA_HIP(hipStreamSynchronize(p->stream));
+  const Layout& L = p->L;
+  const size_t n = (size_t)p->n_obs, bs = L.block_size, nb = L.n_blocks, dd = L.dense_dof, ld = p->n_pad;
+  auto copy = [&](const void* src, size_t need) -> int {
+    if (bytes < need) { set_error("cba_debug_dump: buffer too small"); return CBA_ERR_ARG; }
+    if (need) CBA_HIP(hipMemcpy(out, src, need, hipMemcpyDeviceToHost));
+    return CBA_OK;
+  };
+  auto copy2d = [&](const double* src, size_t rows, size_t cols) -> int {
+    if (bytes < rows * cols * sizeof(double)) { set_error("cba_debug_dump: buffer too small"); return CBA_ERR_ARG; }
+    if (rows && cols)
+      CBA_HIP(hipMemcpy2D(out, cols * sizeof(double), src, ld * sizeof(double), cols * sizeof(double), rows, hipMemcpyDeviceToHost));
+    return CBA_OK;
+  };
+  switch (what) {
+    case CBA_DUMP_COST_VECTOR: return copy(p->cost_ref, n * sizeof(double));
+    case CBA_DUMP_TEST_COST_VECTOR: return copy(p->cost_test, n * sizeof(double));
+    case CBA_DUMP_PIXELS: return copy(p->pixels, 2 * n * sizeof(double));
+    case CBA_DUMP_FLAGS: return copy(p->flags, n);
+    case CBA_DUMP_JACOBIANS: return copy(p->jrec, n * p->rec_doubles * sizeof(double));
+    case CBA_DUMP_BLOCK_DIAG_H: return copy(p->Dblk, nb * bs * bs * sizeof(double));
+    case CBA_DUMP_BLOCK_DIAG_B: return copy(p->bblk, nb * bs * sizeof(double));
+    case CBA_DUMP_OFF_DIAG_H: return copy2d(p->B, nb * bs, dd);
+    case CBA_DUMP_DENSE_H: return copy2d(p->Hdd, dd, dd);
+    case CBA_DUMP_DENSE_B: return copy(p->bd, dd * sizeof(double));
+    case CBA_DUMP_X: {
+      if (bytes < (size_t)L.total_dof * sizeof(double)) { set_error("cba_debug_dump: buffer too small"); return CBA_ERR_ARG; }
+      CBA_HIP(hipMemcpy(out, p->x, (size_t)L.total_dof * sizeof(double), hipMemcpyDeviceToHost));
+      return CBA_OK;
+    }
+    default: set_error("cba_debug_dump: unknown item"); return CBA_ERR_ARG;
+  }
+}
+
+// ---- stateless entry points -----------------------------------------------------------------------
+static int stateless_setup(const cba_camera* camera, const double* grid, int32_t device, double** d_grid, CamDev** d_cam) {
+  if (!camera || !grid || !camera_ok(*camera)) { set_error("bad camera / grid"); return CBA_ERR_ARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device available (the engine has no CPU fallback)"); return CBA_ERR_HIP; }
+  if (device < 0 || device >= ndev) { set_error("bad device ordinal"); return CBA_ERR_ARG; }
+  CBA_HIP(hipSetDevice(device));
+  size_t G = (size_t)camera->grid_w * camera->grid_h;
+  size_t nd = (camera->model_type == CBA_CENTRAL_GENERIC ? 3 : 6) * G;
+  CBA_TRY(dev_alloc(d_grid, nd));
+  CBA_HIP(hipMemcpy(*d_grid, grid, nd * sizeof(double), hipMemcpyHostToDevice));
+  CamDev h = make_camdev(*camera, *d_grid, nullptr, 0);
+  CBA_TRY(dev_alloc(d_cam, 1));
+  CBA_HIP(hipMemcpy(*d_cam, &h, sizeof(CamDev), hipMemcpyHostToDevice));
+  return CBA_OK;
+}
+
+int cba_project(const cba_camera* camera, const double* grid, int64_t n, const double* local_points,
+                const double* init_pixels, double* pixels, uint8_t* ok, int32_t device) {
+  if (n < 0 || (n > 0 && (!local_points || !pixels || !ok))) { set_error("cba_project: bad argument"); return CBA_ERR_ARG; }
+  double* d_grid = nullptr; CamDev* d_cam = nullptr;
+  CBA_TRY(stateless_setup(camera, grid, device, &d_grid, &d_cam));
+  double *d_local = nullptr, *d_init = nullptr, *d_px = nullptr; uint8_t* d_ok = nullptr;
+  CBA_TRY(dev_alloc(&d_local, 3 * (size_t)n)); CBA_TRY(dev_alloc(&d_px, 2 * (size_t)n)); CBA_TRY(dev_alloc(&d_ok, (size_t)n));
+  if (n) CBA_HIP(hipMemcpy(d_local, local_points, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+  if (init_pixels) {
+    CBA_TRY(dev_alloc(&d_init, 2 * (size_t)n));
+    if (n) CBA_HIP(hipMemcpy(d_init, init_pixels, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+  }
+  int rc = launch_project_points(d_cam, camera->model_type, n, d_local, d_init, d_px, d_ok, nullptr);
+  if (rc == CBA_OK && n) {
+    if (hipMemcpy(pixels, d_px, sizeof(double) * 2 * n, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(ok, d_ok, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) { set_error("cba_project: copy back failed"); rc = CBA_ERR_HIP; }
+  }
+  hipFree(d_grid); hipFree(d_cam); hipFree(d_local); hipFree(d_px); hipFree(d_ok); if (d_init) hipFree(d_init);
+  return rc;
+}
+
+int cba_unproject(const cba_camera* camera, const double* grid, int64_t n, const double* pixels, double* lines,
+                  double* jacobians, uint8_t* ok, int32_t device) {
+  if (n < 0 || (n > 0 && (!pixels || !lines || !ok))) { set_error("cba_unproject: bad argument"); return CBA_ERR_ARG; }
+  double* d_grid = nullptr; CamDev* d_cam = nullptr;
+  CBA_TRY(stateless_setup(camera, grid, device, &d_grid, &d_cam));
+  double *d_px = nullptr, *d_lines = nullptr, *d_jac = nullptr; uint8_t* d_ok = nullptr;
+  CBA_TRY(dev_alloc(&d_px, 2 * (size_t)n)); CBA_TRY(dev_alloc(&d_lines, 6 * (size_t)n)); CBA_TRY(dev_alloc(&d_ok, (size_t)n));
+  if (jacobians) CBA_TRY(dev_alloc(&d_jac, 12 * (size_t)n));
+  if (n) CBA_HIP(hipMemcpy(d_px, pixels, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+  int rc = launch_unproject(d_cam, camera->model_type, n, d_px, d_lines, d_jac, d_ok, nullptr);
+  if (rc == CBA_OK && n) {
+    bool okc = hipMemcpy(lines, d_lines, sizeof(double) * 6 * n, hipMemcpyDeviceToHost) == hipSuccess &&
+               hipMemcpy(ok, d_ok, (size_t)n, hipMemcpyDeviceToHost) == hipSuccess;
+    if (okc && jacobians) okc = hipMemcpy(jacobians, d_jac, sizeof(double) * 12 * n, hipMemcpyDeviceToHost) == hipSuccess;
+    if (!okc) { set_error("cba_unproject: copy back failed"); rc = CBA_ERR_HIP; }
+  }
+  hipFree(d_grid); hipFree(d_cam); hipFree(d_px); hipFree(d_lines); hipFree(d_ok); if (d_jac) hipFree(d_jac);
+  return rc;
+}
+
+int cba_schur_solve(int32_t block_size, int32_t n_blocks, int32_t dense_dof, const double* block_diag_H,
+                    const double* off_diag_H, const double* dense_H, const double* block_diag_b,
+                    const double* dense_b, double* x, int32_t device) {
+  if (block_size < 1 || block_size > 6 || n_blocks < 1 || dense_dof < 1 || !block_diag_H || !off_diag_H || !dense_H ||
+      !block_diag_b || !dense_b || !x) { set_error("cba_schur_solve: bad argument"); return CBA_ERR_ARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device available (the engine has no CPU fallback)"); return CBA_ERR_HIP; }
+  if (device < 0 || device >= ndev) { set_error("bad device ordinal"); return CBA_ERR_ARG; }
+  CBA_HIP(hipSetDevice(device));
+  const int bs = block_size, nb = n_blocks, dd = dense_dof, bdof = bs * nb;
+  int n_pad, n_fact; padded_dims(dd, &n_pad, &n_fact);
+  const int ld = n_pad, Kpad = round_up(bdof, 16);
+  double *Dblk, *bblk, *Dinv, *dinvb, *B, *W, *Hdd, *bd, *S, *xd; int* status;
+  CBA_TRY(dev_alloc(&Dblk, (size_t)nb * bs * bs)); CBA_TRY(dev_alloc(&bblk, (size_t)bdof)); CBA_TRY(dev_alloc(&Dinv, (size_t)nb * bs * bs));
+  CBA_TRY(dev_alloc(&dinvb, (size_t)Kpad)); CBA_TRY(dev_alloc(&B, (size_t)Kpad * ld)); CBA_TRY(dev_alloc(&W, (size_t)Kpad * ld));
+  CBA_TRY(dev_alloc(&Hdd, (size_t)ld * ld)); CBA_TRY(dev_alloc(&bd, (size_t)ld)); CBA_TRY(dev_alloc(&S, (size_t)ld * ld));
+  CBA_TRY(dev_alloc(&xd, (size_t)bdof + ld)); CBA_TRY(dev_alloc(&status, 1));
+  CBA_HIP(hipMemset(B, 0, sizeof(double) * (size_t)Kpad * ld)); CBA_HIP(hipMemset(W, 0, sizeof(double) * (size_t)Kpad * ld));
+  CBA_HIP(hipMemset(Hdd, 0, sizeof(double) * (size_t)ld * ld)); CBA_HIP(hipMemset(S, 0, sizeof(double) * (size_t)ld * ld));
+  CBA_HIP(hipMemset(bd, 0, sizeof(double) * ld)); CBA_HIP(hipMemset(status, 0, sizeof(int))); CBA_HIP(hipMemset(dinvb, 0, sizeof(double) * Kpad));
+  CBA_HIP(hipMemset(xd, 0, sizeof(double) * ((size_t)bdof + ld)));
+  // upper triangles only: the reference fills lower triangles with NaN in its golden test, so copy and scrub
+  std::vector<double> hD(block_diag_H, block_diag_H + (size_t)nb * bs * bs), hH((size_t)dd * dd);
+  for (int b = 0; b < nb; ++b)
+    for (int r = 0; r < bs; ++r)
+      for (int c = 0; c < r; ++c) hD[(size_t)b * bs * bs + r * bs + c] = 0.0;
+  for (int r = 0; r < dd; ++r)
+    for (int c = 0; c < dd; ++c) hH[(size_t)r * dd + c] = (c >= r) ? dense_H[(size_t)r * dd + c] : 0.0;
+  CBA_HIP(hipMemcpy(Dblk, hD.data(), sizeof(double) * hD.size(), hipMemcpyHostToDevice));
+  CBA_HIP(hipMemcpy(bblk, block_diag_b, sizeof(double) * bdof, hipMemcpyHostToDevice));
+  CBA_HIP(hipMemcpy2D(B, ld * sizeof(double), off_diag_H, dd * sizeof(double), dd * sizeof(double), bdof, hipMemcpyHostToDevice));
+  CBA_HIP(hipMemcpy2D(Hdd, ld * sizeof(double), hH.data(), dd * sizeof(double), dd * sizeof(double), dd, hipMemcpyHostToDevice));
+  CBA_HIP(hipMemcpy(bd, dense_b, sizeof(double) * dd, hipMemcpyHostToDevice));
+  LdltWorkspace w;
+  CBA_TRY(ldlt_workspace_alloc(w, n_pad));
+  CBA_HIP(hipMemset(w.status, 0, sizeof(int)));
+  hipStream_t s = nullptr;
+  CBA_TRY(launch_block_inverse(Dblk, bblk, 0.0, bs, nb, Dinv, dinvb, status, s));
+  CBA_TRY(launch_dinv_times_B_ld(Dinv, B, bs, nb, dd, ld, W, s));
+  CBA_TRY(schur_gemm(B, W, Kpad, ld, Hdd, S, n_pad, ld, dd, 1, 0.0, s));
+  CBA_TRY(launch_gemv_t_strided(B, bdof, dd, ld, dinvb, bd, S + (ld - 1), ld, s));
+  CBA_TRY(ldlt_factor(S, n_fact, ld, w, s, nullptr));
+  CBA_TRY(ldlt_back_solve(S, n_fact, ld, ld - 1, w, xd + bdof, s));
+  CBA_TRY(launch_gemv_n(W, bdof, dd, ld, xd + bdof, dinvb, xd, s));
+  CBA_HIP(hipDeviceSynchronize());
+  int st[2];
+  CBA_HIP(hipMemcpy(&st[0], status, sizeof(int), hipMemcpyDeviceToHost));
+  CBA_HIP(hipMemcpy(&st[1], w.status, sizeof(int), hipMemcpyDeviceToHost));
+  CBA_HIP(hipMemcpy(x, xd, sizeof(double) * (bdof + dd), hipMemcpyDeviceToHost));
+  ldlt_workspace_free(w);
+  hipFree(Dblk); hipFree(bblk); hipFree(Dinv); hipFree(dinvb); hipFree(B); hipFree(W); hipFree(Hdd); hipFree(bd); hipFree(S); hipFree(xd); hipFree(status);
+  if (st[0] || st[1]) { set_error("cba_schur_solve: zero pivot"); return CBA_ERR_NUMERIC; }
+  return CBA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// Internal declarations shared by the HIP translation units of libcalib_ba_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/cba.h"
+#include "model.hip.h"
+
+namespace cba {
+
+void set_error(const std::string& msg);
+#define CBA_HIP(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      ::cba::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                     \
+      return CBA_ERR_HIP;                                                                      \
+    }                                                                                          \
+  } while (0)
+
+// Variable ordering of JointOptimizationState (joint_optimization.cc:49-59, 142-170).
+struct Layout {
+  int n_cameras, n_images, n_points;
+  int rig_in_state;
+  int first_rig_tr_global, first_camera_tr_rig, first_points, first_intrinsics;
+  int intr_offset[16];
+  int total_dof, block_size, n_blocks, block_dof, dense_dof;
+  int localize_only, eliminate_points;
+};
+
+constexpr int kMaxCameras = 16;
+constexpr int kMaxGridCols = 80;                       // 5 * 16
+constexpr int kMaxCols = 6 + 6 + 3 + kMaxGridCols;     // pose + rig + point + grid
+// Jacobian record per observation (doubles): [res 2][weight 1][pose 2x6][rig 2x6][point 2x3][grid 2xKg]
+constexpr int kRecHeader = 3 + 12 + 12 + 6;
+
+struct DevState {
+  double* rig_tr_global = nullptr;   // 7N
+  double* camera_tr_rig = nullptr;   // 7C
+  double* points = nullptr;          // 3P
+  double* grids[kMaxCameras] = {};   // per camera
+};
+
+// Device-visible description of a pass over the observations.
+struct PassArgs {
+  int64_t n_obs;
+  int n_cameras;
+  const float* obs_xy;
+  const int* obs_point;
+  const int* obs_image;
+  const int* obs_camera;
+  double* last_projection;
+  const double* points;
+  const double* itg;        // [(img*C + cam)*16]: q(4) t(3) R(9)
+  const CamDev* cams;       // device array [C]
+  double fd_delta;
+};
+
+// ---- kernels_obs.hip ----
+int launch_compose_poses(const DevState& st, int N, int C, double* itg, hipStream_t s);
+int launch_tangents(const double* dir_grid, double* tang, int G, hipStream_t s);
+int launch_base_project(const PassArgs& a, int model_mask, double* cost_vec, double* pixels, uint8_t* flags,
+                        hipStream_t s);
+int launch_fd_tasks(const PassArgs& a, int model_mask, int tasks_per_obs, int localize_only, const double* pixels,
+                    const uint8_t* flags, double* fd_out, uint8_t* fd_ok, hipStream_t s);
+int launch_assemble(const PassArgs& a, const Layout& L, const DevState& st, int tasks_per_obs, int rec_doubles,
+                    const double* pixels, uint8_t* flags, const double* fd_out, const uint8_t* fd_ok, double* jrec,
+                    int* cells, hipStream_t s);
+struct AccumTargets {
+  double* Dblk; double* bblk; double* B; double* Hdd; double* bd;
+};
+int launch_accumulate(const PassArgs& a, const Layout& L, int rec_doubles, const uint8_t* flags, const double* jrec,
+                      const int* cells, const uint32_t* pair_tables, const int* pair_counts, AccumTargets t,
+                      hipStream_t s);
+// 8 outputs: [0] sum ref (valid), [1] sum test (valid), [2] masked ref, [3] masked test, [4] count both valid,
+// [5] n valid ref, [6] n valid test, [7] n jac dropped (flags)
+int launch_reduce_costs(const double* ref, const double* test, const uint8_t* flags, int64_t n, double* partials,
+                        double* out8, hipStream_t s);
+int launch_apply_update(const Layout& L, const std::vector<cba_camera>& cams, const DevState& in, const double* x,
+                        DevState& out, hipStream_t s);
+int launch_project_points(const CamDev* cam_dev, int model, int64_t n, const double* local, const double* init,
+                          double* pixels, uint8_t* ok, hipStream_t s);
+int launch_unproject(const CamDev* cam_dev, int model, int64_t n, const double* pixels, double* lines, double* jac,
+                     uint8_t* ok, hipStream_t s);
+
+// ---- kernels_linalg.hip ----
+// Inverse of the (bs x bs) diagonal blocks with lambda added, and Dinv*b.
+int launch_block_inverse(const double* Dblk, const double* bblk, double lambda, int bs, int nb, double* Dinv,
+                         double* dinvb, int* status, hipStream_t s);
+// y[k] = base[k] - sum_j M[k][j] * v[j]   (row dot products) -- pose back-substitution
+int launch_gemv_n(const double* M, int K, int n, int ld, const double* v, const double* base, double* y,
+                  hipStream_t s);
+struct GemmStats { double seconds = 0, flops = 0, bytes = 0; int launches = 0; };
+// In-place blocked LDL^T of a symmetric matrix stored "upper in row-major" (= lower in column-major).
+struct LdltWorkspace {
+  double* X = nullptr;       // panel copy [kPanel][ld]
+  double* invLt = nullptr;   // [kInner][kInner]
+  double* dvec = nullptr;    // n
+  int* status = nullptr;
+  size_t n_alloc = 0;
+};
+int ldlt_workspace_alloc(LdltWorkspace& w, int n);
+void ldlt_workspace_free(LdltWorkspace& w);
+int ldlt_factor(double* S, int n, int ld, LdltWorkspace& w, hipStream_t s, GemmStats* trailing_stats);
+
+}  // namespace cba

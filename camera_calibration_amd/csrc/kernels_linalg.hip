@@ -1,0 +1,570 @@
+// Schur-complement stage of the bundle-adjustment engine (gfx950): block inverses, D^-1 B, the fp64
+// MFMA GEMM  S = H_dd + lambda I - B^T (D^-1 B), and a blocked LDL^T factorisation / solve of the
+// reduced system.  Restates what LMOptimizer::SolveWithSchurComplementDenseOffDiag computes
+// (libvis/src/libvis/lm_optimizer.h:1247-1369 in the reference tree); Eigen's dense LDLT call sites
+// (:1289, :1361) become hand-written kernels.
+//
+// Storage: every symmetric matrix keeps its upper triangle in row-major order (as the reference's
+// accumulator writes it, lm_optimizer_update_accumulator.h:212,256).  Reading the same memory as a
+// column-major matrix gives the lower triangle, so the factorisation below is a textbook
+// right-looking, lower, column-major LDL^T whose "columns" are contiguous memory rows -- every panel
+// operation streams contiguous rows and every product is the one GEMM shape
+//        C[m][n] (-)= sum_k A[k][m] * B[k][n]      (A, B: K x ld row-major, "K-major" operands)
+// which feeds v_mfma_f64_16x16x4_f64 directly from LDS rows.
+// Leading dimensions are padded to multiples of 128 and K to multiples of 16 so the hot loops carry
+// no bounds checks; padded diagonal entries are set to 1.
+#include "cba_internal.h"
+
+namespace cba {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// per-block inverse (bs <= 6) of D_i + lambda I by LDL^T with diagonal pivoting, and D^-1 b.
+// One lane per block; blocks hold only their upper triangle.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_block_inverse(const double* __restrict__ Dblk, const double* __restrict__ bblk, double lambda, int bs,
+                                int nb, double* __restrict__ Dinv, double* __restrict__ dinvb, int* __restrict__ status) {
+  int blk = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blk >= nb) return;
+  double A[6][6], Inv[6][6];
+  for (int r = 0; r < bs; ++r)
+    for (int c = 0; c < bs; ++c) {
+      int lo = r < c ? r : c, hi = r < c ? c : r;
+      A[r][c] = Dblk[(size_t)blk * bs * bs + lo * bs + hi] + (r == c ? lambda : 0.0);
+      Inv[r][c] = (r == c) ? 1.0 : 0.0;
+    }
+  // symmetric Gauss-Jordan with diagonal pivoting on the remaining diagonal (exact for any
+  // non-singular symmetric block, definite or not)
+  int perm[6];
+  bool used[6];
+  for (int i = 0; i < bs; ++i) used[i] = false;
+  bool bad = false;
+  for (int step = 0; step < bs; ++step) {
+    int p = -1; double best = -1.0;
+    for (int i = 0; i < bs; ++i)
+      if (!used[i] && fabs(A[i][i]) > best) { best = fabs(A[i][i]); p = i; }
+    perm[step] = p; used[p] = true;
+    double piv = A[p][p];
+    if (!(fabs(piv) > 0.0)) { bad = true; break; }
+    double ip = 1.0 / piv;
+    for (int c = 0; c < bs; ++c) { A[p][c] *= ip; Inv[p][c] *= ip; }
+    for (int r = 0; r < bs; ++r) {
+      if (r == p) continue;
+      double f = A[r][p];
+      if (f == 0.0) continue;
+      for (int c = 0; c < bs; ++c) { A[r][c] -= f * A[p][c]; Inv[r][c] -= f * Inv[p][c]; }
+    }
+  }
+  (void)perm;
+  if (bad) atomicExch(status, 1);
+  for (int r = 0; r < bs; ++r) {
+    double acc = 0.0;
+    for (int c = 0; c < bs; ++c) {
+      double v = bad ? NAN : 0.5 * (Inv[r][c] + Inv[c][r]);
+      Dinv[(size_t)blk * bs * bs + r * bs + c] = v;
+      acc += v * bblk[(size_t)blk * bs + c];
+    }
+    dinvb[(size_t)blk * bs + r] = acc;
+  }
+}
+int launch_block_inverse(const double* Dblk, const double* bblk, double lambda, int bs, int nb, double* Dinv,
+                         double* dinvb, int* status, hipStream_t s) {
+  if (nb == 0) return CBA_OK;
+  hipLaunchKernelGGL(k_block_inverse, dim3((nb + 63) / 64), dim3(64), 0, s, Dblk, bblk, lambda, bs, nb, Dinv, dinvb, status);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
+// W[blk*bs + r][col] = sum_k Dinv[blk][r][k] * B[blk*bs + k][col]   (lm_optimizer.h:1302-1310)
+__global__ void __launch_bounds__(256) k_dinv_times_B(const double* __restrict__ Dinv, const double* __restrict__ B, int bs,
+                                                      int dd, int ld, double* __restrict__ W) {
+  int blk = blockIdx.y;
+  int col = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ double sD[36];
+  if ((int)threadIdx.x < bs * bs) sD[threadIdx.x] = Dinv[(size_t)blk * bs * bs + threadIdx.x];
+  __syncthreads();
+  if (col >= dd) return;
+  double b[6];
+  for (int k = 0; k < bs; ++k) b[k] = B[((size_t)blk * bs + k) * ld + col];
+  for (int r = 0; r < bs; ++r) {
+    double acc = 0.0;
+    for (int k = 0; k < bs; ++k) acc += sD[r * bs + k] * b[k];
+    W[((size_t)blk * bs + r) * ld + col] = acc;
+  }
+}
+
+// y[j] = base[j] - sum_k M[k][j] v[k]
+__global__ void __launch_bounds__(256) k_gemv_t(const double* __restrict__ M, int K, int n, int ld, const double* __restrict__ v,
+                                                const double* __restrict__ base, double* __restrict__ y, int ystride) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double acc = 0.0;
+  for (int k = 0; k < K; ++k) acc += M[(size_t)k * ld + j] * v[k];
+  y[(size_t)j * ystride] = (base ? base[j] : 0.0) - acc;
+}
+// y[k] = base[k] - sum_j M[k][j] v[j]; one wavefront per row
+__global__ void __launch_bounds__(256) k_gemv_n(const double* __restrict__ M, int K, int n, int ld, const double* __restrict__ v,
+                                                const double* __restrict__ base, double* __restrict__ y) {
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= K) return;
+  double acc = 0.0;
+  const double* r = M + (size_t)row * ld;
+  for (int j = lane; j < n; j += 64) acc += r[j] * v[j];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) y[row] = (base ? base[row] : 0.0) - acc;
+}
+int launch_gemv_n(const double* M, int K, int n, int ld, const double* v, const double* base, double* y, hipStream_t s) {
+  if (K == 0) return CBA_OK;
+  hipLaunchKernelGGL(k_gemv_n, dim3((K + 3) / 4), dim3(256), 0, s, M, K, n, ld, v, base, y);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp64 MFMA GEMM:  C[m][n] = Cin[m][n] + diag(m==n) - sum_k A[k][m] B[k][n]     (SUB = true)
+//                  C[m][n] =                           sum_k A[k][m] B[k][n]     (SUB = false)
+// Block tile TM x TN, 4 wavefronts, KT = 16 rows of A and B per LDS stage (row stride padded by 16
+// doubles so the four k-rows of one MFMA operand fetch land in disjoint bank halves).
+// v_mfma_f64_16x16x4_f64 operand map: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15];
+// result D: column j = l&15, row i = (l>>4) + 4*reg.
+// Tile selection: `upper` launches only tiles whose column range reaches the diagonal (n_tile >= m_tile).
+// The linear block index is permuted so that the blocks of one XCD (blockIdx % 8) own consecutive
+// tiles of the same tile row and share its A panel in that XCD's L2.
+// ------------------------------------------------------------------------------------------------
+constexpr int KT = 16;
+
+struct GemmArgs {
+  const double* A; int lda;     // K x lda, column offset already applied for m_begin = 0 of this call
+  const double* B; int ldb;
+  int K;                        // multiple of KT
+  double* C; int ldc;
+  const double* Cin; int ldcin; // may alias C
+  int m_tiles, n_tiles;         // tile counts of this call
+  int m_off, n_off;             // element offsets of tile (0,0) inside C (and A/B column spaces)
+  int upper;                    // only tiles with (n_off + tn*TN + TN - 1) >= (m_off + tm*TM)
+  int n_real;                   // rows/cols < n_real get diag_add, others 1.0 (only if diag)
+  int diag;                     // add to diagonal entries
+  const double* diag_add_ptr;   // device scalar (lambda) or null
+  double diag_add;              // host scalar used when diag_add_ptr == null
+  double* C2;                   // optional second output  C2[m][n] = value * rowscale[m]  (L = X / d)
+  int ldc2;
+  const double* rowscale_inv;   // d values: C2 = value / d[m]
+  long long total_tiles;
+};
+
+template <int TM, int TN, int WM, int WN, bool SUB>
+__global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
+  constexpr int LDA_S = TM + 16, LDB_S = TN + 16;
+  __shared__ double sA[2][KT * LDA_S];
+  __shared__ double sB[2][KT * LDB_S];
+  constexpr int WAVES_N = TN / WN;
+  constexpr int MI = WM / 16, NJ = WN / 16;
+
+  // ---- tile decode (XCD-aware permutation of the linear block index) ----
+  long long b = blockIdx.x;
+  const long long per_xcd = (g.total_tiles + 7) / 8;
+  long long t = (b & 7) * per_xcd + (b >> 3);
+  if (t >= g.total_tiles) return;
+  int tm, tn;
+  if (g.upper) {
+    // enumerate tile rows; row tm owns tiles tn in [first(tm), n_tiles)
+    // first(tm) = smallest tn with n_off + tn*TN + TN - 1 >= m_off + tm*TM
+    long long rem = t;
+    tm = 0;
+    for (;; ++tm) {
+      long long mrow = (long long)g.m_off + (long long)tm * TM;
+      long long first = (mrow > g.n_off) ? (mrow - g.n_off) / TN : 0;  // first tile whose columns reach row mrow
+      long long cnt = g.n_tiles - first;
+      if (cnt < 0) cnt = 0;
+      if (rem < cnt) { tn = (int)(first + rem); break; }
+      rem -= cnt;
+    }
+  } else {
+    tm = (int)(t / g.n_tiles);
+    tn = (int)(t - (long long)tm * g.n_tiles);
+  }
+  const int m0 = g.m_off + tm * TM, n0 = g.n_off + tn * TN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm0 = (wv / WAVES_N) * WM, wn0 = (wv % WAVES_N) * WN;
+  const int li = lane & 15, lk = lane >> 4;
+
+  v4f64 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+
+  const double* Ag = g.A + m0;
+  const double* Bg = g.B + n0;
+  // stage loader: KT x TM (and KT x TN) doubles as 16-byte pieces
+  constexpr int A_PIECES = KT * TM / 2, B_PIECES = KT * TN / 2;
+  auto load_stage = [&](int buf, int k0) {
+#pragma unroll
+    for (int p = tid; p < A_PIECES; p += 256) {
+      int row = p / (TM / 2), c2 = p % (TM / 2);
+      const double2 v = *reinterpret_cast<const double2*>(Ag + (size_t)(k0 + row) * g.lda + 2 * c2);
+      *reinterpret_cast<double2*>(&sA[buf][row * LDA_S + 2 * c2]) = v;
+    }
+#pragma unroll
+    for (int p = tid; p < B_PIECES; p += 256) {
+      int row = p / (TN / 2), c2 = p % (TN / 2);
+      const double2 v = *reinterpret_cast<const double2*>(Bg + (size_t)(k0 + row) * g.ldb + 2 * c2);
+      *reinterpret_cast<double2*>(&sB[buf][row * LDB_S + 2 * c2]) = v;
+    }
+  };
+
+  const int nk = g.K / KT;
+  if (nk > 0) load_stage(0, 0);
+  __syncthreads();
+  for (int kb = 0; kb < nk; ++kb) {
+    const int buf = kb & 1;
+    if (kb + 1 < nk) load_stage(buf ^ 1, (kb + 1) * KT);
+    const double* a_s = &sA[buf][0];
+    const double* b_s = &sB[buf][0];
+#pragma unroll
+    for (int kk = 0; kk < KT; kk += 4) {
+      double af[MI], bf[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = a_s[(kk + lk) * LDA_S + wm0 + i * 16 + li];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bf[j] = b_s[(kk + lk) * LDB_S + wn0 + j * 16 + li];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  double dadd = 0.0;
+  if (g.diag) dadd = g.diag_add_ptr ? *g.diag_add_ptr : g.diag_add;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int m = m0 + wm0 + i * 16 + lk + 4 * r;
+        int n = n0 + wn0 + j * 16 + li;
+        double v = acc[i][j][r];
+        if (SUB) {
+          double cin = g.Cin[(size_t)m * g.ldcin + n];
+          if (g.diag && m == n) cin += (m < g.n_real) ? dadd : 1.0;
+          v = cin - v;
+        }
+        g.C[(size_t)m * g.ldc + n] = v;
+        if (g.C2) g.C2[(size_t)m * g.ldc2 + n] = v / g.rowscale_inv[m];
+      }
+}
+
+static long long count_upper_tiles(int m_off, int n_off, int m_tiles, int n_tiles, int TM, int TN) {
+  long long total = 0;
+  for (int tm = 0; tm < m_tiles; ++tm) {
+    long long mrow = (long long)m_off + (long long)tm * TM;
+    long long first = (mrow > n_off) ? (mrow - n_off) / TN : 0;
+    long long cnt = n_tiles - first;
+    if (cnt > 0) total += cnt;
+  }
+  return total;
+}
+
+template <int TM, int TN, int WM, int WN, bool SUB>
+static int launch_gemm(GemmArgs g, hipStream_t s) {
+  g.total_tiles = g.upper ? count_upper_tiles(g.m_off, g.n_off, g.m_tiles, g.n_tiles, TM, TN)
+                          : (long long)g.m_tiles * g.n_tiles;
+  if (g.total_tiles <= 0) return CBA_OK;
+  long long blocks = ((g.total_tiles + 7) / 8) * 8;
+  hipLaunchKernelGGL((k_gemm_atb<TM, TN, WM, WN, SUB>), dim3((unsigned)blocks), dim3(256), 0, s, g);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
+int launch_dinv_times_B_ld(const double* Dinv, const double* B, int bs, int nb, int dd, int ld, double* W, hipStream_t s) {
+  if (nb == 0 || dd == 0) return CBA_OK;
+  hipLaunchKernelGGL(k_dinv_times_B, dim3((dd + 255) / 256, nb), dim3(256), 0, s, Dinv, B, bs, dd, ld, W);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+int launch_gemv_t(const double* M, int K, int n, int ld, const double* v, const double* base, double* y, hipStream_t s) {
+  if (n == 0) return CBA_OK;
+  hipLaunchKernelGGL(k_gemv_t, dim3((n + 255) / 256), dim3(256), 0, s, M, K, n, ld, v, base, y, 1);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+int launch_gemv_t_strided(const double* M, int K, int n, int ld, const double* v, const double* base, double* y,
+                          int ystride, hipStream_t s) {
+  if (n == 0) return CBA_OK;
+  hipLaunchKernelGGL(k_gemv_t, dim3((n + 255) / 256), dim3(256), 0, s, M, K, n, ld, v, base, y, ystride);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
+// S = Hdd + lambda I - A^T B on the upper tiles (n_pad x n_pad, all leading dims = ld, multiples of 128)
+int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const double* Cin, double* C, int n_pad, int ld,
+               int n_real, int add_diag, double lambda, hipStream_t s) {
+  GemmArgs g{};
+  g.A = A; g.lda = ldab; g.B = B; g.ldb = ldab; g.K = Kpad;
+  g.C = C; g.ldc = ld; g.Cin = Cin; g.ldcin = ld;
+  g.m_tiles = n_pad / 128; g.n_tiles = n_pad / 128; g.m_off = 0; g.n_off = 0; g.upper = 1;
+  g.n_real = n_real; g.diag = add_diag; g.diag_add_ptr = nullptr; g.diag_add = lambda;
+  g.C2 = nullptr; g.ldc2 = 0; g.rowscale_inv = nullptr;
+  return launch_gemm<128, 128, 64, 64, true>(g, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// blocked LDL^T, lower/column-major view of "upper in row-major" storage.
+//   kInner = 64 : diagonal blocks factored (and their unit-lower factors inverted) by one workgroup
+//   kPanel = 256: trailing updates use K = 256
+// ------------------------------------------------------------------------------------------------
+constexpr int kInner = 64;
+constexpr int kPanel = 256;
+
+// Factor the 64x64 diagonal block at (j0,j0): T = L D L^T.  Writes L (unit lower; L(p,q) at M[j0+q][j0+p], p>q),
+// d into the diagonal and dvec, and invLt[q][p] = (L^-1)(p,q).
+__global__ void __launch_bounds__(256) k_ldlt_diag(double* __restrict__ M, int ld, int j0, double* __restrict__ dvec,
+                                                   double* __restrict__ invLt_all, int* __restrict__ status) {
+  __shared__ double T[kInner][kInner + 1];   // T[i][j], i >= j used (lower, col-major view: T[i][j] = M[j0+j][j0+i])
+  __shared__ double Linv[kInner][kInner + 1];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < kInner * kInner; e += 256) {
+    int q = e / kInner, p = e % kInner;   // memory row q, col p
+    double v = M[(size_t)(j0 + q) * ld + j0 + p];
+    if (p >= q) T[p][q] = v;              // lower(i=p, j=q)
+  }
+  __syncthreads();
+  for (int s = 0; s < kInner; ++s) {
+    double d = T[s][s];
+    if (tid == 0 && !(fabs(d) > 0.0)) atomicExch(status, 2);
+    __syncthreads();
+    // column s of L
+    for (int i = s + 1 + tid; i < kInner; i += 256) T[i][s] = T[i][s] / d;
+    __syncthreads();
+    // trailing update T[i][j] -= L(i,s) d L(j,s), i >= j > s
+    int rem = kInner - s - 1;
+    for (int e = tid; e < rem * rem; e += 256) {
+      int i = s + 1 + e / rem, j = s + 1 + e % rem;
+      if (i >= j) T[i][j] -= T[i][s] * d * T[j][s];
+    }
+    __syncthreads();
+  }
+  // inverse of the unit-lower L, one column per lane (forward substitution)
+  if (tid < kInner) {
+    int c = tid;
+    for (int i = 0; i < kInner; ++i) Linv[i][c] = (i == c) ? 1.0 : 0.0;
+    for (int i = c + 1; i < kInner; ++i) {
+      double acc = 0.0;
+      for (int k = c; k < i; ++k) acc += T[i][k] * Linv[k][c];
+      Linv[i][c] = -acc;
+    }
+  }
+  __syncthreads();
+  double* invLt = invLt_all + (size_t)(j0 / kInner) * kInner * kInner;
+  for (int e = tid; e < kInner * kInner; e += 256) {
+    int q = e / kInner, p = e % kInner;
+    // memory row q, col p: p > q holds L(p,q); p == q holds d
+    if (p >= q) M[(size_t)(j0 + q) * ld + j0 + p] = T[p][q];
+    invLt[q * kInner + p] = (p >= q) ? Linv[p][q] : 0.0;   // invLt[q][p] = invL(p,q)
+  }
+  if (tid < kInner) dvec[j0 + tid] = T[tid][tid];
+}
+
+struct LdltPlan {
+  int n_fact;  // rows factored (multiple of 64)
+  int n_pad;   // matrix dimension incl. padding (multiple of 128)
+};
+
+int ldlt_workspace_alloc(LdltWorkspace& w, int n_pad) {
+  ldlt_workspace_free(w);
+  CBA_HIP(hipMalloc(&w.X, sizeof(double) * (size_t)kPanel * n_pad));
+  CBA_HIP(hipMalloc(&w.invLt, sizeof(double) * (size_t)(n_pad / kInner) * kInner * kInner));
+  CBA_HIP(hipMalloc(&w.dvec, sizeof(double) * (size_t)n_pad));
+  CBA_HIP(hipMalloc(&w.status, sizeof(int)));
+  w.n_alloc = n_pad;
+  return CBA_OK;
+}
+void ldlt_workspace_free(LdltWorkspace& w) {
+  if (w.X) hipFree(w.X);
+  if (w.invLt) hipFree(w.invLt);
+  if (w.dvec) hipFree(w.dvec);
+  if (w.status) hipFree(w.status);
+  w = LdltWorkspace();
+}
+
+// Factor rows [0, n_fact) of the n_pad x n_pad matrix S (ld = n_pad). Columns up to n_pad take part
+// in the panel solves / updates, so a right-hand side stored in a trailing column is forward-
+// substituted and scaled on the fly (it ends up holding D^-1 L^-1 b).
+int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, GemmStats* st) {
+  const int n_pad = ld;
+  for (int k0 = 0; k0 < n_fact; k0 += kPanel) {
+    const int nb = (n_fact - k0 < kPanel) ? (n_fact - k0) : kPanel;
+    for (int j0 = k0; j0 < k0 + nb; j0 += kInner) {
+      hipLaunchKernelGGL(k_ldlt_diag, dim3(1), dim3(256), 0, s, S, ld, j0, w.dvec, w.invLt, w.status);
+      const int c0 = j0 + kInner;  // first column right of the diagonal block
+      if (c0 < n_pad) {
+        // X[p][i] = sum_q invLt[q][p] * S[j0+q][i],  i in [c0, n_pad);  L = X / d written in place
+        GemmArgs g{};
+        g.A = w.invLt + (size_t)(j0 / kInner) * kInner * kInner; g.lda = kInner;
+        g.B = S + (size_t)j0 * ld; g.ldb = ld; g.K = kInner;
+        g.C = w.X + (size_t)(j0 - k0) * n_pad; g.ldc = n_pad; g.Cin = nullptr; g.ldcin = 0;
+        g.m_tiles = 1; g.m_off = 0;
+        // column tiles of 128 starting at the tile that contains c0 (columns < c0 inside it are
+        // recomputed into X only; C2 must not touch them) -> start exactly at c0 when aligned,
+        // otherwise handle the unaligned head with a 64-wide call.
+        g.upper = 0; g.diag = 0;
+        g.rowscale_inv = w.dvec + j0;
+        g.C2 = S + (size_t)j0 * ld; g.ldc2 = ld;
+        int head = c0;
+        if (head % 128 != 0) {
+          // 64-column head [c0, c0+64)
+          GemmArgs h = g;
+          h.n_tiles = 1; h.n_off = head;
+          int rc = launch_gemm<64, 64, 32, 32, false>(h, s);
+          if (rc) return rc;
+          head += 64;
+        }
+        if (head < n_pad) {
+          g.n_tiles = (n_pad - head) / 128; g.n_off = head;
+          int rc = launch_gemm<64, 128, 32, 64, false>(g, s);
+          if (rc) return rc;
+        }
+        // intra-panel update: rows m in [c0, k0+nb), cols n >= m:  S[m][n] -= sum_p L[p][m] X[p][n]
+        if (c0 < k0 + nb) {
+          GemmArgs u{};
+          u.A = S + (size_t)j0 * ld; u.lda = ld;       // L values just written (rows j0..j0+63)
+          u.B = w.X + (size_t)(j0 - k0) * n_pad; u.ldb = n_pad; u.K = kInner;
+          u.C = S; u.ldc = ld; u.Cin = S; u.ldcin = ld;
+          u.m_off = c0; u.m_tiles = (k0 + nb - c0) / 64;
+          u.n_off = c0; u.n_tiles = (n_pad - c0) / 64;
+          u.upper = 1; u.diag = 0;
+          int rc = launch_gemm<64, 64, 32, 32, true>(u, s);
+          if (rc) return rc;
+        }
+      }
+    }
+    // trailing update with the whole panel
+    const int r0 = k0 + nb;
+    if (r0 < n_pad) {
+      GemmArgs u{};
+      u.A = S + (size_t)k0 * ld; u.lda = ld;
+      u.B = w.X; u.ldb = n_pad; u.K = nb;
+      u.C = S; u.ldc = ld; u.Cin = S; u.ldcin = ld;
+      u.upper = 1; u.diag = 0;
+      int rc;
+      if (r0 % 128 == 0) {
+        u.m_off = r0; u.m_tiles = (n_pad - r0) / 128; u.n_off = r0; u.n_tiles = (n_pad - r0) / 128;
+        rc = launch_gemm<128, 128, 64, 64, true>(u, s);
+      } else {
+        u.m_off = r0; u.m_tiles = (n_pad - r0) / 64; u.n_off = r0; u.n_tiles = (n_pad - r0) / 64;
+        rc = launch_gemm<64, 64, 32, 32, true>(u, s);
+      }
+      if (rc) return rc;
+      if (st) {
+        double rows = (double)(n_pad - r0);
+        st->flops += rows * rows * nb;  // 2 * (rows^2 / 2) * nb
+        st->launches += 1;
+      }
+    }
+  }
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
+// Backward substitution L^T x = z for the factored rows; z sits in column `zcol` of S.
+//   x_j = z_j - sum_{i > j} L(i,j) x_i = z_j - sum_{i > j} S[j][i] x[i]
+// Right-looking by panels of 256 rows: the panel's own triangle is solved by one workgroup (four
+// 64-blocks, using the stored inverses of the unit-lower diagonal factors), then every earlier row
+// subtracts its 256-column slice times the new x values (one wavefront per row, coalesced).
+__global__ void k_gather_col(const double* __restrict__ S, int ld, int col, int n, double* __restrict__ x) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) x[j] = S[(size_t)j * ld + col];
+}
+__global__ void __launch_bounds__(256) k_back_panel_diag(const double* __restrict__ S, int ld, int k0, int nb,
+                                                         const double* __restrict__ invLt_all, double* __restrict__ x) {
+  __shared__ double xs[kPanel];
+  __shared__ double t[kInner];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < nb; i += 256) xs[i] = x[k0 + i];
+  __syncthreads();
+  for (int sub = nb / kInner - 1; sub >= 0; --sub) {
+    const int j0 = sub * kInner;   // offset inside the panel
+    for (int p = wv; p < kInner; p += 4) {
+      const double* row = S + (size_t)(k0 + j0 + p) * ld + k0;
+      double acc = 0.0;
+      for (int i = j0 + kInner + lane; i < nb; i += 64) acc += row[i] * xs[i];
+      for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+      if (lane == 0) t[p] = xs[j0 + p] - acc;
+    }
+    __syncthreads();
+    const double* invLt = invLt_all + (size_t)((k0 + j0) / kInner) * kInner * kInner;
+    if (threadIdx.x < kInner) {   // x[q] = sum_{p >= q} invL(p,q) t[p]
+      int q = threadIdx.x;
+      double acc = 0.0;
+      for (int p = q; p < kInner; ++p) acc += invLt[q * kInner + p] * t[p];
+      xs[j0 + q] = acc;
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < nb; i += 256) x[k0 + i] = xs[i];
+}
+__global__ void __launch_bounds__(256) k_back_panel_update(const double* __restrict__ S, int ld, int k0, int nb,
+                                                           double* __restrict__ x) {
+  __shared__ double xs[kPanel];
+  for (int i = threadIdx.x; i < nb; i += 256) xs[i] = x[k0 + i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= k0) return;
+  const double* row = S + (size_t)q * ld + k0;
+  double acc = 0.0;
+  for (int i = lane; i < nb; i += 64) acc += row[i] * xs[i];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) x[q] -= acc;
+}
+int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWorkspace& w, double* x, hipStream_t s) {
+  hipLaunchKernelGGL(k_gather_col, dim3((n_fact + 255) / 256), dim3(256), 0, s, S, ld, zcol, n_fact, x);
+  int last = ((n_fact - 1) / kPanel) * kPanel;
+  for (int k0 = last; k0 >= 0; k0 -= kPanel) {
+    int nb = (n_fact - k0 < kPanel) ? (n_fact - k0) : kPanel;
+    hipLaunchKernelGGL(k_back_panel_diag, dim3(1), dim3(256), 0, s, S, ld, k0, nb, w.invLt, x);
+    if (k0 > 0) hipLaunchKernelGGL(k_back_panel_update, dim3((k0 + 3) / 4), dim3(256), 0, s, S, ld, k0, nb, x);
+  }
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
+// diag(S) += lambda for real rows, = 1 for padding rows (multi-GPU path: after the all-reduce)
+__global__ void k_finish_diag(double* __restrict__ S, int ld, int n_real, int n_pad, double lambda) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pad) return;
+  if (i < n_real) S[(size_t)i * ld + i] += lambda;
+  else S[(size_t)i * ld + i] = 1.0;
+}
+int launch_finish_diag(double* S, int ld, int n_real, int n_pad, double lambda, hipStream_t s) {
+  hipLaunchKernelGGL(k_finish_diag, dim3((n_pad + 255) / 256), dim3(256), 0, s, S, ld, n_real, n_pad, lambda);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+// out[0] = sum of all diagonal entries of the block-diagonal and dense parts (fixed-order reduction)
+__global__ void __launch_bounds__(256) k_diag_sum(const double* __restrict__ Dblk, int bs, int nb, const double* __restrict__ Hdd,
+                                                  int ld, int dd, double* __restrict__ out) {
+  __shared__ double sh[256];
+  double acc = 0.0;
+  const int nblk = bs * nb;
+  for (int i = threadIdx.x; i < nblk; i += 256) { int b = i / bs, k = i % bs; acc += Dblk[(size_t)b * bs * bs + k * bs + k]; }
+  for (int i = threadIdx.x; i < dd; i += 256) acc += Hdd[(size_t)i * ld + i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s]; __syncthreads(); }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+int launch_diag_sum(const double* Dblk, int bs, int nb, const double* Hdd, int ld, int dd, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_diag_sum, dim3(1), dim3(256), 0, s, Dblk, bs, nb, Hdd, ld, dd, out);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
+}  // namespace cba

@@ -1,0 +1,656 @@
+// Per-observation kernels of the bundle-adjustment engine (gfx950).
+//
+//  k_compose_poses   image_tr_global = camera_tr_rig[c] * rig_tr_global[i]   (joint_optimization.cc:277-280)
+//  k_tangents        ComputeTangentsImage                                      (joint_optimization.cc:229-238)
+//  k_base_project    AddReprojectionResidual, residual part                    (joint_optimization.cc:321-347)
+//  k_fd_tasks        the 3 + K finite-difference re-projections                (joint_optimization.cc:357-372,
+//                                                                               central_grid.h:187-245,
+//                                                                               noncentral_generic.h:224-283)
+//  k_assemble        analytic chain to pose / rig / point Jacobians            (joint_optimization.cc:379-438)
+//  k_accumulate      AddResidualWithJacobian -> block-sparse JtJ / Jtr         (lm_optimizer_jtj_accumulator_base.h:287-401,
+//                                                                               lm_optimizer_update_accumulator.h:181-322)
+//  k_reduce_costs    cost sums and CostIsSmallerThan                           (lm_optimizer.h:993-1011)
+//  k_update_*        JointOptimizationState::operator-=                        (joint_optimization.cc:172-214)
+//
+// Parallel decomposition (MI355X-first, not the reference's single loop): the packed observation
+// array is streamed coalesced; every finite-difference projection is its own lane (35 or 83 lanes
+// per observation, neighbouring lanes share the observation's 4x4 control patch through L1); the
+// outer product of one observation is spread over the 64 lanes of a wavefront and lands in HBM with
+// hardware fp64 atomics (global_atomic_add_f64).
+#include "cba_internal.h"
+
+namespace cba {
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void quat_mul(const double* a, const double* b, double* o) {
+  o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  o[2] = a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3];
+  o[3] = a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1];
+}
+// Eigen's quaternion * vector (v + w*uv + q x uv with uv = 2 q x v)
+__device__ __forceinline__ void quat_rotate(const double* q, const double* v, double* o) {
+  double ux = 2 * (q[2] * v[2] - q[3] * v[1]);
+  double uy = 2 * (q[3] * v[0] - q[1] * v[2]);
+  double uz = 2 * (q[1] * v[1] - q[2] * v[0]);
+  o[0] = v[0] + q[0] * ux + (q[2] * uz - q[3] * uy);
+  o[1] = v[1] + q[0] * uy + (q[3] * ux - q[1] * uz);
+  o[2] = v[2] + q[0] * uz + (q[1] * uy - q[2] * ux);
+}
+// rotation matrix of a unit quaternion (Eigen toRotationMatrix form)
+__device__ __forceinline__ void quat_to_matrix(const double* q, double* R) {
+  double tx = 2 * q[1], ty = 2 * q[2], tz = 2 * q[3];
+  double twx = tx * q[0], twy = ty * q[0], twz = tz * q[0];
+  double txx = tx * q[1], txy = ty * q[1], txz = tz * q[1];
+  double tyy = ty * q[2], tyz = tz * q[2], tzz = tz * q[3];
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+  R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+// un-normalised polynomial rotation R(q) differentiated by the analytic Jacobians
+// (joint_optimization_jacobians.h:40-118)
+__device__ __forceinline__ void poly_rotation(const double* q, double* R) {
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  R[0] = 1 - 2 * y * y - 2 * z * z; R[1] = 2 * x * y - 2 * w * z; R[2] = 2 * x * z + 2 * w * y;
+  R[3] = 2 * x * y + 2 * w * z; R[4] = 1 - 2 * x * x - 2 * z * z; R[5] = 2 * y * z - 2 * w * x;
+  R[6] = 2 * x * z - 2 * w * y; R[7] = 2 * y * z + 2 * w * x; R[8] = 1 - 2 * x * x - 2 * y * y;
+}
+// d(R(q) v)/dq folded with QuaternionJacobianWrtLocalUpdate (quaternion_parametrization.h:63-72):
+// M = d(R(q) v)/dq [3x4] * dq/dupdate [4x3]  -> 3x3
+__device__ __forceinline__ void rotated_point_wrt_update(const double* q, const double* v, double* M) {
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  double a = v[0], b = v[1], c = v[2];
+  double D[12];
+  D[0] = 2 * y * c - 2 * z * b;  D[1] = 2 * y * b + 2 * z * c;             D[2] = -4 * y * a + 2 * x * b + 2 * w * c;   D[3] = -4 * z * a - 2 * w * b + 2 * x * c;
+  D[4] = 2 * z * a - 2 * x * c;  D[5] = 2 * y * a - 4 * x * b - 2 * w * c; D[6] = 2 * x * a + 2 * z * c;                D[7] = 2 * w * a - 4 * z * b + 2 * y * c;
+  D[8] = -2 * y * a + 2 * x * b; D[9] = 2 * z * a + 2 * w * b - 4 * x * c; D[10] = -2 * w * a + 2 * z * b - 4 * y * c;  D[11] = 2 * x * a + 2 * y * b;
+  // Q rows (w,x,y,z): [-x -y -z; w z -y; -z w x; y -x w]
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const double* d = D + 4 * r;
+    M[3 * r + 0] = -d[0] * x + d[1] * w - d[2] * z + d[3] * y;
+    M[3 * r + 1] = -d[0] * y + d[1] * z + d[2] * w - d[3] * x;
+    M[3 * r + 2] = -d[0] * z - d[1] * y + d[2] * x + d[3] * w;
+  }
+}
+__device__ __forceinline__ double huber_cost_sq(double sq) { return sq < 1.0 ? 0.5 * sq : (sqrt(sq) - 0.5); }
+__device__ __forceinline__ double huber_weight_sq(double sq) { return sq < 1.0 ? 1.0 : 1.0 / sqrt(sq); }
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_compose_poses(const double* __restrict__ rig, const double* __restrict__ camrig, int N, int C,
+                                double* __restrict__ itg) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * C) return;
+  int i = t / C, c = t % C;
+  const double* a = camrig + 7 * c;   // camera_tr_rig[c]
+  const double* b = rig + 7 * (size_t)i;  // rig_tr_global[i]
+  // Sophus SE3 product (se3.hpp:203-207) + renormalisation (so3.hpp:215-232)
+  double q[4], tr[3];
+  quat_rotate(a, b + 4, tr);
+  quat_mul(a, b, q);
+  double sn = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (sn != 1.0) {
+    double s = 2.0 / (1.0 + sn);
+    q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s;
+  }
+  double* o = itg + 16 * (size_t)t;
+  o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; o[3] = q[3];
+  o[4] = a[4] + tr[0]; o[5] = a[5] + tr[1]; o[6] = a[6] + tr[2];
+  quat_to_matrix(q, o + 7);
+}
+int launch_compose_poses(const DevState& st, int N, int C, double* itg, hipStream_t s) {
+  int n = N * C;
+  hipLaunchKernelGGL(k_compose_poses, dim3((n + 255) / 256), dim3(256), 0, s, st.rig_tr_global, st.camera_tr_rig, N, C, itg);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
+__global__ void k_tangents(const double* __restrict__ grid, double* __restrict__ tang, int G) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  double d[3] = {grid[3 * g], grid[3 * g + 1], grid[3 * g + 2]};
+  double t1[3], t2[3];
+  tangents_of(d, t1, t2);
+  double* o = tang + 6 * (size_t)g;
+  o[0] = t1[0]; o[1] = t1[1]; o[2] = t1[2]; o[3] = t2[0]; o[4] = t2[1]; o[5] = t2[2];
+}
+int launch_tangents(const double* dir_grid, double* tang, int G, hipStream_t s) {
+  hipLaunchKernelGGL(k_tangents, dim3((G + 255) / 256), dim3(256), 0, s, dir_grid, tang, G);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// residual pass: one lane per observation
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void local_point_of(const PassArgs& a, int64_t o, int cam, double* local) {
+  const double* T = a.itg + 16 * ((size_t)a.obs_image[o] * a.n_cameras + cam);
+  const double* p = a.points + 3 * (size_t)a.obs_point[o];
+  double px = p[0], py = p[1], pz = p[2];
+  local[0] = T[7] * px + T[8] * py + T[9] * pz + T[4];
+  local[1] = T[10] * px + T[11] * py + T[12] * pz + T[5];
+  local[2] = T[13] * px + T[14] * py + T[15] * pz + T[6];
+}
+
+template <int MODEL>
+__global__ void __launch_bounds__(256) k_base_project(PassArgs a, double* __restrict__ cost_vec,
+                                                      double* __restrict__ pixels, uint8_t* __restrict__ flags) {
+  int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= a.n_obs) return;
+  int cam = a.obs_camera[o];
+  const CamDev c = a.cams[cam];
+  if (c.model_type != MODEL) return;
+  double local[3];
+  local_point_of(a, o, cam, local);
+  Subst none; none.index = -1;
+  double px = a.last_projection[2 * o], py = a.last_projection[2 * o + 1];
+  if (!in_calibrated_area(c, px, py) || px != px || py != py) center_pixel(c, px, py);
+  bool ok = project_point<MODEL>(c, none, local, px, py);
+  if (!ok) {
+    center_pixel(c, px, py);
+    ok = project_point<MODEL>(c, none, local, px, py);
+  }
+  if (!ok) {
+    cost_vec[o] = -1.0;   // AddInvalidResidual (lm_optimizer_update_accumulator.h:158-160)
+    flags[o] = 0;
+    return;
+  }
+  a.last_projection[2 * o] = px;
+  a.last_projection[2 * o + 1] = py;
+  pixels[2 * o] = px;
+  pixels[2 * o + 1] = py;
+  double rx = px - (double)a.obs_xy[2 * o], ry = py - (double)a.obs_xy[2 * o + 1];
+  cost_vec[o] = huber_cost_sq(rx * rx + ry * ry);
+  flags[o] = 1;
+}
+int launch_base_project(const PassArgs& a, int model_mask, double* cost_vec, double* pixels, uint8_t* flags,
+                        hipStream_t s) {
+  if (a.n_obs == 0) return CBA_OK;
+  dim3 grid((unsigned)((a.n_obs + 255) / 256)), block(256);
+  if (model_mask & 1) hipLaunchKernelGGL(k_base_project<kCentral>, grid, block, 0, s, a, cost_vec, pixels, flags);
+  if (model_mask & 2) hipLaunchKernelGGL(k_base_project<kNoncentral>, grid, block, 0, s, a, cost_vec, pixels, flags);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// finite-difference tasks: one lane per (observation, task)
+//   task 0..2      : local point component += kDelta                (joint_optimization.cc:357-372)
+//   task 3..3+K-1  : grid parameter (cell, d) += delta in its local parametrisation
+// ------------------------------------------------------------------------------------------------
+template <int MODEL>
+__global__ void __launch_bounds__(256) k_fd_tasks(PassArgs a, int tasks_per_obs, int localize_only,
+                                                  const double* __restrict__ pixels, const uint8_t* __restrict__ flags,
+                                                  double* __restrict__ fd_out, uint8_t* __restrict__ fd_ok) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t o = t / tasks_per_obs;
+  int k = (int)(t - o * tasks_per_obs);
+  if (o >= a.n_obs) return;
+  if (!(flags[o] & 1)) return;
+  int cam = a.obs_camera[o];
+  const CamDev c = a.cams[cam];
+  if (c.model_type != MODEL) return;
+  constexpr int PER = (MODEL == kCentral) ? 2 : 5;
+  const int n_tasks = 3 + (localize_only ? 0 : PER * 16);
+  if (k >= n_tasks) return;
+  double local[3];
+  local_point_of(a, o, cam, local);
+  const double bx = pixels[2 * o], by = pixels[2 * o + 1];
+  double px = bx, py = by;
+  double delta;
+  bool ok;
+  Subst sub; sub.index = -1;
+  if (k < 3) {
+    delta = a.fd_delta * (MODEL == kCentral ? sqrt(local[0] * local[0] + local[1] * local[1] + local[2] * local[2]) : 0.1);
+    local[k] += delta;
+    ok = project_point<MODEL>(c, sub, local, px, py);
+  } else {
+    delta = a.fd_delta;
+    int g = k - 3;
+    int cell = g / PER, d = g - cell * PER;
+    double gx, gy;
+    pixel_to_grid(c, bx, by, gx, gy);
+    int ix = (int)floor(gx), iy = (int)floor(gy);
+    int cx = ix + (cell & 3) - 1, cy = iy + (cell >> 2) - 1;
+    if (cx < 0 || cy < 0 || cx >= c.gw || cy >= c.gh) {  // CHECK() in the reference; cannot happen inside the rectangle
+      fd_ok[t] = 0;
+      return;
+    }
+    int seq = cx + cy * c.gw;
+    sub.index = seq;
+    const double* gd = c.grid + 3 * (size_t)seq;
+    const double* tg = c.tangents + 6 * (size_t)seq;
+    double o1 = (d == 0) ? delta : 0.0, o2 = (d == 1) ? delta : 0.0;
+    // ApplyLocalUpdateToDirection / ApplyLocalUpdateToLine (direction_parametrization.h:45-55,
+    // line_parametrization.h:107-120): always renormalises the direction
+    double nd[3] = {gd[0] + o1 * tg[0] + o2 * tg[3], gd[1] + o1 * tg[1] + o2 * tg[4], gd[2] + o1 * tg[2] + o2 * tg[5]};
+    normalize3(nd[0], nd[1], nd[2]);
+    sub.d[0] = nd[0]; sub.d[1] = nd[1]; sub.d[2] = nd[2];
+    if (MODEL == kNoncentral) {
+      const double* go = c.grid + 3 * (size_t)c.gw * c.gh + 3 * (size_t)seq;
+      double o3 = (d == 2) ? delta : 0.0, o4 = (d == 3) ? delta : 0.0, o5 = (d == 4) ? delta : 0.0;
+      sub.o[0] = go[0] + o3 * tg[0] + o4 * tg[3] + o5 * gd[0];
+      sub.o[1] = go[1] + o3 * tg[1] + o4 * tg[4] + o5 * gd[1];
+      sub.o[2] = go[2] + o3 * tg[2] + o4 * tg[5] + o5 * gd[2];
+    }
+    ok = project_point<MODEL>(c, sub, local, px, py);
+  }
+  fd_out[2 * t] = (px - bx) / delta;
+  fd_out[2 * t + 1] = (py - by) / delta;
+  fd_ok[t] = ok ? 1 : 0;
+}
+int launch_fd_tasks(const PassArgs& a, int model_mask, int tasks_per_obs, int localize_only, const double* pixels,
+                    const uint8_t* flags, double* fd_out, uint8_t* fd_ok, hipStream_t s) {
+  if (a.n_obs == 0) return CBA_OK;
+  int64_t total = a.n_obs * tasks_per_obs;
+  dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (model_mask & 1)
+    hipLaunchKernelGGL(k_fd_tasks<kCentral>, grid, block, 0, s, a, tasks_per_obs, localize_only, pixels, flags, fd_out, fd_ok);
+  if (model_mask & 2)
+    hipLaunchKernelGGL(k_fd_tasks<kNoncentral>, grid, block, 0, s, a, tasks_per_obs, localize_only, pixels, flags, fd_out, fd_ok);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// assemble the Jacobian record of one observation (one lane per observation)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_assemble(PassArgs a, int rig_in_state, int localize_only,
+                                                  const double* __restrict__ rig7, const double* __restrict__ camrig7,
+                                                  int tasks_per_obs, int rec_doubles, const double* __restrict__ pixels,
+                                                  uint8_t* __restrict__ flags, const double* __restrict__ fd_out,
+                                                  const uint8_t* __restrict__ fd_ok, double* __restrict__ jrec,
+                                                  int* __restrict__ cells) {
+  int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= a.n_obs) return;
+  uint8_t f = flags[o];
+  if (!(f & 1)) return;
+  int cam = a.obs_camera[o];
+  const CamDev c = a.cams[cam];
+  const int per = c.params_per_point;
+  const int Kg = localize_only ? 0 : per * 16;
+  const int n_tasks = 3 + Kg;
+  double* rec = jrec + (size_t)o * rec_doubles;
+  double px = pixels[2 * o], py = pixels[2 * o + 1];
+  double rx = px - (double)a.obs_xy[2 * o], ry = py - (double)a.obs_xy[2 * o + 1];
+  rec[0] = rx; rec[1] = ry;
+  rec[2] = huber_weight_sq(rx * rx + ry * ry);
+  const uint8_t* okp = fd_ok + (size_t)o * tasks_per_obs;
+  bool all_ok = true;
+  for (int k = 0; k < n_tasks; ++k) all_ok = all_ok && (okp[k] != 0);
+  if (!all_ok) {  // residual is kept, Jacobian dropped (joint_optimization.cc:373-376, 446-448)
+    flags[o] = 1;
+    return;
+  }
+  const double* fd = fd_out + 2 * (size_t)o * tasks_per_obs;
+  double pwl[6];  // d pixel / d local point, 2x3
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { pwl[k] = fd[2 * k]; pwl[3 + k] = fd[2 * k + 1]; }
+  const double* p = a.points + 3 * (size_t)a.obs_point[o];
+  const int img = a.obs_image[o];
+  double* Jpose = rec + 3;
+  double* Jrig = rec + 15;
+  double* Jpt = rec + 27;
+  if (rig_in_state) {
+    // local = R(qc) (R(qr) p + tr) + tc            (ComputeRigJacobian, joint_optimization_jacobians.h:121-343)
+    const double* qc = camrig7 + 7 * (size_t)cam;
+    const double* qr = rig7 + 7 * (size_t)img;
+    double Rc[9], Rr[9], Mr[9], Mc[9];
+    poly_rotation(qc, Rc);
+    poly_rotation(qr, Rr);
+    rotated_point_wrt_update(qr, p, Mr);
+    double v[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) v[r] = Rr[3 * r] * p[0] + Rr[3 * r + 1] * p[1] + Rr[3 * r + 2] * p[2] + qr[4 + r];
+    rotated_point_wrt_update(qc, v, Mc);
+    double A[6];  // pwl * Rc  (2x3)
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) A[3 * r + k] = pwl[3 * r] * Rc[k] + pwl[3 * r + 1] * Rc[3 + k] + pwl[3 * r + 2] * Rc[6 + k];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        Jpose[6 * r + k] = A[3 * r] * Mr[k] + A[3 * r + 1] * Mr[3 + k] + A[3 * r + 2] * Mr[6 + k];
+        Jpose[6 * r + 3 + k] = A[3 * r + k];
+        Jrig[6 * r + k] = pwl[3 * r] * Mc[k] + pwl[3 * r + 1] * Mc[3 + k] + pwl[3 * r + 2] * Mc[6 + k];
+        Jrig[6 * r + 3 + k] = pwl[3 * r + k];
+        Jpt[3 * r + k] = A[3 * r] * Rr[k] + A[3 * r + 1] * Rr[3 + k] + A[3 * r + 2] * Rr[6 + k];
+      }
+  } else {
+    // single camera: Jacobian wrt. a left update of image_q_global (joint_optimization.cc:392-397, 431-437)
+    const double* q = a.itg + 16 * ((size_t)img * a.n_cameras + cam);
+    double M[9], R[9];
+    rotated_point_wrt_update(q, p, M);
+    poly_rotation(q, R);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        Jpose[6 * r + k] = pwl[3 * r] * M[k] + pwl[3 * r + 1] * M[3 + k] + pwl[3 * r + 2] * M[6 + k];
+        Jpose[6 * r + 3 + k] = pwl[3 * r + k];
+        Jrig[6 * r + k] = 0.0; Jrig[6 * r + 3 + k] = 0.0;
+        Jpt[3 * r + k] = pwl[3 * r] * R[k] + pwl[3 * r + 1] * R[3 + k] + pwl[3 * r + 2] * R[6 + k];
+      }
+  }
+  double* Jg = rec + kRecHeader;
+  for (int k = 0; k < Kg; ++k) {
+    Jg[k] = fd[2 * (3 + k)];
+    Jg[Kg + k] = fd[2 * (3 + k) + 1];
+  }
+  double gx, gy;
+  pixel_to_grid(c, px, py, gx, gy);
+  cells[2 * o] = (int)floor(gx) - 1;
+  cells[2 * o + 1] = (int)floor(gy) - 1;
+  flags[o] = 3;
+}
+int launch_assemble(const PassArgs& a, const Layout& L, const DevState& st, int tasks_per_obs, int rec_doubles,
+                    const double* pixels, uint8_t* flags, const double* fd_out, const uint8_t* fd_ok, double* jrec,
+                    int* cells, hipStream_t s) {
+  if (a.n_obs == 0) return CBA_OK;
+  hipLaunchKernelGGL(k_assemble, dim3((unsigned)((a.n_obs + 255) / 256)), dim3(256), 0, s, a, L.rig_in_state,
+                     L.localize_only, st.rig_tr_global, st.camera_tr_rig, tasks_per_obs, rec_doubles, pixels, flags,
+                     fd_out, fd_ok, jrec, cells);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// JtJ / Jtr accumulation: one wavefront per observation.  The K columns of the observation's
+// Jacobian (ascending global variable index) are staged in LDS; the K(K+1)/2 upper-triangle
+// products are dealt to the 64 lanes through a (row,col) pair table and added with hardware fp64
+// atomics to the block-diagonal / off-diagonal / dense parts (GetPartOfHAndB,
+// lm_optimizer_update_accumulator.h:478-505).  Only upper triangles are written.
+// ------------------------------------------------------------------------------------------------
+struct AccumLayout {
+  int rig_in_state, eliminate_points, localize_only;
+  int first_rig_tr_global, first_camera_tr_rig, first_points;
+  int block_dof, block_size, dense_dof;
+};
+
+__global__ void __launch_bounds__(256) k_accumulate(PassArgs a, AccumLayout L, int rec_doubles,
+                                                    const uint8_t* __restrict__ flags, const double* __restrict__ jrec,
+                                                    const int* __restrict__ cells, const uint32_t* __restrict__ pair_tables,
+                                                    const int* __restrict__ pair_counts, AccumTargets T) {
+  __shared__ double sJ0[4][kMaxCols];
+  __shared__ double sJ1[4][kMaxCols];
+  __shared__ double sW0[4][kMaxCols];
+  __shared__ double sW1[4][kMaxCols];
+  __shared__ int sIdx[4][kMaxCols];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int64_t o = (int64_t)blockIdx.x * 4 + wv;
+  if (o >= a.n_obs) return;
+  if (flags[o] != 3) return;  // wave-uniform
+  const int cam = a.obs_camera[o];
+  const CamDev c = a.cams[cam];
+  const int per = c.params_per_point;
+  const int Kg = L.localize_only ? 0 : per * 16;
+  const int nrig = L.rig_in_state ? 6 : 0;
+  const int K = 6 + nrig + 3 + Kg;
+  const double* rec = jrec + (size_t)o * rec_doubles;
+  const double w = rec[2];
+  const int pose_idx = L.first_rig_tr_global + 6 * a.obs_image[o];
+  const int rig_idx = L.first_camera_tr_rig + 6 * cam;
+  const int point_idx = L.first_points + 3 * a.obs_point[o];
+  const int cx0 = cells[2 * o], cy0 = cells[2 * o + 1];
+  for (int k = lane; k < K; k += 64) {
+    int idx; double j0, j1;
+    int kk = k;
+    // ascending index order: [point] pose [rig] [point] grid  (joint_optimization.cc:490-590)
+    if (L.eliminate_points) {
+      if (kk < 3) { idx = point_idx + kk; j0 = rec[27 + kk]; j1 = rec[30 + kk]; goto done; }
+      kk -= 3;
+    }
+    if (kk < 6) { idx = pose_idx + kk; j0 = rec[3 + kk]; j1 = rec[9 + kk]; goto done; }
+    kk -= 6;
+    if (nrig) {
+      if (kk < 6) { idx = rig_idx + kk; j0 = rec[15 + kk]; j1 = rec[21 + kk]; goto done; }
+      kk -= 6;
+    }
+    if (!L.eliminate_points) {
+      if (kk < 3) { idx = point_idx + kk; j0 = rec[27 + kk]; j1 = rec[30 + kk]; goto done; }
+      kk -= 3;
+    }
+    {
+      int cell = kk / per, d = kk - cell * per;
+      int seq = (cx0 + (cell & 3)) + (cy0 + (cell >> 2)) * c.gw;
+      idx = L.block_dof + c.intr_offset + per * seq + d;
+      j0 = rec[kRecHeader + kk]; j1 = rec[kRecHeader + Kg + kk];
+    }
+  done:
+    sIdx[wv][k] = idx;
+    sJ0[wv][k] = j0; sJ1[wv][k] = j1;
+    sW0[wv][k] = w * j0; sW1[wv][k] = w * j1;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  const double r0 = rec[0], r1 = rec[1];
+  // b += Jw^T r
+  for (int k = lane; k < K; k += 64) {
+    int row = sIdx[wv][k];
+    double v = r0 * sW0[wv][k] + r1 * sW1[wv][k];
+    if (row < L.block_dof) unsafeAtomicAdd(T.bblk + row, v);
+    else unsafeAtomicAdd(T.bd + (row - L.block_dof), v);
+  }
+  // table selection: tables are indexed by K class (set up on the host): slot = per==2 ? 0 : 1
+  const int slot = (per == 2) ? 0 : 1;
+  const int npairs = pair_counts[slot];
+  const uint32_t* table = pair_tables + (size_t)slot * (kMaxCols * (kMaxCols + 1) / 2);
+  for (int e = lane; e < npairs; e += 64) {
+    uint32_t pr = table[e];
+    int i = pr >> 16, k = pr & 0xffff;
+    double v = sW0[wv][i] * sJ0[wv][k] + sW1[wv][i] * sJ1[wv][k];
+    int row = sIdx[wv][i], col = sIdx[wv][k];
+    if (row < L.block_dof) {
+      if (col < L.block_dof) {
+        int blk = row / L.block_size;
+        int base = blk * L.block_size;
+        unsafeAtomicAdd(T.Dblk + (size_t)blk * L.block_size * L.block_size + (row - base) * L.block_size + (col - base), v);
+      } else {
+        unsafeAtomicAdd(T.B + (size_t)row * L.dense_dof + (col - L.block_dof), v);
+      }
+    } else {
+      unsafeAtomicAdd(T.Hdd + (size_t)(row - L.block_dof) * L.dense_dof + (col - L.block_dof), v);
+    }
+  }
+}
+int launch_accumulate(const PassArgs& a, const Layout& L, int rec_doubles, const uint8_t* flags, const double* jrec,
+                      const int* cells, const uint32_t* pair_tables, const int* pair_counts, AccumTargets t,
+                      hipStream_t s) {
+  if (a.n_obs == 0) return CBA_OK;
+  AccumLayout al;
+  al.rig_in_state = L.rig_in_state; al.eliminate_points = L.eliminate_points; al.localize_only = L.localize_only;
+  al.first_rig_tr_global = L.first_rig_tr_global; al.first_camera_tr_rig = L.first_camera_tr_rig;
+  al.first_points = L.first_points; al.block_dof = L.block_dof; al.block_size = L.block_size; al.dense_dof = L.dense_dof;
+  hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((a.n_obs + 3) / 4)), dim3(256), 0, s, a, al, rec_doubles, flags, jrec,
+                     cells, pair_tables, pair_counts, t);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// deterministic cost reductions (fixed assignment of observations to lanes, fixed trees)
+// ------------------------------------------------------------------------------------------------
+constexpr int kRedBlocks = 256;
+__global__ void __launch_bounds__(256) k_reduce_costs_partial(const double* __restrict__ ref, const double* __restrict__ test,
+                                                              const uint8_t* __restrict__ flags, int64_t n,
+                                                              double* __restrict__ partials) {
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)kRedBlocks * 256) {
+    double r = ref ? ref[i] : -1.0, t = test ? test[i] : -1.0;
+    if (r >= 0) { acc[0] += r; acc[5] += 1; }
+    if (t >= 0) { acc[1] += t; acc[6] += 1; }
+    if (r >= 0 && t >= 0) { acc[2] += r; acc[3] += t; acc[4] += 1; }
+    if (flags && flags[i] == 1) acc[7] += 1;
+  }
+  __shared__ double sh[8][256];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sh[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x < 8) partials[blockIdx.x * 8 + threadIdx.x] = sh[threadIdx.x][0];
+}
+__global__ void k_reduce_costs_final(const double* __restrict__ partials, double* __restrict__ out8) {
+  int k = threadIdx.x;
+  if (k >= 8) return;
+  double s = 0;
+  for (int b = 0; b < kRedBlocks; ++b) s += partials[b * 8 + k];
+  out8[k] = s;
+}
+int launch_reduce_costs(const double* ref, const double* test, const uint8_t* flags, int64_t n, double* partials,
+                        double* out8, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_costs_partial, dim3(kRedBlocks), dim3(256), 0, s, ref, test, flags, n, partials);
+  hipLaunchKernelGGL(k_reduce_costs_final, dim3(1), dim3(64), 0, s, partials, out8);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// state update: state_out = state_in - x
+// ------------------------------------------------------------------------------------------------
+// ApplyLocalUpdateToQuaternion incl. the fp32-typed norm / sinc (quaternion_parametrization.h:39-61),
+// then SE3d(q, t) normalises (so3.hpp:536-541).
+__device__ __forceinline__ void pose_minus(const double* in, const double* d, double* out) {
+  double u[3] = {-d[0], -d[1], -d[2]};
+  const float n = (float)sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+  double q[4];
+  if (n == 0.0f) {
+    q[0] = in[0]; q[1] = in[1]; q[2] = in[2]; q[3] = in[3];
+  } else {
+    // fp32 sin/cos evaluated via fp64 and rounded once (faithfully rounded fp32 result)
+    const float sn = (float)sin((double)n), cs = (float)cos((double)n);
+    const float sbu = sn / n;
+    double uq[4] = {(double)cs, (double)sbu * u[0], (double)sbu * u[1], (double)sbu * u[2]};
+    quat_mul(uq, in, q);
+  }
+  double len = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  out[0] = q[0] / len; out[1] = q[1] / len; out[2] = q[2] / len; out[3] = q[3] / len;
+  out[4] = in[4] - d[3]; out[5] = in[5] - d[4]; out[6] = in[6] - d[5];
+}
+__global__ void k_update_poses(const double* __restrict__ in, const double* __restrict__ x, int n, double* __restrict__ out,
+                               int apply) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (apply) {
+    pose_minus(in + 7 * (size_t)i, x + 6 * (size_t)i, out + 7 * (size_t)i);
+  } else {
+    for (int k = 0; k < 7; ++k) out[7 * (size_t)i + k] = in[7 * (size_t)i + k];
+  }
+}
+__global__ void k_update_points(const double* __restrict__ in, const double* __restrict__ x, int n, double* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = in[i] - x[i];
+}
+// SubtractDelta: central_grid.h:168-184 / noncentral_generic.h:195-219 (tangents recomputed from the
+// current direction, full renormalisation)
+__global__ void k_update_grid(const double* __restrict__ in, const double* __restrict__ x, int G, int per, int apply,
+                              double* __restrict__ out) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  double d[3] = {in[3 * g], in[3 * g + 1], in[3 * g + 2]};
+  if (!apply) {
+    out[3 * g] = d[0]; out[3 * g + 1] = d[1]; out[3 * g + 2] = d[2];
+    if (per == 5) for (int k = 0; k < 3; ++k) out[3 * (size_t)G + 3 * g + k] = in[3 * (size_t)G + 3 * g + k];
+    return;
+  }
+  double t1[3], t2[3];
+  tangents_of(d, t1, t2);
+  const double* dx = x + (size_t)per * g;
+  double o1 = -dx[0], o2 = -dx[1];
+  double nd[3] = {d[0] + o1 * t1[0] + o2 * t2[0], d[1] + o1 * t1[1] + o2 * t2[1], d[2] + o1 * t1[2] + o2 * t2[2]};
+  normalize3(nd[0], nd[1], nd[2]);
+  out[3 * g] = nd[0]; out[3 * g + 1] = nd[1]; out[3 * g + 2] = nd[2];
+  if (per == 5) {
+    double o3 = -dx[2], o4 = -dx[3], o5 = -dx[4];
+    const double* oi = in + 3 * (size_t)G + 3 * g;
+    double* oo = out + 3 * (size_t)G + 3 * g;
+    for (int k = 0; k < 3; ++k) oo[k] = oi[k] + o3 * t1[k] + o4 * t2[k] + o5 * d[k];
+  }
+}
+int launch_apply_update(const Layout& L, const std::vector<cba_camera>& cams, const DevState& in, const double* x,
+                        DevState& out, hipStream_t s) {
+  int N = L.n_images, C = L.n_cameras, P = L.n_points;
+  if (N > 0)
+    hipLaunchKernelGGL(k_update_poses, dim3((N + 255) / 256), dim3(256), 0, s, in.rig_tr_global,
+                       x + L.first_rig_tr_global, N, out.rig_tr_global, 1);
+  hipLaunchKernelGGL(k_update_poses, dim3((C + 255) / 256), dim3(256), 0, s, in.camera_tr_rig,
+                     x + (L.rig_in_state ? L.first_camera_tr_rig : 0), C, out.camera_tr_rig, L.rig_in_state);
+  hipLaunchKernelGGL(k_update_points, dim3((3 * P + 255) / 256), dim3(256), 0, s, in.points, x + L.first_points, 3 * P,
+                     out.points);
+  for (int c = 0; c < C; ++c) {
+    int G = cams[c].grid_w * cams[c].grid_h;
+    int per = cams[c].model_type == CBA_CENTRAL_GENERIC ? 2 : 5;
+    hipLaunchKernelGGL(k_update_grid, dim3((G + 255) / 256), dim3(256), 0, s, in.grids[c],
+                       x + (L.localize_only ? 0 : L.block_dof + L.intr_offset[c]), G, per, L.localize_only ? 0 : 1,
+                       out.grids[c]);
+  }
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stateless model-level kernels (cba_project / cba_unproject)
+// ------------------------------------------------------------------------------------------------
+template <int MODEL>
+__global__ void __launch_bounds__(256) k_project_points(const CamDev* __restrict__ camp, int64_t n,
+                                                        const double* __restrict__ local, const double* __restrict__ init,
+                                                        double* __restrict__ pixels, uint8_t* __restrict__ ok) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const CamDev c = *camp;
+  Subst none; none.index = -1;
+  double px, py;
+  if (init) { px = init[2 * i]; py = init[2 * i + 1]; }
+  else center_pixel(c, px, py);
+  double lp[3] = {local[3 * i], local[3 * i + 1], local[3 * i + 2]};
+  bool r = in_calibrated_area(c, px, py) && project_point<MODEL>(c, none, lp, px, py);
+  pixels[2 * i] = px; pixels[2 * i + 1] = py;
+  ok[i] = r ? 1 : 0;
+}
+int launch_project_points(const CamDev* cam_dev, int model, int64_t n, const double* local, const double* init,
+                          double* pixels, uint8_t* ok, hipStream_t s) {
+  if (n == 0) return CBA_OK;
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (model == kCentral) hipLaunchKernelGGL(k_project_points<kCentral>, grid, block, 0, s, cam_dev, n, local, init, pixels, ok);
+  else hipLaunchKernelGGL(k_project_points<kNoncentral>, grid, block, 0, s, cam_dev, n, local, init, pixels, ok);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
+template <int MODEL>
+__global__ void __launch_bounds__(256) k_unproject(const CamDev* __restrict__ camp, int64_t n, const double* __restrict__ pixels,
+                                                   double* __restrict__ lines, double* __restrict__ jac,
+                                                   uint8_t* __restrict__ ok) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const CamDev c = *camp;
+  Subst none; none.index = -1;
+  double d[3] = {0, 0, 0}, o[3] = {0, 0, 0}, jd[6] = {0, 0, 0, 0, 0, 0}, jo[6] = {0, 0, 0, 0, 0, 0};
+  bool r;
+  if (jac) r = unproject_jac<MODEL>(c, none, pixels[2 * i], pixels[2 * i + 1], d, o, jd, jo);
+  else r = unproject<MODEL>(c, none, pixels[2 * i], pixels[2 * i + 1], d, o);
+  for (int k = 0; k < 3; ++k) { lines[6 * i + k] = d[k]; lines[6 * i + 3 + k] = (MODEL == kNoncentral) ? o[k] : 0.0; }
+  if (jac)
+    for (int k = 0; k < 6; ++k) { jac[12 * i + k] = jd[k]; jac[12 * i + 6 + k] = (MODEL == kNoncentral) ? jo[k] : 0.0; }
+  ok[i] = r ? 1 : 0;
+}
+int launch_unproject(const CamDev* cam_dev, int model, int64_t n, const double* pixels, double* lines, double* jac,
+                     uint8_t* ok, hipStream_t s) {
+  if (n == 0) return CBA_OK;
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (model == kCentral) hipLaunchKernelGGL(k_unproject<kCentral>, grid, block, 0, s, cam_dev, n, pixels, lines, jac, ok);
+  else hipLaunchKernelGGL(k_unproject<kNoncentral>, grid, block, 0, s, cam_dev, n, pixels, lines, jac, ok);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
+}  // namespace cba

@@ -1,0 +1,341 @@
+"""ctypes binding of libcalib_ba_hip.so (include/cba.h) and the Python host mirror of the reference's
+``OptimizeJointly`` entry point.
+
+The library is hand-written HIP for gfx950; there is no CPU fallback -- importing works anywhere, but
+every compute call raises :class:`EngineError` when the shared object or a GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from .problem import CENTRAL_GENERIC, Camera, Problem, State
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcalib_ba_hip.so")
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class CbaCamera(C.Structure):
+    _fields_ = [("model_type", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("calib_min_x", C.c_int32), ("calib_min_y", C.c_int32),
+                ("calib_max_x", C.c_int32), ("calib_max_y", C.c_int32),
+                ("grid_w", C.c_int32), ("grid_h", C.c_int32)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class CbaConfig(C.Structure):
+    _fields_ = [("n_cameras", C.c_int32), ("cameras", C.POINTER(CbaCamera)),
+                ("n_images", C.c_int32), ("n_points", C.c_int32),
+                ("numerical_diff_delta", C.c_double),
+                ("localize_only", C.c_int32), ("eliminate_points", C.c_int32), ("device", C.c_int32),
+                ("allreduce", ALLREDUCE_FN), ("allreduce_user", C.c_void_p),
+                ("n_images_global", C.c_int32),
+                ("reduce_buffer", C.c_void_p), ("reduce_buffer_doubles", C.c_int64)]
+
+
+class CbaReport(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("lambda_", C.c_double),
+                ("accepted", C.c_int32), ("lm_attempts", C.c_int32),
+                ("n_residuals_valid", C.c_int64), ("n_jacobians_dropped", C.c_int64),
+                ("t_jac", C.c_double), ("t_solve", C.c_double), ("t_cost", C.c_double),
+                ("t_accumulate", C.c_double), ("t_gemm", C.c_double), ("t_factor", C.c_double)]
+
+
+# every symbol include/cba.h declares (tests check that the library exports all of them)
+EXPORTED_SYMBOLS = [
+    "cba_last_error", "cba_version", "cba_create", "cba_destroy", "cba_set_observations", "cba_set_state",
+    "cba_get_state", "cba_get_last_projection", "cba_step", "cba_cost", "cba_project", "cba_unproject",
+    "cba_schur_solve", "cba_debug_dump", "cba_debug_accumulate", "cba_debug_solve", "cba_debug_apply_update",
+    "cba_total_dof", "cba_dense_dof", "cba_jacobian_record_doubles", "cba_reduce_buffer_doubles",
+    "cba_kernel_stats",
+]
+
+DUMP_COST_VECTOR, DUMP_PIXELS, DUMP_FLAGS, DUMP_JACOBIANS = 1, 2, 3, 4
+DUMP_BLOCK_DIAG_H, DUMP_BLOCK_DIAG_B, DUMP_OFF_DIAG_H, DUMP_DENSE_H, DUMP_DENSE_B, DUMP_X = 5, 6, 7, 8, 9, 10
+DUMP_TEST_COST_VECTOR = 11
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Loads libcalib_ba_hip.so; fails loudly if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(f"{LIB_PATH} is missing -- run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                          "the engine has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    dp = C.POINTER(C.c_double)
+    vp = C.c_void_p
+    L.cba_last_error.restype = C.c_char_p
+    L.cba_version.restype = C.c_char_p
+    L.cba_create.argtypes = [C.POINTER(CbaConfig), C.POINTER(vp)]
+    L.cba_destroy.argtypes = [vp]
+    L.cba_destroy.restype = None
+    L.cba_set_observations.argtypes = [vp, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_int32),
+                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp]
+    L.cba_set_state.argtypes = [vp, dp, dp, dp, C.POINTER(dp)]
+    L.cba_get_state.argtypes = [vp, dp, dp, dp, C.POINTER(dp)]
+    L.cba_get_last_projection.argtypes = [vp, dp]
+    L.cba_step.argtypes = [vp, C.c_double, C.c_int32, C.c_double, C.POINTER(CbaReport)]
+    L.cba_cost.argtypes = [vp, dp, C.POINTER(C.c_int64), dp]
+    L.cba_project.argtypes = [C.POINTER(CbaCamera), dp, C.c_int64, dp, dp, dp, C.POINTER(C.c_uint8), C.c_int32]
+    L.cba_unproject.argtypes = [C.POINTER(CbaCamera), dp, C.c_int64, dp, dp, dp, C.POINTER(C.c_uint8), C.c_int32]
+    L.cba_schur_solve.argtypes = [C.c_int32, C.c_int32, C.c_int32, dp, dp, dp, dp, dp, dp, C.c_int32]
+    L.cba_debug_dump.argtypes = [vp, C.c_int32, vp, C.c_size_t]
+    L.cba_debug_accumulate.argtypes = [vp, dp]
+    L.cba_debug_solve.argtypes = [vp, C.c_double]
+    L.cba_debug_apply_update.argtypes = [vp, dp]
+    L.cba_total_dof.argtypes = [vp]
+    L.cba_dense_dof.argtypes = [vp]
+    L.cba_jacobian_record_doubles.argtypes = [vp]
+    L.cba_reduce_buffer_doubles.argtypes = [C.POINTER(CbaConfig)]
+    L.cba_reduce_buffer_doubles.restype = C.c_int64
+    L.cba_kernel_stats.argtypes = [vp, C.c_int32, dp, dp, dp, C.POINTER(C.c_int32)]
+    _lib = L
+    return L
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().cba_last_error()
+        raise EngineError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+def _dp(a: np.ndarray):
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _cam_struct(cam: Camera) -> CbaCamera:
+    return CbaCamera(cam.model_type, cam.width, cam.height, cam.calib_min_x, cam.calib_min_y,
+                     cam.calib_max_x, cam.calib_max_y, cam.grid_w, cam.grid_h)
+
+
+@dataclass
+class StepReport:
+    """OptimizationReport (libvis lm_optimizer.h:55-77) + the values OptimizeJointly returns by pointer."""
+    initial_cost: float
+    final_cost: float
+    final_lambda: float
+    accepted: bool
+    lm_attempts: int
+    n_residuals_valid: int
+    n_jacobians_dropped: int
+    t_jac: float
+    t_solve: float
+    t_cost: float
+    t_accumulate: float
+    t_gemm: float
+    t_factor: float
+
+
+class Engine:
+    """Device-resident BA problem (cba_problem)."""
+
+    def __init__(self, problem: Problem, device: int = 0, allreduce: Optional[Callable[[int, int], int]] = None,
+                 n_images_global: int = 0, reduce_buffer_ptr: int = 0, reduce_buffer_doubles: int = 0):
+        self.L = load()
+        self.problem = problem
+        self._cams = (CbaCamera * problem.n_cameras)(*[_cam_struct(c) for c in problem.cameras])
+        self._cb = None
+        if allreduce is not None:
+            def _cb(ptr, count, user, _f=allreduce):
+                try:
+                    return int(_f(int(ptr), int(count)) or 0)
+                except Exception:  # never let an exception cross the C boundary
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._cb = ALLREDUCE_FN(_cb)
+        cfg = CbaConfig(problem.n_cameras, self._cams, problem.n_images, problem.n_points, problem.fd_delta,
+                        int(problem.localize_only), int(problem.eliminate_points), device,
+                        self._cb if self._cb is not None else ALLREDUCE_FN(0), None, n_images_global,
+                        reduce_buffer_ptr or None, reduce_buffer_doubles)
+        self._cfg = cfg
+        self._h = C.c_void_p()
+        _check(self.L.cba_create(C.byref(cfg), C.byref(self._h)), "cba_create")
+        _check(self.L.cba_set_observations(
+            self._h, problem.n_obs, problem.obs_xy.ctypes.data_as(C.POINTER(C.c_float)),
+            problem.obs_point.ctypes.data_as(C.POINTER(C.c_int32)),
+            problem.obs_image.ctypes.data_as(C.POINTER(C.c_int32)),
+            problem.obs_camera.ctypes.data_as(C.POINTER(C.c_int32)), None), "cba_set_observations")
+
+    @staticmethod
+    def reduce_buffer_doubles(problem: Problem) -> int:
+        cams = (CbaCamera * problem.n_cameras)(*[_cam_struct(c) for c in problem.cameras])
+        cfg = CbaConfig(problem.n_cameras, cams, problem.n_images, problem.n_points, problem.fd_delta,
+                        int(problem.localize_only), int(problem.eliminate_points), 0, ALLREDUCE_FN(0), None, 0, None, 0)
+        return int(load().cba_reduce_buffer_doubles(C.byref(cfg)))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self.L.cba_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- state ---------------------------------------------------------------------------------
+    def set_state(self, st: State) -> None:
+        grids = (C.POINTER(C.c_double) * len(st.grids))(*[_dp(g) for g in st.grids])
+        _check(self.L.cba_set_state(self._h, _dp(st.rig_tr_global), _dp(st.camera_tr_rig), _dp(st.points), grids),
+               "cba_set_state")
+
+    def get_state(self, like: State) -> State:
+        out = like.copy()
+        grids = (C.POINTER(C.c_double) * len(out.grids))(*[_dp(g) for g in out.grids])
+        _check(self.L.cba_get_state(self._h, _dp(out.rig_tr_global), _dp(out.camera_tr_rig), _dp(out.points), grids),
+               "cba_get_state")
+        return out
+
+    def get_last_projection(self) -> np.ndarray:
+        out = np.zeros((self.problem.n_obs, 2))
+        _check(self.L.cba_get_last_projection(self._h, _dp(out)), "cba_get_last_projection")
+        return out
+
+    # -- optimisation ----------------------------------------------------------------------------
+    def step(self, init_lambda: float = -1.0, max_lm_attempts: int = 50, init_lambda_factor: float = 0.00001) -> StepReport:
+        r = CbaReport()
+        _check(self.L.cba_step(self._h, init_lambda, max_lm_attempts, init_lambda_factor, C.byref(r)), "cba_step")
+        return StepReport(r.initial_cost, r.final_cost, r.lambda_, bool(r.accepted), r.lm_attempts,
+                          r.n_residuals_valid, r.n_jacobians_dropped, r.t_jac, r.t_solve, r.t_cost,
+                          r.t_accumulate, r.t_gemm, r.t_factor)
+
+    def cost(self, want_vector: bool = False):
+        cost = C.c_double(0)
+        nv = C.c_int64(0)
+        vec = np.zeros(self.problem.n_obs) if want_vector else None
+        _check(self.L.cba_cost(self._h, C.byref(cost), C.byref(nv), _dp(vec) if vec is not None else None), "cba_cost")
+        return (cost.value, nv.value, vec) if want_vector else (cost.value, nv.value)
+
+    def kernel_stats(self, which: int):
+        s, f, b = C.c_double(0), C.c_double(0), C.c_double(0)
+        n = C.c_int32(0)
+        _check(self.L.cba_kernel_stats(self._h, which, C.byref(s), C.byref(f), C.byref(b), C.byref(n)), "cba_kernel_stats")
+        return dict(seconds=s.value, flops=f.value, bytes=b.value, launches=n.value)
+
+    # -- parity / debug ----------------------------------------------------------------------------
+    def debug_accumulate(self) -> float:
+        cost = C.c_double(0)
+        _check(self.L.cba_debug_accumulate(self._h, C.byref(cost)), "cba_debug_accumulate")
+        return cost.value
+
+    def debug_solve(self, lam: float) -> np.ndarray:
+        _check(self.L.cba_debug_solve(self._h, lam), "cba_debug_solve")
+        return self.dump(DUMP_X)
+
+    def debug_apply_update(self, x: np.ndarray) -> None:
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.size == self.problem.total_dof
+        _check(self.L.cba_debug_apply_update(self._h, _dp(x)), "cba_debug_apply_update")
+
+    def dump(self, what: int) -> np.ndarray:
+        p = self.problem
+        n, bs, nb, dd = p.n_obs, p.block_size, p.n_blocks, p.dense_dof
+        rec = self.L.cba_jacobian_record_doubles(self._h)
+        shapes = {
+            DUMP_COST_VECTOR: ((n,), np.float64), DUMP_TEST_COST_VECTOR: ((n,), np.float64),
+            DUMP_PIXELS: ((n, 2), np.float64), DUMP_FLAGS: ((n,), np.uint8),
+            DUMP_JACOBIANS: ((n, rec), np.float64),
+            DUMP_BLOCK_DIAG_H: ((nb, bs, bs), np.float64), DUMP_BLOCK_DIAG_B: ((nb * bs,), np.float64),
+            DUMP_OFF_DIAG_H: ((nb * bs, dd), np.float64), DUMP_DENSE_H: ((dd, dd), np.float64),
+            DUMP_DENSE_B: ((dd,), np.float64), DUMP_X: ((p.total_dof,), np.float64),
+        }
+        shape, dt = shapes[what]
+        out = np.zeros(shape, dtype=dt)
+        _check(self.L.cba_debug_dump(self._h, what, out.ctypes.data_as(C.c_void_p), out.nbytes), "cba_debug_dump")
+        return out
+
+
+# ---- stateless model-level API (CameraModel::Project / Unproject) -----------------------------------
+def project(cam: Camera, grid: np.ndarray, local_points: np.ndarray, init: Optional[np.ndarray] = None, device: int = 0):
+    L = load()
+    g = np.ascontiguousarray(grid, dtype=np.float64)
+    pts = np.ascontiguousarray(local_points, dtype=np.float64).reshape(-1, 3)
+    n = pts.shape[0]
+    px = np.zeros((n, 2))
+    ok = np.zeros(n, dtype=np.uint8)
+    ini = None if init is None else np.ascontiguousarray(init, dtype=np.float64).reshape(-1, 2)
+    cs = _cam_struct(cam)
+    _check(L.cba_project(C.byref(cs), _dp(g), n, _dp(pts), _dp(ini) if ini is not None else None, _dp(px),
+                         ok.ctypes.data_as(C.POINTER(C.c_uint8)), device), "cba_project")
+    return px, ok.astype(bool)
+
+
+def unproject(cam: Camera, grid: np.ndarray, pixels: np.ndarray, with_jacobian: bool = False, device: int = 0):
+    L = load()
+    g = np.ascontiguousarray(grid, dtype=np.float64)
+    px = np.ascontiguousarray(pixels, dtype=np.float64).reshape(-1, 2)
+    n = px.shape[0]
+    lines = np.zeros((n, 6))
+    jac = np.zeros((n, 6, 2)) if with_jacobian else None
+    ok = np.zeros(n, dtype=np.uint8)
+    cs = _cam_struct(cam)
+    _check(L.cba_unproject(C.byref(cs), _dp(g), n, _dp(px), _dp(lines), _dp(jac) if jac is not None else None,
+                           ok.ctypes.data_as(C.POINTER(C.c_uint8)), device), "cba_unproject")
+    return (lines, jac, ok.astype(bool)) if with_jacobian else (lines, ok.astype(bool))
+
+
+def schur_solve(block_diag_H: np.ndarray, off_diag_H: np.ndarray, dense_H: np.ndarray, block_diag_b: np.ndarray,
+                dense_b: np.ndarray, device: int = 0) -> np.ndarray:
+    """LMOptimizer::SolveWithSchurComplementDenseOffDiag on host arrays (reference layout)."""
+    L = load()
+    bD = np.ascontiguousarray(block_diag_H, dtype=np.float64)
+    nb, bs = bD.shape[0], bD.shape[1]
+    oH = np.ascontiguousarray(off_diag_H, dtype=np.float64)
+    dH = np.ascontiguousarray(dense_H, dtype=np.float64)
+    bb = np.ascontiguousarray(block_diag_b, dtype=np.float64)
+    db = np.ascontiguousarray(dense_b, dtype=np.float64)
+    dd = dH.shape[0]
+    x = np.zeros(nb * bs + dd)
+    _check(L.cba_schur_solve(bs, nb, dd, _dp(bD), _dp(oH), _dp(dH), _dp(bb), _dp(db), _dp(x), device), "cba_schur_solve")
+    return x
+
+
+# ---- host mirror of the reference entry point ---------------------------------------------------------
+def optimize_jointly(problem: Problem, state: State, max_iteration_count: int, init_lambda: float = -1.0,
+                     device: int = 0, engine: Optional[Engine] = None, print_progress: bool = False):
+    """Python mirror of ``vis::OptimizeJointly`` (APP/bundle_adjustment/joint_optimization.h:53-70).
+
+    ``problem`` carries numerical_diff_delta / localize_only / eliminate_points; regularization_weight
+    must be 0 as in the reference (the branch is disabled there, joint_optimization.cc:299-305).
+    Returns (final_cost, final_lambda, performed_an_iteration, new_state, reports).
+    """
+    own = engine is None
+    eng = engine or Engine(problem, device)
+    try:
+        eng.set_state(state)
+        final_cost = -1.0
+        final_lambda = init_lambda
+        performed = False
+        reports: List[StepReport] = []
+        for it in range(max_iteration_count):   # joint_optimization.cc:906-940
+            rep = eng.step(init_lambda)
+            reports.append(rep)
+            final_cost = rep.final_cost
+            init_lambda = final_lambda = rep.final_lambda
+            if print_progress:
+                print(f"LMOptimizer: [{it}] cost {rep.initial_cost:.9g} -> {rep.final_cost:.9g}, lambda {rep.final_lambda:.3g}, "
+                      f"attempts {rep.lm_attempts}")
+            if not rep.accepted:
+                break
+            performed = True
+        return final_cost, final_lambda, performed, eng.get_state(state), reports
+    finally:
+        if own:
+            eng.close()

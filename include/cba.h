@@ -1,0 +1,184 @@
+/*
+ * cba.h -- C-ABI of the MI355X-native bundle-adjustment engine (libcalib_ba_hip.so).
+ *
+ * Drop-in boundary for the reference's JointOptimization path.  The reference has no FFI layer;
+ * the seam is the free function
+ *
+ *   double vis::OptimizeJointly(Dataset&, BAState*, int max_iteration_count, double init_lambda,
+ *                               double numerical_diff_delta, double regularization_weight,
+ *                               bool localize_only, bool eliminate_points, SchurMode schur_mode,
+ *                               double* final_lambda, bool* performed_an_iteration, ...)
+ *   -- applications/camera_calibration/src/camera_calibration/bundle_adjustment/joint_optimization.h:53-70
+ *
+ * A host adapter with exactly that signature (camera_calibration_amd/host/joint_optimization_hip.cc)
+ * marshals Dataset/BAState into the packed arrays below and calls cba_step once per outer iteration
+ * (the reference runs optimizer.Optimize(max_iteration_count = 1) per outer iteration,
+ * joint_optimization.cc:906-940).  See INTEGRATION.md for the reference-side binding.
+ *
+ * Conventions: plain pointers and sizes only; all arrays are HOST pointers unless stated; fp64
+ * unless stated; every call returns CBA_OK (0) or a negative error code and never aborts.
+ * File:line citations are relative to the reference tree; APP = applications/camera_calibration/
+ * src/camera_calibration, LV = libvis/src/libvis.
+ */
+#ifndef CBA_H_
+#define CBA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  CBA_OK = 0,
+  CBA_ERR_ARG = -1,        /* bad argument (replaces the reference's CHECK() aborts) */
+  CBA_ERR_HIP = -2,        /* HIP runtime error; cba_last_error() has the text */
+  CBA_ERR_STATE = -3,      /* call sequence error (e.g. step before set_state) */
+  CBA_ERR_NUMERIC = -4,    /* factorisation broke down (zero pivot) */
+  CBA_ERR_UNSUPPORTED = -5
+};
+
+/* CameraModel::Type of the two generic models (APP/models/camera_model.h:44-52) */
+enum { CBA_CENTRAL_GENERIC = 0, CBA_NONCENTRAL_GENERIC = 1 };
+
+/* Calibrated rectangle and grid resolution of one camera: the constructor arguments of
+ * CentralGenericModel / NoncentralGenericModel (APP/models/central_generic.h:54-58). */
+typedef struct {
+  int32_t model_type;
+  int32_t width, height;
+  int32_t calib_min_x, calib_min_y, calib_max_x, calib_max_y;
+  int32_t grid_w, grid_h;
+} cba_camera;
+
+/* Cross-rank sum of a DEVICE fp64 buffer (image sharding).  Called on the host with the
+ * engine's stream idle; must return after the reduced values are visible on the device. */
+typedef int (*cba_allreduce_fn)(void* device_ptr, int64_t count, void* user);
+
+typedef struct {
+  int32_t n_cameras;
+  const cba_camera* cameras;
+  int32_t n_images;          /* used imagesets (BAState::image_used already applied, joint_optimization.cc:80-90) */
+  int32_t n_points;
+  double numerical_diff_delta;   /* OptimizeJointly argument */
+  int32_t localize_only;         /* OptimizeJointly argument */
+  int32_t eliminate_points;      /* OptimizeJointly argument (0 = eliminate imageset poses, the CLI's mode) */
+  int32_t device;                /* HIP device ordinal */
+  /* multi-GPU (optional): this rank owns a contiguous range of the imagesets; dense-part blocks are
+   * summed over ranks with `allreduce` once per Gauss-Newton step. */
+  cba_allreduce_fn allreduce;
+  void* allreduce_user;
+  int32_t n_images_global;       /* total imagesets over all ranks (0 = n_images) */
+  void* reduce_buffer;           /* optional caller-owned DEVICE buffer used for the reduced system */
+  int64_t reduce_buffer_doubles; /* its size; must be >= cba_reduce_buffer_doubles() */
+} cba_config;
+
+/* OptimizationReport (LV/lm_optimizer.h:55-77) + what OptimizeJointly returns through pointers */
+typedef struct {
+  double initial_cost;     /* cost of the residual+Jacobian pass */
+  double final_cost;       /* report.final_cost */
+  double lambda;           /* optimizer.lambda() after the call (-> *final_lambda) */
+  int32_t accepted;        /* report.num_iterations_performed (0/1) (-> *performed_an_iteration) */
+  int32_t lm_attempts;
+  int64_t n_residuals_valid;   /* residuals with cost >= 0 in the Jacobian pass (global) */
+  int64_t n_jacobians_dropped; /* valid residuals added without Jacobian (joint_optimization.cc:373-376, 446-448) */
+  double t_jac;            /* cost_and_jacobian_evaluation_time of the Jacobian pass [s] */
+  double t_solve;          /* solve_time [s] */
+  double t_cost;           /* cost-only passes [s] */
+  double t_accumulate;     /* part of t_jac spent in the JtJ accumulation kernel [s] */
+  double t_gemm;           /* part of t_solve: Schur complement GEMM [s] */
+  double t_factor;         /* part of t_solve: reduced-system factorisation [s] */
+} cba_report;
+
+typedef struct cba_problem cba_problem; /* opaque, device-resident */
+
+const char* cba_last_error(void);
+const char* cba_version(void);
+
+int cba_create(const cba_config* config, cba_problem** out);
+void cba_destroy(cba_problem* p);
+
+/* Dataset -> packed observations, sorted image-major, then camera, then feature order (the loop
+ * order of JointOptimizationCostFunction::Compute, joint_optimization.cc:273-291).
+ * xy: 2n fp32 PointFeature::xy; point_index: PointFeature::index; image_index: sequential index of
+ * the (used) imageset on this rank; last_projection: 2n PointFeature::last_projection or NULL (zeros). */
+int cba_set_observations(cba_problem* p, int64_t n, const float* xy, const int32_t* point_index,
+                         const int32_t* image_index, const int32_t* camera_index,
+                         const double* last_projection);
+
+/* BAState -> device. rig_tr_global 7N (qw qx qy qz tx ty tz), camera_tr_rig 7C, points 3P,
+ * grids[c]: 3G doubles row-major (index gx + gy*grid_w, Image<Vec3d>); non-central: direction grid
+ * followed by the point grid. */
+int cba_set_state(cba_problem* p, const double* rig_tr_global, const double* camera_tr_rig,
+                  const double* points, const double* const* grids);
+int cba_get_state(cba_problem* p, double* rig_tr_global, double* camera_tr_rig, double* points,
+                  double* const* grids);
+int cba_get_last_projection(cba_problem* p, double* out /* 2n */);
+
+/* One optimizer.Optimize(max_iteration_count = 1) call of OptimizeJointly's loop
+ * (joint_optimization.cc:916-925, LV/lm_optimizer.h:629-991): residual+Jacobian pass, JtJ/Jtr
+ * accumulation, then up to max_lm_attempts x { Schur solve, state update, cost-only pass,
+ * CostIsSmallerThan }.  init_lambda < 0 selects the automatic init_lambda_factor * mean(diag H). */
+int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double init_lambda_factor,
+             cba_report* report);
+
+/* Compute<false> on the current state (VerifyCost, joint_optimization.cc:866-877; also the report
+ * statistics F4).  cost_vector (n, host, may be NULL) gets the per-residual Huber cost or -1. */
+int cba_cost(cba_problem* p, double* cost, int64_t* n_valid, double* cost_vector);
+
+/* ---- stateless model-level entry points (CameraModel API) ---- */
+/* CameraModel::Project / ProjectWithInitialEstimate for n local points (APP/models/central_grid.h:79-97,
+ * central_generic.cc:433-519, noncentral_generic.cc:156-264). init_pixels NULL = start at the centre
+ * of the calibrated area. ok[i] = return value. */
+int cba_project(const cba_camera* camera, const double* grid, int64_t n, const double* local_points,
+                const double* init_pixels, double* pixels, uint8_t* ok, int32_t device);
+/* CameraModel::Unproject / UnprojectWithJacobian (central_generic.h:97-105, central_generic.cc:521-549,
+ * noncentral twins). lines: 6n (direction, origin); jacobians: 12n (6x2 row-major) or NULL. */
+int cba_unproject(const cba_camera* camera, const double* grid, int64_t n, const double* pixels,
+                  double* lines, double* jacobians, uint8_t* ok, int32_t device);
+
+/* ---- solver-level entry point ---- */
+/* LMOptimizer::SolveWithSchurComplementDenseOffDiag (LV/lm_optimizer.h:1247-1369) on host arrays in
+ * the reference's layout (symmetric parts: upper triangles only are read).  x = [block part; dense]. */
+int cba_schur_solve(int32_t block_size, int32_t n_blocks, int32_t dense_dof, const double* block_diag_H,
+                    const double* off_diag_H, const double* dense_H, const double* block_diag_b,
+                    const double* dense_b, double* x, int32_t device);
+
+/* ---- parity/debug access (read-only views of the last cba_step / cba_debug_* call) ---- */
+enum {
+  CBA_DUMP_COST_VECTOR = 1,      /* n doubles: Jacobian-pass residual costs (-1 invalid) */
+  CBA_DUMP_PIXELS = 2,           /* 2n doubles: projected pixels of the Jacobian pass */
+  CBA_DUMP_FLAGS = 3,            /* n bytes: bit0 valid, bit1 has_jacobian */
+  CBA_DUMP_JACOBIANS = 4,        /* n * cba_jacobian_record_doubles() doubles */
+  CBA_DUMP_BLOCK_DIAG_H = 5,     /* n_blocks*bs*bs, upper triangles, WITHOUT lambda */
+  CBA_DUMP_BLOCK_DIAG_B = 6,
+  CBA_DUMP_OFF_DIAG_H = 7,       /* (n_blocks*bs) x dense_dof row-major */
+  CBA_DUMP_DENSE_H = 8,          /* dense_dof x dense_dof row-major, upper triangle, WITHOUT lambda */
+  CBA_DUMP_DENSE_B = 9,
+  CBA_DUMP_X = 10,               /* total_dof doubles: last update vector */
+  CBA_DUMP_TEST_COST_VECTOR = 11 /* n doubles: cost vector of the last cost-only pass */
+};
+int cba_debug_dump(cba_problem* p, int32_t what, void* out, size_t bytes);
+/* Runs only the residual+Jacobian pass + accumulation on the current state (no solve). */
+int cba_debug_accumulate(cba_problem* p, double* cost);
+/* Solves the accumulated system for the given lambda (no state update); x via CBA_DUMP_X. */
+int cba_debug_solve(cba_problem* p, double lambda);
+/* state -= x for a caller-provided x (JointOptimizationState::operator-=, joint_optimization.cc:172-214);
+ * the result becomes the current state. */
+int cba_debug_apply_update(cba_problem* p, const double* x);
+
+int32_t cba_total_dof(const cba_problem* p);
+int32_t cba_dense_dof(const cba_problem* p);
+/* layout of one CBA_DUMP_JACOBIANS record: [res 2][weight 1][pose 2x6][rig 2x6][point 2x3][grid 2xK] */
+int32_t cba_jacobian_record_doubles(const cba_problem* p);
+int64_t cba_reduce_buffer_doubles(const cba_config* config);
+/* device-side event timing of the dominant kernels of the last cba_step (bench roofline):
+ * which: 0 = Schur GEMM, 1 = trailing-update GEMMs of the factorisation, 2 = accumulation,
+ * 3 = finite-difference projection kernel. Returns seconds (<0 on error) and flop/byte counts. */
+int cba_kernel_stats(cba_problem* p, int32_t which, double* seconds, double* flops, double* bytes,
+                     int32_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CBA_H_ */

@@ -1,0 +1,268 @@
+"""GPU parity tests: the HIP engine (through the C-ABI, include/cba.h) against the CPU oracle on the
+same seeded inputs.  Tolerances: validity masks / indices bit-exact, pixels
+<= 1e-9 px, cost rel <= 1e-12 per pass (we allow 1e-10 for atomically accumulated sums), update vector
+x rel <= 1e-8.
+"""
+import numpy as np
+import pytest
+
+from camera_calibration_amd import engine as eng
+from camera_calibration_amd import synthetic as syn
+from camera_calibration_amd.problem import CENTRAL_GENERIC, NONCENTRAL_GENERIC, Camera, Problem, State
+from camera_calibration_amd.se3 import se3_exp, se3_identity, se3_mul
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_project(cam, grid, pts):
+    return orc.project(cam, grid, pts)
+
+
+def _xy1_grid(w, h):
+    gy, gx = np.meshgrid(np.arange(float(h)), np.arange(float(w)), indexing="ij")
+    g = np.stack([gx, gy, np.ones_like(gx)], -1).reshape(-1, 3)
+    return g / np.linalg.norm(g, axis=1, keepdims=True)
+
+
+# ---------------------------------------------------------------------------------------------------
+# model level
+# ---------------------------------------------------------------------------------------------------
+def test_schur_complement2_golden_vector_on_gpu():
+    # libvis/src/libvis/test/lm_optimizer.cc:470-557 through cba_schur_solve
+    nan = float("nan")
+    bD = np.array([[[1, 5], [nan, 6]], [[9, 5], [nan, 4]]], dtype=float)
+    oH = np.array([[3, 4], [7, 8], [7, 6], [3, 2]], dtype=float)
+    dH = np.array([[1, 4], [nan, 7]], dtype=float)
+    x = eng.schur_solve(bD, oH, dH, np.array([1.0, 2, 3, 4]), np.array([5.0, 6]))
+    np.testing.assert_allclose(x, [73.667, 171.667, 189.667, -294.333, 465.667, -582.0], atol=0.3)
+    H = np.array([[1, 5, 0, 0, 3, 4], [5, 6, 0, 0, 7, 8], [0, 0, 9, 5, 7, 6], [0, 0, 5, 4, 3, 2],
+                  [3, 7, 7, 3, 1, 4], [4, 8, 6, 2, 4, 7]], dtype=float)
+    np.testing.assert_allclose(x, np.linalg.solve(H, np.arange(1.0, 7.0)), rtol=1e-9)
+
+
+@pytest.mark.parametrize("bs,nb,dd", [(6, 7, 300), (3, 11, 200), (6, 40, 1100)])
+def test_schur_solve_matches_oracle_random_spd(bs, nb, dd):
+    rng = np.random.default_rng(bs * 100 + nb)
+    n = bs * nb + dd
+    J = rng.normal(size=(2 * n, n))
+    H = J.T @ J / n + 1e-3 * np.eye(n)
+    # zero the off-block parts of the block-diagonal region to give it the Schur structure
+    for b in range(nb):
+        for b2 in range(nb):
+            if b != b2:
+                H[b * bs:(b + 1) * bs, b2 * bs:(b2 + 1) * bs] = 0
+    b = rng.normal(size=n)
+    s = orc.System(bs, nb, dd)
+    for k in range(nb):
+        s.block_diag_H[k] = np.triu(H[k * bs:(k + 1) * bs, k * bs:(k + 1) * bs])
+    s.off_diag_H[:] = H[:bs * nb, bs * nb:]
+    s.dense_H[:] = np.triu(H[bs * nb:, bs * nb:])
+    s.block_diag_b[:] = b[:bs * nb]
+    s.dense_b[:] = b[bs * nb:]
+    x_ref = orc.schur_solve(s)
+    x = eng.schur_solve(s.block_diag_H, s.off_diag_H, s.dense_H, s.block_diag_b, s.dense_b)
+    np.testing.assert_allclose(x, x_ref, rtol=1e-8, atol=1e-10 * np.abs(x_ref).max())
+    np.testing.assert_allclose(H @ x, b, rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("model", [CENTRAL_GENERIC, NONCENTRAL_GENERIC])
+def test_unproject_and_project_match_oracle(model):
+    cam = Camera(model, 640, 480, 10, 20, 640 - 5, 480 - 8, 8, 6)
+    g = _xy1_grid(8, 6)
+    rng = np.random.default_rng(0)
+    if model == NONCENTRAL_GENERIC:
+        g = np.stack([g, 0.01 * rng.uniform(-1, 1, size=g.shape)])
+    px = np.array([10.0, 20.0]) + rng.uniform(0, 1, (400, 2)) * np.array([640 - 14, 480 - 27])
+    l_ref, ok_ref = orc.unproject(cam, g, px)
+    l_gpu, ok_gpu = eng.unproject(cam, g, px)
+    assert np.array_equal(ok_ref, ok_gpu)
+    np.testing.assert_allclose(l_gpu, l_ref, atol=1e-13)
+    lj_ref, J_ref, okj_ref = orc.unproject(cam, g, px, with_jacobian=True)
+    lj_gpu, J_gpu, okj_gpu = eng.unproject(cam, g, px, with_jacobian=True)
+    assert np.array_equal(okj_ref, okj_gpu)
+    np.testing.assert_allclose(lj_gpu, lj_ref, atol=1e-13 if model == CENTRAL_GENERIC else 1e-12)
+    np.testing.assert_allclose(J_gpu, J_ref, atol=1e-13 + 1e-11 * np.abs(J_ref).max())
+    # projection of points along the unprojected lines
+    depth = rng.uniform(1.0, 5.0, size=(400, 1))
+    pts = l_ref[:, 3:] + depth * l_ref[:, :3]
+    p_ref, okp_ref = orc.project(cam, g, pts)
+    p_gpu, okp_gpu = eng.project(cam, g, pts)
+    assert np.array_equal(okp_ref, okp_gpu)
+    assert okp_ref.all()
+    np.testing.assert_allclose(p_gpu, p_ref, atol=1e-9)
+    np.testing.assert_allclose(p_gpu, px, atol=1e-4)
+    # out-of-rectangle pixels and unreachable points are flagged identically
+    bad_px = np.array([[5.0, 100.0], [636.0, 100.0], [100.0, 473.0], [100.0, 100.0]])
+    assert np.array_equal(orc.unproject(cam, g, bad_px)[1], eng.unproject(cam, g, bad_px)[1])
+    far = np.array([[-50.0, 0.3, 1.0], [0.2, -40.0, 1.0], [3.0, 2.0, 1.0]])
+    assert np.array_equal(orc.project(cam, g, far)[1], eng.project(cam, g, far)[1])
+
+
+def test_empty_inputs():
+    cam = Camera(CENTRAL_GENERIC, 64, 48, 0, 0, 63, 47, 5, 5)
+    g = _xy1_grid(5, 5)
+    px, ok = eng.project(cam, g, np.zeros((0, 3)))
+    assert px.shape == (0, 2) and ok.shape == (0,)
+    l, ok = eng.unproject(cam, g, np.zeros((0, 2)))
+    assert l.shape == (0, 6)
+
+
+# ---------------------------------------------------------------------------------------------------
+# problem level
+# ---------------------------------------------------------------------------------------------------
+def _records_to_arrays(recs, n, Kg):
+    valid = np.array([r.valid for r in recs], dtype=np.uint8)
+    hasj = np.array([r.has_jacobian for r in recs], dtype=np.uint8)
+    pix = np.array([[r.pixel[0], r.pixel[1]] for r in recs])
+    J = np.zeros((n, 33 + 2 * Kg))
+    for i, r in enumerate(recs):
+        if not r.has_jacobian:
+            continue
+        J[i, 0:2] = r.residual[:]
+        J[i, 2] = r.weight
+        J[i, 3:15] = r.pose_jac[:]
+        J[i, 15:27] = r.rig_jac[:]
+        J[i, 27:33] = r.point_jac[:]
+        J[i, 33:33 + 2 * Kg] = r.grid_jac[:2 * Kg]
+    return valid, hasj, pix, J
+
+
+def _compare_pass(pb, st, rel_H=1e-9):
+    """Jacobian pass + accumulation + solve + update on identical state: engine vs oracle."""
+    op = orc.OracleProblem(pb)
+    sysm = op.new_system()
+    cost_ref, vec_ref, recs = op.jacobian_pass(st, sysm, want_records=True)
+    e = eng.Engine(pb)
+    e.set_state(st)
+    cost = e.debug_accumulate()
+    vec = e.dump(eng.DUMP_COST_VECTOR)
+    flags = e.dump(eng.DUMP_FLAGS)
+    Kg = 0 if pb.localize_only else max(c.params_per_grid_point for c in pb.cameras) * 16
+    valid, hasj, pix_ref, J_ref = _records_to_arrays(recs, pb.n_obs, Kg)
+    # masks bit-exact
+    assert np.array_equal(flags & 1, valid)
+    assert np.array_equal((flags >> 1) & 1, hasj)
+    assert np.array_equal(vec >= 0, vec_ref >= 0)
+    m = valid.astype(bool)
+    pix = e.dump(eng.DUMP_PIXELS)
+    np.testing.assert_allclose(pix[m], pix_ref[m], atol=1e-9)
+    np.testing.assert_allclose(vec[m], vec_ref[m], atol=1e-9 * (1 + np.abs(vec_ref[m])))
+    assert abs(cost - cost_ref) <= 1e-9 * max(1.0, abs(cost_ref))
+    # warm-start cache written back
+    np.testing.assert_allclose(e.get_last_projection()[m], op.last_projection[m], atol=1e-9)
+    # per-observation Jacobians.  Finite differences of two converged projections: agreement is
+    # limited by the projections' own convergence noise / delta
+    J = e.dump(eng.DUMP_JACOBIANS)
+    hj = hasj.astype(bool)
+    scale = np.abs(J_ref[hj]).max()
+    np.testing.assert_allclose(J[hj][:, :33 + 2 * Kg], J_ref[hj], atol=2e-5 * scale)
+    # normal equations
+    bD = e.dump(eng.DUMP_BLOCK_DIAG_H)
+    for name, a, b in [("block_diag_H", bD, sysm.block_diag_H),
+                       ("block_diag_b", e.dump(eng.DUMP_BLOCK_DIAG_B), sysm.block_diag_b),
+                       ("off_diag_H", e.dump(eng.DUMP_OFF_DIAG_H), sysm.off_diag_H),
+                       ("dense_H", np.triu(e.dump(eng.DUMP_DENSE_H)), np.triu(sysm.dense_H)),
+                       ("dense_b", e.dump(eng.DUMP_DENSE_B), sysm.dense_b)]:
+        if name == "block_diag_H":
+            a = np.array([np.triu(x) for x in a]); b = np.array([np.triu(x) for x in b])
+        tol = 2e-5 * np.abs(b).max()
+        assert np.abs(a - b).max() <= tol, f"{name}: {np.abs(a - b).max()} > {tol}"
+    # solve the *oracle's* system on the GPU solver and the engine's own system end-to-end
+    lam = 1e-5 * (np.trace(sysm.dense_H) + sum(np.trace(b) for b in sysm.block_diag_H)) / pb.total_dof
+    s2 = orc.System(sysm.block_size, sysm.n_blocks, sysm.dense_dof)
+    for fld in ("block_diag_H", "off_diag_H", "dense_H", "block_diag_b", "dense_b"):
+        getattr(s2, fld)[...] = getattr(sysm, fld)
+    s2.add_lambda(lam)
+    x_ref = orc.schur_solve(s2)
+    x_gpu_solver = eng.schur_solve(s2.block_diag_H, s2.off_diag_H, s2.dense_H, s2.block_diag_b, s2.dense_b)
+    np.testing.assert_allclose(x_gpu_solver, x_ref, rtol=1e-8, atol=1e-8 * np.abs(x_ref).max())
+    x = e.debug_solve(lam)
+    np.testing.assert_allclose(x, x_ref, atol=5e-4 * np.abs(x_ref).max())
+    # state update on the same x
+    st_ref = op.apply_update(st, x_ref)
+    e.debug_apply_update(x_ref)
+    st_gpu = e.get_state(st)
+    np.testing.assert_allclose(st_gpu.points, st_ref.points, atol=1e-15, rtol=1e-15)
+    # quaternion update goes through an fp32 sine/cosine (reference quirk): 1 ulp(fp32) of the update size
+    np.testing.assert_allclose(st_gpu.rig_tr_global, st_ref.rig_tr_global, atol=2e-7 * max(1e-3, np.abs(x_ref[:6 * pb.n_images]).max()) + 1e-15)
+    np.testing.assert_allclose(st_gpu.camera_tr_rig, st_ref.camera_tr_rig, atol=1e-8)
+    for g_gpu, g_ref in zip(st_gpu.grids, st_ref.grids):
+        np.testing.assert_allclose(g_gpu, g_ref, atol=1e-14)
+    e.close()
+
+
+@pytest.mark.parametrize("num_cameras", [1, 2])
+def test_first_iteration_parity_reference_fixture(num_cameras):
+    pb, st, gt = syn.reference_test_problem(num_cameras, oracle_project, seed=0)
+    _compare_pass(pb, st)
+
+
+def test_first_iteration_parity_noncentral():
+    pb, st, gt = syn.reference_test_problem(1, oracle_project, seed=3, num_points=60, num_poses=25,
+                                            model_type=NONCENTRAL_GENERIC)
+    pb.fd_delta = 1e-3
+    _compare_pass(pb, st)
+
+
+def test_first_iteration_parity_eliminate_points():
+    pb, st, gt = syn.reference_test_problem(1, oracle_project, seed=5, num_points=70, num_poses=30)
+    pb.eliminate_points = True
+    _compare_pass(pb, st)
+
+
+def test_cost_pass_matches_oracle_and_invalid_residuals():
+    pb, st, gt = syn.reference_test_problem(1, oracle_project, seed=1, num_points=80, num_poses=30)
+    # push some points behind / far outside so that projections fail
+    st.points[::7] *= 30.0
+    op = orc.OracleProblem(pb)
+    c_ref, v_ref = op.cost_pass(st)
+    e = eng.Engine(pb)
+    e.set_state(st)
+    c, nv, v = e.cost(want_vector=True)
+    assert np.array_equal(v >= 0, v_ref >= 0)
+    assert (v_ref < 0).any()
+    assert nv == int((v_ref >= 0).sum())
+    m = v_ref >= 0
+    np.testing.assert_allclose(v[m], v_ref[m], rtol=1e-9, atol=1e-9)
+    assert abs(c - c_ref) <= 1e-9 * abs(c_ref)
+    e.close()
+
+
+@pytest.mark.parametrize("num_cameras", [1, 2])
+def test_optimize_jointly_trajectory_matches_oracle(num_cameras):
+    """Restated TestOptimizeJointly (APP/test/util.h:275-571): same iterates as the oracle, cost <= 1e-6*C."""
+    pb, st0, gt = syn.reference_test_problem(num_cameras, oracle_project, seed=0)
+    op = orc.OracleProblem(pb)
+    st_ref = st0.copy()
+    e = eng.Engine(pb)
+    e.set_state(st0)
+    lam_ref = lam = -1.0
+    cost = np.inf
+    for it in range(20 * num_cameras):
+        r = op.optimize_jointly(st_ref, 1, lam_ref)
+        rep = e.step(lam)
+        lam_ref, lam, cost = r["final_lambda"], rep.final_lambda, rep.final_cost
+        if it < 4:  # while the cost is far above the fp32-measurement floor the trajectories coincide
+            assert rep.accepted == r["performed"]
+            assert rep.lm_attempts == r["lm_attempts"]
+            assert abs(rep.final_cost - r["cost"]) <= 1e-5 * abs(r["cost"]) + 1e-9
+            assert abs(lam - lam_ref) <= 1e-6 * lam_ref
+        if not rep.accepted:
+            break
+    assert cost <= num_cameras * 1e-6
+    st_gpu = e.get_state(st0)
+    # converged parameters agree with the oracle's (same gauge: both follow the same iterates)
+    np.testing.assert_allclose(st_gpu.points, st_ref.points, atol=1e-5)
+    np.testing.assert_allclose(st_gpu.rig_tr_global, st_ref.rig_tr_global, atol=1e-5)
+    for a, b in zip(st_gpu.grids, st_ref.grids):
+        np.testing.assert_allclose(a, b, atol=1e-5)
+    e.close()
+
+
+def test_python_optimize_jointly_mirror():
+    pb, st0, gt = syn.reference_test_problem(1, oracle_project, seed=2, num_points=60, num_poses=30)
+    cost, lam, performed, st, reports = eng.optimize_jointly(pb, st0, max_iteration_count=6)
+    assert performed and len(reports) >= 1
+    assert cost < reports[0].initial_cost * 1e-3
+    assert lam > 0
