@@ -72,6 +72,13 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own copy of the HIP runtime (same SONAME libamdhip64.so.7).  Importing it first
+    # makes the dynamic loader resolve our NEEDED entry to that copy, so that device pointers and
+    # streams are shared by one runtime when torch.distributed does the all-reduce.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(LIB_PATH):
         raise EngineError(f"{LIB_PATH} is missing -- run `python -c 'import __graft_entry__ as g; g.build()'`; "
                           "the engine has no CPU fallback")

@@ -147,7 +147,7 @@ def _compare_pass(pb, st, rel_H=1e-9):
     m = valid.astype(bool)
     pix = e.dump(eng.DUMP_PIXELS)
     np.testing.assert_allclose(pix[m], pix_ref[m], atol=1e-9)
-    np.testing.assert_allclose(vec[m], vec_ref[m], atol=1e-9 * (1 + np.abs(vec_ref[m])))
+    np.testing.assert_allclose(vec[m], vec_ref[m], rtol=1e-9, atol=1e-9)
     assert abs(cost - cost_ref) <= 1e-9 * max(1.0, abs(cost_ref))
     # warm-start cache written back
     np.testing.assert_allclose(e.get_last_projection()[m], op.last_projection[m], atol=1e-9)
