@@ -18,7 +18,8 @@ void set_error(const std::string& msg) { g_error = msg; }
 // implemented in kernels_linalg.hip
 int launch_dinv_times_B_ld(const double* Dinv, const double* B, int bs, int nb, int dd, int ld, double* W, hipStream_t s);
 int launch_gemv_t_strided(const double* M, int K, int n, int ld, const double* v, const double* base, double* y,
-                          int ystride, hipStream_t s);
+                          int ystride, double* partial_ws, hipStream_t s);
+int gemv_t_workspace_doubles(int n);
 int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const double* Cin, double* C, int n_pad, int ld,
                int n_real, int add_diag, double lambda, hipStream_t s);
 int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWorkspace& w, double* x, hipStream_t s);
@@ -118,7 +119,7 @@ struct cba_problem {
   int n_pad = 0, n_fact = 0, Kpad = 0;
   double* Dblk = nullptr; double* bblk = nullptr; double* B = nullptr; double* Hdd = nullptr; double* bd = nullptr;
   double* Dinv = nullptr; double* dinvb = nullptr; double* W = nullptr; double* S = nullptr; bool S_owned = true;
-  double* x = nullptr; double* scal = nullptr;
+  double* x = nullptr; double* scal = nullptr; double* gemv_ws = nullptr;
   int* status = nullptr;
   LdltWorkspace ldlt;
   KernelTimer timers[4];
@@ -254,7 +255,7 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
   }
   if (rep) rep->t_gemm += now_s() - t0;
   // right-hand side: S[j][n_pad-1] = bd[j] - sum_k B[k][j] dinvb[k]
-  CBA_TRY(launch_gemv_t_strided(p->B, L.block_dof, dd, ld, p->dinvb, p->bd, p->S + (ld - 1), ld, p->stream));
+  CBA_TRY(launch_gemv_t_strided(p->B, L.block_dof, dd, ld, p->dinvb, p->bd, p->S + (ld - 1), ld, p->gemv_ws, p->stream));
   if (multi) {
     CBA_TRY(allreduce(p, p->S, (int64_t)ld * ld));
     CBA_TRY(launch_finish_diag(p->S, ld, dd, p->n_pad, lambda, p->stream));
@@ -374,6 +375,7 @@ int cba_create(const cba_config* config, cba_problem** out) {
   CBA_TRY(dev_alloc(&p->x, (size_t)L.block_dof + p->n_pad));
   CBA_HIP(hipMemset(p->x, 0, sizeof(double) * ((size_t)L.block_dof + p->n_pad)));
   CBA_TRY(dev_alloc(&p->scal, 16));
+  CBA_TRY(dev_alloc(&p->gemv_ws, (size_t)gemv_t_workspace_doubles(p->n_pad)));
   CBA_TRY(dev_alloc(&p->status, 1));
   CBA_TRY(ldlt_workspace_alloc(p->ldlt, p->n_pad));
   *out = p;
@@ -397,7 +399,7 @@ void cba_destroy(cba_problem* p) {
   F(p->pair_tables); F(p->pair_counts); F(p->red_partials); F(p->red8);
   F(p->Dblk); F(p->bblk); F(p->B); F(p->Hdd); F(p->bd); F(p->Dinv); F(p->dinvb); F(p->W);
   if (p->S_owned) F(p->S);
-  F(p->x); F(p->scal); F(p->status);
+  F(p->x); F(p->scal); F(p->status); F(p->gemv_ws);
   ldlt_workspace_free(p->ldlt);
   for (auto& t : p->timers) { if (t.e0) hipEventDestroy(t.e0); if (t.e1) hipEventDestroy(t.e1); }
   if (p->stream) hipStreamDestroy(p->stream);
@@ -722,7 +724,8 @@ int cba_schur_solve(int32_t block_size, int32_t n_blocks, int32_t dense_dof, con
   const int bs = block_size, nb = n_blocks, dd = dense_dof, bdof = bs * nb;
   int n_pad, n_fact; padded_dims(dd, &n_pad, &n_fact);
   const int ld = n_pad, Kpad = round_up(bdof, 16);
-  double *Dblk, *bblk, *Dinv, *dinvb, *B, *W, *Hdd, *bd, *S, *xd; int* status;
+  double *Dblk, *bblk, *Dinv, *dinvb, *B, *W, *Hdd, *bd, *S, *xd, *gws; int* status;
+  CBA_TRY(dev_alloc(&gws, (size_t)gemv_t_workspace_doubles(dd)));
   CBA_TRY(dev_alloc(&Dblk, (size_t)nb * bs * bs)); CBA_TRY(dev_alloc(&bblk, (size_t)bdof)); CBA_TRY(dev_alloc(&Dinv, (size_t)nb * bs * bs));
   CBA_TRY(dev_alloc(&dinvb, (size_t)Kpad)); CBA_TRY(dev_alloc(&B, (size_t)Kpad * ld)); CBA_TRY(dev_alloc(&W, (size_t)Kpad * ld));
   CBA_TRY(dev_alloc(&Hdd, (size_t)ld * ld)); CBA_TRY(dev_alloc(&bd, (size_t)ld)); CBA_TRY(dev_alloc(&S, (size_t)ld * ld));
@@ -750,7 +753,7 @@ int cba_schur_solve(int32_t block_size, int32_t n_blocks, int32_t dense_dof, con
   CBA_TRY(launch_block_inverse(Dblk, bblk, 0.0, bs, nb, Dinv, dinvb, status, s));
   CBA_TRY(launch_dinv_times_B_ld(Dinv, B, bs, nb, dd, ld, W, s));
   CBA_TRY(schur_gemm(B, W, Kpad, ld, Hdd, S, n_pad, ld, dd, 1, 0.0, s));
-  CBA_TRY(launch_gemv_t_strided(B, bdof, dd, ld, dinvb, bd, S + (ld - 1), ld, s));
+  CBA_TRY(launch_gemv_t_strided(B, bdof, dd, ld, dinvb, bd, S + (ld - 1), ld, gws, s));
   CBA_TRY(ldlt_factor(S, n_fact, ld, w, s, nullptr));
   CBA_TRY(ldlt_back_solve(S, n_fact, ld, ld - 1, w, xd + bdof, s));
   CBA_TRY(launch_gemv_n(W, bdof, dd, ld, xd + bdof, dinvb, xd, s));
@@ -760,7 +763,7 @@ int cba_schur_solve(int32_t block_size, int32_t n_blocks, int32_t dense_dof, con
   CBA_HIP(hipMemcpy(&st[1], w.status, sizeof(int), hipMemcpyDeviceToHost));
   CBA_HIP(hipMemcpy(x, xd, sizeof(double) * (bdof + dd), hipMemcpyDeviceToHost));
   ldlt_workspace_free(w);
-  hipFree(Dblk); hipFree(bblk); hipFree(Dinv); hipFree(dinvb); hipFree(B); hipFree(W); hipFree(Hdd); hipFree(bd); hipFree(S); hipFree(xd); hipFree(status);
+  hipFree(Dblk); hipFree(bblk); hipFree(Dinv); hipFree(dinvb); hipFree(B); hipFree(W); hipFree(Hdd); hipFree(bd); hipFree(S); hipFree(xd); hipFree(status); hipFree(gws);
   if (st[0] || st[1]) { set_error("cba_schur_solve: zero pivot"); return CBA_ERR_NUMERIC; }
   return CBA_OK;
 }

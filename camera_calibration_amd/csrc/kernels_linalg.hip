@@ -94,15 +94,6 @@ __global__ void __launch_bounds__(256) k_dinv_times_B(const double* __restrict__
   }
 }
 
-// y[j] = base[j] - sum_k M[k][j] v[k]
-__global__ void __launch_bounds__(256) k_gemv_t(const double* __restrict__ M, int K, int n, int ld, const double* __restrict__ v,
-                                                const double* __restrict__ base, double* __restrict__ y, int ystride) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  double acc = 0.0;
-  for (int k = 0; k < K; ++k) acc += M[(size_t)k * ld + j] * v[k];
-  y[(size_t)j * ystride] = (base ? base[j] : 0.0) - acc;
-}
 // y[k] = base[k] - sum_j M[k][j] v[j]; one wavefront per row
 __global__ void __launch_bounds__(256) k_gemv_n(const double* __restrict__ M, int K, int n, int ld, const double* __restrict__ v,
                                                 const double* __restrict__ base, double* __restrict__ y) {
@@ -199,44 +190,97 @@ __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
 
   const double* Ag = g.A + m0;
   const double* Bg = g.B + n0;
-  // stage loader: KT x TM (and KT x TN) doubles as 16-byte pieces
-  constexpr int A_PIECES = KT * TM / 2, B_PIECES = KT * TN / 2;
-  auto load_stage = [&](int buf, int k0) {
-#pragma unroll
-    for (int p = tid; p < A_PIECES; p += 256) {
-      int row = p / (TM / 2), c2 = p % (TM / 2);
-      const double2 v = *reinterpret_cast<const double2*>(Ag + (size_t)(k0 + row) * g.lda + 2 * c2);
-      *reinterpret_cast<double2*>(&sA[buf][row * LDA_S + 2 * c2]) = v;
-    }
-#pragma unroll
-    for (int p = tid; p < B_PIECES; p += 256) {
-      int row = p / (TN / 2), c2 = p % (TN / 2);
-      const double2 v = *reinterpret_cast<const double2*>(Bg + (size_t)(k0 + row) * g.ldb + 2 * c2);
-      *reinterpret_cast<double2*>(&sB[buf][row * LDB_S + 2 * c2]) = v;
-    }
-  };
-
   const int nk = g.K / KT;
-  if (nk > 0) load_stage(0, 0);
-  __syncthreads();
-  for (int kb = 0; kb < nk; ++kb) {
-    const int buf = kb & 1;
-    if (kb + 1 < nk) load_stage(buf ^ 1, (kb + 1) * KT);
-    const double* a_s = &sA[buf][0];
-    const double* b_s = &sB[buf][0];
-#pragma unroll
-    for (int kk = 0; kk < KT; kk += 4) {
-      double af[MI], bf[NJ];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = a_s[(kk + lk) * LDA_S + wm0 + i * 16 + li];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) bf[j] = b_s[(kk + lk) * LDB_S + wn0 + j * 16 + li];
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
+  if constexpr (TM == 128 && TN == 128) {
+    // Stage pipeline with LDS-DMA (global_load_lds_dwordx4): each wavefront-instruction moves one
+    // 1 KiB row segment (64 lanes x 16 B) of the K-major operand straight into its (padded) LDS row,
+    // no staging registers.  The slab for stage kb+1 is in flight while the MFMAs consume stage kb;
+    // one vmcnt(0) + barrier per stage.
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+#define CBA_DMA_STAGE(buf_, k0_)                                                                                   \
+  {                                                                                                                \
+    _Pragma("unroll") for (int j = 0; j < KT / 4; ++j) {                                                           \
+      const int row = wv * (KT / 4) + j;                                                                           \
+      __builtin_amdgcn_global_load_lds((gbl_ptr)(Ag + (size_t)((k0_) + row) * g.lda + 2 * lane),                   \
+                                       (lds_ptr)&sA[(buf_)][row * LDA_S], 16, 0, 0);                               \
+      __builtin_amdgcn_global_load_lds((gbl_ptr)(Bg + (size_t)((k0_) + row) * g.ldb + 2 * lane),                   \
+                                       (lds_ptr)&sB[(buf_)][row * LDB_S], 16, 0, 0);                               \
+    }                                                                                                              \
+  }
+    CBA_DMA_STAGE(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    for (int kb = 0; kb < nk; ++kb) {
+      const int buf = kb & 1;
+      if (kb + 1 < nk) CBA_DMA_STAGE(buf ^ 1, (kb + 1) * KT);
+      const double* a_s = &sA[buf][0];
+      const double* b_s = &sB[buf][0];
+#pragma unroll
+      for (int kk = 0; kk < KT; kk += 4) {
+        double af[MI], bf[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = a_s[(kk + lk) * LDA_S + wm0 + i * 16 + li];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bf[j] = b_s[(kk + lk) * LDB_S + wn0 + j * 16 + li];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+#undef CBA_DMA_STAGE
+  } else {
+    // small-tile variant (panel operations): register-staged double buffering
+    constexpr int A_PER = KT * TM / 2 / 256, B_PER = KT * TN / 2 / 256;
+    constexpr int A_ROWSTEP = 256 / (TM / 2), B_ROWSTEP = 256 / (TN / 2);
+    const int a_row = tid / (TM / 2), a_c2 = tid % (TM / 2);
+    const int b_row = tid / (TN / 2), b_c2 = tid % (TN / 2);
+    double2 ra[A_PER], rb[B_PER];
+#define CBA_GLOAD(k0_)                                                                                          \
+  {                                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < A_PER; ++j)                                                           \
+        ra[j] = *reinterpret_cast<const double2*>(Ag + (size_t)((k0_) + a_row + j * A_ROWSTEP) * g.lda + 2 * a_c2); \
+    _Pragma("unroll") for (int j = 0; j < B_PER; ++j)                                                           \
+        rb[j] = *reinterpret_cast<const double2*>(Bg + (size_t)((k0_) + b_row + j * B_ROWSTEP) * g.ldb + 2 * b_c2); \
+  }
+#define CBA_SSTORE(buf_)                                                                                        \
+  {                                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < A_PER; ++j)                                                           \
+        *reinterpret_cast<double2*>(&sA[(buf_)][(a_row + j * A_ROWSTEP) * LDA_S + 2 * a_c2]) = ra[j];           \
+    _Pragma("unroll") for (int j = 0; j < B_PER; ++j)                                                           \
+        *reinterpret_cast<double2*>(&sB[(buf_)][(b_row + j * B_ROWSTEP) * LDB_S + 2 * b_c2]) = rb[j];           \
+  }
+    CBA_GLOAD(0);
+    CBA_SSTORE(0);
+    __syncthreads();
+    for (int kb = 0; kb < nk; ++kb) {
+      const int buf = kb & 1;
+      // the slab after the last one is a re-read of the last slab (stays in bounds, result unused)
+      const int knext = (kb + 1 < nk) ? (kb + 1) * KT : kb * KT;
+      CBA_GLOAD(knext);
+      const double* a_s = &sA[buf][0];
+      const double* b_s = &sB[buf][0];
+#pragma unroll
+      for (int kk = 0; kk < KT; kk += 4) {
+        double af[MI], bf[NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = a_s[(kk + lk) * LDA_S + wm0 + i * 16 + li];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bf[j] = b_s[(kk + lk) * LDB_S + wn0 + j * 16 + li];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+      CBA_SSTORE(buf ^ 1);
+      __syncthreads();
+    }
+#undef CBA_GLOAD
+#undef CBA_SSTORE
   }
 
   // ---- epilogue ----
@@ -289,19 +333,37 @@ int launch_dinv_times_B_ld(const double* Dinv, const double* B, int bs, int nb, 
   CBA_HIP(hipGetLastError());
   return CBA_OK;
 }
-int launch_gemv_t(const double* M, int K, int n, int ld, const double* v, const double* base, double* y, hipStream_t s) {
-  if (n == 0) return CBA_OK;
-  hipLaunchKernelGGL(k_gemv_t, dim3((n + 255) / 256), dim3(256), 0, s, M, K, n, ld, v, base, y, 1);
-  CBA_HIP(hipGetLastError());
-  return CBA_OK;
+// y[j*ystride] = base[j] - sum_k M[k][j] v[k] in two deterministic stages: kGemvChunks row chunks
+// produce partial sums (coalesced along j), a second kernel adds them in fixed order.
+constexpr int kGemvChunks = 64;
+__global__ void __launch_bounds__(256) k_gemv_t_partial(const double* __restrict__ M, int K, int n, int ld,
+                                                        const double* __restrict__ v, double* __restrict__ partial) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int c = blockIdx.y;
+  int per = (K + kGemvChunks - 1) / kGemvChunks;
+  int k0 = c * per, k1 = k0 + per < K ? k0 + per : K;
+  if (j >= n) return;
+  double acc = 0.0;
+  for (int k = k0; k < k1; ++k) acc += M[(size_t)k * ld + j] * v[k];
+  partial[(size_t)c * n + j] = acc;
+}
+__global__ void __launch_bounds__(256) k_gemv_t_final(const double* __restrict__ partial, int n, const double* __restrict__ base,
+                                                      double* __restrict__ y, int ystride) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double acc = 0.0;
+  for (int c = 0; c < kGemvChunks; ++c) acc += partial[(size_t)c * n + j];
+  y[(size_t)j * ystride] = (base ? base[j] : 0.0) - acc;
 }
 int launch_gemv_t_strided(const double* M, int K, int n, int ld, const double* v, const double* base, double* y,
-                          int ystride, hipStream_t s) {
+                          int ystride, double* partial_ws, hipStream_t s) {
   if (n == 0) return CBA_OK;
-  hipLaunchKernelGGL(k_gemv_t, dim3((n + 255) / 256), dim3(256), 0, s, M, K, n, ld, v, base, y, ystride);
+  hipLaunchKernelGGL(k_gemv_t_partial, dim3((n + 255) / 256, kGemvChunks), dim3(256), 0, s, M, K, n, ld, v, partial_ws);
+  hipLaunchKernelGGL(k_gemv_t_final, dim3((n + 255) / 256), dim3(256), 0, s, partial_ws, n, base, y, ystride);
   CBA_HIP(hipGetLastError());
   return CBA_OK;
 }
+int gemv_t_workspace_doubles(int n) { return kGemvChunks * n; }
 
 // S = Hdd + lambda I - A^T B on the upper tiles (n_pad x n_pad, all leading dims = ld, multiples of 128)
 int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const double* Cin, double* C, int n_pad, int ld,
@@ -323,53 +385,81 @@ int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const doubl
 constexpr int kInner = 64;
 constexpr int kPanel = 256;
 
-// Factor the 64x64 diagonal block at (j0,j0): T = L D L^T.  Writes L (unit lower; L(p,q) at M[j0+q][j0+p], p>q),
-// d into the diagonal and dvec, and invLt[q][p] = (L^-1)(p,q).
+// Factor the 64x64 diagonal block at (j0,j0): T = L D L^T, and invert the unit-lower factor.
+// Writes L (L(p,q), p>q, at M[j0+q][j0+p]), d into the diagonal and dvec, and invLt[q][p] = (L^-1)(p,q).
+// One workgroup; every lane keeps a cyclic 4x4 sub-grid of T and of X = L^-1 in registers
+// (element (i,j) with i = ti + 16a, j = tj + 16b).  Step s broadcasts column s of T and row s of X
+// through LDS and applies the two rank-1 updates
+//     T[i][j] -= l_i d l_j   (i,j > s),        X[i][c] -= l_i X[s][c]   (i > s, c <= s)
+// -- the second is the product form L^-1 = (I - l_62 e_62^T) ... (I - l_0 e_0^T).  One barrier per step.
 __global__ void __launch_bounds__(256) k_ldlt_diag(double* __restrict__ M, int ld, int j0, double* __restrict__ dvec,
                                                    double* __restrict__ invLt_all, int* __restrict__ status) {
-  __shared__ double T[kInner][kInner + 1];   // T[i][j], i >= j used (lower, col-major view: T[i][j] = M[j0+j][j0+i])
-  __shared__ double Linv[kInner][kInner + 1];
-  const int tid = threadIdx.x;
-  for (int e = tid; e < kInner * kInner; e += 256) {
-    int q = e / kInner, p = e % kInner;   // memory row q, col p
-    double v = M[(size_t)(j0 + q) * ld + j0 + p];
-    if (p >= q) T[p][q] = v;              // lower(i=p, j=q)
-  }
-  __syncthreads();
+  __shared__ double colbuf[2][kInner];
+  __shared__ double rowbuf[2][kInner];
+  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  double T[4][4], X[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      int i = ti + 16 * a, j = tj + 16 * b;
+      int lo = i < j ? i : j, hi = i < j ? j : i;           // symmetric fill from the stored upper triangle
+      T[a][b] = M[(size_t)(j0 + lo) * ld + j0 + hi];
+      X[a][b] = (i == j) ? 1.0 : 0.0;
+    }
+  bool bad = false;
   for (int s = 0; s < kInner; ++s) {
-    double d = T[s][s];
-    if (tid == 0 && !(fabs(d) > 0.0)) atomicExch(status, 2);
-    __syncthreads();
-    // column s of L
-    for (int i = s + 1 + tid; i < kInner; i += 256) T[i][s] = T[i][s] / d;
-    __syncthreads();
-    // trailing update T[i][j] -= L(i,s) d L(j,s), i >= j > s
-    int rem = kInner - s - 1;
-    for (int e = tid; e < rem * rem; e += 256) {
-      int i = s + 1 + e / rem, j = s + 1 + e % rem;
-      if (i >= j) T[i][j] -= T[i][s] * d * T[j][s];
+    const int sa = s >> 4, sr = s & 15, pb = s & 1;
+    if (tj == sr) {                                          // owners of column s publish it
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (b == sa) colbuf[pb][ti + 16 * a] = T[a][b];
+    }
+    if (ti == sr) {                                          // owners of row s of X publish it
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (a == sa) rowbuf[pb][tj + 16 * b] = X[a][b];
     }
     __syncthreads();
-  }
-  // inverse of the unit-lower L, one column per lane (forward substitution)
-  if (tid < kInner) {
-    int c = tid;
-    for (int i = 0; i < kInner; ++i) Linv[i][c] = (i == c) ? 1.0 : 0.0;
-    for (int i = c + 1; i < kInner; ++i) {
-      double acc = 0.0;
-      for (int k = c; k < i; ++k) acc += T[i][k] * Linv[k][c];
-      Linv[i][c] = -acc;
+    const double d = colbuf[pb][s];
+    if (!(fabs(d) > 0.0)) bad = true;
+    const double invd = 1.0 / d;
+    double li[4], lj[4], xr[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { int i = ti + 16 * a; li[a] = (i > s) ? colbuf[pb][i] * invd : 0.0; }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { int j = tj + 16 * b; lj[b] = (j > s) ? colbuf[pb][j] : 0.0; xr[b] = rowbuf[pb][j]; }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        T[a][b] -= li[a] * lj[b];                            // l_i d l_j with lj holding d*l_j
+        X[a][b] -= li[a] * xr[b];
+      }
+    if (tj == sr) {                                          // store column s of L in place of T[:,s]
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (b == sa && ti + 16 * a > s) T[a][b] = li[a];
     }
   }
-  __syncthreads();
+  if (bad && tid == 0) atomicExch(status, 2);
   double* invLt = invLt_all + (size_t)(j0 / kInner) * kInner * kInner;
-  for (int e = tid; e < kInner * kInner; e += 256) {
-    int q = e / kInner, p = e % kInner;
-    // memory row q, col p: p > q holds L(p,q); p == q holds d
-    if (p >= q) M[(size_t)(j0 + q) * ld + j0 + p] = T[p][q];
-    invLt[q * kInner + p] = (p >= q) ? Linv[p][q] : 0.0;   // invLt[q][p] = invL(p,q)
-  }
-  if (tid < kInner) dvec[j0 + tid] = T[tid][tid];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      int i = ti + 16 * a, j = tj + 16 * b;
+      // memory row q = j, column p = i holds L(p,q) for p > q and d for p == q
+      if (i >= j) M[(size_t)(j0 + j) * ld + j0 + i] = T[a][b];
+      invLt[j * kInner + i] = (i >= j) ? X[a][b] : 0.0;     // invLt[q][p] = invL(p,q)
+      if (i == j) dvec[j0 + i] = T[a][b];
+    }
 }
 
 struct LdltPlan {
@@ -486,25 +576,32 @@ __global__ void __launch_bounds__(256) k_back_panel_diag(const double* __restric
                                                          const double* __restrict__ invLt_all, double* __restrict__ x) {
   __shared__ double xs[kPanel];
   __shared__ double t[kInner];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // lane layout: row p = tid / 4 (64 rows), quarter = tid % 4 splits the dot products; the four
+  // partial sums sit in adjacent lanes and are combined with two shuffles.  All loads of one lane
+  // are independent, so a sub-block costs about one L2 round trip instead of one per row.
+  const int p = threadIdx.x >> 2, qt = threadIdx.x & 3;
   for (int i = threadIdx.x; i < nb; i += 256) xs[i] = x[k0 + i];
   __syncthreads();
   for (int sub = nb / kInner - 1; sub >= 0; --sub) {
     const int j0 = sub * kInner;   // offset inside the panel
-    for (int p = wv; p < kInner; p += 4) {
+    {
       const double* row = S + (size_t)(k0 + j0 + p) * ld + k0;
       double acc = 0.0;
-      for (int i = j0 + kInner + lane; i < nb; i += 64) acc += row[i] * xs[i];
-      for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-      if (lane == 0) t[p] = xs[j0 + p] - acc;
+      for (int i = j0 + kInner + qt; i < nb; i += 4) acc += row[i] * xs[i];
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      if (qt == 0) t[p] = xs[j0 + p] - acc;
     }
     __syncthreads();
-    const double* invLt = invLt_all + (size_t)((k0 + j0) / kInner) * kInner * kInner;
-    if (threadIdx.x < kInner) {   // x[q] = sum_{p >= q} invL(p,q) t[p]
-      int q = threadIdx.x;
+    {
+      // x[q] = sum_{p' >= q} invL(p',q) t[p'] = sum_{p'} invLt[q][p'] t[p']   (q = p here)
+      const double* invLt = invLt_all + (size_t)((k0 + j0) / kInner) * kInner * kInner + (size_t)p * kInner;
       double acc = 0.0;
-      for (int p = q; p < kInner; ++p) acc += invLt[q * kInner + p] * t[p];
-      xs[j0 + q] = acc;
+      for (int pp = qt; pp < kInner; pp += 4) acc += invLt[pp] * t[pp];
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      __syncthreads();
+      if (qt == 0) xs[j0 + p] = acc;
     }
     __syncthreads();
   }
