@@ -96,10 +96,12 @@ int launch_gemv_n(const double* M, int K, int n, int ld, const double* v, const 
 struct GemmStats { double seconds = 0, flops = 0, bytes = 0; int launches = 0; };
 // In-place blocked LDL^T of a symmetric matrix stored "upper in row-major" (= lower in column-major).
 struct LdltWorkspace {
-  double* X = nullptr;       // panel copy [kPanel][ld]
+  double* X = nullptr;       // two panel copies [2][kPanel][ld]
   double* invLt = nullptr;   // [kInner][kInner]
   double* dvec = nullptr;    // n
   int* status = nullptr;
+  hipStream_t panel_stream = nullptr;   // high-priority side stream for look-ahead panel factorisation
+  hipEvent_t ev_panel = nullptr, ev_strip = nullptr;
   size_t n_alloc = 0;
 };
 int ldlt_workspace_alloc(LdltWorkspace& w, int n);

@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
   __shared__ double sB[2][KT * LDB_S];
   constexpr int WAVES_N = TN / WN;
   constexpr int MI = WM / 16, NJ = WN / 16;
+  if constexpr (TM < 128) __builtin_amdgcn_s_setprio(2);   // panel-sized products are on the critical path
 
   // ---- tile decode (XCD-aware permutation of the linear block index) ----
   long long b = blockIdx.x;
@@ -380,7 +381,7 @@ int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const doubl
 // ------------------------------------------------------------------------------------------------
 // blocked LDL^T, lower/column-major view of "upper in row-major" storage.
 //   kInner = 64 : diagonal blocks factored (and their unit-lower factors inverted) by one workgroup
-//   kPanel = 256: trailing updates use K = 256
+//   kPanel = 512: trailing updates use K = 512 (halves the read+write traffic of the trailing matrix)
 // ------------------------------------------------------------------------------------------------
 constexpr int kInner = 64;
 constexpr int kPanel = 256;
@@ -392,10 +393,61 @@ constexpr int kPanel = 256;
 // through LDS and applies the two rank-1 updates
 //     T[i][j] -= l_i d l_j   (i,j > s),        X[i][c] -= l_i X[s][c]   (i > s, c <= s)
 // -- the second is the product form L^-1 = (I - l_62 e_62^T) ... (I - l_0 e_0^T).  One barrier per step.
+// One segment of 16 elimination steps s = 16*SA + sr.  SA is a compile-time constant so that the
+// register holding column / row s (index SA of the cyclic 4x4 sub-grid) is addressed statically --
+// a run-time register index costs 3x per step (measured: 0.38 us vs 1.05 us).
+template <int SA>
+__device__ __forceinline__ void ldlt_diag_segment(double (&T)[4][4], double (&X)[4][4], double (*colbuf)[kInner],
+                                                  double (*rowbuf)[kInner], int ti, int tj, int nsteps, bool& bad) {
+#pragma nounroll
+  for (int sr = 0; sr < 16; ++sr) {
+    const int s = 16 * SA + sr, pb = sr & 1;
+    if (s >= nsteps) return;
+    if (tj == sr) {                                          // owners of column s publish it
+#pragma unroll
+      for (int a = 0; a < 4; ++a) colbuf[pb][ti + 16 * a] = T[a][SA];
+    }
+    if (ti == sr) {                                          // owners of row s of X publish it
+#pragma unroll
+      for (int b = 0; b < 4; ++b) rowbuf[pb][tj + 16 * b] = X[SA][b];
+    }
+    __syncthreads();
+    const double d = colbuf[pb][s];
+    if (!(fabs(d) > 0.0)) bad = true;
+    const double invd = 1.0 / d;
+    double li[4], lj[4], xr[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { const int i = ti + 16 * a; li[a] = (i > s) ? colbuf[pb][i] * invd : 0.0; }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { const int j = tj + 16 * b; lj[b] = (j > s) ? colbuf[pb][j] : 0.0; xr[b] = rowbuf[pb][j]; }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        T[a][b] -= li[a] * lj[b];                            // l_i d l_j with lj holding d*l_j
+        X[a][b] -= li[a] * xr[b];
+      }
+    if (tj == sr) {                                          // store column s of L in place of T[:,s]
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        if (ti + 16 * a > s) T[a][SA] = li[a];
+    }
+  }
+}
+
+// Factor the 64x64 diagonal block at (j0,j0): T = L D L^T, and invert the unit-lower factor.
+// Writes L (L(p,q), p>q, at M[j0+q][j0+p]), d into the diagonal and dvec, and invLt[q][p] = (L^-1)(p,q).
+// One workgroup; every lane keeps a cyclic 4x4 sub-grid of T and of X = L^-1 in registers
+// (element (i,j) with i = ti + 16a, j = tj + 16b).  Step s broadcasts column s of T and row s of X
+// through LDS and applies the two rank-1 updates
+//     T[i][j] -= l_i d l_j   (i,j > s),        X[i][c] -= l_i X[s][c]   (i > s, c <= s)
+// -- the second is the product form L^-1 = (I - l_62 e_62^T) ... (I - l_0 e_0^T).  One barrier per step.
+template <int NSTEPS = kInner>
 __global__ void __launch_bounds__(256) k_ldlt_diag(double* __restrict__ M, int ld, int j0, double* __restrict__ dvec,
                                                    double* __restrict__ invLt_all, int* __restrict__ status) {
   __shared__ double colbuf[2][kInner];
   __shared__ double rowbuf[2][kInner];
+  __builtin_amdgcn_s_setprio(3);   // latency-critical: runs underneath the bulk trailing-update GEMM
   const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
   double T[4][4], X[4][4];
 #pragma unroll
@@ -408,46 +460,10 @@ __global__ void __launch_bounds__(256) k_ldlt_diag(double* __restrict__ M, int l
       X[a][b] = (i == j) ? 1.0 : 0.0;
     }
   bool bad = false;
-  for (int s = 0; s < kInner; ++s) {
-    const int sa = s >> 4, sr = s & 15, pb = s & 1;
-    if (tj == sr) {                                          // owners of column s publish it
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-          if (b == sa) colbuf[pb][ti + 16 * a] = T[a][b];
-    }
-    if (ti == sr) {                                          // owners of row s of X publish it
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-          if (a == sa) rowbuf[pb][tj + 16 * b] = X[a][b];
-    }
-    __syncthreads();
-    const double d = colbuf[pb][s];
-    if (!(fabs(d) > 0.0)) bad = true;
-    const double invd = 1.0 / d;
-    double li[4], lj[4], xr[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) { int i = ti + 16 * a; li[a] = (i > s) ? colbuf[pb][i] * invd : 0.0; }
-#pragma unroll
-    for (int b = 0; b < 4; ++b) { int j = tj + 16 * b; lj[b] = (j > s) ? colbuf[pb][j] : 0.0; xr[b] = rowbuf[pb][j]; }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        T[a][b] -= li[a] * lj[b];                            // l_i d l_j with lj holding d*l_j
-        X[a][b] -= li[a] * xr[b];
-      }
-    if (tj == sr) {                                          // store column s of L in place of T[:,s]
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-          if (b == sa && ti + 16 * a > s) T[a][b] = li[a];
-    }
-  }
+  ldlt_diag_segment<0>(T, X, colbuf, rowbuf, ti, tj, NSTEPS, bad);
+  ldlt_diag_segment<1>(T, X, colbuf, rowbuf, ti, tj, NSTEPS, bad);
+  ldlt_diag_segment<2>(T, X, colbuf, rowbuf, ti, tj, NSTEPS, bad);
+  ldlt_diag_segment<3>(T, X, colbuf, rowbuf, ti, tj, NSTEPS, bad);
   if (bad && tid == 0) atomicExch(status, 2);
   double* invLt = invLt_all + (size_t)(j0 / kInner) * kInner * kInner;
 #pragma unroll
@@ -462,17 +478,17 @@ __global__ void __launch_bounds__(256) k_ldlt_diag(double* __restrict__ M, int l
     }
 }
 
-struct LdltPlan {
-  int n_fact;  // rows factored (multiple of 64)
-  int n_pad;   // matrix dimension incl. padding (multiple of 128)
-};
-
 int ldlt_workspace_alloc(LdltWorkspace& w, int n_pad) {
   ldlt_workspace_free(w);
-  CBA_HIP(hipMalloc(&w.X, sizeof(double) * (size_t)kPanel * n_pad));
+  CBA_HIP(hipMalloc(&w.X, sizeof(double) * 2 * (size_t)kPanel * n_pad));   // two panel buffers (look-ahead)
   CBA_HIP(hipMalloc(&w.invLt, sizeof(double) * (size_t)(n_pad / kInner) * kInner * kInner));
   CBA_HIP(hipMalloc(&w.dvec, sizeof(double) * (size_t)n_pad));
   CBA_HIP(hipMalloc(&w.status, sizeof(int)));
+  int lo = 0, hi = 0;
+  CBA_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  CBA_HIP(hipStreamCreateWithPriority(&w.panel_stream, hipStreamNonBlocking, hi));
+  CBA_HIP(hipEventCreateWithFlags(&w.ev_panel, hipEventDisableTiming));
+  CBA_HIP(hipEventCreateWithFlags(&w.ev_strip, hipEventDisableTiming));
   w.n_alloc = n_pad;
   return CBA_OK;
 }
@@ -481,77 +497,107 @@ void ldlt_workspace_free(LdltWorkspace& w) {
   if (w.invLt) hipFree(w.invLt);
   if (w.dvec) hipFree(w.dvec);
   if (w.status) hipFree(w.status);
+  if (w.panel_stream) hipStreamDestroy(w.panel_stream);
+  if (w.ev_panel) hipEventDestroy(w.ev_panel);
+  if (w.ev_strip) hipEventDestroy(w.ev_strip);
   w = LdltWorkspace();
 }
 
 // Factor rows [0, n_fact) of the n_pad x n_pad matrix S (ld = n_pad). Columns up to n_pad take part
 // in the panel solves / updates, so a right-hand side stored in a trailing column is forward-
 // substituted and scaled on the fly (it ends up holding D^-1 L^-1 b).
+//
+// Look-ahead: the trailing update of panel k is issued in two launches on the main stream -- first
+// the two tile rows that form panel k+1, then the rest.  As soon as the first part is done the
+// (latency-bound, few-workgroup) factorisation of panel k+1 starts on a high-priority side stream
+// and runs underneath the bulk of the update, which keeps the MFMA pipes busy.
+static int factor_panel(double* S, int ld, int k0, int nb, double* Xk, LdltWorkspace& w, hipStream_t s) {
+  const int n_pad = ld;
+  for (int j0 = k0; j0 < k0 + nb; j0 += kInner) {
+    hipLaunchKernelGGL(k_ldlt_diag<kInner>, dim3(1), dim3(256), 0, s, S, ld, j0, w.dvec, w.invLt, w.status);
+    const int c0 = j0 + kInner;  // first column right of the diagonal block
+    if (c0 >= n_pad) continue;
+    // X[p][i] = sum_q invLt[q][p] * S[j0+q][i],  i in [c0, n_pad);  L = X / d written in place
+    GemmArgs g{};
+    g.A = w.invLt + (size_t)(j0 / kInner) * kInner * kInner; g.lda = kInner;
+    g.B = S + (size_t)j0 * ld; g.ldb = ld; g.K = kInner;
+    g.C = Xk + (size_t)(j0 - k0) * n_pad; g.ldc = n_pad; g.Cin = nullptr; g.ldcin = 0;
+    g.m_tiles = 1; g.m_off = 0;
+    g.upper = 0; g.diag = 0;
+    g.rowscale_inv = w.dvec + j0;
+    g.C2 = S + (size_t)j0 * ld; g.ldc2 = ld;
+    int head = c0;
+    if (head % 128 != 0) {  // unaligned 64-column head [c0, c0+64)
+      GemmArgs h = g;
+      h.n_tiles = 1; h.n_off = head;
+      int rc = launch_gemm<64, 64, 32, 32, false>(h, s);
+      if (rc) return rc;
+      head += 64;
+    }
+    if (head < n_pad) {
+      g.n_tiles = (n_pad - head) / 128; g.n_off = head;
+      int rc = launch_gemm<64, 128, 32, 64, false>(g, s);
+      if (rc) return rc;
+    }
+    // intra-panel update: rows m in [c0, k0+nb), cols n >= m:  S[m][n] -= sum_p L[p][m] X[p][n]
+    if (c0 < k0 + nb) {
+      GemmArgs u{};
+      u.A = S + (size_t)j0 * ld; u.lda = ld;       // L values just written (rows j0..j0+63)
+      u.B = Xk + (size_t)(j0 - k0) * n_pad; u.ldb = n_pad; u.K = kInner;
+      u.C = S; u.ldc = ld; u.Cin = S; u.ldcin = ld;
+      u.m_off = c0; u.m_tiles = (k0 + nb - c0) / 64;
+      u.n_off = c0; u.n_tiles = (n_pad - c0) / 64;
+      u.upper = 1; u.diag = 0;
+      int rc = launch_gemm<64, 64, 32, 32, true>(u, s);
+      if (rc) return rc;
+    }
+  }
+  return CBA_OK;
+}
+
 int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, GemmStats* st) {
   const int n_pad = ld;
-  for (int k0 = 0; k0 < n_fact; k0 += kPanel) {
+  hipStream_t s2 = w.panel_stream;
+  // the side stream may start once everything queued on the main stream so far (assembly of S) is done
+  CBA_HIP(hipEventRecord(w.ev_strip, s));
+  CBA_HIP(hipStreamWaitEvent(s2, w.ev_strip, 0));
+  int kidx = 0;
+  for (int k0 = 0; k0 < n_fact; k0 += kPanel, ++kidx) {
     const int nb = (n_fact - k0 < kPanel) ? (n_fact - k0) : kPanel;
-    for (int j0 = k0; j0 < k0 + nb; j0 += kInner) {
-      hipLaunchKernelGGL(k_ldlt_diag, dim3(1), dim3(256), 0, s, S, ld, j0, w.dvec, w.invLt, w.status);
-      const int c0 = j0 + kInner;  // first column right of the diagonal block
-      if (c0 < n_pad) {
-        // X[p][i] = sum_q invLt[q][p] * S[j0+q][i],  i in [c0, n_pad);  L = X / d written in place
-        GemmArgs g{};
-        g.A = w.invLt + (size_t)(j0 / kInner) * kInner * kInner; g.lda = kInner;
-        g.B = S + (size_t)j0 * ld; g.ldb = ld; g.K = kInner;
-        g.C = w.X + (size_t)(j0 - k0) * n_pad; g.ldc = n_pad; g.Cin = nullptr; g.ldcin = 0;
-        g.m_tiles = 1; g.m_off = 0;
-        // column tiles of 128 starting at the tile that contains c0 (columns < c0 inside it are
-        // recomputed into X only; C2 must not touch them) -> start exactly at c0 when aligned,
-        // otherwise handle the unaligned head with a 64-wide call.
-        g.upper = 0; g.diag = 0;
-        g.rowscale_inv = w.dvec + j0;
-        g.C2 = S + (size_t)j0 * ld; g.ldc2 = ld;
-        int head = c0;
-        if (head % 128 != 0) {
-          // 64-column head [c0, c0+64)
-          GemmArgs h = g;
-          h.n_tiles = 1; h.n_off = head;
-          int rc = launch_gemm<64, 64, 32, 32, false>(h, s);
-          if (rc) return rc;
-          head += 64;
-        }
-        if (head < n_pad) {
-          g.n_tiles = (n_pad - head) / 128; g.n_off = head;
-          int rc = launch_gemm<64, 128, 32, 64, false>(g, s);
-          if (rc) return rc;
-        }
-        // intra-panel update: rows m in [c0, k0+nb), cols n >= m:  S[m][n] -= sum_p L[p][m] X[p][n]
-        if (c0 < k0 + nb) {
-          GemmArgs u{};
-          u.A = S + (size_t)j0 * ld; u.lda = ld;       // L values just written (rows j0..j0+63)
-          u.B = w.X + (size_t)(j0 - k0) * n_pad; u.ldb = n_pad; u.K = kInner;
-          u.C = S; u.ldc = ld; u.Cin = S; u.ldcin = ld;
-          u.m_off = c0; u.m_tiles = (k0 + nb - c0) / 64;
-          u.n_off = c0; u.n_tiles = (n_pad - c0) / 64;
-          u.upper = 1; u.diag = 0;
-          int rc = launch_gemm<64, 64, 32, 32, true>(u, s);
-          if (rc) return rc;
-        }
-      }
-    }
+    double* Xk = w.X + (size_t)(kidx & 1) * kPanel * n_pad;
+    int rc = factor_panel(S, ld, k0, nb, Xk, w, s2);
+    if (rc) return rc;
+    CBA_HIP(hipEventRecord(w.ev_panel, s2));
+    CBA_HIP(hipStreamWaitEvent(s, w.ev_panel, 0));
     // trailing update with the whole panel
     const int r0 = k0 + nb;
     if (r0 < n_pad) {
       GemmArgs u{};
       u.A = S + (size_t)k0 * ld; u.lda = ld;
-      u.B = w.X; u.ldb = n_pad; u.K = nb;
+      u.B = Xk; u.ldb = n_pad; u.K = nb;
       u.C = S; u.ldc = ld; u.Cin = S; u.ldcin = ld;
       u.upper = 1; u.diag = 0;
-      int rc;
       if (r0 % 128 == 0) {
-        u.m_off = r0; u.m_tiles = (n_pad - r0) / 128; u.n_off = r0; u.n_tiles = (n_pad - r0) / 128;
+        const int mt = (n_pad - r0) / 128;
+        const int head_tiles = mt < kPanel / 128 ? mt : kPanel / 128;   // tile rows of the next panel
+        u.n_off = r0; u.n_tiles = mt;
+        u.m_off = r0; u.m_tiles = head_tiles;
         rc = launch_gemm<128, 128, 64, 64, true>(u, s);
+        if (rc) return rc;
+        CBA_HIP(hipEventRecord(w.ev_strip, s));
+        CBA_HIP(hipStreamWaitEvent(s2, w.ev_strip, 0));
+        if (mt > head_tiles) {
+          u.m_off = r0 + head_tiles * 128; u.m_tiles = mt - head_tiles;
+          rc = launch_gemm<128, 128, 64, 64, true>(u, s);
+          if (rc) return rc;
+        }
       } else {
         u.m_off = r0; u.m_tiles = (n_pad - r0) / 64; u.n_off = r0; u.n_tiles = (n_pad - r0) / 64;
         rc = launch_gemm<64, 64, 32, 32, true>(u, s);
+        if (rc) return rc;
+        CBA_HIP(hipEventRecord(w.ev_strip, s));
+        CBA_HIP(hipStreamWaitEvent(s2, w.ev_strip, 0));
       }
-      if (rc) return rc;
       if (st) {
         double rows = (double)(n_pad - r0);
         st->flops += rows * rows * nb;  // 2 * (rows^2 / 2) * nb

@@ -1,0 +1,77 @@
+// Developer harness (not shipped): times the linear-algebra kernels of the engine in isolation.
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -mllvm -amdgpu-mfma-vgpr-form tools/bench_linalg.hip -o tools/bin/bench_linalg
+#include "../camera_calibration_amd/csrc/kernels_linalg.hip"
+#include <cstdio>
+#include <vector>
+#include <cmath>
+namespace cba { void set_error(const std::string& m) { fprintf(stderr, "error: %s\n", m.c_str()); } }
+using namespace cba;
+namespace cba {
+int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const double* Cin, double* C, int n_pad, int ld, int n_real, int add_diag, double lambda, hipStream_t s);
+int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWorkspace& w, double* x, hipStream_t s);
+}
+static float timeit(hipEvent_t e0, hipEvent_t e1) { float ms; hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); return ms; }
+int main(int argc, char** argv) {
+  int n = argc > 1 ? atoi(argv[1]) : 12544;
+  int K = argc > 2 ? atoi(argv[2]) : 3008;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  // SPD matrix S = G^T G / K + I built on the device with the Schur GEMM itself
+  double *A, *S, *H;
+  hipMalloc(&A, sizeof(double) * (size_t)K * n); hipMalloc(&S, sizeof(double) * (size_t)n * n); hipMalloc(&H, sizeof(double) * (size_t)n * n);
+  std::vector<double> hA((size_t)K * n);
+  for (size_t i = 0; i < hA.size(); ++i) hA[i] = ((double)((i * 2654435761u) % 2001) / 1000.0 - 1.0) * 0.05;
+  hipMemcpy(A, hA.data(), hA.size() * 8, hipMemcpyHostToDevice);
+  hipMemset(H, 0, sizeof(double) * (size_t)n * n);
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0);
+    schur_gemm(A, A, K, n, H, S, n, n, n - 1, 1, -1.0 * K * 0.001, nullptr);  // S = -lambda' I - A^T A  (negative definite: fine for LDL^T)
+    hipEventRecord(e1);
+    float ms = timeit(e0, e1);
+    double nt = n / 128.0, tiles = nt * (nt + 1) / 2;
+    printf("schur_gemm n=%d K=%d: %.3f ms  %.2f TFLOP/s\n", n, K, ms, tiles * 2.0 * 128 * 128 * K / ms / 1e9);
+  }
+  LdltWorkspace w; ldlt_workspace_alloc(w, n);
+  hipMemset(w.status, 0, 4);
+  // diag kernel alone, 200 launches on the first block of a scratch copy
+  double* T; hipMalloc(&T, sizeof(double) * (size_t)64 * n);
+  hipMemcpy(T, S, sizeof(double) * (size_t)64 * n, hipMemcpyDeviceToDevice);
+  hipEventRecord(e0);
+  for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(k_ldlt_diag<64>, dim3(1), dim3(256), 0, 0, T, n, 0, w.dvec, w.invLt, w.status);
+  hipEventRecord(e1);
+  printf("k_ldlt_diag<64>: %.2f us per launch (200 back-to-back)\n", timeit(e0, e1) * 1000 / 200);
+  hipEventRecord(e0);
+  for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(k_ldlt_diag<0>, dim3(1), dim3(256), 0, 0, T, n, 0, w.dvec, w.invLt, w.status);
+  hipEventRecord(e1);
+  printf("k_ldlt_diag<0> (load/store only): %.2f us per launch\n", timeit(e0, e1) * 1000 / 200);
+#define TIME_DIAG(NS) \
+  hipMemcpy(T, S, sizeof(double) * (size_t)64 * n, hipMemcpyDeviceToDevice); \
+  hipEventRecord(e0); \
+  for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(k_ldlt_diag<NS>, dim3(1), dim3(256), 0, 0, T, n, 0, w.dvec, w.invLt, w.status); \
+  hipEventRecord(e1); \
+  printf("k_ldlt_diag<%d>: %.2f us per launch\n", NS, timeit(e0, e1) * 1000 / 200);
+  TIME_DIAG(8) TIME_DIAG(16) TIME_DIAG(17) TIME_DIAG(24) TIME_DIAG(32) TIME_DIAG(48) TIME_DIAG(64)
+  hipEventRecord(e0);
+  for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(k_ldlt_diag<64>, dim3(256), dim3(256), 0, 0, T, n, 0, w.dvec, w.invLt, w.status);
+  hipEventRecord(e1);
+  printf("k_ldlt_diag<64> x256 blocks (same data, clock test): %.2f us per launch\n", timeit(e0, e1) * 1000 / 200);
+  int n_fact = n - 128;
+  for (int rep = 0; rep < 2; ++rep) {
+    schur_gemm(A, A, K, n, H, S, n, n, n - 1, 1, -1.0 * K * 0.001, nullptr);
+    hipDeviceSynchronize();
+    GemmStats gs;
+    hipEventRecord(e0);
+    ldlt_factor(S, n_fact, n, w, nullptr, &gs);
+    hipEventRecord(e1);
+    float ms = timeit(e0, e1);
+    printf("ldlt_factor n_fact=%d: %.3f ms  (trailing %.3f TFLOP -> %.2f TFLOP/s overall)\n", n_fact, ms, gs.flops / 1e12, gs.flops / ms / 1e9);
+    double* x; hipMalloc(&x, sizeof(double) * n);
+    hipEventRecord(e0);
+    ldlt_back_solve(S, n_fact, n, n - 1, w, x, nullptr);
+    hipEventRecord(e1);
+    printf("ldlt_back_solve: %.3f ms\n", timeit(e0, e1));
+    hipFree(x);
+  }
+  int st; hipMemcpy(&st, w.status, 4, hipMemcpyDeviceToHost);
+  printf("status %d\n", st);
+  return 0;
+}
