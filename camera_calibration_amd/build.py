@@ -57,5 +57,23 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+HOST_DIR = os.path.join(HERE, "host")
+HOST_LIB = os.path.join(HERE, "libcalib_ba_host.so")
+HOST_SOURCES = ["joint_optimization_hip.cc", "host_test_shim.cc"]
+HOST_HEADERS = ["vis_types.h", "camera_model.h", "dataset.h", "joint_optimization.h"]
+
+
+def build_host(force: bool = False) -> str:
+    """C++ host adapter (reference API mirror) linked against libcalib_ba_hip.so."""
+    deps = [os.path.join(HOST_DIR, f) for f in HOST_SOURCES + HOST_HEADERS] + [LIB]
+    if not force and os.path.exists(HOST_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB) for d in deps):
+        return HOST_LIB
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", HOST_LIB,
+           *[os.path.join(HOST_DIR, f) for f in HOST_SOURCES], "-L" + HERE, "-lcalib_ba_hip", "-Wl,-rpath,$ORIGIN"]
+    subprocess.check_call(cmd)
+    return HOST_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv))

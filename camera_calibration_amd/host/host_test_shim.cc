@@ -1,0 +1,81 @@
+// extern "C" shim used by the tests to drive the C++ host adapter from Python: builds Dataset / BAState /
+// CameraModel objects from packed arrays, calls vis::OptimizeJointly with the reference's signature
+// (as APP/test/util.h:452-469 does) and copies the result back.
+#include "joint_optimization.h"
+
+using namespace vis;
+
+extern "C" int cba_host_optimize_jointly(
+    int n_cameras, const cba_camera* cams, const double* const* grids_in, double* const* grids_out,
+    int n_imagesets_total, const uint8_t* image_used, double* rig_tr_global /*7 per imageset (all, used or not)*/,
+    double* camera_tr_rig, int n_points, double* points,
+    int64_t n_obs, const float* xy, const int32_t* point_index, const int32_t* imageset_index /*original*/, const int32_t* camera_index,
+    int max_iteration_count, double init_lambda, double numerical_diff_delta, int localize_only, int eliminate_points,
+    double* final_cost, double* final_lambda, int* performed_an_iteration, double* last_projection_out) {
+  Dataset dataset(n_cameras);
+  BAState state;
+  for (int c = 0; c < n_cameras; ++c) {
+    const cba_camera& k = cams[c];
+    dataset.SetImageSize(c, Vec2i(k.width, k.height));
+    std::shared_ptr<CameraModel> m;
+    if (k.model_type == CBA_CENTRAL_GENERIC)
+      m.reset(new CentralGenericModel(k.grid_w, k.grid_h, k.calib_min_x, k.calib_min_y, k.calib_max_x, k.calib_max_y, k.width, k.height));
+    else
+      m.reset(new NoncentralGenericModel(k.grid_w, k.grid_h, k.calib_min_x, k.calib_min_y, k.calib_max_x, k.calib_max_y, k.width, k.height));
+    m->set_abi_grid(grids_in[c]);
+    state.intrinsics.push_back(m);
+    const double* p = camera_tr_rig + 7 * c;
+    state.camera_tr_rig.push_back(SE3d(Quaterniond(p[0], p[1], p[2], p[3]), Vec3d(p[4], p[5], p[6])));
+  }
+  for (int i = 0; i < n_imagesets_total; ++i) {
+    dataset.NewImageset();
+    const double* p = rig_tr_global + 7 * (size_t)i;
+    state.rig_tr_global.push_back(SE3d(Quaterniond(p[0], p[1], p[2], p[3]), Vec3d(p[4], p[5], p[6])));
+    state.image_used.push_back(image_used[i] != 0);
+  }
+  for (int p = 0; p < n_points; ++p) {
+    state.points.push_back(Vec3d(points[3 * p], points[3 * p + 1], points[3 * p + 2]));
+    state.feature_id_to_points_index[1000 + p] = p;   // feature id -> point index
+  }
+  std::vector<PointFeature*> order;
+  for (int64_t o = 0; o < n_obs; ++o) {
+    auto& feats = dataset.GetImageset(imageset_index[o])->FeaturesOfCamera(camera_index[o]);
+    feats.emplace_back(Vec2f(xy[2 * o], xy[2 * o + 1]), 1000 + point_index[o]);
+  }
+  state.ComputeFeatureIdToPointsIndex(&dataset);
+  bool performed = false;
+  double lam = init_lambda;
+  double cost = OptimizeJointly(dataset, &state, max_iteration_count, init_lambda, numerical_diff_delta, /*regularization_weight*/ 0,
+                                localize_only != 0, eliminate_points != 0, SchurMode::Dense, &lam, &performed,
+                                /*debug_verify_cost*/ true, false, false, false, false, /*print_progress*/ false);
+  *final_cost = cost; *final_lambda = lam; *performed_an_iteration = performed ? 1 : 0;
+  for (int c = 0; c < n_cameras; ++c) {
+    std::vector<double> g = state.intrinsics[c]->abi_grid();
+    for (size_t i = 0; i < g.size(); ++i) grids_out[c][i] = g[i];
+    const Quaterniond& q = state.camera_tr_rig[c].unit_quaternion();
+    double* p = camera_tr_rig + 7 * c;
+    p[0] = q.w(); p[1] = q.x(); p[2] = q.y(); p[3] = q.z();
+    for (int k = 0; k < 3; ++k) p[4 + k] = state.camera_tr_rig[c].translation().v[k];
+  }
+  for (int i = 0; i < n_imagesets_total; ++i) {
+    const Quaterniond& q = state.rig_tr_global[i].unit_quaternion();
+    double* p = rig_tr_global + 7 * (size_t)i;
+    p[0] = q.w(); p[1] = q.x(); p[2] = q.y(); p[3] = q.z();
+    for (int k = 0; k < 3; ++k) p[4 + k] = state.rig_tr_global[i].translation().v[k];
+  }
+  for (int p = 0; p < n_points; ++p) for (int k = 0; k < 3; ++k) points[3 * p + k] = state.points[p].v[k];
+  if (last_projection_out) {
+    // same traversal order as the input arrays were appended in (per imageset/camera feature vectors keep input order)
+    std::vector<size_t> cursor((size_t)n_imagesets_total * n_cameras, 0);
+    for (int64_t o = 0; o < n_obs; ++o) {
+      size_t key = (size_t)imageset_index[o] * n_cameras + camera_index[o];
+      const PointFeature& f = dataset.GetImageset(imageset_index[o])->FeaturesOfCamera(camera_index[o])[cursor[key]++];
+      last_projection_out[2 * o] = f.last_projection.x(); last_projection_out[2 * o + 1] = f.last_projection.y();
+    }
+  }
+  // a model-level call through the mirrored CameraModel API
+  Vec2d px;
+  Vec3d probe = state.camera_tr_rig[0] * (state.rig_tr_global[0] * state.points[0]);
+  (void)state.intrinsics[0]->Project(probe, &px);
+  return 0;
+}

@@ -1,0 +1,99 @@
+"""world_size-2 test of the image-sharded Gauss-Newton step on CPU (gloo backend).
+
+The device path (cba_step with an all-reduce callback) cannot run here (no GPU), so each rank builds
+its shard's normal equations with the oracle and goes through exactly the exchange the engine does:
+one all-reduce of [partial reduced matrix | partial right-hand side], lambda added once after the
+reduction, 8-double scalar all-reduces for the cost bookkeeping, replicated solve, local pose
+back-substitution.  The result must equal the single-process oracle step.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+
+from camera_calibration_amd import distributed as dist_mod  # noqa: E402
+from camera_calibration_amd import synthetic as syn  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_project(cam, grid, pts):
+    return orc.project(cam, grid, pts)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pb, st, _ = syn.reference_test_problem(2, _oracle_project, seed=21, num_points=40, num_poses=12)
+    shards = dist_mod.shard_images(np.bincount(pb.obs_image, minlength=pb.n_images), world)
+    b, e = shards[rank]
+    sub, sst = pb.image_slice(b, e), st.image_slice(b, e)
+    op = orc.OracleProblem(sub)
+    sysm = op.new_system()
+    cost, vec, _ = op.jacobian_pass(sst, sysm)
+    # scalar all-reduce #1: cost, valid count, diagonal sum for the automatic lambda (lm_optimizer.h:766-781)
+    dsum = sum(np.trace(B) for B in sysm.block_diag_H) + np.trace(sysm.dense_H)
+    scal = torch.tensor([cost, float((vec >= 0).sum()), dsum], dtype=torch.float64)
+    dist.all_reduce(scal)
+    total_dof = 6 * pb.n_images + pb.dense_dof
+    lam = 1e-5 * scal[2].item() / total_dof
+    # the one big exchange: [S_partial (upper) | s_partial]
+    S, s, W, Db = dist_mod.local_reduced_system(sysm.block_diag_H, sysm.off_diag_H, sysm.dense_H,
+                                                sysm.block_diag_b, sysm.dense_b, lam)
+    buf = torch.from_numpy(np.concatenate([S.ravel(), s]))
+    dist.all_reduce(buf)
+    D = pb.dense_dof
+    xd = dist_mod.solve_reduced(buf[:D * D].numpy().reshape(D, D), buf[D * D:].numpy(), lam)
+    xb = Db - W @ xd   # local pose back-substitution
+    # candidate state of the shard, cost-only pass, masked sums (CostIsSmallerThan) all-reduced
+    x_local = np.concatenate([xb, xd])
+    cand = op.apply_update(sst, x_local)
+    c2, v2 = op.cost_pass(cand)
+    both = (vec >= 0) & (v2 >= 0)
+    red = torch.tensor([vec[both].sum(), v2[both].sum(), float(both.sum()), c2], dtype=torch.float64)
+    dist.all_reduce(red)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), b=b, e=e, xb=xb, xd=xd, lam=lam, cost=scal[0].item(),
+             red=red.numpy(), poses=cand.rig_tr_global, points=cand.points)
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_step_equals_single_process(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    pb, st, _ = syn.reference_test_problem(2, _oracle_project, seed=21, num_points=40, num_poses=12)
+    op = orc.OracleProblem(pb)
+    sysm = op.new_system()
+    cost, vec, _ = op.jacobian_pass(st, sysm)
+    lam = 1e-5 * (sum(np.trace(B) for B in sysm.block_diag_H) + np.trace(sysm.dense_H)) / pb.total_dof
+    sysm.add_lambda(lam)
+    x_ref = orc.schur_solve(sysm)
+    cand = op.apply_update(st, x_ref)
+    c2, v2 = op.cost_pass(cand)
+    both = (vec >= 0) & (v2 >= 0)
+    r = [np.load(os.path.join(str(tmp_path), f"rank{k}.npz")) for k in range(world)]
+    assert r[0]["b"] == 0 and r[-1]["e"] == pb.n_images and r[0]["e"] == r[1]["b"]
+    scale = np.abs(x_ref).max()
+    for k in range(world):
+        assert abs(r[k]["lam"] - lam) <= 1e-12 * lam
+        assert abs(r[k]["cost"] - cost) <= 1e-10 * cost
+        np.testing.assert_allclose(r[k]["xd"], x_ref[pb.block_dof:], rtol=1e-7, atol=1e-9 * scale)
+        np.testing.assert_allclose(r[k]["xb"], x_ref[6 * int(r[k]["b"]):6 * int(r[k]["e"])], rtol=1e-7, atol=1e-9 * scale)
+        # identical accept/reject inputs on every rank
+        np.testing.assert_allclose(r[k]["red"], [vec[both].sum(), v2[both].sum(), both.sum(), c2], rtol=1e-6)
+        np.testing.assert_allclose(r[k]["poses"], cand.rig_tr_global[int(r[k]["b"]):int(r[k]["e"])], atol=1e-9)
+        np.testing.assert_allclose(r[k]["points"], cand.points, atol=1e-9)
+    np.testing.assert_array_equal(r[0]["xd"], r[1]["xd"])   # replicated solve is bit-identical

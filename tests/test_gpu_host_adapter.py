@@ -1,0 +1,83 @@
+"""GPU test of the C++ host adapter (camera_calibration_amd/host): vis::OptimizeJointly with the
+reference's signature over mirrored Dataset / BAState / CameraModel objects, driven through an
+extern "C" shim.  One imageset is marked unused (BAState::image_used) to exercise the sequential
+re-indexing of joint_optimization.cc:80-90."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from camera_calibration_amd import engine as eng
+from camera_calibration_amd import synthetic as syn
+from camera_calibration_amd.problem import Problem, State
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_project(cam, grid, pts):
+    return orc.project(cam, grid, pts)
+
+
+def _host_lib():
+    eng.load()
+    path = os.path.join(os.path.dirname(eng.LIB_PATH), "libcalib_ba_host.so")
+    L = C.CDLL(path)
+    dp = C.POINTER(C.c_double)
+    L.cba_host_optimize_jointly.argtypes = [
+        C.c_int, C.POINTER(eng.CbaCamera), C.POINTER(dp), C.POINTER(dp), C.c_int, C.POINTER(C.c_uint8), dp, dp, C.c_int, dp,
+        C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+        C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, dp, dp, C.POINTER(C.c_int), dp]
+    return L
+
+
+@pytest.mark.parametrize("num_cameras", [1, 2])
+def test_cpp_optimize_jointly_matches_engine_and_oracle(num_cameras):
+    pb, st0, _ = syn.reference_test_problem(num_cameras, oracle_project, seed=13, num_points=50, num_poses=16)
+    unused = 5
+    image_used = np.ones(pb.n_images, dtype=np.uint8)
+    image_used[unused] = 0
+    # reference semantics: the unused imageset keeps its features in the Dataset but is skipped
+    keep = pb.obs_image != unused
+    seq = np.cumsum(image_used) - 1
+    sub = Problem(pb.cameras, pb.n_images - 1, pb.n_points, pb.obs_xy[keep], pb.obs_point[keep],
+                  seq[pb.obs_image[keep]].astype(np.int32), pb.obs_camera[keep], pb.fd_delta)
+    sub_st = State(st0.rig_tr_global[image_used.astype(bool)], st0.camera_tr_rig, st0.points, st0.grids)
+    iters = 3
+    # oracle
+    op = orc.OracleProblem(sub)
+    st_ref = sub_st.copy()
+    lam = -1.0
+    for _ in range(iters):
+        r = op.optimize_jointly(st_ref, 1, lam); lam = r["final_lambda"]
+    # C++ adapter
+    L = _host_lib()
+    cams = (eng.CbaCamera * pb.n_cameras)(*[eng._cam_struct(c) for c in pb.cameras])
+    dp = C.POINTER(C.c_double)
+    g_in = [np.ascontiguousarray(g) for g in st0.grids]
+    g_out = [np.zeros_like(g) for g in g_in]
+    gi = (dp * pb.n_cameras)(*[g.ctypes.data_as(dp) for g in g_in])
+    go = (dp * pb.n_cameras)(*[g.ctypes.data_as(dp) for g in g_out])
+    rig = st0.rig_tr_global.copy(); camrig = st0.camera_tr_rig.copy(); pts = st0.points.copy()
+    cost, flam, performed = C.c_double(0), C.c_double(0), C.c_int(0)
+    lastp = np.zeros((pb.n_obs, 2))
+    rc = L.cba_host_optimize_jointly(
+        pb.n_cameras, cams, gi, go, pb.n_images, image_used.ctypes.data_as(C.POINTER(C.c_uint8)), rig.ctypes.data_as(dp),
+        camrig.ctypes.data_as(dp), pb.n_points, pts.ctypes.data_as(dp), pb.n_obs, pb.obs_xy.ctypes.data_as(C.POINTER(C.c_float)),
+        pb.obs_point.ctypes.data_as(C.POINTER(C.c_int32)), pb.obs_image.ctypes.data_as(C.POINTER(C.c_int32)),
+        pb.obs_camera.ctypes.data_as(C.POINTER(C.c_int32)), iters, -1.0, pb.fd_delta, 0, 0,
+        C.byref(cost), C.byref(flam), C.byref(performed), lastp.ctypes.data_as(dp))
+    assert rc == 0 and performed.value == 1
+    assert abs(cost.value - r["cost"]) <= 1e-5 * abs(r["cost"]) + 1e-9
+    assert abs(flam.value - lam) <= 1e-6 * lam
+    # unused imageset untouched, used ones updated like the oracle's
+    np.testing.assert_array_equal(rig[unused], st0.rig_tr_global[unused])
+    np.testing.assert_allclose(rig[image_used.astype(bool)], st_ref.rig_tr_global, atol=1e-6)
+    np.testing.assert_allclose(pts, st_ref.points, atol=1e-6)
+    np.testing.assert_allclose(camrig, st_ref.camera_tr_rig, atol=1e-6)
+    for a, b in zip(g_out, st_ref.grids):
+        np.testing.assert_allclose(a, b, atol=1e-6)
+    # warm-start cache written back for used imagesets only
+    assert np.all(lastp[~keep] == 0)
+    np.testing.assert_allclose(lastp[keep], op.last_projection, atol=1e-6)
