@@ -143,6 +143,7 @@ struct GemmArgs {
   int ldc2;
   const double* rowscale_inv;   // d values: C2 = value / d[m]
   long long total_tiles;
+  int epi_mode;                 // developer switch (bench harness): 0 normal, 1 no Cin read, 2 no store
 };
 
 template <int TM, int TN, int WM, int WN, bool SUB>
@@ -183,11 +184,32 @@ __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
   const int wm0 = (wv / WAVES_N) * WM, wn0 = (wv % WAVES_N) * WN;
   const int li = lane & 15, lk = lane >> 4;
 
+  // SUB: the accumulators start as -(Cin + diag) so that the read of the C tile overlaps the first
+  // operand slab (and the co-resident workgroup's MFMAs) instead of sitting in the epilogue; the
+  // result is C = -acc.  (Measured: the epilogue read cost 0.44 ms per 1.2 GB trailing update.)
   v4f64 acc[MI][NJ];
+  if (SUB && g.epi_mode != 1) {
+    double dadd0 = 0.0;
+    if (g.diag) dadd0 = g.diag_add_ptr ? *g.diag_add_ptr : g.diag_add;
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + wm0 + i * 16 + lk + 4 * r;
+          const int n = n0 + wn0 + j * 16 + li;
+          double cin = g.Cin[(size_t)m * g.ldcin + n];
+          if (g.diag && m == n) cin += (m < g.n_real) ? dadd0 : 1.0;
+          acc[i][j][r] = -cin;
+        }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  }
+
 
   const double* Ag = g.A + m0;
   const double* Bg = g.B + n0;
@@ -285,22 +307,17 @@ __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
   }
 
   // ---- epilogue ----
-  double dadd = 0.0;
-  if (g.diag) dadd = g.diag_add_ptr ? *g.diag_add_ptr : g.diag_add;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int m = m0 + wm0 + i * 16 + lk + 4 * r;
-        int n = n0 + wn0 + j * 16 + li;
+        const int m = m0 + wm0 + i * 16 + lk + 4 * r;
+        const int n = n0 + wn0 + j * 16 + li;
         double v = acc[i][j][r];
-        if (SUB) {
-          double cin = g.Cin[(size_t)m * g.ldcin + n];
-          if (g.diag && m == n) cin += (m < g.n_real) ? dadd : 1.0;
-          v = cin - v;
-        }
+        if (g.epi_mode == 2) { if (v == 1.2345e300) g.C[(size_t)m * g.ldc + n] = v; continue; }
+        if (SUB) v = -v;
         g.C[(size_t)m * g.ldc + n] = v;
         if (g.C2) g.C2[(size_t)m * g.ldc2 + n] = v / g.rowscale_inv[m];
       }

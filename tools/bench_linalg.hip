@@ -30,6 +30,19 @@ int main(int argc, char** argv) {
     double nt = n / 128.0, tiles = nt * (nt + 1) / 2;
     printf("schur_gemm n=%d K=%d: %.3f ms  %.2f TFLOP/s\n", n, K, ms, tiles * 2.0 * 128 * 128 * K / ms / 1e9);
   }
+  // trailing-update shaped GEMMs (C -= A^T B, upper tiles) for several K
+  for (int mode : {0, 1, 2, 0}) for (int Kt : {16, 256, 512}) {
+    GemmArgs u{}; u.epi_mode = mode;
+    u.A = A; u.lda = n; u.B = A; u.ldb = n; u.K = Kt; u.C = S; u.ldc = n; u.Cin = S; u.ldcin = n;
+    u.m_off = 0; u.m_tiles = n / 128; u.n_off = 0; u.n_tiles = n / 128; u.upper = 1; u.diag = 0;
+    launch_gemm<128, 128, 64, 64, true>(u, nullptr);
+    hipEventRecord(e0);
+    for (int r = 0; r < 5; ++r) launch_gemm<128, 128, 64, 64, true>(u, nullptr);
+    hipEventRecord(e1);
+    float ms = timeit(e0, e1) / 5;
+    double nt = n / 128.0, tiles = nt * (nt + 1) / 2;
+    printf("trailing-shaped gemm mode=%d n=%d K=%d: %.3f ms  %.2f TFLOP/s\n", mode, n, Kt, ms, tiles * 2.0 * 128 * 128 * Kt / ms / 1e9);
+  }
   LdltWorkspace w; ldlt_workspace_alloc(w, n);
   hipMemset(w.status, 0, 4);
   // diag kernel alone, 200 launches on the first block of a scratch copy
