@@ -25,6 +25,7 @@ int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const doubl
 int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWorkspace& w, double* x, hipStream_t s);
 int launch_finish_diag(double* S, int ld, int n_real, int n_pad, double lambda, hipStream_t s);
 int launch_diag_sum(const double* Dblk, int bs, int nb, const double* Hdd, int ld, int dd, double* out, hipStream_t s);
+int make_main_stream(hipStream_t* s);
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static double now_s() {
@@ -318,7 +319,7 @@ int cba_create(const cba_config* config, cba_problem** out) {
   make_layout(p->cfg, p->L);
   const Layout& L = p->L;
   if (L.total_dof <= 0) { delete p; set_error("empty problem"); return CBA_ERR_ARG; }
-  CBA_HIP(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  CBA_TRY(make_main_stream(&p->stream));
   for (int c = 0; c < L.n_cameras; ++c) p->model_mask |= (p->cams[c].model_type == CBA_CENTRAL_GENERIC) ? 1 : 2;
   const int maxKg = L.localize_only ? 0 : ((p->model_mask & 2) ? 80 : 32);
   p->tasks_per_obs = 3 + maxKg;

@@ -13,6 +13,8 @@
 // which feeds v_mfma_f64_16x16x4_f64 directly from LDS rows.
 // Leading dimensions are padded to multiples of 128 and K to multiples of 16 so the hot loops carry
 // no bounds checks; padded diagonal entries are set to 1.
+#include <cstdlib>
+
 #include "cba_internal.h"
 
 namespace cba {
@@ -495,17 +497,59 @@ __global__ void __launch_bounds__(256) k_ldlt_diag(double* __restrict__ M, int l
     }
 }
 
+int panel_cu_count() {
+  static int n = -1;
+  if (n < 0) {
+    const char* e = getenv("CBA_PANEL_CUS");
+    n = e ? atoi(e) : 8;
+    if (n < 0 || n > 128) n = 8;
+  }
+  return n;
+}
+void panel_cu_mask(uint32_t* mask8, bool panel) {
+  const int n = panel_cu_count();
+  for (int i = 0; i < 8; ++i) mask8[i] = 0;
+  for (int bit = 0; bit < 256; ++bit) {
+    bool is_panel = bit < n;
+    if (is_panel == panel) mask8[bit >> 5] |= (1u << (bit & 31));
+  }
+}
+int make_main_stream(hipStream_t* s) {
+  if (panel_cu_count() > 0) {
+    uint32_t mask[8];
+    panel_cu_mask(mask, /*panel=*/false);
+    CBA_HIP(hipExtStreamCreateWithCUMask(s, 8, mask));
+  } else {
+    CBA_HIP(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+  }
+  return CBA_OK;
+}
+
 int ldlt_workspace_alloc(LdltWorkspace& w, int n_pad) {
   ldlt_workspace_free(w);
   CBA_HIP(hipMalloc(&w.X, sizeof(double) * 2 * (size_t)kPanel * n_pad));   // two panel buffers (look-ahead)
   CBA_HIP(hipMalloc(&w.invLt, sizeof(double) * (size_t)(n_pad / kInner) * kInner * kInner));
   CBA_HIP(hipMalloc(&w.dvec, sizeof(double) * (size_t)n_pad));
   CBA_HIP(hipMalloc(&w.status, sizeof(int)));
-  int lo = 0, hi = 0;
-  CBA_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-  CBA_HIP(hipStreamCreateWithPriority(&w.panel_stream, hipStreamNonBlocking, hi));
+  // The panel chain is latency-bound and ran ~1.5x slower when its small kernels shared CUs with the
+  // bulk GEMM, so it gets CUs of its own: CBA_PANEL_CUS compute units (default 8 = one per XCD; mask
+  // bits are interleaved over the XCDs), taken out of the main stream's mask by make_main_stream().
+  {
+    uint32_t mask[8];
+    panel_cu_mask(mask, /*panel=*/true);
+    if (panel_cu_count() > 0) {
+      CBA_HIP(hipExtStreamCreateWithCUMask(&w.panel_stream, 8, mask));
+    } else {
+      int lo = 0, hi = 0;
+      CBA_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      CBA_HIP(hipStreamCreateWithPriority(&w.panel_stream, hipStreamNonBlocking, hi));
+    }
+  }
+  CBA_HIP(hipStreamCreateWithFlags(&w.far_stream, hipStreamNonBlocking));
   CBA_HIP(hipEventCreateWithFlags(&w.ev_panel, hipEventDisableTiming));
   CBA_HIP(hipEventCreateWithFlags(&w.ev_strip, hipEventDisableTiming));
+  CBA_HIP(hipEventCreateWithFlags(&w.ev_strip2, hipEventDisableTiming));
+  CBA_HIP(hipEventCreateWithFlags(&w.ev_chain, hipEventDisableTiming));
   w.n_alloc = n_pad;
   return CBA_OK;
 }
@@ -515,8 +559,11 @@ void ldlt_workspace_free(LdltWorkspace& w) {
   if (w.dvec) hipFree(w.dvec);
   if (w.status) hipFree(w.status);
   if (w.panel_stream) hipStreamDestroy(w.panel_stream);
+  if (w.far_stream) hipStreamDestroy(w.far_stream);
   if (w.ev_panel) hipEventDestroy(w.ev_panel);
   if (w.ev_strip) hipEventDestroy(w.ev_strip);
+  if (w.ev_strip2) hipEventDestroy(w.ev_strip2);
+  if (w.ev_chain) hipEventDestroy(w.ev_chain);
   w = LdltWorkspace();
 }
 
@@ -524,96 +571,121 @@ void ldlt_workspace_free(LdltWorkspace& w) {
 // in the panel solves / updates, so a right-hand side stored in a trailing column is forward-
 // substituted and scaled on the fly (it ends up holding D^-1 L^-1 b).
 //
-// Look-ahead: the trailing update of panel k is issued in two launches on the main stream -- first
-// the two tile rows that form panel k+1, then the rest.  As soon as the first part is done the
-// (latency-bound, few-workgroup) factorisation of panel k+1 starts on a high-priority side stream
-// and runs underneath the bulk of the update, which keeps the MFMA pipes busy.
-static int factor_panel(double* S, int ld, int k0, int nb, double* Xk, LdltWorkspace& w, hipStream_t s) {
-  const int n_pad = ld;
-  for (int j0 = k0; j0 < k0 + nb; j0 += kInner) {
-    hipLaunchKernelGGL(k_ldlt_diag<kInner>, dim3(1), dim3(256), 0, s, S, ld, j0, w.dvec, w.invLt, w.status);
-    const int c0 = j0 + kInner;  // first column right of the diagonal block
-    if (c0 >= n_pad) continue;
-    // X[p][i] = sum_q invLt[q][p] * S[j0+q][i],  i in [c0, n_pad);  L = X / d written in place
-    GemmArgs g{};
-    g.A = w.invLt + (size_t)(j0 / kInner) * kInner * kInner; g.lda = kInner;
-    g.B = S + (size_t)j0 * ld; g.ldb = ld; g.K = kInner;
-    g.C = Xk + (size_t)(j0 - k0) * n_pad; g.ldc = n_pad; g.Cin = nullptr; g.ldcin = 0;
-    g.m_tiles = 1; g.m_off = 0;
-    g.upper = 0; g.diag = 0;
-    g.rowscale_inv = w.dvec + j0;
-    g.C2 = S + (size_t)j0 * ld; g.ldc2 = ld;
-    int head = c0;
-    if (head % 128 != 0) {  // unaligned 64-column head [c0, c0+64)
-      GemmArgs h = g;
-      h.n_tiles = 1; h.n_off = head;
-      int rc = launch_gemm<64, 64, 32, 32, false>(h, s);
-      if (rc) return rc;
-      head += 64;
-    }
-    if (head < n_pad) {
-      g.n_tiles = (n_pad - head) / 128; g.n_off = head;
-      int rc = launch_gemm<64, 128, 32, 64, false>(g, s);
-      if (rc) return rc;
-    }
-    // intra-panel update: rows m in [c0, k0+nb), cols n >= m:  S[m][n] -= sum_p L[p][m] X[p][n]
-    if (c0 < k0 + nb) {
-      GemmArgs u{};
-      u.A = S + (size_t)j0 * ld; u.lda = ld;       // L values just written (rows j0..j0+63)
-      u.B = Xk + (size_t)(j0 - k0) * n_pad; u.ldb = n_pad; u.K = kInner;
-      u.C = S; u.ldc = ld; u.Cin = S; u.ldcin = ld;
-      u.m_off = c0; u.m_tiles = (k0 + nb - c0) / 64;
-      u.n_off = c0; u.n_tiles = (n_pad - c0) / 64;
-      u.upper = 1; u.diag = 0;
-      int rc = launch_gemm<64, 64, 32, 32, true>(u, s);
-      if (rc) return rc;
-    }
+// Three streams:
+//   chain : the latency-bound pivot chain -- per 64-block: diagonal factor, then the solve / update
+//           restricted to the panel's own 256 columns ("near", 1-6 workgroups each);
+//   far   : the same solve / update for the columns right of the panel, which nothing in the chain
+//           waits for;
+//   main  : trailing updates with K = 256 on the MFMA GEMM, issued as (a') the next panel's diagonal
+//           tiles (releases the chain), (a'') the rest of the next panel's rows (releases far), (b) the
+//           bulk.  The next panel is factored underneath (b) (look-ahead).
+static int trsm_cols(double* S, int ld, int j0, int k0, int col_begin, int col_end, double* Xk, LdltWorkspace& w, hipStream_t s) {
+  // X[p][i] = sum_q invLt[q][p] * S[j0+q][i], i in [col_begin, col_end); L = X / d written in place
+  if (col_begin >= col_end) return CBA_OK;
+  GemmArgs g{};
+  g.A = w.invLt + (size_t)(j0 / kInner) * kInner * kInner; g.lda = kInner;
+  g.B = S + (size_t)j0 * ld; g.ldb = ld; g.K = kInner;
+  g.C = Xk + (size_t)(j0 - k0) * ld; g.ldc = ld; g.Cin = nullptr; g.ldcin = 0;
+  g.m_tiles = 1; g.m_off = 0; g.upper = 0; g.diag = 0;
+  g.rowscale_inv = w.dvec + j0;
+  g.C2 = S + (size_t)j0 * ld; g.ldc2 = ld;
+  int c = col_begin;
+  if (c % 128 != 0) {  // unaligned 64-column head
+    GemmArgs h = g; h.n_tiles = 1; h.n_off = c;
+    int rc = launch_gemm<64, 64, 32, 32, false>(h, s);
+    if (rc) return rc;
+    c += 64;
+  }
+  const int n128 = (col_end - c) / 128;
+  if (n128 > 0) {
+    GemmArgs h = g; h.n_tiles = n128; h.n_off = c;
+    int rc = launch_gemm<64, 128, 32, 64, false>(h, s);
+    if (rc) return rc;
+    c += 128 * n128;
+  }
+  if (c < col_end) {   // 64-column tail
+    GemmArgs h = g; h.n_tiles = 1; h.n_off = c;
+    int rc = launch_gemm<64, 64, 32, 32, false>(h, s);
+    if (rc) return rc;
   }
   return CBA_OK;
+}
+// S[m][n] -= sum_p L[p][m] X[p][n] for rows m in [m_begin, m_end), cols n in [n_begin, n_end) (64-tiles)
+static int update_block(double* S, int ld, int j0, int k0, int m_begin, int m_end, int n_begin, int n_end, int upper,
+                        double* Xk, hipStream_t s) {
+  if (m_begin >= m_end || n_begin >= n_end) return CBA_OK;
+  GemmArgs u{};
+  u.A = S + (size_t)j0 * ld; u.lda = ld;       // L values (rows j0..j0+63)
+  u.B = Xk + (size_t)(j0 - k0) * ld; u.ldb = ld; u.K = kInner;
+  u.C = S; u.ldc = ld; u.Cin = S; u.ldcin = ld;
+  u.m_off = m_begin; u.m_tiles = (m_end - m_begin) / 64;
+  u.n_off = n_begin; u.n_tiles = (n_end - n_begin) / 64;
+  u.upper = upper; u.diag = 0;
+  return launch_gemm<64, 64, 32, 32, true>(u, s);
 }
 
 int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, GemmStats* st) {
   const int n_pad = ld;
-  hipStream_t s2 = w.panel_stream;
-  // the side stream may start once everything queued on the main stream so far (assembly of S) is done
+  hipStream_t s2 = w.panel_stream, s3 = w.far_stream;
+  // the side streams may start once everything queued on the main stream so far (assembly of S) is done
   CBA_HIP(hipEventRecord(w.ev_strip, s));
   CBA_HIP(hipStreamWaitEvent(s2, w.ev_strip, 0));
+  CBA_HIP(hipStreamWaitEvent(s3, w.ev_strip, 0));
   int kidx = 0;
   for (int k0 = 0; k0 < n_fact; k0 += kPanel, ++kidx) {
     const int nb = (n_fact - k0 < kPanel) ? (n_fact - k0) : kPanel;
+    const int e0 = k0 + nb;   // first column right of the panel
     double* Xk = w.X + (size_t)(kidx & 1) * kPanel * n_pad;
-    int rc = factor_panel(S, ld, k0, nb, Xk, w, s2);
-    if (rc) return rc;
-    CBA_HIP(hipEventRecord(w.ev_panel, s2));
+    int rc;
+    for (int j0 = k0; j0 < e0; j0 += kInner) {
+      const int c0 = j0 + kInner;
+      // ---- chain: factor the diagonal block, near solve, near update ----
+      hipLaunchKernelGGL(k_ldlt_diag<kInner>, dim3(1), dim3(256), 0, s2, S, ld, j0, w.dvec, w.invLt, w.status);
+      if ((rc = trsm_cols(S, ld, j0, k0, c0, e0, Xk, w, s2))) return rc;
+      if ((rc = update_block(S, ld, j0, k0, c0, e0, c0, e0, /*upper*/ 1, Xk, s2))) return rc;
+      CBA_HIP(hipEventRecord(w.ev_chain, s2));
+      // ---- far: columns right of the panel ----
+      CBA_HIP(hipStreamWaitEvent(s3, w.ev_chain, 0));
+      if ((rc = trsm_cols(S, ld, j0, k0, e0, n_pad, Xk, w, s3))) return rc;
+      if ((rc = update_block(S, ld, j0, k0, c0, e0, e0, n_pad, /*upper*/ 0, Xk, s3))) return rc;
+    }
+    CBA_HIP(hipEventRecord(w.ev_panel, s3));     // far is queued behind every chain event of this panel
     CBA_HIP(hipStreamWaitEvent(s, w.ev_panel, 0));
-    // trailing update with the whole panel
-    const int r0 = k0 + nb;
+    // ---- trailing update with the whole panel (main stream) ----
+    const int r0 = e0;
     if (r0 < n_pad) {
       GemmArgs u{};
       u.A = S + (size_t)k0 * ld; u.lda = ld;
       u.B = Xk; u.ldb = n_pad; u.K = nb;
       u.C = S; u.ldc = ld; u.Cin = S; u.ldcin = ld;
-      u.upper = 1; u.diag = 0;
+      u.diag = 0;
       if (r0 % 128 == 0) {
         const int mt = (n_pad - r0) / 128;
-        const int head_tiles = mt < kPanel / 128 ? mt : kPanel / 128;   // tile rows of the next panel
-        u.n_off = r0; u.n_tiles = mt;
-        u.m_off = r0; u.m_tiles = head_tiles;
-        rc = launch_gemm<128, 128, 64, 64, true>(u, s);
-        if (rc) return rc;
+        const int head = mt < kPanel / 128 ? mt : kPanel / 128;   // tile rows of the next panel
+        // (a') diagonal tiles of the next panel -> releases the chain
+        u.upper = 1; u.m_off = r0; u.m_tiles = head; u.n_off = r0; u.n_tiles = head;
+        if ((rc = launch_gemm<128, 128, 64, 64, true>(u, s))) return rc;
         CBA_HIP(hipEventRecord(w.ev_strip, s));
         CBA_HIP(hipStreamWaitEvent(s2, w.ev_strip, 0));
-        if (mt > head_tiles) {
-          u.m_off = r0 + head_tiles * 128; u.m_tiles = mt - head_tiles;
-          rc = launch_gemm<128, 128, 64, 64, true>(u, s);
-          if (rc) return rc;
+        // (a'') rest of the next panel's rows -> releases far
+        if (mt > head) {
+          u.upper = 0; u.m_off = r0; u.m_tiles = head; u.n_off = r0 + head * 128; u.n_tiles = mt - head;
+          if ((rc = launch_gemm<128, 128, 64, 64, true>(u, s))) return rc;
+        }
+        CBA_HIP(hipEventRecord(w.ev_strip2, s));
+        CBA_HIP(hipStreamWaitEvent(s3, w.ev_strip2, 0));
+        // (b) bulk
+        if (mt > head) {
+          u.upper = 1; u.m_off = r0 + head * 128; u.m_tiles = mt - head; u.n_off = r0 + head * 128; u.n_tiles = mt - head;
+          if ((rc = launch_gemm<128, 128, 64, 64, true>(u, s))) return rc;
         }
       } else {
+        u.upper = 1;
         u.m_off = r0; u.m_tiles = (n_pad - r0) / 64; u.n_off = r0; u.n_tiles = (n_pad - r0) / 64;
-        rc = launch_gemm<64, 64, 32, 32, true>(u, s);
-        if (rc) return rc;
+        if ((rc = launch_gemm<64, 64, 32, 32, true>(u, s))) return rc;
         CBA_HIP(hipEventRecord(w.ev_strip, s));
         CBA_HIP(hipStreamWaitEvent(s2, w.ev_strip, 0));
+        CBA_HIP(hipStreamWaitEvent(s3, w.ev_strip, 0));
       }
       if (st) {
         double rows = (double)(n_pad - r0);

@@ -68,15 +68,17 @@ int main(int argc, char** argv) {
   hipEventRecord(e1);
   printf("k_ldlt_diag<64> x256 blocks (same data, clock test): %.2f us per launch\n", timeit(e0, e1) * 1000 / 200);
   int n_fact = n - 128;
+  hipStream_t ms; make_main_stream(&ms);
+  printf("panel CUs reserved: %d\n", panel_cu_count());
   for (int rep = 0; rep < 2; ++rep) {
     schur_gemm(A, A, K, n, H, S, n, n, n - 1, 1, -1.0 * K * 0.001, nullptr);
     hipDeviceSynchronize();
     GemmStats gs;
-    hipEventRecord(e0);
-    ldlt_factor(S, n_fact, n, w, nullptr, &gs);
-    hipEventRecord(e1);
-    float ms = timeit(e0, e1);
-    printf("ldlt_factor n_fact=%d: %.3f ms  (trailing %.3f TFLOP -> %.2f TFLOP/s overall)\n", n_fact, ms, gs.flops / 1e12, gs.flops / ms / 1e9);
+    hipEventRecord(e0, ms);
+    ldlt_factor(S, n_fact, n, w, ms, &gs);
+    hipEventRecord(e1, ms);
+    float ms_ = timeit(e0, e1);
+    printf("ldlt_factor n_fact=%d: %.3f ms  (trailing %.3f TFLOP -> %.2f TFLOP/s overall)\n", n_fact, ms_, gs.flops / 1e12, gs.flops / ms_ / 1e9);
     double* x; hipMalloc(&x, sizeof(double) * n);
     hipEventRecord(e0);
     ldlt_back_solve(S, n_fact, n, n - 1, w, x, nullptr);
