@@ -39,6 +39,8 @@ def parse_args():
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config id (1-5)")
     ap.add_argument("--imagesets", type=int, default=0, help="imagesets per GPU (0 = the config's count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-allreduce", action="store_true",
+                    help="exercise the multi-GPU all-reduce path even with one rank (1-GPU validation of the N>1 code)")
     ap.add_argument("--cpu-sample-images", type=int, default=6)
     return ap.parse_args()
 
@@ -102,8 +104,12 @@ def main():
         print("bench.py: no GPU available (the engine has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_allreduce
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from camera_calibration_amd import engine as eng
@@ -120,7 +126,7 @@ def main():
 
     allreduce = None
     reduce_ptr, reduce_n, keep = 0, 0, None
-    if world > 1:
+    if use_dist:
         reduce_n = eng.Engine.reduce_buffer_doubles(pb)
         keep = torch.zeros(reduce_n, dtype=torch.float64, device=f"cuda:{local_rank}")
         reduce_ptr = keep.data_ptr()
@@ -131,7 +137,7 @@ def main():
 
     n_obs_local = pb.n_obs
     n_obs_t = torch.tensor([n_obs_local], dtype=torch.float64, device=f"cuda:{local_rank}")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(n_obs_t)
     n_obs_total = int(n_obs_t.item())
 
@@ -139,7 +145,7 @@ def main():
     reports = []
     for _ in range(args.warmup):
         rep = e.step(lam); lam = rep.final_lambda
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     agg = {k: {"seconds": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0} for k in range(4)}
@@ -152,14 +158,15 @@ def main():
             for f in agg[k]:
                 agg[k][f] += s[f]
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
+    out = None
     if rank == 0:
         ms_per_step = elapsed / max(1, args.steps) * 1e3
         value = n_obs_total * args.steps / elapsed / 1e6
@@ -176,7 +183,7 @@ def main():
                                    f"{'central' if pb.cameras[0].model_type == 0 else 'non-central'}-generic "
                                    f"{pb.cameras[0].grid_w}x{pb.cameras[0].grid_h} grid, {n_img} imagesets/GPU x {world} GPU, "
                                    f"{n_obs_total} observations, reduced system D={pb.dense_dof}",
-                       "parallelism": f"image-sharded x{world}" if world > 1 else "single GPU",
+                       "parallelism": f"image-sharded x{world}" if world > 1 else ("single GPU (all-reduce path forced)" if use_dist else "single GPU"),
                        "lm_attempts_per_step": [r.lm_attempts for r in reports],
                        "cost": [reports[0].initial_cost, reports[-1].final_cost]},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -199,10 +206,17 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(pb, st0, min(args.cpu_sample_images, pb.n_images), n_obs_total, n_img)
             except Exception as ex:  # the baseline is a reported extra, never a reason to lose the line
                 out["cpu_baseline"] = {"error": repr(ex)}
-        print(json.dumps(out))
     e.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio; flush it first so the JSON line is the last line
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

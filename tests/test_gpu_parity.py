@@ -266,3 +266,63 @@ def test_python_optimize_jointly_mirror():
     assert performed and len(reports) >= 1
     assert cost < reports[0].initial_cost * 1e-3
     assert lam > 0
+
+
+def test_allreduce_callback_path_matches_plain_path():
+    """The multi-GPU code path (reduced system built without lambda, all-reduce callback, lambda added
+    after the reduction, scalar reductions) with an identity all-reduce must give the single-GPU result."""
+    pb, st0, gt = syn.reference_test_problem(2, oracle_project, seed=6, num_points=60, num_poses=20)
+    calls = []
+
+    def identity_allreduce(ptr, count):
+        calls.append(count)
+        return 0
+
+    e1 = eng.Engine(pb)
+    e2 = eng.Engine(pb, allreduce=identity_allreduce, n_images_global=pb.n_images)
+    e1.set_state(st0); e2.set_state(st0)
+    lam1 = lam2 = -1.0
+    for _ in range(3):
+        r1 = e1.step(lam1); r2 = e2.step(lam2)
+        lam1, lam2 = r1.final_lambda, r2.final_lambda
+        assert r1.accepted == r2.accepted and r1.lm_attempts == r2.lm_attempts
+        assert abs(r1.final_cost - r2.final_cost) <= 1e-6 * abs(r1.final_cost)
+        assert abs(lam1 - lam2) <= 1e-9 * lam1
+    assert max(calls) == eng.Engine.reduce_buffer_doubles(pb) and min(calls) in (1, 8)
+    s1, s2 = e1.get_state(st0), e2.get_state(st0)
+    np.testing.assert_allclose(s1.points, s2.points, atol=1e-7)
+    e1.close(); e2.close()
+
+
+def test_full_size_config2_properties():
+    """BASELINE configs[1] at full size (500 imagesets, 84x60 grid, D = 12 525): size-independent checks.
+    * the update solves the damped normal equations: both block rows of (H + lambda I) x = b have small residual;
+    * an accepted step lowers the cost on the residuals valid in both passes; masks stay consistent."""
+    proj = lambda cam, grid, pts: eng.project(cam, grid, pts)
+    pb, st0, gt = syn.baseline_config(2, proj, n_imagesets=500)
+    assert pb.dense_dof == 12525 and pb.n_obs > 300000
+    e = eng.Engine(pb)
+    e.set_state(st0)
+    cost0 = e.debug_accumulate()
+    flags = e.dump(eng.DUMP_FLAGS)
+    assert (flags == 3).mean() > 0.99
+    bD = e.dump(eng.DUMP_BLOCK_DIAG_H); bb = e.dump(eng.DUMP_BLOCK_DIAG_B)
+    B = e.dump(eng.DUMP_OFF_DIAG_H); H = e.dump(eng.DUMP_DENSE_H); bd = e.dump(eng.DUMP_DENSE_B)
+    lam = 1e-5 * (np.trace(H) + sum(np.trace(b) for b in bD)) / pb.total_dof
+    x = e.debug_solve(lam)
+    xb, xd = x[:pb.block_dof], x[pb.block_dof:]
+    Hs = np.triu(H) + np.triu(H, 1).T
+    r_dense = B.T @ xb + Hs @ xd + lam * xd - bd
+    Ds = np.array([np.triu(b) + np.triu(b, 1).T for b in bD])
+    r_block = np.einsum("nij,nj->ni", Ds, xb.reshape(-1, 6)).ravel() + lam * xb + B @ xd - bb
+    assert np.abs(r_dense).max() <= 1e-7 * np.abs(bd).max()
+    assert np.abs(r_block).max() <= 1e-7 * np.abs(bb).max()
+    del H, Hs, B
+    rep = e.step(-1.0)
+    assert rep.accepted and rep.final_cost < 0.5 * rep.initial_cost
+    assert abs(rep.initial_cost - cost0) <= 1e-9 * cost0
+    assert rep.n_residuals_valid == int((flags & 1).sum())
+    v_ref = e.dump(eng.DUMP_COST_VECTOR); v_new = e.dump(eng.DUMP_TEST_COST_VECTOR)
+    both = (v_ref >= 0) & (v_new >= 0)
+    assert v_new[both].sum() < v_ref[both].sum()
+    e.close()
