@@ -662,9 +662,10 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
       if (r0 % 128 == 0) {
         const int mt = (n_pad - r0) / 128;
         const int head = mt < kPanel / 128 ? mt : kPanel / 128;   // tile rows of the next panel
-        // (a') diagonal tiles of the next panel -> releases the chain
-        u.upper = 1; u.m_off = r0; u.m_tiles = head; u.n_off = r0; u.n_tiles = head;
-        if ((rc = launch_gemm<128, 128, 64, 64, true>(u, s))) return rc;
+        // (a') diagonal block of the next panel -> releases the chain.  64x64 tiles: ten small tiles on ten
+        // CUs finish several times sooner than three 128x128 tiles, and this launch is on the critical path.
+        u.upper = 1; u.m_off = r0; u.m_tiles = head * 2; u.n_off = r0; u.n_tiles = head * 2;
+        if ((rc = launch_gemm<64, 64, 32, 32, true>(u, s))) return rc;
         CBA_HIP(hipEventRecord(w.ev_strip, s));
         CBA_HIP(hipStreamWaitEvent(s2, w.ev_strip, 0));
         // (a'') rest of the next panel's rows -> releases far

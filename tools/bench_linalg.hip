@@ -74,6 +74,7 @@ int main(int argc, char** argv) {
     schur_gemm(A, A, K, n, H, S, n, n, n - 1, 1, -1.0 * K * 0.001, nullptr);
     hipDeviceSynchronize();
     GemmStats gs;
+    hipMemset(w.status, 0, 4);
     hipEventRecord(e0, ms);
     ldlt_factor(S, n_fact, n, w, ms, &gs);
     hipEventRecord(e1, ms);
