@@ -550,6 +550,7 @@ int ldlt_workspace_alloc(LdltWorkspace& w, int n_pad) {
   CBA_HIP(hipEventCreateWithFlags(&w.ev_strip, hipEventDisableTiming));
   CBA_HIP(hipEventCreateWithFlags(&w.ev_strip2, hipEventDisableTiming));
   CBA_HIP(hipEventCreateWithFlags(&w.ev_chain, hipEventDisableTiming));
+  CBA_HIP(hipEventCreateWithFlags(&w.ev_bulk, hipEventDisableTiming));
   w.n_alloc = n_pad;
   return CBA_OK;
 }
@@ -564,6 +565,7 @@ void ldlt_workspace_free(LdltWorkspace& w) {
   if (w.ev_strip) hipEventDestroy(w.ev_strip);
   if (w.ev_strip2) hipEventDestroy(w.ev_strip2);
   if (w.ev_chain) hipEventDestroy(w.ev_chain);
+  if (w.ev_bulk) hipEventDestroy(w.ev_bulk);
   w = LdltWorkspace();
 }
 
@@ -631,6 +633,7 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
   CBA_HIP(hipEventRecord(w.ev_strip, s));
   CBA_HIP(hipStreamWaitEvent(s2, w.ev_strip, 0));
   CBA_HIP(hipStreamWaitEvent(s3, w.ev_strip, 0));
+  CBA_HIP(hipEventRecord(w.ev_bulk, s));
   int kidx = 0;
   for (int k0 = 0; k0 < n_fact; k0 += kPanel, ++kidx) {
     const int nb = (n_fact - k0 < kPanel) ? (n_fact - k0) : kPanel;
@@ -668,18 +671,21 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
         if ((rc = launch_gemm<64, 64, 32, 32, true>(u, s))) return rc;
         CBA_HIP(hipEventRecord(w.ev_strip, s));
         CBA_HIP(hipStreamWaitEvent(s2, w.ev_strip, 0));
-        // (a'') rest of the next panel's rows -> releases far
+        // (a'') rest of the next panel's rows: issued on the far stream (it is what the next panel's far
+        // work waits for) so that it runs next to the bulk update instead of in front of it.  It writes
+        // rows that the previous bulk update also wrote, hence the wait on ev_bulk.
         if (mt > head) {
-          u.upper = 0; u.m_off = r0; u.m_tiles = head; u.n_off = r0 + head * 128; u.n_tiles = mt - head;
-          if ((rc = launch_gemm<128, 128, 64, 64, true>(u, s))) return rc;
+          CBA_HIP(hipStreamWaitEvent(s3, w.ev_bulk, 0));
+          GemmArgs v = u;
+          v.upper = 0; v.m_off = r0; v.m_tiles = head; v.n_off = r0 + head * 128; v.n_tiles = mt - head;
+          if ((rc = launch_gemm<128, 128, 64, 64, true>(v, s3))) return rc;
         }
-        CBA_HIP(hipEventRecord(w.ev_strip2, s));
-        CBA_HIP(hipStreamWaitEvent(s3, w.ev_strip2, 0));
         // (b) bulk
         if (mt > head) {
           u.upper = 1; u.m_off = r0 + head * 128; u.m_tiles = mt - head; u.n_off = r0 + head * 128; u.n_tiles = mt - head;
           if ((rc = launch_gemm<128, 128, 64, 64, true>(u, s))) return rc;
         }
+        CBA_HIP(hipEventRecord(w.ev_bulk, s));
       } else {
         u.upper = 1;
         u.m_off = r0; u.m_tiles = (n_pad - r0) / 64; u.n_off = r0; u.n_tiles = (n_pad - r0) / 64;
