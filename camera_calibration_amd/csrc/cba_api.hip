@@ -26,6 +26,8 @@ int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWor
 int launch_finish_diag(double* S, int ld, int n_real, int n_pad, double lambda, hipStream_t s);
 int launch_diag_sum(const double* Dblk, int bs, int nb, const double* Hdd, int ld, int dd, double* out, hipStream_t s);
 int make_main_stream(hipStream_t* s);
+int64_t packed_upper_doubles(int n_pad);
+int launch_pack_upper(const double* S, int n_pad, double* P, int unpack, hipStream_t s);
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static double now_s() {
@@ -119,7 +121,7 @@ struct cba_problem {
   // system
   int n_pad = 0, n_fact = 0, Kpad = 0;
   double* Dblk = nullptr; double* bblk = nullptr; double* B = nullptr; double* Hdd = nullptr; double* bd = nullptr;
-  double* Dinv = nullptr; double* dinvb = nullptr; double* W = nullptr; double* S = nullptr; bool S_owned = true;
+  double* Dinv = nullptr; double* dinvb = nullptr; double* W = nullptr; double* S = nullptr; bool S_owned = true; double* P = nullptr; bool P_owned = true;
   double* x = nullptr; double* scal = nullptr; double* gemv_ws = nullptr;
   int* status = nullptr;
   LdltWorkspace ldlt;
@@ -258,7 +260,9 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
   // right-hand side: S[j][n_pad-1] = bd[j] - sum_k B[k][j] dinvb[k]
   CBA_TRY(launch_gemv_t_strided(p->B, L.block_dof, dd, ld, p->dinvb, p->bd, p->S + (ld - 1), ld, p->gemv_ws, p->stream));
   if (multi) {
-    CBA_TRY(allreduce(p, p->S, (int64_t)ld * ld));
+    CBA_TRY(launch_pack_upper(p->S, p->n_pad, p->P, 0, p->stream));
+    CBA_TRY(allreduce(p, p->P, packed_upper_doubles(p->n_pad)));
+    CBA_TRY(launch_pack_upper(p->S, p->n_pad, p->P, 1, p->stream));
     CBA_TRY(launch_finish_diag(p->S, ld, dd, p->n_pad, lambda, p->stream));
   }
   t0 = now_s();
@@ -296,7 +300,7 @@ int64_t cba_reduce_buffer_doubles(const cba_config* config) {
   if (!config || !config->cameras) return 0;
   Layout L; make_layout(*config, L);
   int n_pad, n_fact; padded_dims(L.dense_dof, &n_pad, &n_fact);
-  return (int64_t)n_pad * n_pad;
+  return packed_upper_doubles(n_pad);
 }
 
 int cba_create(const cba_config* config, cba_problem** out) {
@@ -364,11 +368,16 @@ int cba_create(const cba_config* config, cba_problem** out) {
   CBA_TRY(dev_alloc(&p->W, (size_t)p->Kpad * p->n_pad));
   CBA_TRY(dev_alloc(&p->Hdd, (size_t)p->n_pad * p->n_pad));
   CBA_TRY(dev_alloc(&p->bd, (size_t)p->n_pad));
-  if (config->reduce_buffer) {
-    if (config->reduce_buffer_doubles < (int64_t)p->n_pad * p->n_pad) { set_error("reduce_buffer too small"); return CBA_ERR_ARG; }
-    p->S = static_cast<double*>(config->reduce_buffer); p->S_owned = false;
-  } else {
-    CBA_TRY(dev_alloc(&p->S, (size_t)p->n_pad * p->n_pad));
+  CBA_TRY(dev_alloc(&p->S, (size_t)p->n_pad * p->n_pad));
+  if (config->allreduce) {
+    // the reduced system crosses ranks as its upper 128-row blocks only (half the all-reduce volume)
+    const int64_t need = packed_upper_doubles(p->n_pad);
+    if (config->reduce_buffer) {
+      if (config->reduce_buffer_doubles < need) { set_error("reduce_buffer too small"); return CBA_ERR_ARG; }
+      p->P = static_cast<double*>(config->reduce_buffer); p->P_owned = false;
+    } else {
+      CBA_TRY(dev_alloc(&p->P, (size_t)need));
+    }
   }
   CBA_HIP(hipMemset(p->S, 0, sizeof(double) * (size_t)p->n_pad * p->n_pad));
   CBA_HIP(hipMemset(p->W, 0, sizeof(double) * (size_t)p->Kpad * p->n_pad));
@@ -400,6 +409,7 @@ void cba_destroy(cba_problem* p) {
   F(p->pair_tables); F(p->pair_counts); F(p->red_partials); F(p->red8);
   F(p->Dblk); F(p->bblk); F(p->B); F(p->Hdd); F(p->bd); F(p->Dinv); F(p->dinvb); F(p->W);
   if (p->S_owned) F(p->S);
+  if (p->P_owned) F(p->P);
   F(p->x); F(p->scal); F(p->status); F(p->gemv_ws);
   ldlt_workspace_free(p->ldlt);
   for (auto& t : p->timers) { if (t.e0) hipEventDestroy(t.e0); if (t.e1) hipEventDestroy(t.e1); }

@@ -775,6 +775,33 @@ int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWor
   return CBA_OK;
 }
 
+// Packed upper 128-row blocks of an n_pad x n_pad matrix: block i keeps rows [128 i, 128 i + 128) and
+// columns [128 i, n_pad), rows contiguous.  This is what crosses ranks in the multi-GPU path.
+int64_t packed_upper_doubles(int n_pad) {
+  int64_t total = 0;
+  for (int i = 0; i * 128 < n_pad; ++i) total += (int64_t)128 * (n_pad - 128 * i);
+  return total;
+}
+__global__ void __launch_bounds__(256) k_pack_upper(double* __restrict__ S, int n_pad, double* __restrict__ P, int unpack) {
+  const int row = blockIdx.x;                 // one workgroup per matrix row
+  const int blk = row >> 7;
+  const int c0 = blk << 7;
+  const int width = n_pad - c0;
+  // offset of block blk = sum_{j<blk} 128 (n_pad - 128 j) = 128 (blk n_pad - 64 blk (blk - 1))
+  const size_t off = (size_t)128 * ((size_t)blk * n_pad - (size_t)64 * blk * (blk - 1)) + (size_t)(row - c0) * width;
+  double* s = S + (size_t)row * n_pad + c0;
+  double* p = P + off;
+  for (int c = threadIdx.x * 2; c < width; c += 512) {
+    if (unpack) *reinterpret_cast<double2*>(s + c) = *reinterpret_cast<const double2*>(p + c);
+    else *reinterpret_cast<double2*>(p + c) = *reinterpret_cast<const double2*>(s + c);
+  }
+}
+int launch_pack_upper(const double* S, int n_pad, double* P, int unpack, hipStream_t s) {
+  hipLaunchKernelGGL(k_pack_upper, dim3(n_pad), dim3(256), 0, s, const_cast<double*>(S), n_pad, P, unpack);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
 // diag(S) += lambda for real rows, = 1 for padding rows (multi-GPU path: after the all-reduce)
 __global__ void k_finish_diag(double* __restrict__ S, int ld, int n_real, int n_pad, double lambda) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -69,7 +69,7 @@ typedef struct {
   cba_allreduce_fn allreduce;
   void* allreduce_user;
   int32_t n_images_global;       /* total imagesets over all ranks (0 = n_images) */
-  void* reduce_buffer;           /* optional caller-owned DEVICE buffer used for the reduced system */
+  void* reduce_buffer;           /* optional caller-owned DEVICE buffer for the packed reduced system (all-reduced in place) */
   int64_t reduce_buffer_doubles; /* its size; must be >= cba_reduce_buffer_doubles() */
 } cba_config;
 
