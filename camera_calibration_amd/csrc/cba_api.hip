@@ -344,9 +344,14 @@ int cba_create(const cba_config* config, cba_problem** out) {
     for (int slot = 0; slot < 2; ++slot) {
       int Kg = L.localize_only ? 0 : (slot == 0 ? 32 : 80);
       int K = 6 + (L.rig_in_state ? 6 : 0) + 3 + Kg;
+      // pairs with both columns in the pose/rig ("hot") range are accumulated in registers by the kernel
+      const int nh = 6 + (L.rig_in_state ? 6 : 0), h0 = L.eliminate_points ? 3 : 0;
       int e = 0;
       for (int i = 0; i < K; ++i)
-        for (int k = i; k < K; ++k) tab[slot * stride + e++] = ((uint32_t)i << 16) | (uint32_t)k;
+        for (int k = i; k < K; ++k) {
+          const bool hot = i >= h0 && i < h0 + nh && k >= h0 && k < h0 + nh;
+          if (!hot) tab[slot * stride + e++] = ((uint32_t)i << 16) | (uint32_t)k;
+        }
       counts[slot] = e;
     }
     CBA_TRY(dev_alloc(&p->pair_tables, tab.size()));

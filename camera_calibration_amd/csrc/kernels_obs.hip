@@ -371,6 +371,33 @@ struct AccumLayout {
   int block_dof, block_size, dense_dof;
 };
 
+// One wavefront walks kAccChunk consecutive observations.  Entries whose row AND column belong to the
+// imageset pose / rig pose ("hot": every observation of the same image and camera hits the same few
+// addresses, and the rig blocks are hit by every observation of the camera) are summed in registers
+// over the chunk and flushed with one atomic per entry when the (image, camera) key changes; all other
+// entries go straight to HBM with hardware fp64 atomics.
+constexpr int kAccChunk = 8;
+constexpr int kHotMax = 12;                       // pose 6 + rig 6
+constexpr int kHotPairs = kHotMax * (kHotMax + 1) / 2;   // 78
+
+__device__ __forceinline__ void acc_add_H(const AccumLayout& L, const AccumTargets& T, int row, int col, double v) {
+  if (row < L.block_dof) {
+    if (col < L.block_dof) {
+      int blk = row / L.block_size;
+      int base = blk * L.block_size;
+      unsafeAtomicAdd(T.Dblk + (size_t)blk * L.block_size * L.block_size + (row - base) * L.block_size + (col - base), v);
+    } else {
+      unsafeAtomicAdd(T.B + (size_t)row * L.dense_dof + (col - L.block_dof), v);
+    }
+  } else {
+    unsafeAtomicAdd(T.Hdd + (size_t)(row - L.block_dof) * L.dense_dof + (col - L.block_dof), v);
+  }
+}
+__device__ __forceinline__ void acc_add_b(const AccumLayout& L, const AccumTargets& T, int row, double v) {
+  if (row < L.block_dof) unsafeAtomicAdd(T.bblk + row, v);
+  else unsafeAtomicAdd(T.bd + (row - L.block_dof), v);
+}
+
 __global__ void __launch_bounds__(256) k_accumulate(PassArgs a, AccumLayout L, int rec_doubles,
                                                     const uint8_t* __restrict__ flags, const double* __restrict__ jrec,
                                                     const int* __restrict__ cells, const uint32_t* __restrict__ pair_tables,
@@ -381,81 +408,115 @@ __global__ void __launch_bounds__(256) k_accumulate(PassArgs a, AccumLayout L, i
   __shared__ double sW1[4][kMaxCols];
   __shared__ int sIdx[4][kMaxCols];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int64_t o = (int64_t)blockIdx.x * 4 + wv;
-  if (o >= a.n_obs) return;
-  if (flags[o] != 3) return;  // wave-uniform
-  const int cam = a.obs_camera[o];
-  const CamDev c = a.cams[cam];
-  const int per = c.params_per_point;
-  const int Kg = L.localize_only ? 0 : per * 16;
+  const int64_t o_begin = ((int64_t)blockIdx.x * 4 + wv) * kAccChunk;
   const int nrig = L.rig_in_state ? 6 : 0;
-  const int K = 6 + nrig + 3 + Kg;
-  const double* rec = jrec + (size_t)o * rec_doubles;
-  const double w = rec[2];
-  const int pose_idx = L.first_rig_tr_global + 6 * a.obs_image[o];
-  const int rig_idx = L.first_camera_tr_rig + 6 * cam;
-  const int point_idx = L.first_points + 3 * a.obs_point[o];
-  const int cx0 = cells[2 * o], cy0 = cells[2 * o + 1];
-  for (int k = lane; k < K; k += 64) {
-    int idx; double j0, j1;
-    int kk = k;
-    // ascending index order: [point] pose [rig] [point] grid  (joint_optimization.cc:490-590)
-    if (L.eliminate_points) {
-      if (kk < 3) { idx = point_idx + kk; j0 = rec[27 + kk]; j1 = rec[30 + kk]; goto done; }
-      kk -= 3;
+  const int nh = 6 + nrig;                       // hot columns
+  const int h0 = L.eliminate_points ? 3 : 0;     // their first position in the ascending column list
+  const int nhp = nh * (nh + 1) / 2;             // hot pairs
+  // hot slots of this lane: slot s < nhp is pair (hi, hk); slot nhp + i is b entry i.  Two slots per lane.
+  int hs_i[2], hs_k[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int sidx = lane + 64 * t;
+    hs_i[t] = -1; hs_k[t] = -1;
+    if (sidx < nhp) {
+      int rem = sidx, i = 0;
+      while (rem >= nh - i) { rem -= nh - i; ++i; }
+      hs_i[t] = i; hs_k[t] = i + rem;
+    } else if (sidx < nhp + nh) {
+      hs_i[t] = sidx - nhp; hs_k[t] = -2;        // b entry
     }
-    if (kk < 6) { idx = pose_idx + kk; j0 = rec[3 + kk]; j1 = rec[9 + kk]; goto done; }
-    kk -= 6;
-    if (nrig) {
-      if (kk < 6) { idx = rig_idx + kk; j0 = rec[15 + kk]; j1 = rec[21 + kk]; goto done; }
-      kk -= 6;
-    }
-    if (!L.eliminate_points) {
-      if (kk < 3) { idx = point_idx + kk; j0 = rec[27 + kk]; j1 = rec[30 + kk]; goto done; }
-      kk -= 3;
-    }
-    {
-      int cell = kk / per, d = kk - cell * per;
-      int seq = (cx0 + (cell & 3)) + (cy0 + (cell >> 2)) * c.gw;
-      idx = L.block_dof + c.intr_offset + per * seq + d;
-      j0 = rec[kRecHeader + kk]; j1 = rec[kRecHeader + Kg + kk];
-    }
-  done:
-    sIdx[wv][k] = idx;
-    sJ0[wv][k] = j0; sJ1[wv][k] = j1;
-    sW0[wv][k] = w * j0; sW1[wv][k] = w * j1;
   }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  const double r0 = rec[0], r1 = rec[1];
-  // b += Jw^T r
-  for (int k = lane; k < K; k += 64) {
-    int row = sIdx[wv][k];
-    double v = r0 * sW0[wv][k] + r1 * sW1[wv][k];
-    if (row < L.block_dof) unsafeAtomicAdd(T.bblk + row, v);
-    else unsafeAtomicAdd(T.bd + (row - L.block_dof), v);
-  }
-  // table selection: tables are indexed by K class (set up on the host): slot = per==2 ? 0 : 1
-  const int slot = (per == 2) ? 0 : 1;
-  const int npairs = pair_counts[slot];
-  const uint32_t* table = pair_tables + (size_t)slot * (kMaxCols * (kMaxCols + 1) / 2);
-  for (int e = lane; e < npairs; e += 64) {
-    uint32_t pr = table[e];
-    int i = pr >> 16, k = pr & 0xffff;
-    double v = sW0[wv][i] * sJ0[wv][k] + sW1[wv][i] * sJ1[wv][k];
-    int row = sIdx[wv][i], col = sIdx[wv][k];
-    if (row < L.block_dof) {
-      if (col < L.block_dof) {
-        int blk = row / L.block_size;
-        int base = blk * L.block_size;
-        unsafeAtomicAdd(T.Dblk + (size_t)blk * L.block_size * L.block_size + (row - base) * L.block_size + (col - base), v);
-      } else {
-        unsafeAtomicAdd(T.B + (size_t)row * L.dense_dof + (col - L.block_dof), v);
+  double hot[2] = {0.0, 0.0};
+  int cur_pose = -1, cur_rig = -1;
+  auto flush = [&]() {
+    if (cur_pose < 0) return;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (hs_i[t] < 0) continue;
+      int row = hs_i[t] < 6 ? cur_pose + hs_i[t] : cur_rig + hs_i[t] - 6;
+      if (hs_k[t] == -2) acc_add_b(L, T, row, hot[t]);
+      else acc_add_H(L, T, row, hs_k[t] < 6 ? cur_pose + hs_k[t] : cur_rig + hs_k[t] - 6, hot[t]);
+      hot[t] = 0.0;
+    }
+  };
+  for (int c = 0; c < kAccChunk; ++c) {
+    const int64_t o = o_begin + c;
+    if (o >= a.n_obs) break;
+    if (flags[o] != 3) continue;  // wave-uniform
+    const int cam = a.obs_camera[o];
+    const CamDev cd = a.cams[cam];
+    const int per = cd.params_per_point;
+    const int Kg = L.localize_only ? 0 : per * 16;
+    const int K = 6 + nrig + 3 + Kg;
+    const double* rec = jrec + (size_t)o * rec_doubles;
+    const double w = rec[2];
+    const int pose_idx = L.first_rig_tr_global + 6 * a.obs_image[o];
+    const int rig_idx = L.first_camera_tr_rig + 6 * cam;
+    const int point_idx = L.first_points + 3 * a.obs_point[o];
+    if (pose_idx != cur_pose || rig_idx != cur_rig) {
+      flush();
+      cur_pose = pose_idx; cur_rig = rig_idx;
+    }
+    const int cx0 = cells[2 * o], cy0 = cells[2 * o + 1];
+    __builtin_amdgcn_wave_barrier();   // previous iteration's LDS reads are done before overwriting
+    for (int k = lane; k < K; k += 64) {
+      int idx; double j0, j1;
+      int kk = k;
+      // ascending index order: [point] pose [rig] [point] grid  (joint_optimization.cc:490-590)
+      if (L.eliminate_points) {
+        if (kk < 3) { idx = point_idx + kk; j0 = rec[27 + kk]; j1 = rec[30 + kk]; goto done; }
+        kk -= 3;
       }
-    } else {
-      unsafeAtomicAdd(T.Hdd + (size_t)(row - L.block_dof) * L.dense_dof + (col - L.block_dof), v);
+      if (kk < 6) { idx = pose_idx + kk; j0 = rec[3 + kk]; j1 = rec[9 + kk]; goto done; }
+      kk -= 6;
+      if (nrig) {
+        if (kk < 6) { idx = rig_idx + kk; j0 = rec[15 + kk]; j1 = rec[21 + kk]; goto done; }
+        kk -= 6;
+      }
+      if (!L.eliminate_points) {
+        if (kk < 3) { idx = point_idx + kk; j0 = rec[27 + kk]; j1 = rec[30 + kk]; goto done; }
+        kk -= 3;
+      }
+      {
+        int cell = kk / per, d = kk - cell * per;
+        int seq = (cx0 + (cell & 3)) + (cy0 + (cell >> 2)) * cd.gw;
+        idx = L.block_dof + cd.intr_offset + per * seq + d;
+        j0 = rec[kRecHeader + kk]; j1 = rec[kRecHeader + Kg + kk];
+      }
+    done:
+      sIdx[wv][k] = idx;
+      sJ0[wv][k] = j0; sJ1[wv][k] = j1;
+      sW0[wv][k] = w * j0; sW1[wv][k] = w * j1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const double r0 = rec[0], r1 = rec[1];
+    // hot entries -> registers
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (hs_i[t] < 0) continue;
+      const int i = h0 + hs_i[t];
+      if (hs_k[t] == -2) hot[t] += r0 * sW0[wv][i] + r1 * sW1[wv][i];
+      else { const int k = h0 + hs_k[t]; hot[t] += sW0[wv][i] * sJ0[wv][k] + sW1[wv][i] * sJ1[wv][k]; }
+    }
+    // b += Jw^T r (non-hot positions)
+    for (int k = lane; k < K; k += 64) {
+      if (k >= h0 && k < h0 + nh) continue;
+      acc_add_b(L, T, sIdx[wv][k], r0 * sW0[wv][k] + r1 * sW1[wv][k]);
+    }
+    // remaining upper-triangle products (the pair tables exclude hot-hot pairs)
+    const int slot = (per == 2) ? 0 : 1;
+    const int npairs = pair_counts[slot];
+    const uint32_t* table = pair_tables + (size_t)slot * (kMaxCols * (kMaxCols + 1) / 2);
+    for (int e = lane; e < npairs; e += 64) {
+      uint32_t pr = table[e];
+      int i = pr >> 16, k = pr & 0xffff;
+      double v = sW0[wv][i] * sJ0[wv][k] + sW1[wv][i] * sJ1[wv][k];
+      acc_add_H(L, T, sIdx[wv][i], sIdx[wv][k], v);
     }
   }
+  flush();
 }
 int launch_accumulate(const PassArgs& a, const Layout& L, int rec_doubles, const uint8_t* flags, const double* jrec,
                       const int* cells, const uint32_t* pair_tables, const int* pair_counts, AccumTargets t,
@@ -465,7 +526,7 @@ int launch_accumulate(const PassArgs& a, const Layout& L, int rec_doubles, const
   al.rig_in_state = L.rig_in_state; al.eliminate_points = L.eliminate_points; al.localize_only = L.localize_only;
   al.first_rig_tr_global = L.first_rig_tr_global; al.first_camera_tr_rig = L.first_camera_tr_rig;
   al.first_points = L.first_points; al.block_dof = L.block_dof; al.block_size = L.block_size; al.dense_dof = L.dense_dof;
-  hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((a.n_obs + 3) / 4)), dim3(256), 0, s, a, al, rec_doubles, flags, jrec,
+  hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((a.n_obs + 4 * kAccChunk - 1) / (4 * kAccChunk))), dim3(256), 0, s, a, al, rec_doubles, flags, jrec,
                      cells, pair_tables, pair_counts, t);
   CBA_HIP(hipGetLastError());
   return CBA_OK;
