@@ -21,7 +21,9 @@ int launch_gemv_t_strided(const double* M, int K, int n, int ld, const double* v
                           int ystride, double* partial_ws, hipStream_t s);
 int gemv_t_workspace_doubles(int n);
 int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const double* Cin, double* C, int n_pad, int ld,
-               int n_real, int add_diag, double lambda, hipStream_t s);
+               int n_real, int add_diag, double lambda, const unsigned long long* kmask, hipStream_t s);
+int schur_mask_words(int Kpad);
+int launch_touch_mask(const double* B, int Kpad, int n_pad, int ld, unsigned long long* mask, hipStream_t s);
 int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWorkspace& w, double* x, hipStream_t s);
 int launch_finish_diag(double* S, int ld, int n_real, int n_pad, double lambda, hipStream_t s);
 int launch_diag_sum(const double* Dblk, int bs, int nb, const double* Hdd, int ld, int dd, double* out, hipStream_t s);
@@ -123,6 +125,7 @@ struct cba_problem {
   double* Dblk = nullptr; double* bblk = nullptr; double* B = nullptr; double* Hdd = nullptr; double* bd = nullptr;
   double* Dinv = nullptr; double* dinvb = nullptr; double* W = nullptr; double* S = nullptr; bool S_owned = true; double* P = nullptr; bool P_owned = true;
   double* x = nullptr; double* scal = nullptr; double* gemv_ws = nullptr;
+  unsigned long long* kmask = nullptr;   // block-sparsity of B per (column tile, K slab), rebuilt after every accumulation
   int* status = nullptr;
   LdltWorkspace ldlt;
   KernelTimer timers[4];
@@ -235,6 +238,7 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   CBA_TRY(launch_accumulate(a, Lp, p->rec_doubles, p->flags, p->jrec, p->cells, p->pair_tables, p->pair_counts, T, p->stream));
   CBA_TRY(timer_end(p, 2, 0, 0, 1));
   if (t_acc) *t_acc += now_s() - t0;
+  CBA_TRY(launch_touch_mask(p->B, p->Kpad, p->n_pad, p->n_pad, p->kmask, p->stream));
   p->have_system = true;
   return CBA_OK;
 }
@@ -250,7 +254,7 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
   CBA_TRY(launch_dinv_times_B_ld(p->Dinv, p->B, bs, nb, dd, ld, p->W, p->stream));
   double t0 = now_s();
   CBA_TRY(timer_begin(p, 0));
-  CBA_TRY(schur_gemm(p->B, p->W, p->Kpad, ld, p->Hdd, p->S, p->n_pad, ld, dd, multi ? 0 : 1, lambda, p->stream));
+  CBA_TRY(schur_gemm(p->B, p->W, p->Kpad, ld, p->Hdd, p->S, p->n_pad, ld, dd, multi ? 0 : 1, lambda, p->kmask, p->stream));
   {
     double nt = p->n_pad / 128.0;
     double tiles = nt * (nt + 1) / 2;
@@ -390,6 +394,7 @@ int cba_create(const cba_config* config, cba_problem** out) {
   CBA_TRY(dev_alloc(&p->x, (size_t)L.block_dof + p->n_pad));
   CBA_HIP(hipMemset(p->x, 0, sizeof(double) * ((size_t)L.block_dof + p->n_pad)));
   CBA_TRY(dev_alloc(&p->scal, 16));
+  CBA_TRY(dev_alloc(&p->kmask, (size_t)(p->n_pad / 128) * schur_mask_words(p->Kpad)));
   CBA_TRY(dev_alloc(&p->gemv_ws, (size_t)gemv_t_workspace_doubles(p->n_pad)));
   CBA_TRY(dev_alloc(&p->status, 1));
   CBA_TRY(ldlt_workspace_alloc(p->ldlt, p->n_pad));
@@ -415,7 +420,7 @@ void cba_destroy(cba_problem* p) {
   F(p->Dblk); F(p->bblk); F(p->B); F(p->Hdd); F(p->bd); F(p->Dinv); F(p->dinvb); F(p->W);
   if (p->S_owned) F(p->S);
   if (p->P_owned) F(p->P);
-  F(p->x); F(p->scal); F(p->status); F(p->gemv_ws);
+  F(p->x); F(p->scal); F(p->status); F(p->gemv_ws); F(p->kmask);
   ldlt_workspace_free(p->ldlt);
   for (auto& t : p->timers) { if (t.e0) hipEventDestroy(t.e0); if (t.e1) hipEventDestroy(t.e1); }
   if (p->stream) hipStreamDestroy(p->stream);
@@ -768,7 +773,7 @@ int cba_schur_solve(int32_t block_size, int32_t n_blocks, int32_t dense_dof, con
   hipStream_t s = nullptr;
   CBA_TRY(launch_block_inverse(Dblk, bblk, 0.0, bs, nb, Dinv, dinvb, status, s));
   CBA_TRY(launch_dinv_times_B_ld(Dinv, B, bs, nb, dd, ld, W, s));
-  CBA_TRY(schur_gemm(B, W, Kpad, ld, Hdd, S, n_pad, ld, dd, 1, 0.0, s));
+  CBA_TRY(schur_gemm(B, W, Kpad, ld, Hdd, S, n_pad, ld, dd, 1, 0.0, nullptr, s));
   CBA_TRY(launch_gemv_t_strided(B, bdof, dd, ld, dinvb, bd, S + (ld - 1), ld, gws, s));
   CBA_TRY(ldlt_factor(S, n_fact, ld, w, s, nullptr));
   CBA_TRY(ldlt_back_solve(S, n_fact, ld, ld - 1, w, xd + bdof, s));

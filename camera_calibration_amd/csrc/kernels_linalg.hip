@@ -145,6 +145,8 @@ struct GemmArgs {
   int ldc2;
   const double* rowscale_inv;   // d values: C2 = value / d[m]
   long long total_tiles;
+  const unsigned long long* kmask;  // optional block-sparsity mask [column tile][kmask_words], bit = K slab of 16 rows
+  int kmask_words;
   int epi_mode;                 // developer switch (bench harness): 0 normal, 1 no Cin read, 2 no store
 };
 
@@ -233,12 +235,30 @@ __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
                                        (lds_ptr)&sB[(buf_)][row * LDB_S], 16, 0, 0);                               \
     }                                                                                                              \
   }
-    CBA_DMA_STAGE(0, 0);
+    // Block-sparse K loop: `kmask` (optional) holds, per 128-column tile, one bit per 16-row K slab that
+    // contains any non-zero.  A slab contributes to tile (tm, tn) only if both column tiles touch it --
+    // in bundle adjustment an imageset's rows of B are non-zero only at the points it sees and the grid
+    // cells it covers -- so the loop walks the set bits of mask[tm] & mask[tn].
+    auto next_slab = [&](int after) -> int {
+      if (!g.kmask) return after + 1;
+      const unsigned long long* ma = g.kmask + (size_t)(m0 >> 7) * g.kmask_words;
+      const unsigned long long* mb = g.kmask + (size_t)(n0 >> 7) * g.kmask_words;
+      int s = after + 1;
+      while (s < nk) {
+        unsigned long long bits = (ma[s >> 6] & mb[s >> 6]) >> (s & 63);
+        if (bits) return s + __builtin_ctzll(bits);
+        s = (s | 63) + 1;
+      }
+      return nk;
+    };
+    int kb = next_slab(-1);
+    if (kb < nk) CBA_DMA_STAGE(0, kb * KT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kb = 0; kb < nk; ++kb) {
-      const int buf = kb & 1;
-      if (kb + 1 < nk) CBA_DMA_STAGE(buf ^ 1, (kb + 1) * KT);
+    int buf = 0;
+    while (kb < nk) {
+      const int nxt = next_slab(kb);
+      if (nxt < nk) CBA_DMA_STAGE(buf ^ 1, nxt * KT);
       const double* a_s = &sA[buf][0];
       const double* b_s = &sB[buf][0];
 #pragma unroll
@@ -256,6 +276,8 @@ __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      kb = nxt;
+      buf ^= 1;
     }
 #undef CBA_DMA_STAGE
   } else {
@@ -386,9 +408,33 @@ int launch_gemv_t_strided(const double* M, int K, int n, int ld, const double* v
 int gemv_t_workspace_doubles(int n) { return kGemvChunks * n; }
 
 // S = Hdd + lambda I - A^T B on the upper tiles (n_pad x n_pad, all leading dims = ld, multiples of 128)
+// bit (tile t, slab k) = any non-zero in B[16k .. 16k+15][128t .. 128t+127]
+__global__ void __launch_bounds__(256) k_touch_mask(const double* __restrict__ B, int ld, unsigned long long* __restrict__ mask,
+                                                    int words) {
+  const int slab = blockIdx.x, tile = blockIdx.y;
+  const double* p = B + (size_t)slab * 16 * ld + (size_t)tile * 128;
+  bool nz = false;
+  for (int e = threadIdx.x; e < 16 * 128; e += 256) nz = nz || (p[(size_t)(e >> 7) * ld + (e & 127)] != 0.0);
+  __shared__ int any;
+  if (threadIdx.x == 0) any = 0;
+  __syncthreads();
+  if (nz) any = 1;
+  __syncthreads();
+  if (threadIdx.x == 0 && any) atomicOr(mask + (size_t)tile * words + (slab >> 6), 1ull << (slab & 63));
+}
+int schur_mask_words(int Kpad) { return (Kpad / 16 + 63) / 64; }
+int launch_touch_mask(const double* B, int Kpad, int n_pad, int ld, unsigned long long* mask, hipStream_t s) {
+  const int words = schur_mask_words(Kpad);
+  CBA_HIP(hipMemsetAsync(mask, 0, sizeof(unsigned long long) * (size_t)(n_pad / 128) * words, s));
+  hipLaunchKernelGGL(k_touch_mask, dim3(Kpad / 16, n_pad / 128), dim3(256), 0, s, B, ld, mask, words);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
 int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const double* Cin, double* C, int n_pad, int ld,
-               int n_real, int add_diag, double lambda, hipStream_t s) {
+               int n_real, int add_diag, double lambda, const unsigned long long* kmask, hipStream_t s) {
   GemmArgs g{};
+  g.kmask = kmask; g.kmask_words = schur_mask_words(Kpad);
   g.A = A; g.lda = ldab; g.B = B; g.ldb = ldab; g.K = Kpad;
   g.C = C; g.ldc = ld; g.Cin = Cin; g.ldcin = ld;
   g.m_tiles = n_pad / 128; g.n_tiles = n_pad / 128; g.m_off = 0; g.n_off = 0; g.upper = 1;

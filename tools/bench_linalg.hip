@@ -7,7 +7,7 @@
 namespace cba { void set_error(const std::string& m) { fprintf(stderr, "error: %s\n", m.c_str()); } }
 using namespace cba;
 namespace cba {
-int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const double* Cin, double* C, int n_pad, int ld, int n_real, int add_diag, double lambda, hipStream_t s);
+
 int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWorkspace& w, double* x, hipStream_t s);
 }
 static float timeit(hipEvent_t e0, hipEvent_t e1) { float ms; hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); return ms; }
@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
   hipMemset(H, 0, sizeof(double) * (size_t)n * n);
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(e0);
-    schur_gemm(A, A, K, n, H, S, n, n, n - 1, 1, -1.0 * K * 0.001, nullptr);  // S = -lambda' I - A^T A  (negative definite: fine for LDL^T)
+    schur_gemm(A, A, K, n, H, S, n, n, n - 1, 1, -1.0 * K * 0.001, nullptr, nullptr);  // S = -lambda' I - A^T A  (negative definite: fine for LDL^T)
     hipEventRecord(e1);
     float ms = timeit(e0, e1);
     double nt = n / 128.0, tiles = nt * (nt + 1) / 2;
@@ -71,7 +71,7 @@ int main(int argc, char** argv) {
   hipStream_t ms; make_main_stream(&ms);
   printf("panel CUs reserved: %d\n", panel_cu_count());
   for (int rep = 0; rep < 2; ++rep) {
-    schur_gemm(A, A, K, n, H, S, n, n, n - 1, 1, -1.0 * K * 0.001, nullptr);
+    schur_gemm(A, A, K, n, H, S, n, n, n - 1, 1, -1.0 * K * 0.001, nullptr, nullptr);
     hipDeviceSynchronize();
     GemmStats gs;
     hipMemset(w.status, 0, 4);
