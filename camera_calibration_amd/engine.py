@@ -346,3 +346,29 @@ def optimize_jointly(problem: Problem, state: State, max_iteration_count: int, i
     finally:
         if own:
             eng.close()
+
+
+def run_bundle_adjustment(engine: Engine, state: State, max_iteration_count: int = 100,
+                          cost_reduction_threshold: float = 1e-4, print_progress: bool = False):
+    """Outer convergence loop of the reference's ``RunBundleAdjustment`` (APP/calibration.cc:187-304):
+    repeated ``OptimizeJointly(max_iteration_count=1)`` carrying lambda, stop when no update was
+    performed or ``cost >= last_cost - threshold`` (:298).  The state stays device-resident between
+    iterations (the reference rebuilds everything per call).  Gauge beautification
+    (ChooseNiceCameraOrientation, :248-254) and state saving are outside the hot path and not done here.
+    Returns (final_cost, iterations, reports)."""
+    engine.set_state(state)
+    lam = -1.0
+    last_cost = float("inf")
+    reports: List[StepReport] = []
+    for it in range(max_iteration_count):
+        rep = engine.step(lam)
+        reports.append(rep)
+        lam = rep.final_lambda
+        if print_progress:
+            print(f"[{it}] cost {rep.final_cost:.9g} lambda {lam:.3g} attempts {rep.lm_attempts}")
+        if not rep.accepted:
+            break
+        if rep.final_cost >= last_cost - cost_reduction_threshold:
+            break
+        last_cost = rep.final_cost
+    return reports[-1].final_cost, len(reports), reports
