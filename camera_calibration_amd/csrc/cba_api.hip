@@ -119,6 +119,8 @@ struct cba_problem {
   double* cost_ref = nullptr; double* cost_test = nullptr; double* pixels = nullptr; uint8_t* flags = nullptr;
   double* fd_out = nullptr; uint8_t* fd_ok = nullptr; double* jrec = nullptr; int* cells = nullptr;
   uint32_t* pair_tables = nullptr; int* pair_counts = nullptr;
+  std::vector<int> cell_base_host; int* cell_base = nullptr; int* cell_count = nullptr; int* cell_start = nullptr; int* cell_fill = nullptr;
+  int* cell_order = nullptr;
   double* red_partials = nullptr; double* red8 = nullptr;
   // system
   int n_pad = 0, n_fact = 0, Kpad = 0;
@@ -236,6 +238,9 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   Layout Lp = L;
   Lp.dense_dof = p->n_pad;  // row stride used by the kernel
   CBA_TRY(launch_accumulate(a, Lp, p->rec_doubles, p->flags, p->jrec, p->cells, p->pair_tables, p->pair_counts, T, p->stream));
+  if (!L.localize_only)
+    CBA_TRY(launch_accumulate_cells(a, p->cams, p->cell_base_host, p->rec_doubles, p->n_pad, p->flags, p->jrec, p->cells, p->cell_base,
+                                    p->cell_count, p->cell_start, p->cell_fill, p->cell_order, p->Hdd, p->stream));
   CBA_TRY(timer_end(p, 2, 0, 0, 1));
   if (t_acc) *t_acc += now_s() - t0;
   CBA_TRY(launch_touch_mask(p->B, p->Kpad, p->n_pad, p->n_pad, p->kmask, p->stream));
@@ -354,7 +359,8 @@ int cba_create(const cba_config* config, cba_problem** out) {
       for (int i = 0; i < K; ++i)
         for (int k = i; k < K; ++k) {
           const bool hot = i >= h0 && i < h0 + nh && k >= h0 && k < h0 + nh;
-          if (!hot) tab[slot * stride + e++] = ((uint32_t)i << 16) | (uint32_t)k;
+          const bool grid_grid = i >= K - Kg && k >= K - Kg;   // summed per grid cell by k_accumulate_cells
+          if (!hot && !grid_grid) tab[slot * stride + e++] = ((uint32_t)i << 16) | (uint32_t)k;
         }
       counts[slot] = e;
     }
@@ -362,6 +368,14 @@ int cba_create(const cba_config* config, cba_problem** out) {
     CBA_TRY(dev_alloc(&p->pair_counts, 2));
     CBA_HIP(hipMemcpy(p->pair_tables, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     CBA_HIP(hipMemcpy(p->pair_counts, counts, sizeof(counts), hipMemcpyHostToDevice));
+  }
+  {
+    p->cell_base_host.assign(L.n_cameras + 1, 0);
+    for (int c = 0; c < L.n_cameras; ++c) p->cell_base_host[c + 1] = p->cell_base_host[c] + p->cams[c].grid_w * p->cams[c].grid_h;
+    const size_t nk = (size_t)p->cell_base_host.back();
+    CBA_TRY(dev_alloc(&p->cell_base, p->cell_base_host.size()));
+    CBA_HIP(hipMemcpy(p->cell_base, p->cell_base_host.data(), sizeof(int) * p->cell_base_host.size(), hipMemcpyHostToDevice));
+    CBA_TRY(dev_alloc(&p->cell_count, nk + 1)); CBA_TRY(dev_alloc(&p->cell_start, nk + 1)); CBA_TRY(dev_alloc(&p->cell_fill, nk + 1));
   }
   CBA_TRY(dev_alloc(&p->red_partials, 256 * 8));
   CBA_TRY(dev_alloc(&p->red8, 16));
@@ -417,6 +431,7 @@ void cba_destroy(cba_problem* p) {
   for (int c = 0; c < kMaxCameras; ++c) F(p->tangents[c]);
   F(p->cost_ref); F(p->cost_test); F(p->pixels); F(p->flags); F(p->fd_out); F(p->fd_ok); F(p->jrec); F(p->cells);
   F(p->pair_tables); F(p->pair_counts); F(p->red_partials); F(p->red8);
+  F(p->cell_base); F(p->cell_count); F(p->cell_start); F(p->cell_fill); F(p->cell_order);
   F(p->Dblk); F(p->bblk); F(p->B); F(p->Hdd); F(p->bd); F(p->Dinv); F(p->dinvb); F(p->W);
   if (p->S_owned) F(p->S);
   if (p->P_owned) F(p->P);
@@ -442,7 +457,7 @@ int cba_set_observations(cba_problem* p, int64_t n, const float* xy, const int32
   CBA_HIP(hipSetDevice(p->device));
   auto F = [](void* q) { if (q) hipFree(q); };
   F(p->obs_xy); F(p->obs_point); F(p->obs_image); F(p->obs_camera); F(p->last_projection);
-  F(p->cost_ref); F(p->cost_test); F(p->pixels); F(p->flags); F(p->fd_out); F(p->fd_ok); F(p->jrec); F(p->cells);
+  F(p->cost_ref); F(p->cost_test); F(p->pixels); F(p->flags); F(p->fd_out); F(p->fd_ok); F(p->jrec); F(p->cells); F(p->cell_order);
   p->n_obs = n;
   CBA_TRY(dev_alloc(&p->obs_xy, 2 * (size_t)n)); CBA_TRY(dev_alloc(&p->obs_point, (size_t)n));
   CBA_TRY(dev_alloc(&p->obs_image, (size_t)n)); CBA_TRY(dev_alloc(&p->obs_camera, (size_t)n));
@@ -451,6 +466,7 @@ int cba_set_observations(cba_problem* p, int64_t n, const float* xy, const int32
   CBA_TRY(dev_alloc(&p->pixels, 2 * (size_t)n)); CBA_TRY(dev_alloc(&p->flags, (size_t)n));
   CBA_TRY(dev_alloc(&p->fd_out, 2 * (size_t)n * p->tasks_per_obs)); CBA_TRY(dev_alloc(&p->fd_ok, (size_t)n * p->tasks_per_obs));
   CBA_TRY(dev_alloc(&p->jrec, (size_t)n * p->rec_doubles)); CBA_TRY(dev_alloc(&p->cells, 2 * (size_t)n));
+  CBA_TRY(dev_alloc(&p->cell_order, (size_t)n));
   if (n > 0) {
     CBA_HIP(hipMemcpy(p->obs_xy, xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice));
     CBA_HIP(hipMemcpy(p->obs_point, point_index, sizeof(int) * n, hipMemcpyHostToDevice));

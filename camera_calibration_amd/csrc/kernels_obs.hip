@@ -518,6 +518,128 @@ __global__ void __launch_bounds__(256) k_accumulate(PassArgs a, AccumLayout L, i
   }
   flush();
 }
+// ------------------------------------------------------------------------------------------------
+// grid x grid block of JtJ, grouped by grid cell.  All observations whose 4x4 control patch starts at
+// the same cell add their K_g x K_g products to the same entries of H_dd, so they are first bucketed by
+// (camera, cell) with a counting sort and then one wavefront per cell sums its bucket in registers
+// (528 entries for the central model, 3240 for the non-central one) and issues ONE atomic per entry.
+// This removes 58 % (central) / 81 % (non-central) of the atomics of the per-observation scatter.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_cell_count(PassArgs a, const uint8_t* __restrict__ flags, const int* __restrict__ cells,
+                                                    const int* __restrict__ cell_base, int* __restrict__ count) {
+  int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= a.n_obs || flags[o] != 3) return;
+  const int cam = a.obs_camera[o];
+  const int gw = a.cams[cam].gw;
+  atomicAdd(count + cell_base[cam] + cells[2 * o + 1] * gw + cells[2 * o], 1);
+}
+__global__ void __launch_bounds__(1024) k_cell_scan(const int* __restrict__ count, int n, int* __restrict__ start) {
+  __shared__ int sh[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    int i = base + threadIdx.x;
+    int v = (i < n) ? count[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      int t = (threadIdx.x >= off) ? sh[threadIdx.x - off] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < n) start[i] = carry + sh[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += sh[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) start[n] = carry;
+}
+__global__ void __launch_bounds__(256) k_cell_fill(PassArgs a, const uint8_t* __restrict__ flags, const int* __restrict__ cells,
+                                                   const int* __restrict__ cell_base, const int* __restrict__ start,
+                                                   int* __restrict__ fill, int* __restrict__ order) {
+  int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= a.n_obs || flags[o] != 3) return;
+  const int cam = a.obs_camera[o];
+  const int key = cell_base[cam] + cells[2 * o + 1] * a.cams[cam].gw + cells[2 * o];
+  order[start[key] + atomicAdd(fill + key, 1)] = (int)o;
+}
+template <int PER>
+__global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, int key0, int n_cells, int rec_doubles, int ld,
+                                                          const double* __restrict__ jrec, const int* __restrict__ start,
+                                                          const int* __restrict__ order, double* __restrict__ Hdd) {
+  constexpr int KG = PER * 16;
+  constexpr int NPAIR = KG * (KG + 1) / 2;
+  constexpr int NE = (NPAIR + 63) / 64;
+  __shared__ double sJ0[4][KG];
+  __shared__ double sJ1[4][KG];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int cell = blockIdx.x * 4 + wv;
+  if (cell >= n_cells) return;
+  const int o_begin = start[key0 + cell], o_end = start[key0 + cell + 1];
+  if (o_begin == o_end) return;
+  // this lane's pairs (i <= k), enumerated row by row
+  unsigned short pi[NE], pk[NE];
+#pragma unroll
+  for (int t = 0; t < NE; ++t) {
+    int e = lane + 64 * t;
+    int i = 0;
+    if (e < NPAIR) { int rem = e; while (rem >= KG - i) { rem -= KG - i; ++i; } pi[t] = (unsigned short)i; pk[t] = (unsigned short)(i + rem); }
+    else { pi[t] = 0; pk[t] = 0; }
+  }
+  double acc[NE];
+#pragma unroll
+  for (int t = 0; t < NE; ++t) acc[t] = 0.0;
+  for (int idx = o_begin; idx < o_end; ++idx) {
+    const int o = order[idx];
+    const double* rec = jrec + (size_t)o * rec_doubles;
+    const double w = rec[2];
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < KG; k += 64) { sJ0[wv][k] = rec[kRecHeader + k]; sJ1[wv][k] = rec[kRecHeader + KG + k]; }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+    for (int t = 0; t < NE; ++t) {
+      const int i = pi[t], k = pk[t];
+      acc[t] += w * (sJ0[wv][i] * sJ0[wv][k] + sJ1[wv][i] * sJ1[wv][k]);
+    }
+  }
+  const CamDev cd = a.cams[cam];
+  const int cy0 = cell / cd.gw, cx0 = cell - cy0 * cd.gw;
+#pragma unroll
+  for (int t = 0; t < NE; ++t) {
+    if (lane + 64 * t >= NPAIR) continue;
+    const int i = pi[t], k = pk[t];
+    const int ci = i / PER, di = i - ci * PER, ck = k / PER, dk = k - ck * PER;
+    const int row = cd.intr_offset + PER * ((cx0 + (ci & 3)) + (cy0 + (ci >> 2)) * cd.gw) + di;
+    const int col = cd.intr_offset + PER * ((cx0 + (ck & 3)) + (cy0 + (ck >> 2)) * cd.gw) + dk;
+    unsafeAtomicAdd(Hdd + (size_t)row * ld + col, acc[t]);
+  }
+}
+int launch_accumulate_cells(const PassArgs& a, const std::vector<cba_camera>& cams, const std::vector<int>& cell_base_host,
+                            int rec_doubles, int ld, const uint8_t* flags, const double* jrec, const int* cells,
+                            const int* cell_base, int* count, int* start, int* fill, int* order, double* Hdd, hipStream_t s) {
+  if (a.n_obs == 0) return CBA_OK;
+  const int n_keys = cell_base_host.back();
+  CBA_HIP(hipMemsetAsync(count, 0, sizeof(int) * (size_t)n_keys, s));
+  CBA_HIP(hipMemsetAsync(fill, 0, sizeof(int) * (size_t)n_keys, s));
+  dim3 grid((unsigned)((a.n_obs + 255) / 256)), block(256);
+  hipLaunchKernelGGL(k_cell_count, grid, block, 0, s, a, flags, cells, cell_base, count);
+  hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, s, count, n_keys, start);
+  hipLaunchKernelGGL(k_cell_fill, grid, block, 0, s, a, flags, cells, cell_base, start, fill, order);
+  for (size_t c = 0; c < cams.size(); ++c) {
+    const int n_cells = cams[c].grid_w * cams[c].grid_h;
+    dim3 g2((unsigned)((n_cells + 3) / 4));
+    if (cams[c].model_type == CBA_CENTRAL_GENERIC)
+      hipLaunchKernelGGL(k_accumulate_cells<2>, g2, block, 0, s, a, (int)c, cell_base_host[c], n_cells, rec_doubles, ld, jrec, start, order, Hdd);
+    else
+      hipLaunchKernelGGL(k_accumulate_cells<5>, g2, block, 0, s, a, (int)c, cell_base_host[c], n_cells, rec_doubles, ld, jrec, start, order, Hdd);
+  }
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
 int launch_accumulate(const PassArgs& a, const Layout& L, int rec_doubles, const uint8_t* flags, const double* jrec,
                       const int* cells, const uint32_t* pair_tables, const int* pair_counts, AccumTargets t,
                       hipStream_t s) {
