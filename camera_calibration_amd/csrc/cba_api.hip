@@ -2,6 +2,7 @@
 // (LMOptimizer::OptimizeImpl, libvis/src/libvis/lm_optimizer.h:629-991 in the reference tree) and the
 // stateless model / solver entry points.  Everything numerical runs in the HIP kernels of
 // kernels_obs.hip / kernels_linalg.hip; there is no CPU fallback.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -121,6 +122,9 @@ struct cba_problem {
   uint32_t* pair_tables = nullptr; int* pair_counts = nullptr;
   std::vector<int> cell_base_host; int* cell_base = nullptr; int* cell_count = nullptr; int* cell_start = nullptr; int* cell_fill = nullptr;
   int* cell_order = nullptr;
+  // imageset -> position of its 6x6 block / rows of B.  Imagesets are sorted by the vertical centre of
+  // their observations so that the 16-row K slabs of the Schur product touch few grid-row tiles.
+  std::vector<int> pose_slot_host; int* pose_slot = nullptr;
   double* red_partials = nullptr; double* red8 = nullptr;
   // system
   int n_pad = 0, n_fact = 0, Kpad = 0;
@@ -188,6 +192,7 @@ static PassArgs pass_args(cba_problem* p, int which) {
   a.last_projection = p->last_projection;
   a.points = p->st[which].points; a.itg = p->itg; a.cams = p->cams_dev[which];
   a.fd_delta = p->cfg.numerical_diff_delta;
+  a.pose_slot = p->pose_slot;
   return a;
 }
 
@@ -261,9 +266,17 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
   CBA_TRY(timer_begin(p, 0));
   CBA_TRY(schur_gemm(p->B, p->W, p->Kpad, ld, p->Hdd, p->S, p->n_pad, ld, dd, multi ? 0 : 1, lambda, p->kmask, p->stream));
   {
-    double nt = p->n_pad / 128.0;
-    double tiles = nt * (nt + 1) / 2;
-    CBA_TRY(timer_end(p, 0, tiles * 2.0 * 128 * 128 * p->Kpad, tiles * (2.0 * 128 * 128 * 8 + 2.0 * p->Kpad * 128 * 8), 1));
+    // algorithmic flops of this launch = K slabs actually multiplied (block-sparse loop), from the touch masks
+    const int nt = p->n_pad / 128, words = schur_mask_words(p->Kpad);
+    std::vector<unsigned long long> hm((size_t)nt * words);
+    CBA_HIP(hipMemcpyAsync(hm.data(), p->kmask, hm.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, p->stream));
+    CBA_HIP(hipStreamSynchronize(p->stream));
+    double slabs = 0;
+    for (int tm = 0; tm < nt; ++tm)
+      for (int tn = tm; tn < nt; ++tn)
+        for (int w = 0; w < words; ++w) slabs += __builtin_popcountll(hm[(size_t)tm * words + w] & hm[(size_t)tn * words + w]);
+    const double tiles = nt * (nt + 1) / 2.0;
+    CBA_TRY(timer_end(p, 0, slabs * 2.0 * 128 * 128 * 16, tiles * 2.0 * 128 * 128 * 8 + slabs * 2.0 * 16 * 128 * 8, 1));
   }
   if (rep) rep->t_gemm += now_s() - t0;
   // right-hand side: S[j][n_pad-1] = bd[j] - sum_k B[k][j] dinvb[k]
@@ -431,7 +444,7 @@ void cba_destroy(cba_problem* p) {
   for (int c = 0; c < kMaxCameras; ++c) F(p->tangents[c]);
   F(p->cost_ref); F(p->cost_test); F(p->pixels); F(p->flags); F(p->fd_out); F(p->fd_ok); F(p->jrec); F(p->cells);
   F(p->pair_tables); F(p->pair_counts); F(p->red_partials); F(p->red8);
-  F(p->cell_base); F(p->cell_count); F(p->cell_start); F(p->cell_fill); F(p->cell_order);
+  F(p->cell_base); F(p->cell_count); F(p->cell_start); F(p->cell_fill); F(p->cell_order); F(p->pose_slot);
   F(p->Dblk); F(p->bblk); F(p->B); F(p->Hdd); F(p->bd); F(p->Dinv); F(p->dinvb); F(p->W);
   if (p->S_owned) F(p->S);
   if (p->P_owned) F(p->P);
@@ -475,6 +488,20 @@ int cba_set_observations(cba_problem* p, int64_t n, const float* xy, const int32
     if (last_projection) CBA_HIP(hipMemcpy(p->last_projection, last_projection, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
     else CBA_HIP(hipMemset(p->last_projection, 0, sizeof(double) * 2 * n));
     CBA_HIP(hipMemset(p->flags, 0, (size_t)n));
+  }
+  // block order of the imagesets (eliminate_points = 0 only: the pose blocks are the Schur blocks)
+  if (p->pose_slot) { hipFree(p->pose_slot); p->pose_slot = nullptr; }
+  p->pose_slot_host.clear();
+  if (!L.eliminate_points && L.n_images > 0 && n > 0) {
+    std::vector<double> sy(L.n_images, 0.0); std::vector<int> cnt(L.n_images, 0);
+    for (int64_t i = 0; i < n; ++i) { sy[image_index[i]] += xy[2 * i + 1]; cnt[image_index[i]] += 1; }
+    std::vector<int> order(L.n_images);
+    for (int i = 0; i < L.n_images; ++i) { order[i] = i; sy[i] = cnt[i] ? sy[i] / cnt[i] : 0.0; }
+    std::stable_sort(order.begin(), order.end(), [&](int u, int v) { return sy[u] < sy[v]; });
+    p->pose_slot_host.assign(L.n_images, 0);
+    for (int r = 0; r < L.n_images; ++r) p->pose_slot_host[order[r]] = r;
+    CBA_TRY(dev_alloc(&p->pose_slot, (size_t)L.n_images));
+    CBA_HIP(hipMemcpy(p->pose_slot, p->pose_slot_host.data(), sizeof(int) * L.n_images, hipMemcpyHostToDevice));
   }
   p->have_obs = true; p->have_system = false;
   return CBA_OK;
@@ -560,8 +587,14 @@ int cba_debug_solve(cba_problem* p, double lambda) {
 int cba_debug_apply_update(cba_problem* p, const double* x) {
   if (!p || !x || !p->have_state) { set_error("cba_debug_apply_update: bad argument"); return CBA_ERR_STATE; }
   CBA_HIP(hipSetDevice(p->device));
-  CBA_HIP(hipMemcpy(p->x, x, sizeof(double) * p->L.total_dof, hipMemcpyHostToDevice));
-  CBA_TRY(launch_apply_update(p->L, p->cams, p->st[p->cur], p->x, p->st[p->cur ^ 1], p->stream));
+  {
+    std::vector<double> xp(x, x + p->L.total_dof);
+    if (!p->pose_slot_host.empty())
+      for (int i = 0; i < p->L.n_images; ++i)
+        for (int k = 0; k < 6; ++k) xp[p->L.first_rig_tr_global + 6 * p->pose_slot_host[i] + k] = x[p->L.first_rig_tr_global + 6 * i + k];
+    CBA_HIP(hipMemcpy(p->x, xp.data(), sizeof(double) * p->L.total_dof, hipMemcpyHostToDevice));
+  }
+  CBA_TRY(launch_apply_update(p->L, p->cams, p->st[p->cur], p->x, p->st[p->cur ^ 1], p->pose_slot, p->stream));
   CBA_HIP(hipStreamSynchronize(p->stream));
   p->cur ^= 1;
   p->have_system = false;
@@ -618,7 +651,7 @@ int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double
     }
     t0 = now_s();
     const int cand = p->cur ^ 1;
-    CBA_TRY(launch_apply_update(L, p->cams, p->st[p->cur], p->x, p->st[cand], p->stream));
+    CBA_TRY(launch_apply_update(L, p->cams, p->st[p->cur], p->x, p->st[cand], p->pose_slot, p->stream));
     CBA_TRY(upload_camdevs(p, cand));
     CBA_TRY(residual_pass(p, cand, p->cost_test));
     CBA_TRY(launch_reduce_costs(p->cost_ref, p->cost_test, nullptr, p->n_obs, p->red_partials, p->red8, p->stream));
@@ -671,20 +704,30 @@ int cba_debug_dump(cba_problem* p, int32_t what, void* out, size_t bytes) {
       CBA_HIP(hipMemcpy2D(out, cols * sizeof(double), src, ld * sizeof(double), cols * sizeof(double), rows, hipMemcpyDeviceToHost));
     return CBA_OK;
   };
+  // block-part items are stored in slot order on the device; present them in imageset order
+  auto unpermute_rows = [&](size_t row_doubles) {
+    if (p->pose_slot_host.empty()) return;
+    std::vector<double> tmp((size_t)nb * bs * row_doubles);
+    std::memcpy(tmp.data(), out, tmp.size() * sizeof(double));
+    double* o = static_cast<double*>(out);
+    for (size_t i = 0; i < nb; ++i)
+      std::memcpy(o + i * bs * row_doubles, tmp.data() + (size_t)p->pose_slot_host[i] * bs * row_doubles, bs * row_doubles * sizeof(double));
+  };
   switch (what) {
     case CBA_DUMP_COST_VECTOR: return copy(p->cost_ref, n * sizeof(double));
     case CBA_DUMP_TEST_COST_VECTOR: return copy(p->cost_test, n * sizeof(double));
     case CBA_DUMP_PIXELS: return copy(p->pixels, 2 * n * sizeof(double));
     case CBA_DUMP_FLAGS: return copy(p->flags, n);
     case CBA_DUMP_JACOBIANS: return copy(p->jrec, n * p->rec_doubles * sizeof(double));
-    case CBA_DUMP_BLOCK_DIAG_H: return copy(p->Dblk, nb * bs * bs * sizeof(double));
-    case CBA_DUMP_BLOCK_DIAG_B: return copy(p->bblk, nb * bs * sizeof(double));
-    case CBA_DUMP_OFF_DIAG_H: return copy2d(p->B, nb * bs, dd);
+    case CBA_DUMP_BLOCK_DIAG_H: { int rc = copy(p->Dblk, nb * bs * bs * sizeof(double)); if (rc == CBA_OK) unpermute_rows(bs); return rc; }
+    case CBA_DUMP_BLOCK_DIAG_B: { int rc = copy(p->bblk, nb * bs * sizeof(double)); if (rc == CBA_OK) unpermute_rows(1); return rc; }
+    case CBA_DUMP_OFF_DIAG_H: { int rc = copy2d(p->B, nb * bs, dd); if (rc == CBA_OK) unpermute_rows(dd); return rc; }
     case CBA_DUMP_DENSE_H: return copy2d(p->Hdd, dd, dd);
     case CBA_DUMP_DENSE_B: return copy(p->bd, dd * sizeof(double));
     case CBA_DUMP_X: {
       if (bytes < (size_t)L.total_dof * sizeof(double)) { set_error("cba_debug_dump: buffer too small"); return CBA_ERR_ARG; }
       CBA_HIP(hipMemcpy(out, p->x, (size_t)L.total_dof * sizeof(double), hipMemcpyDeviceToHost));
+      if (!p->pose_slot_host.empty()) unpermute_rows(1);   // the block part comes first in x (eliminate_points = 0)
       return CBA_OK;
     }
     default: set_error("cba_debug_dump: unknown item"); return CBA_ERR_ARG;

@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(256) k_accumulate(PassArgs a, AccumLayout L, i
     const int K = 6 + nrig + 3 + Kg;
     const double* rec = jrec + (size_t)o * rec_doubles;
     const double w = rec[2];
-    const int pose_idx = L.first_rig_tr_global + 6 * a.obs_image[o];
+    const int pose_idx = L.first_rig_tr_global + 6 * (a.pose_slot ? a.pose_slot[a.obs_image[o]] : a.obs_image[o]);
     const int rig_idx = L.first_camera_tr_rig + 6 * cam;
     const int point_idx = L.first_points + 3 * a.obs_point[o];
     if (pose_idx != cur_pose || rig_idx != cur_rig) {
@@ -719,11 +719,11 @@ __device__ __forceinline__ void pose_minus(const double* in, const double* d, do
   out[4] = in[4] - d[3]; out[5] = in[5] - d[4]; out[6] = in[6] - d[5];
 }
 __global__ void k_update_poses(const double* __restrict__ in, const double* __restrict__ x, int n, double* __restrict__ out,
-                               int apply) {
+                               int apply, const int* __restrict__ slot) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (apply) {
-    pose_minus(in + 7 * (size_t)i, x + 6 * (size_t)i, out + 7 * (size_t)i);
+    pose_minus(in + 7 * (size_t)i, x + 6 * (size_t)(slot ? slot[i] : i), out + 7 * (size_t)i);
   } else {
     for (int k = 0; k < 7; ++k) out[7 * (size_t)i + k] = in[7 * (size_t)i + k];
   }
@@ -760,13 +760,13 @@ __global__ void k_update_grid(const double* __restrict__ in, const double* __res
   }
 }
 int launch_apply_update(const Layout& L, const std::vector<cba_camera>& cams, const DevState& in, const double* x,
-                        DevState& out, hipStream_t s) {
+                        DevState& out, const int* pose_slot, hipStream_t s) {
   int N = L.n_images, C = L.n_cameras, P = L.n_points;
   if (N > 0)
     hipLaunchKernelGGL(k_update_poses, dim3((N + 255) / 256), dim3(256), 0, s, in.rig_tr_global,
-                       x + L.first_rig_tr_global, N, out.rig_tr_global, 1);
+                       x + L.first_rig_tr_global, N, out.rig_tr_global, 1, pose_slot);
   hipLaunchKernelGGL(k_update_poses, dim3((C + 255) / 256), dim3(256), 0, s, in.camera_tr_rig,
-                     x + (L.rig_in_state ? L.first_camera_tr_rig : 0), C, out.camera_tr_rig, L.rig_in_state);
+                     x + (L.rig_in_state ? L.first_camera_tr_rig : 0), C, out.camera_tr_rig, L.rig_in_state, (const int*)nullptr);
   hipLaunchKernelGGL(k_update_points, dim3((3 * P + 255) / 256), dim3(256), 0, s, in.points, x + L.first_points, 3 * P,
                      out.points);
   for (int c = 0; c < C; ++c) {
