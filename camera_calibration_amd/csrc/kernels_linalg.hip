@@ -145,6 +145,7 @@ struct GemmArgs {
   int ldc2;
   const double* rowscale_inv;   // d values: C2 = value / d[m]
   long long total_tiles;
+  int chunk;                    // tiles per XCD chunk (set by launch_gemm)
   const unsigned long long* kmask;  // optional block-sparsity mask [column tile][kmask_words], bit = K slab of 16 rows
   int kmask_words;
   int epi_mode;                 // developer switch (bench harness): 0 normal, 1 no Cin read, 2 no store
@@ -160,9 +161,14 @@ __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
   if constexpr (TM < 128) __builtin_amdgcn_s_setprio(2);   // panel-sized products are on the critical path
 
   // ---- tile decode (XCD-aware permutation of the linear block index) ----
+  // Workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on it).  Tiles are dealt
+  // to the XCDs in chunks of 64 consecutive tiles of the row-major upper-triangle order: the 64
+  // workgroup slots of an XCD share one A panel (and neighbouring B panels) in its L2, and chunks from
+  // all parts of the matrix land on every XCD, which balances the block-sparse K loops.
   long long b = blockIdx.x;
-  const long long per_xcd = (g.total_tiles + 7) / 8;
-  long long t = (b & 7) * per_xcd + (b >> 3);
+  const long long q = b >> 3;
+  const long long cq = q / g.chunk;
+  long long t = (cq * 8 + (b & 7)) * g.chunk + (q - cq * g.chunk);
   if (t >= g.total_tiles) return;
   int tm, tn;
   if (g.upper) {
@@ -239,13 +245,16 @@ __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
     // contains any non-zero.  A slab contributes to tile (tm, tn) only if both column tiles touch it --
     // in bundle adjustment an imageset's rows of B are non-zero only at the points it sees and the grid
     // cells it covers -- so the loop walks the set bits of mask[tm] & mask[tn].
+    const unsigned long long* ma = g.kmask ? g.kmask + (size_t)(m0 >> 7) * g.kmask_words : nullptr;
+    const unsigned long long* mb = g.kmask ? g.kmask + (size_t)(n0 >> 7) * g.kmask_words : nullptr;
+    int mword = -1;
+    unsigned long long mbits = 0;
     auto next_slab = [&](int after) -> int {
       if (!g.kmask) return after + 1;
-      const unsigned long long* ma = g.kmask + (size_t)(m0 >> 7) * g.kmask_words;
-      const unsigned long long* mb = g.kmask + (size_t)(n0 >> 7) * g.kmask_words;
       int s = after + 1;
       while (s < nk) {
-        unsigned long long bits = (ma[s >> 6] & mb[s >> 6]) >> (s & 63);
+        if ((s >> 6) != mword) { mword = s >> 6; mbits = ma[mword] & mb[mword]; }   // one load per 64 slabs
+        unsigned long long bits = mbits >> (s & 63);
         if (bits) return s + __builtin_ctzll(bits);
         s = (s | 63) + 1;
       }
@@ -363,7 +372,13 @@ static int launch_gemm(GemmArgs g, hipStream_t s) {
   g.total_tiles = g.upper ? count_upper_tiles(g.m_off, g.n_off, g.m_tiles, g.n_tiles, TM, TN)
                           : (long long)g.m_tiles * g.n_tiles;
   if (g.total_tiles <= 0) return CBA_OK;
-  long long blocks = ((g.total_tiles + 7) / 8) * 8;
+  // chunk = 64 tiles for big launches; small launches use smaller chunks so that all eight XCDs get work
+  long long per = (g.total_tiles + 7) / 8;
+  // dense launches: one contiguous range per XCD (best L2 reuse); block-sparse launches: chunks of 64
+  // interleaved over the XCDs so that dense and sparse regions of the matrix are spread evenly
+  g.chunk = (int)((g.kmask && per > 64) ? 64 : (per < 1 ? 1 : per));
+  long long chunks = (g.total_tiles + g.chunk - 1) / g.chunk;
+  long long blocks = ((chunks + 7) / 8) * 8 * g.chunk;
   hipLaunchKernelGGL((k_gemm_atb<TM, TN, WM, WN, SUB>), dim3((unsigned)blocks), dim3(256), 0, s, g);
   CBA_HIP(hipGetLastError());
   return CBA_OK;
