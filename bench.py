@@ -41,7 +41,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-allreduce", action="store_true",
                     help="exercise the multi-GPU all-reduce path even with one rank (1-GPU validation of the N>1 code)")
-    ap.add_argument("--cpu-sample-images", type=int, default=6)
+    ap.add_argument("--cpu-sample-images", type=int, default=100)
     ap.add_argument("--no-convergence", action="store_true", help="skip the wall-clock-to-convergence run")
     return ap.parse_args()
 
@@ -50,8 +50,8 @@ def cpu_baseline(pb, st0, n_sample_images, n_obs_total, n_images_total):
     """Oracle (CPU restatement, 1 thread like the reference) timed on a bounded sample of this workload.
 
     Jacobian + cost passes: the first `n_sample_images` imagesets, scaled by observation count.
-    Solve: SolveWithSchurComplementDenseOffDiag restated, timed on a leading sub-system of 1024 dense
-    unknowns and scaled by the flop model  6N*D^2 (Schur product) + D^3/3 (LDLT)."""
+    Solve: SolveWithSchurComplementDenseOffDiag restated, timed on a synthetic SPD system of 2560 dense
+    unknowns / 100 pose blocks (about 10 s) and scaled by the flop model  6N*D^2 (Schur product) + D^3/3 (LDLT)."""
     from oracle import oracle as orc
     sub = pb.image_slice(0, n_sample_images)
     sst = st0.image_slice(0, n_sample_images)
@@ -64,7 +64,7 @@ def cpu_baseline(pb, st0, n_sample_images, n_obs_total, n_images_total):
     t_cost = time.perf_counter() - t0
     scale_obs = n_obs_total / max(1, sub.n_obs)
     # solve on a synthetic SPD system of reduced size
-    Ds, Ns = 1024, 32
+    Ds, Ns = 2560, 100
     rng = np.random.default_rng(0)
     s = orc.System(6, Ns, Ds)
     A = rng.normal(size=(Ds, Ds)); s.dense_H[:] = np.triu(A @ A.T + Ds * np.eye(Ds))

@@ -66,7 +66,8 @@ static void padded_dims(int dd, int* n_pad, int* n_fact) {
   *n_pad = np; *n_fact = nf;
 }
 
-static CamDev make_camdev(const cba_camera& c, const double* grid, const double* tangents, int intr_offset) {
+static CamDev make_camdev(const cba_camera& c, const double* grid, const double* tangents, int intr_offset,
+                          const int* gperm = nullptr) {
   CamDev d;
   d.model_type = c.model_type;
   d.gw = c.grid_w; d.gh = c.grid_h;
@@ -76,7 +77,7 @@ static CamDev make_camdev(const cba_camera& c, const double* grid, const double*
   d.span_y = (double)(c.calib_max_y + 1 - c.calib_min_y);
   d.jscale_x = (double)(((float)c.grid_w - 3.f) / (float)(c.calib_max_x + 1 - c.calib_min_x));
   d.jscale_y = (double)(((float)c.grid_h - 3.f) / (float)(c.calib_max_y + 1 - c.calib_min_y));
-  d.grid = grid; d.tangents = tangents; d.intr_offset = intr_offset;
+  d.grid = grid; d.tangents = tangents; d.intr_offset = intr_offset; d.gperm = gperm;
   d.params_per_point = c.model_type == CBA_CENTRAL_GENERIC ? 2 : 5;
   return d;
 }
@@ -122,9 +123,12 @@ struct cba_problem {
   uint32_t* pair_tables = nullptr; int* pair_counts = nullptr;
   std::vector<int> cell_base_host; int* cell_base = nullptr; int* cell_count = nullptr; int* cell_start = nullptr; int* cell_fill = nullptr;
   int* cell_order = nullptr;
-  // imageset -> position of its 6x6 block / rows of B.  Imagesets are sorted by the vertical centre of
-  // their observations so that the 16-row K slabs of the Schur product touch few grid-row tiles.
+  // imageset -> position of its 6x6 block / rows of B.  Imagesets are sorted along a Z-order curve of the
+  // centre of their observations so that the 16-row K slabs of the Schur product touch few grid tiles.
   std::vector<int> pose_slot_host; int* pose_slot = nullptr;
+  // control point -> rank in the engine's tiled order of the grid unknowns, per camera (see build_grid_order)
+  int* gperm[kMaxCameras] = {};
+  std::vector<int> dense_perm_host;   // reference dense column -> engine dense column (identity outside the grids)
   double* red_partials = nullptr; double* red8 = nullptr;
   // system
   int n_pad = 0, n_fact = 0, Kpad = 0;
@@ -176,10 +180,40 @@ static int alloc_state(cba_problem* p, DevState& s) {
   return CBA_OK;
 }
 
+// Engine-internal order of a camera's grid unknowns: control points are numbered tile by tile (8x8
+// points for the central model = 128 columns, 5x5 for the non-central one = 125 columns) instead of
+// row by row.  An imageset's rows of B are non-zero on the control points under its footprint, a 2-D
+// region of the grid; with 2-D tiles that region intersects about half as many 128-column tiles of
+// the Schur product as with 1-D runs of a grid row, and the block-sparse K loop skips the rest.
+// The order is internal: cba_debug_dump / cba_get_state present everything in the reference order.
+static int build_grid_order(cba_problem* p) {
+  const Layout& L = p->L;
+  p->dense_perm_host.resize(L.dense_dof);
+  for (int i = 0; i < L.dense_dof; ++i) p->dense_perm_host[i] = i;
+  if (L.localize_only) return CBA_OK;
+  for (int c = 0; c < L.n_cameras; ++c) {
+    const int gw = p->cams[c].grid_w, gh = p->cams[c].grid_h;
+    const int per = p->cams[c].model_type == CBA_CENTRAL_GENERIC ? 2 : 5;
+    const int tile = per == 2 ? 8 : 5;
+    std::vector<int> perm((size_t)gw * gh);
+    int rank = 0;
+    for (int ty = 0; ty < gh; ty += tile)
+      for (int tx = 0; tx < gw; tx += tile)
+        for (int y = ty; y < std::min(gh, ty + tile); ++y)
+          for (int x = tx; x < std::min(gw, tx + tile); ++x) perm[x + (size_t)y * gw] = rank++;
+    CBA_TRY(dev_alloc(&p->gperm[c], perm.size()));
+    CBA_HIP(hipMemcpy(p->gperm[c], perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice));
+    for (size_t g = 0; g < perm.size(); ++g)
+      for (int d = 0; d < per; ++d)
+        p->dense_perm_host[L.intr_offset[c] + per * g + d] = L.intr_offset[c] + per * perm[g] + d;
+  }
+  return CBA_OK;
+}
+
 static int upload_camdevs(cba_problem* p, int which) {
   std::vector<CamDev> h(p->L.n_cameras);
   for (int c = 0; c < p->L.n_cameras; ++c)
-    h[c] = make_camdev(p->cams[c], p->st[which].grids[c], p->tangents[c], p->L.intr_offset[c]);
+    h[c] = make_camdev(p->cams[c], p->st[which].grids[c], p->tangents[c], p->L.intr_offset[c], p->gperm[c]);
   CBA_HIP(hipMemcpyAsync(p->cams_dev[which], h.data(), sizeof(CamDev) * h.size(), hipMemcpyHostToDevice, p->stream));
   CBA_HIP(hipStreamSynchronize(p->stream));
   return CBA_OK;
@@ -354,6 +388,7 @@ int cba_create(const cba_config* config, cba_problem** out) {
   CBA_TRY(alloc_state(p, p->st[1]));
   CBA_TRY(dev_alloc(&p->itg, 16 * (size_t)L.n_images * L.n_cameras));
   for (int c = 0; c < L.n_cameras; ++c) CBA_TRY(dev_alloc(&p->tangents[c], 6 * (size_t)p->cams[c].grid_w * p->cams[c].grid_h));
+  CBA_TRY(build_grid_order(p));
   CBA_TRY(dev_alloc(&p->cams_dev[0], L.n_cameras));
   CBA_TRY(dev_alloc(&p->cams_dev[1], L.n_cameras));
   CBA_TRY(upload_camdevs(p, 0));
@@ -441,7 +476,7 @@ void cba_destroy(cba_problem* p) {
     F(p->cams_dev[s]);
   }
   F(p->itg);
-  for (int c = 0; c < kMaxCameras; ++c) F(p->tangents[c]);
+  for (int c = 0; c < kMaxCameras; ++c) { F(p->tangents[c]); F(p->gperm[c]); }
   F(p->cost_ref); F(p->cost_test); F(p->pixels); F(p->flags); F(p->fd_out); F(p->fd_ok); F(p->jrec); F(p->cells);
   F(p->pair_tables); F(p->pair_counts); F(p->red_partials); F(p->red8);
   F(p->cell_base); F(p->cell_count); F(p->cell_start); F(p->cell_fill); F(p->cell_order); F(p->pose_slot);
@@ -493,11 +528,24 @@ int cba_set_observations(cba_problem* p, int64_t n, const float* xy, const int32
   if (p->pose_slot) { hipFree(p->pose_slot); p->pose_slot = nullptr; }
   p->pose_slot_host.clear();
   if (!L.eliminate_points && L.n_images > 0 && n > 0) {
-    std::vector<double> sy(L.n_images, 0.0); std::vector<int> cnt(L.n_images, 0);
-    for (int64_t i = 0; i < n; ++i) { sy[image_index[i]] += xy[2 * i + 1]; cnt[image_index[i]] += 1; }
-    std::vector<int> order(L.n_images);
-    for (int i = 0; i < L.n_images; ++i) { order[i] = i; sy[i] = cnt[i] ? sy[i] / cnt[i] : 0.0; }
-    std::stable_sort(order.begin(), order.end(), [&](int u, int v) { return sy[u] < sy[v]; });
+    // sort key: Z-order (Morton) index of the centre of the imageset's observations on an 8x8 raster of
+    // the image, then the vertical centre -- neighbours in the order have overlapping 2-D footprints
+    std::vector<double> sx(L.n_images, 0.0), sy(L.n_images, 0.0); std::vector<int> cnt(L.n_images, 0);
+    double max_x = 1.0, max_y = 1.0;
+    for (int64_t i = 0; i < n; ++i) {
+      sx[image_index[i]] += xy[2 * i]; sy[image_index[i]] += xy[2 * i + 1]; cnt[image_index[i]] += 1;
+      max_x = std::max(max_x, (double)xy[2 * i]); max_y = std::max(max_y, (double)xy[2 * i + 1]);
+    }
+    std::vector<int> order(L.n_images), key(L.n_images, 0);
+    for (int i = 0; i < L.n_images; ++i) {
+      order[i] = i;
+      sx[i] = cnt[i] ? sx[i] / cnt[i] : 0.0; sy[i] = cnt[i] ? sy[i] / cnt[i] : 0.0;
+      const int qx = std::min(7, (int)(8.0 * sx[i] / (max_x + 1.0))), qy = std::min(7, (int)(8.0 * sy[i] / (max_y + 1.0)));
+      int k = 0;
+      for (int b = 0; b < 3; ++b) k |= (((qx >> b) & 1) << (2 * b)) | (((qy >> b) & 1) << (2 * b + 1));
+      key[i] = k;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int u, int v) { return key[u] != key[v] ? key[u] < key[v] : sy[u] < sy[v]; });
     p->pose_slot_host.assign(L.n_images, 0);
     for (int r = 0; r < L.n_images; ++r) p->pose_slot_host[order[r]] = r;
     CBA_TRY(dev_alloc(&p->pose_slot, (size_t)L.n_images));
@@ -592,9 +640,10 @@ int cba_debug_apply_update(cba_problem* p, const double* x) {
     if (!p->pose_slot_host.empty())
       for (int i = 0; i < p->L.n_images; ++i)
         for (int k = 0; k < 6; ++k) xp[p->L.first_rig_tr_global + 6 * p->pose_slot_host[i] + k] = x[p->L.first_rig_tr_global + 6 * i + k];
+    for (int i = 0; i < p->L.dense_dof; ++i) xp[p->L.block_dof + p->dense_perm_host[i]] = x[p->L.block_dof + i];
     CBA_HIP(hipMemcpy(p->x, xp.data(), sizeof(double) * p->L.total_dof, hipMemcpyHostToDevice));
   }
-  CBA_TRY(launch_apply_update(p->L, p->cams, p->st[p->cur], p->x, p->st[p->cur ^ 1], p->pose_slot, p->stream));
+  CBA_TRY(launch_apply_update(p->L, p->cams, p->st[p->cur], p->x, p->st[p->cur ^ 1], p->pose_slot, p->gperm, p->stream));
   CBA_HIP(hipStreamSynchronize(p->stream));
   p->cur ^= 1;
   p->have_system = false;
@@ -651,7 +700,7 @@ int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double
     }
     t0 = now_s();
     const int cand = p->cur ^ 1;
-    CBA_TRY(launch_apply_update(L, p->cams, p->st[p->cur], p->x, p->st[cand], p->pose_slot, p->stream));
+    CBA_TRY(launch_apply_update(L, p->cams, p->st[p->cur], p->x, p->st[cand], p->pose_slot, p->gperm, p->stream));
     CBA_TRY(upload_camdevs(p, cand));
     CBA_TRY(residual_pass(p, cand, p->cost_test));
     CBA_TRY(launch_reduce_costs(p->cost_ref, p->cost_test, nullptr, p->n_obs, p->red_partials, p->red8, p->stream));
@@ -713,6 +762,16 @@ int cba_debug_dump(cba_problem* p, int32_t what, void* out, size_t bytes) {
     for (size_t i = 0; i < nb; ++i)
       std::memcpy(o + i * bs * row_doubles, tmp.data() + (size_t)p->pose_slot_host[i] * bs * row_doubles, bs * row_doubles * sizeof(double));
   };
+  // dense-part items use the engine's tiled grid order on the device; present them in the reference order
+  const std::vector<int>& dperm = p->dense_perm_host;
+  auto unpermute_cols = [&](size_t rows, size_t row_offset_in_out) {   // out[r][j] = tmp[r][dperm[j]]
+    double* o = static_cast<double*>(out) + row_offset_in_out;
+    std::vector<double> tmp(dd);
+    for (size_t r = 0; r < rows; ++r) {
+      std::memcpy(tmp.data(), o + r * dd, dd * sizeof(double));
+      for (size_t j = 0; j < dd; ++j) o[r * dd + j] = tmp[dperm[j]];
+    }
+  };
   switch (what) {
     case CBA_DUMP_COST_VECTOR: return copy(p->cost_ref, n * sizeof(double));
     case CBA_DUMP_TEST_COST_VECTOR: return copy(p->cost_test, n * sizeof(double));
@@ -721,13 +780,32 @@ int cba_debug_dump(cba_problem* p, int32_t what, void* out, size_t bytes) {
     case CBA_DUMP_JACOBIANS: return copy(p->jrec, n * p->rec_doubles * sizeof(double));
     case CBA_DUMP_BLOCK_DIAG_H: { int rc = copy(p->Dblk, nb * bs * bs * sizeof(double)); if (rc == CBA_OK) unpermute_rows(bs); return rc; }
     case CBA_DUMP_BLOCK_DIAG_B: { int rc = copy(p->bblk, nb * bs * sizeof(double)); if (rc == CBA_OK) unpermute_rows(1); return rc; }
-    case CBA_DUMP_OFF_DIAG_H: { int rc = copy2d(p->B, nb * bs, dd); if (rc == CBA_OK) unpermute_rows(dd); return rc; }
-    case CBA_DUMP_DENSE_H: return copy2d(p->Hdd, dd, dd);
-    case CBA_DUMP_DENSE_B: return copy(p->bd, dd * sizeof(double));
+    case CBA_DUMP_OFF_DIAG_H: {
+      int rc = copy2d(p->B, nb * bs, dd);
+      if (rc == CBA_OK) { unpermute_rows(dd); unpermute_cols(nb * bs, 0); }
+      return rc;
+    }
+    case CBA_DUMP_DENSE_H: {
+      int rc = copy2d(p->Hdd, dd, dd);
+      if (rc != CBA_OK) return rc;
+      // upper triangle in the engine order -> upper triangle in the reference order
+      std::vector<double> tmp(dd * dd);
+      std::memcpy(tmp.data(), out, tmp.size() * sizeof(double));
+      double* o = static_cast<double*>(out);
+      for (size_t i = 0; i < dd; ++i)
+        for (size_t j = 0; j < dd; ++j) {
+          if (j < i) { o[i * dd + j] = 0.0; continue; }
+          const size_t a = dperm[i], b = dperm[j];
+          o[i * dd + j] = a <= b ? tmp[a * dd + b] : tmp[b * dd + a];
+        }
+      return CBA_OK;
+    }
+    case CBA_DUMP_DENSE_B: { int rc = copy(p->bd, dd * sizeof(double)); if (rc == CBA_OK) unpermute_cols(1, 0); return rc; }
     case CBA_DUMP_X: {
       if (bytes < (size_t)L.total_dof * sizeof(double)) { set_error("cba_debug_dump: buffer too small"); return CBA_ERR_ARG; }
       CBA_HIP(hipMemcpy(out, p->x, (size_t)L.total_dof * sizeof(double), hipMemcpyDeviceToHost));
       if (!p->pose_slot_host.empty()) unpermute_rows(1);   // the block part comes first in x (eliminate_points = 0)
+      unpermute_cols(1, L.block_dof);
       return CBA_OK;
     }
     default: set_error("cba_debug_dump: unknown item"); return CBA_ERR_ARG;

@@ -84,7 +84,7 @@ int launch_accumulate_cells(const PassArgs& a, const std::vector<cba_camera>& ca
 int launch_reduce_costs(const double* ref, const double* test, const uint8_t* flags, int64_t n, double* partials,
                         double* out8, hipStream_t s);
 int launch_apply_update(const Layout& L, const std::vector<cba_camera>& cams, const DevState& in, const double* x,
-                        DevState& out, const int* pose_slot, hipStream_t s);
+                        DevState& out, const int* pose_slot, int* const* gperm, hipStream_t s);
 int launch_project_points(const CamDev* cam_dev, int model, int64_t n, const double* local, const double* init,
                           double* pixels, uint8_t* ok, hipStream_t s);
 int launch_unproject(const CamDev* cam_dev, int model, int64_t n, const double* pixels, double* lines, double* jac,

@@ -461,7 +461,7 @@ int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const doubl
 // ------------------------------------------------------------------------------------------------
 // blocked LDL^T, lower/column-major view of "upper in row-major" storage.
 //   kInner = 64 : diagonal blocks factored (and their unit-lower factors inverted) by one workgroup
-//   kPanel = 512: trailing updates use K = 512 (halves the read+write traffic of the trailing matrix)
+//   kPanel = 256: trailing updates use K = 256
 // ------------------------------------------------------------------------------------------------
 constexpr int kInner = 64;
 constexpr int kPanel = 256;
@@ -469,50 +469,87 @@ constexpr int kPanel = 256;
 // Factor the 64x64 diagonal block at (j0,j0): T = L D L^T, and invert the unit-lower factor.
 // Writes L (L(p,q), p>q, at M[j0+q][j0+p]), d into the diagonal and dvec, and invLt[q][p] = (L^-1)(p,q).
 // One workgroup; every lane keeps a cyclic 4x4 sub-grid of T and of X = L^-1 in registers
-// (element (i,j) with i = ti + 16a, j = tj + 16b).  Step s broadcasts column s of T and row s of X
-// through LDS and applies the two rank-1 updates
+// (element (i,j) with i = ti + 16a, j = tj + 16b).  Step s reads column s of T and row s of X
+// from LDS and applies the two rank-1 updates
 //     T[i][j] -= l_i d l_j   (i,j > s),        X[i][c] -= l_i X[s][c]   (i > s, c <= s)
 // -- the second is the product form L^-1 = (I - l_62 e_62^T) ... (I - l_0 e_0^T).  One barrier per step.
+
+// Reciprocal of a pivot: v_rcp_f64 refined by two Newton steps (the IEEE division expands to ~3x as
+// many dependent instructions, and 1/d sits on the critical path of every elimination step).
+__device__ __forceinline__ double pivot_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+
+// One elimination step s = 16*SA + SR-or-sr of the register-resident 64x64 LDL^T.  Column s of T and
+// row s of X were published to colbuf/rowbuf[s & 1] by the previous step.  The step first updates the
+// entries of column s+1 / row s+1 (register index SAN of the cyclic sub-grid, owners tj / ti == nsr),
+// publishes them for the next step, and only then applies the rest of the rank-1 updates, which
+// therefore overlap the LDS round trip and the barrier.
+template <int SA, int SAN>
+__device__ __forceinline__ void ldlt_diag_step(double (&T)[4][4], double (&X)[4][4], double (*colbuf)[kInner],
+                                               double (*rowbuf)[kInner], int ti, int tj, int sr, int nsr, bool& bad) {
+  const int s = 16 * SA + sr, pb = s & 1;
+  // all LDS reads of the step are issued back to back (one round trip), masks are applied afterwards
+  const double d = colbuf[pb][s];
+  double li[4], lj[4], xr[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) li[a] = colbuf[pb][ti + 16 * a];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) { lj[b] = colbuf[pb][tj + 16 * b]; xr[b] = rowbuf[pb][tj + 16 * b]; }
+  if (!(fabs(d) > 0.0)) bad = true;
+  const double invd = pivot_rcp(d);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) li[a] = (ti + 16 * a > s) ? li[a] * invd : 0.0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) lj[b] = (tj + 16 * b > s) ? lj[b] : 0.0;
+  if constexpr (SAN < 4) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) T[a][SAN] -= li[a] * lj[SAN];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) X[SAN][b] -= li[SAN] * xr[b];
+    if (tj == nsr) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) colbuf[pb ^ 1][ti + 16 * a] = T[a][SAN];
+    }
+    if (ti == nsr) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) rowbuf[pb ^ 1][tj + 16 * b] = X[SAN][b];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (b != SAN) T[a][b] -= li[a] * lj[b];               // l_i d l_j with lj holding d*l_j
+      if (a != SAN) X[a][b] -= li[a] * xr[b];
+    }
+  if (tj == sr) {                                           // store column s of L in place of T[:,s]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+      if (ti + 16 * a > s) T[a][SA] = li[a];
+  }
+  __syncthreads();
+}
+
 // One segment of 16 elimination steps s = 16*SA + sr.  SA is a compile-time constant so that the
-// register holding column / row s (index SA of the cyclic 4x4 sub-grid) is addressed statically --
-// a run-time register index costs 3x per step (measured: 0.38 us vs 1.05 us).
+// registers holding column / row s (index SA of the cyclic 4x4 sub-grid) are addressed statically --
+// a run-time register index costs 3x per step (measured: 0.38 us vs 1.05 us).  The last step of a
+// segment publishes into the next segment's register index and is peeled.
 template <int SA>
 __device__ __forceinline__ void ldlt_diag_segment(double (&T)[4][4], double (&X)[4][4], double (*colbuf)[kInner],
                                                   double (*rowbuf)[kInner], int ti, int tj, int nsteps, bool& bad) {
 #pragma nounroll
-  for (int sr = 0; sr < 16; ++sr) {
-    const int s = 16 * SA + sr, pb = sr & 1;
-    if (s >= nsteps) return;
-    if (tj == sr) {                                          // owners of column s publish it
-#pragma unroll
-      for (int a = 0; a < 4; ++a) colbuf[pb][ti + 16 * a] = T[a][SA];
-    }
-    if (ti == sr) {                                          // owners of row s of X publish it
-#pragma unroll
-      for (int b = 0; b < 4; ++b) rowbuf[pb][tj + 16 * b] = X[SA][b];
-    }
-    __syncthreads();
-    const double d = colbuf[pb][s];
-    if (!(fabs(d) > 0.0)) bad = true;
-    const double invd = 1.0 / d;
-    double li[4], lj[4], xr[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) { const int i = ti + 16 * a; li[a] = (i > s) ? colbuf[pb][i] * invd : 0.0; }
-#pragma unroll
-    for (int b = 0; b < 4; ++b) { const int j = tj + 16 * b; lj[b] = (j > s) ? colbuf[pb][j] : 0.0; xr[b] = rowbuf[pb][j]; }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        T[a][b] -= li[a] * lj[b];                            // l_i d l_j with lj holding d*l_j
-        X[a][b] -= li[a] * xr[b];
-      }
-    if (tj == sr) {                                          // store column s of L in place of T[:,s]
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-        if (ti + 16 * a > s) T[a][SA] = li[a];
-    }
+  for (int sr = 0; sr < 15; ++sr) {
+    if (16 * SA + sr >= nsteps) return;
+    ldlt_diag_step<SA, SA>(T, X, colbuf, rowbuf, ti, tj, sr, sr + 1, bad);
   }
+  if (16 * SA + 15 >= nsteps) return;
+  ldlt_diag_step<SA, SA + 1>(T, X, colbuf, rowbuf, ti, tj, 15, 0, bad);
 }
 
 // Factor the 64x64 diagonal block at (j0,j0): T = L D L^T, and invert the unit-lower factor.
@@ -539,6 +576,15 @@ __global__ void __launch_bounds__(256) k_ldlt_diag(double* __restrict__ M, int l
       T[a][b] = M[(size_t)(j0 + lo) * ld + j0 + hi];
       X[a][b] = (i == j) ? 1.0 : 0.0;
     }
+  if (tj == 0) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) colbuf[0][ti + 16 * a] = T[a][0];
+  }
+  if (ti == 0) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) rowbuf[0][tj + 16 * b] = X[0][b];
+  }
+  __syncthreads();
   bool bad = false;
   ldlt_diag_segment<0>(T, X, colbuf, rowbuf, ti, tj, NSTEPS, bad);
   ldlt_diag_segment<1>(T, X, colbuf, rowbuf, ti, tj, NSTEPS, bad);

@@ -481,7 +481,7 @@ __global__ void __launch_bounds__(256) k_accumulate(PassArgs a, AccumLayout L, i
       {
         int cell = kk / per, d = kk - cell * per;
         int seq = (cx0 + (cell & 3)) + (cy0 + (cell >> 2)) * cd.gw;
-        idx = L.block_dof + cd.intr_offset + per * seq + d;
+        idx = L.block_dof + grid_column(cd, seq, d);
         j0 = rec[kRecHeader + kk]; j1 = rec[kRecHeader + Kg + kk];
       }
     done:
@@ -612,8 +612,9 @@ __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, i
     if (lane + 64 * t >= NPAIR) continue;
     const int i = pi[t], k = pk[t];
     const int ci = i / PER, di = i - ci * PER, ck = k / PER, dk = k - ck * PER;
-    const int row = cd.intr_offset + PER * ((cx0 + (ci & 3)) + (cy0 + (ci >> 2)) * cd.gw) + di;
-    const int col = cd.intr_offset + PER * ((cx0 + (ck & 3)) + (cy0 + (ck >> 2)) * cd.gw) + dk;
+    int row = grid_column(cd, (cx0 + (ci & 3)) + (cy0 + (ci >> 2)) * cd.gw, di);
+    int col = grid_column(cd, (cx0 + (ck & 3)) + (cy0 + (ck >> 2)) * cd.gw, dk);
+    if (row > col) { const int t2 = row; row = col; col = t2; }   // tiled order is not monotone in the patch order
     unsafeAtomicAdd(Hdd + (size_t)row * ld + col, acc[t]);
   }
 }
@@ -736,7 +737,7 @@ __global__ void k_update_points(const double* __restrict__ in, const double* __r
 // SubtractDelta: central_grid.h:168-184 / noncentral_generic.h:195-219 (tangents recomputed from the
 // current direction, full renormalisation)
 __global__ void k_update_grid(const double* __restrict__ in, const double* __restrict__ x, int G, int per, int apply,
-                              double* __restrict__ out) {
+                              const int* __restrict__ gperm, double* __restrict__ out) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= G) return;
   double d[3] = {in[3 * g], in[3 * g + 1], in[3 * g + 2]};
@@ -747,7 +748,7 @@ __global__ void k_update_grid(const double* __restrict__ in, const double* __res
   }
   double t1[3], t2[3];
   tangents_of(d, t1, t2);
-  const double* dx = x + (size_t)per * g;
+  const double* dx = x + (size_t)per * (gperm ? gperm[g] : g);
   double o1 = -dx[0], o2 = -dx[1];
   double nd[3] = {d[0] + o1 * t1[0] + o2 * t2[0], d[1] + o1 * t1[1] + o2 * t2[1], d[2] + o1 * t1[2] + o2 * t2[2]};
   normalize3(nd[0], nd[1], nd[2]);
@@ -760,7 +761,7 @@ __global__ void k_update_grid(const double* __restrict__ in, const double* __res
   }
 }
 int launch_apply_update(const Layout& L, const std::vector<cba_camera>& cams, const DevState& in, const double* x,
-                        DevState& out, const int* pose_slot, hipStream_t s) {
+                        DevState& out, const int* pose_slot, int* const* gperm, hipStream_t s) {
   int N = L.n_images, C = L.n_cameras, P = L.n_points;
   if (N > 0)
     hipLaunchKernelGGL(k_update_poses, dim3((N + 255) / 256), dim3(256), 0, s, in.rig_tr_global,
@@ -774,7 +775,7 @@ int launch_apply_update(const Layout& L, const std::vector<cba_camera>& cams, co
     int per = cams[c].model_type == CBA_CENTRAL_GENERIC ? 2 : 5;
     hipLaunchKernelGGL(k_update_grid, dim3((G + 255) / 256), dim3(256), 0, s, in.grids[c],
                        x + (L.localize_only ? 0 : L.block_dof + L.intr_offset[c]), G, per, L.localize_only ? 0 : 1,
-                       out.grids[c]);
+                       gperm ? gperm[c] : nullptr, out.grids[c]);
   }
   CBA_HIP(hipGetLastError());
   return CBA_OK;

@@ -31,7 +31,13 @@ struct CamDev {
   const double* tangents; // 6G (t1,t2) of the direction grid (Jacobian pass only)
   int intr_offset;        // first dense column of this camera's intrinsics
   int params_per_point;   // 2 or 5
+  const int* gperm;       // control point (gx + gy*gw) -> rank in the engine's tiled unknown order (null = identity)
 };
+
+// Dense column of parameter d of control point `seq` of this camera (engine-internal order).
+__device__ __forceinline__ int grid_column(const CamDev& c, int seq, int d) {
+  return c.intr_offset + c.params_per_point * (c.gperm ? c.gperm[seq] : seq) + d;
+}
 
 // A control point replaced by a perturbed copy (index < 0: none).
 struct Subst {
