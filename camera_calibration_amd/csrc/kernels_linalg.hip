@@ -461,10 +461,24 @@ int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const doubl
 // ------------------------------------------------------------------------------------------------
 // blocked LDL^T, lower/column-major view of "upper in row-major" storage.
 //   kInner = 64 : diagonal blocks factored (and their unit-lower factors inverted) by one workgroup
-//   kPanel = 256: trailing updates use K = 256
+//   kPanel = 256: panel width of the chain-bound tail and of the back substitution
+//   kPanelWide = 512: panel width while the bulk update is the bottleneck (the leading part of the matrix):
+//                the GEMM reaches 53 instead of 46 TFLOP/s at K = 512 because the read+write of the C
+//                tile is amortised over twice the flops
 // ------------------------------------------------------------------------------------------------
 constexpr int kInner = 64;
 constexpr int kPanel = 256;
+constexpr int kPanelWide = 512;
+// panels are kPanelWide wide while more than this many rows remain (env CBA_WIDE_ROWS overrides; 0 = never)
+static int wide_rows_threshold() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CBA_WIDE_ROWS"); v = e ? atoi(e) : 6144; if (v < 0) v = 6144; }
+  return v;
+}
+static int panel_width_at(int k0, int n_fact) {
+  const int thr = wide_rows_threshold();
+  return (thr > 0 && n_fact - k0 > thr && n_fact - k0 >= kPanelWide) ? kPanelWide : kPanel;
+}
 
 // Factor the 64x64 diagonal block at (j0,j0): T = L D L^T, and invert the unit-lower factor.
 // Writes L (L(p,q), p>q, at M[j0+q][j0+p]), d into the diagonal and dvec, and invLt[q][p] = (L^-1)(p,q).
@@ -634,7 +648,7 @@ int make_main_stream(hipStream_t* s) {
 
 int ldlt_workspace_alloc(LdltWorkspace& w, int n_pad) {
   ldlt_workspace_free(w);
-  CBA_HIP(hipMalloc(&w.X, sizeof(double) * 2 * (size_t)kPanel * n_pad));   // two panel buffers (look-ahead)
+  CBA_HIP(hipMalloc(&w.X, sizeof(double) * 2 * (size_t)kPanelWide * n_pad));   // two panel buffers (look-ahead)
   CBA_HIP(hipMalloc(&w.invLt, sizeof(double) * (size_t)(n_pad / kInner) * kInner * kInner));
   CBA_HIP(hipMalloc(&w.dvec, sizeof(double) * (size_t)n_pad));
   CBA_HIP(hipMalloc(&w.status, sizeof(int)));
@@ -652,12 +666,26 @@ int ldlt_workspace_alloc(LdltWorkspace& w, int n_pad) {
       CBA_HIP(hipStreamCreateWithPriority(&w.panel_stream, hipStreamNonBlocking, hi));
     }
   }
-  CBA_HIP(hipStreamCreateWithFlags(&w.far_stream, hipStreamNonBlocking));
-  CBA_HIP(hipEventCreateWithFlags(&w.ev_panel, hipEventDisableTiming));
-  CBA_HIP(hipEventCreateWithFlags(&w.ev_strip, hipEventDisableTiming));
-  CBA_HIP(hipEventCreateWithFlags(&w.ev_strip2, hipEventDisableTiming));
-  CBA_HIP(hipEventCreateWithFlags(&w.ev_chain, hipEventDisableTiming));
-  CBA_HIP(hipEventCreateWithFlags(&w.ev_bulk, hipEventDisableTiming));
+  {
+    uint32_t mask[8];
+    panel_cu_mask(mask, /*panel=*/true);
+    if (panel_cu_count() > 0) CBA_HIP(hipExtStreamCreateWithCUMask(&w.mid_stream, 8, mask));
+    else CBA_HIP(hipStreamCreateWithFlags(&w.mid_stream, hipStreamNonBlocking));
+  }
+  // the far stream carries wide launches; like the main stream it stays off the chain's CUs
+  if (panel_cu_count() > 0) {
+    uint32_t mask[8];
+    panel_cu_mask(mask, /*panel=*/false);
+    CBA_HIP(hipExtStreamCreateWithCUMask(&w.far_stream, 8, mask));
+  } else {
+    CBA_HIP(hipStreamCreateWithFlags(&w.far_stream, hipStreamNonBlocking));
+  }
+  CBA_HIP(hipEventCreateWithFlags(&w.ev_panel, hipEventDisableTiming | hipEventDisableSystemFence));
+  CBA_HIP(hipEventCreateWithFlags(&w.ev_strip, hipEventDisableTiming | hipEventDisableSystemFence));
+  CBA_HIP(hipEventCreateWithFlags(&w.ev_mid, hipEventDisableTiming | hipEventDisableSystemFence));
+  CBA_HIP(hipEventCreateWithFlags(&w.ev_aa, hipEventDisableTiming | hipEventDisableSystemFence));
+  CBA_HIP(hipEventCreateWithFlags(&w.ev_chain, hipEventDisableTiming | hipEventDisableSystemFence));
+  CBA_HIP(hipEventCreateWithFlags(&w.ev_bulk, hipEventDisableTiming | hipEventDisableSystemFence));
   w.n_alloc = n_pad;
   return CBA_OK;
 }
@@ -668,9 +696,11 @@ void ldlt_workspace_free(LdltWorkspace& w) {
   if (w.status) hipFree(w.status);
   if (w.panel_stream) hipStreamDestroy(w.panel_stream);
   if (w.far_stream) hipStreamDestroy(w.far_stream);
+  if (w.mid_stream) hipStreamDestroy(w.mid_stream);
   if (w.ev_panel) hipEventDestroy(w.ev_panel);
   if (w.ev_strip) hipEventDestroy(w.ev_strip);
-  if (w.ev_strip2) hipEventDestroy(w.ev_strip2);
+  if (w.ev_mid) hipEventDestroy(w.ev_mid);
+  if (w.ev_aa) hipEventDestroy(w.ev_aa);
   if (w.ev_chain) hipEventDestroy(w.ev_chain);
   if (w.ev_bulk) hipEventDestroy(w.ev_bulk);
   w = LdltWorkspace();
@@ -680,14 +710,16 @@ void ldlt_workspace_free(LdltWorkspace& w) {
 // in the panel solves / updates, so a right-hand side stored in a trailing column is forward-
 // substituted and scaled on the fly (it ends up holding D^-1 L^-1 b).
 //
-// Three streams:
+// Four streams:
 //   chain : the latency-bound pivot chain -- per 64-block: diagonal factor, then the solve / update
-//           restricted to the panel's own 256 columns ("near", 1-6 workgroups each);
-//   far   : the same solve / update for the columns right of the panel, which nothing in the chain
-//           waits for;
-//   main  : trailing updates with K = 256 on the MFMA GEMM, issued as (a') the next panel's diagonal
-//           tiles (releases the chain), (a'') the rest of the next panel's rows (releases far), (b) the
-//           bulk.  The next panel is factored underneath (b) (look-ahead).
+//           restricted to the panel's own 256 columns ("near", 1-6 workgroups each); after the last
+//           block it also solves that block for the next panel's columns and applies (a'), the update of
+//           the next panel's diagonal block, so that the next panel starts without a stream hop;
+//   mid   : the same solve / update for the next panel's 256 columns (what (a') needs);
+//   far   : ... and for everything right of that, plus (a''), the update of the rest of the next
+//           panel's rows;
+//   main  : (b) the bulk trailing update with K = 256 on the MFMA GEMM.  The next panel is factored
+//           underneath (b) (look-ahead).
 static int trsm_cols(double* S, int ld, int j0, int k0, int col_begin, int col_end, double* Xk, LdltWorkspace& w, hipStream_t s) {
   // X[p][i] = sum_q invLt[q][p] * S[j0+q][i], i in [col_begin, col_end); L = X / d written in place
   if (col_begin >= col_end) return CBA_OK;
@@ -735,58 +767,82 @@ static int update_block(double* S, int ld, int j0, int k0, int m_begin, int m_en
 
 int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, GemmStats* st) {
   const int n_pad = ld;
-  hipStream_t s2 = w.panel_stream, s3 = w.far_stream;
+  hipStream_t s2 = w.panel_stream, s3 = w.far_stream, s4 = w.mid_stream;
+  if (getenv("CBA_SERIAL")) { s2 = s; s3 = s; s4 = s; }   // developer switch: one stream (profiling the bulk GEMM alone)
   // the side streams may start once everything queued on the main stream so far (assembly of S) is done
   CBA_HIP(hipEventRecord(w.ev_strip, s));
   CBA_HIP(hipStreamWaitEvent(s2, w.ev_strip, 0));
   CBA_HIP(hipStreamWaitEvent(s3, w.ev_strip, 0));
+  CBA_HIP(hipStreamWaitEvent(s4, w.ev_strip, 0));
   CBA_HIP(hipEventRecord(w.ev_bulk, s));
   int kidx = 0;
-  for (int k0 = 0; k0 < n_fact; k0 += kPanel, ++kidx) {
-    const int nb = (n_fact - k0 < kPanel) ? (n_fact - k0) : kPanel;
+  for (int k0 = 0, pw = 0; k0 < n_fact; k0 += pw, ++kidx) {
+    pw = panel_width_at(k0, n_fact);
+    const int nb = (n_fact - k0 < pw) ? (n_fact - k0) : pw;
     const int e0 = k0 + nb;   // first column right of the panel
-    double* Xk = w.X + (size_t)(kidx & 1) * kPanel * n_pad;
+    double* Xk = w.X + (size_t)(kidx & 1) * kPanelWide * n_pad;
+    const int pw_next = e0 < n_fact ? panel_width_at(e0, n_fact) : kPanel;
+    const int r0 = e0;
+    // look-ahead structure: the next panel's columns [e0, nx) are kept ahead of the rest
+    const bool more = e0 < n_fact;                 // the last panel needs no trailing update
+    const bool la = more && (r0 < n_pad) && (r0 % 128 == 0);
+    const int mt = la ? (n_pad - r0) / 128 : 0;
+    const int head = mt < pw_next / 128 ? mt : pw_next / 128;   // 128-tile rows of the next panel
+    const int nx = la ? r0 + head * 128 : e0;
     int rc;
+    GemmArgs u{};                                  // trailing update with the whole panel
+    u.A = S + (size_t)k0 * ld; u.lda = ld;
+    u.B = Xk; u.ldb = n_pad; u.K = nb;
+    u.C = S; u.ldc = ld; u.Cin = S; u.ldcin = ld;
+    u.diag = 0;
     for (int j0 = k0; j0 < e0; j0 += kInner) {
       const int c0 = j0 + kInner;
+      const bool last = (c0 == e0);
       // ---- chain: factor the diagonal block, near solve, near update ----
       hipLaunchKernelGGL(k_ldlt_diag<kInner>, dim3(1), dim3(256), 0, s2, S, ld, j0, w.dvec, w.invLt, w.status);
       if ((rc = trsm_cols(S, ld, j0, k0, c0, e0, Xk, w, s2))) return rc;
       if ((rc = update_block(S, ld, j0, k0, c0, e0, c0, e0, /*upper*/ 1, Xk, s2))) return rc;
       CBA_HIP(hipEventRecord(w.ev_chain, s2));
-      // ---- far: columns right of the panel ----
+      if (last && la) {
+        // the last block's solve on the next panel's columns and (a') stay on the chain stream
+        CBA_HIP(hipStreamWaitEvent(s2, w.ev_mid, 0));      // mid updates of the earlier blocks
+        if ((rc = trsm_cols(S, ld, j0, k0, e0, nx, Xk, w, s2))) return rc;
+        CBA_HIP(hipStreamWaitEvent(s2, w.ev_bulk, 0));     // the previous bulk update wrote the same block
+        // (a') diagonal block of the next panel.  64x64 tiles: ten small tiles on ten CUs finish several
+        // times sooner than three 128x128 tiles, and this launch is on the critical path.
+        GemmArgs v = u;
+        v.upper = 1; v.m_off = r0; v.m_tiles = head * 2; v.n_off = r0; v.n_tiles = head * 2;
+        if ((rc = launch_gemm<64, 64, 32, 32, true>(v, s2))) return rc;
+        CBA_HIP(hipEventRecord(w.ev_strip, s2));
+      }
+      // ---- mid: the next panel's columns ----
+      if (!last && nx > e0) {
+        CBA_HIP(hipStreamWaitEvent(s4, w.ev_chain, 0));
+        if ((rc = trsm_cols(S, ld, j0, k0, e0, nx, Xk, w, s4))) return rc;
+        if ((rc = update_block(S, ld, j0, k0, c0, e0, e0, nx, /*upper*/ 0, Xk, s4))) return rc;
+        CBA_HIP(hipEventRecord(w.ev_mid, s4));
+      }
+      // ---- far: everything right of that ----
       CBA_HIP(hipStreamWaitEvent(s3, w.ev_chain, 0));
-      if ((rc = trsm_cols(S, ld, j0, k0, e0, n_pad, Xk, w, s3))) return rc;
-      if ((rc = update_block(S, ld, j0, k0, c0, e0, e0, n_pad, /*upper*/ 0, Xk, s3))) return rc;
+      if ((rc = trsm_cols(S, ld, j0, k0, nx, n_pad, Xk, w, s3))) return rc;
+      if ((rc = update_block(S, ld, j0, k0, c0, e0, nx, n_pad, /*upper*/ 0, Xk, s3))) return rc;
     }
     CBA_HIP(hipEventRecord(w.ev_panel, s3));     // far is queued behind every chain event of this panel
     CBA_HIP(hipStreamWaitEvent(s, w.ev_panel, 0));
-    // ---- trailing update with the whole panel (main stream) ----
-    const int r0 = e0;
-    if (r0 < n_pad) {
-      GemmArgs u{};
-      u.A = S + (size_t)k0 * ld; u.lda = ld;
-      u.B = Xk; u.ldb = n_pad; u.K = nb;
-      u.C = S; u.ldc = ld; u.Cin = S; u.ldcin = ld;
-      u.diag = 0;
-      if (r0 % 128 == 0) {
-        const int mt = (n_pad - r0) / 128;
-        const int head = mt < kPanel / 128 ? mt : kPanel / 128;   // tile rows of the next panel
-        // (a') diagonal block of the next panel -> releases the chain.  64x64 tiles: ten small tiles on ten
-        // CUs finish several times sooner than three 128x128 tiles, and this launch is on the critical path.
-        u.upper = 1; u.m_off = r0; u.m_tiles = head * 2; u.n_off = r0; u.n_tiles = head * 2;
-        if ((rc = launch_gemm<64, 64, 32, 32, true>(u, s))) return rc;
-        CBA_HIP(hipEventRecord(w.ev_strip, s));
-        CBA_HIP(hipStreamWaitEvent(s2, w.ev_strip, 0));
-        // (a'') rest of the next panel's rows: issued on the far stream (it is what the next panel's far
+    if (more && r0 < n_pad) {
+      if (la) {
+        // (a'') rest of the next panel's rows, on the far stream (it is what the next panel's mid / far
         // work waits for) so that it runs next to the bulk update instead of in front of it.  It writes
         // rows that the previous bulk update also wrote, hence the wait on ev_bulk.
+        CBA_HIP(hipStreamWaitEvent(s3, w.ev_strip, 0));    // the chain's solve on the next panel's columns
         if (mt > head) {
           CBA_HIP(hipStreamWaitEvent(s3, w.ev_bulk, 0));
           GemmArgs v = u;
           v.upper = 0; v.m_off = r0; v.m_tiles = head; v.n_off = r0 + head * 128; v.n_tiles = mt - head;
           if ((rc = launch_gemm<128, 128, 64, 64, true>(v, s3))) return rc;
         }
+        CBA_HIP(hipEventRecord(w.ev_aa, s3));
+        CBA_HIP(hipStreamWaitEvent(s4, w.ev_aa, 0));
         // (b) bulk
         if (mt > head) {
           u.upper = 1; u.m_off = r0 + head * 128; u.m_tiles = mt - head; u.n_off = r0 + head * 128; u.n_tiles = mt - head;
@@ -800,6 +856,7 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
         CBA_HIP(hipEventRecord(w.ev_strip, s));
         CBA_HIP(hipStreamWaitEvent(s2, w.ev_strip, 0));
         CBA_HIP(hipStreamWaitEvent(s3, w.ev_strip, 0));
+        CBA_HIP(hipStreamWaitEvent(s4, w.ev_strip, 0));
       }
       if (st) {
         double rows = (double)(n_pad - r0);
@@ -808,6 +865,11 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
       }
     }
   }
+  // everything the side streams did is ordered before whatever follows on the main stream
+  CBA_HIP(hipEventRecord(w.ev_strip, s2));
+  CBA_HIP(hipStreamWaitEvent(s, w.ev_strip, 0));
+  CBA_HIP(hipEventRecord(w.ev_mid, s4));
+  CBA_HIP(hipStreamWaitEvent(s, w.ev_mid, 0));
   CBA_HIP(hipGetLastError());
   return CBA_OK;
 }

@@ -2,6 +2,7 @@
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -mllvm -amdgpu-mfma-vgpr-form tools/bench_linalg.hip -o tools/bin/bench_linalg
 #include "../camera_calibration_amd/csrc/kernels_linalg.hip"
 #include <cstdio>
+#include <chrono>
 #include <vector>
 #include <cmath>
 namespace cba { void set_error(const std::string& m) { fprintf(stderr, "error: %s\n", m.c_str()); } }
@@ -76,9 +77,12 @@ int main(int argc, char** argv) {
     GemmStats gs;
     hipMemset(w.status, 0, 4);
     hipEventRecord(e0, ms);
+    auto h0 = std::chrono::steady_clock::now();
     ldlt_factor(S, n_fact, n, w, ms, &gs);
+    auto h1 = std::chrono::steady_clock::now();
     hipEventRecord(e1, ms);
     float ms_ = timeit(e0, e1);
+    printf("host enqueue time of ldlt_factor: %.3f ms\n", std::chrono::duration<double, std::milli>(h1 - h0).count());
     printf("ldlt_factor n_fact=%d: %.3f ms  (trailing %.3f TFLOP -> %.2f TFLOP/s overall)\n", n_fact, ms_, gs.flops / 1e12, gs.flops / ms_ / 1e9);
     double* x; hipMalloc(&x, sizeof(double) * n);
     hipEventRecord(e0);
