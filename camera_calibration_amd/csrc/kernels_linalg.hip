@@ -883,40 +883,61 @@ __global__ void k_gather_col(const double* __restrict__ S, int ld, int col, int 
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n) x[j] = S[(size_t)j * ld + col];
 }
-__global__ void __launch_bounds__(256) k_back_panel_diag(const double* __restrict__ S, int ld, int k0, int nb,
-                                                         const double* __restrict__ invLt_all, double* __restrict__ x) {
+// Panel triangle of the back substitution.  1024 lanes: row p = tid / 16 of the current 64-block, 16 lanes
+// per row.  Every lane first loads ALL matrix entries it will need for the four 64-blocks (its slices of
+// the rows of L right of each block and of the stored inverse blocks, 64 doubles) with independent loads
+// -- one L2 round trip for the whole panel instead of two per block -- and the four dependent block
+// solves then run out of registers and LDS.
+__global__ void __launch_bounds__(1024) k_back_panel_diag(const double* __restrict__ S, int ld, int k0, int nb,
+                                                          const double* __restrict__ invLt_all, double* __restrict__ x) {
+  constexpr int NB = kPanel / kInner;          // 4 blocks
+  constexpr int LPER = (kPanel - kInner) / 16; // 12 columns of L per lane and block (at most)
+  constexpr int IPER = kInner / 16;            // 4 entries of the inverse per lane and block
   __shared__ double xs[kPanel];
   __shared__ double t[kInner];
-  // lane layout: row p = tid / 4 (64 rows), quarter = tid % 4 splits the dot products; the four
-  // partial sums sit in adjacent lanes and are combined with two shuffles.  All loads of one lane
-  // are independent, so a sub-block costs about one L2 round trip instead of one per row.
-  const int p = threadIdx.x >> 2, qt = threadIdx.x & 3;
-  for (int i = threadIdx.x; i < nb; i += 256) xs[i] = x[k0 + i];
+  const int p = threadIdx.x >> 4, l = threadIdx.x & 15;
+  const int nblk = nb / kInner;
+  double Lr[NB][LPER], Ir[NB][IPER];
+#pragma unroll
+  for (int sub = 0; sub < NB; ++sub) {
+    const int j0 = sub * kInner;
+    const bool live = sub < nblk;
+    const double* row = S + (size_t)(k0 + j0 + p) * ld + k0;
+#pragma unroll
+    for (int i = 0; i < LPER; ++i) {
+      const int col = j0 + kInner + l + 16 * i;
+      Lr[sub][i] = (live && col < nb) ? row[col] : 0.0;
+    }
+    const double* inv = invLt_all + (size_t)((k0 + j0) / kInner) * kInner * kInner + (size_t)p * kInner;
+#pragma unroll
+    for (int i = 0; i < IPER; ++i) Ir[sub][i] = live ? inv[l + 16 * i] : 0.0;
+  }
+  if (threadIdx.x < kPanel) xs[threadIdx.x] = (threadIdx.x < nb) ? x[k0 + threadIdx.x] : 0.0;
   __syncthreads();
-  for (int sub = nb / kInner - 1; sub >= 0; --sub) {
-    const int j0 = sub * kInner;   // offset inside the panel
-    {
-      const double* row = S + (size_t)(k0 + j0 + p) * ld + k0;
-      double acc = 0.0;
-      for (int i = j0 + kInner + qt; i < nb; i += 4) acc += row[i] * xs[i];
-      acc += __shfl_xor(acc, 1, 64);
-      acc += __shfl_xor(acc, 2, 64);
-      if (qt == 0) t[p] = xs[j0 + p] - acc;
+#pragma unroll
+  for (int sub = NB - 1; sub >= 0; --sub) {
+    if (sub >= nblk) continue;   // uniform
+    const int j0 = sub * kInner;
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < LPER; ++i) {
+      const int col = j0 + kInner + l + 16 * i;
+      if (col < kPanel) acc += Lr[sub][i] * xs[col];
     }
+    acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64); acc += __shfl_xor(acc, 8, 64);
+    if (l == 0) t[p] = xs[j0 + p] - acc;
     __syncthreads();
-    {
-      // x[q] = sum_{p' >= q} invL(p',q) t[p'] = sum_{p'} invLt[q][p'] t[p']   (q = p here)
-      const double* invLt = invLt_all + (size_t)((k0 + j0) / kInner) * kInner * kInner + (size_t)p * kInner;
-      double acc = 0.0;
-      for (int pp = qt; pp < kInner; pp += 4) acc += invLt[pp] * t[pp];
-      acc += __shfl_xor(acc, 1, 64);
-      acc += __shfl_xor(acc, 2, 64);
-      __syncthreads();
-      if (qt == 0) xs[j0 + p] = acc;
-    }
+    // x[q] = sum_{p' >= q} invL(p',q) t[p'] = sum_{p'} invLt[q][p'] t[p']   (q = p here)
+    double a2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < IPER; ++i) a2 += Ir[sub][i] * t[l + 16 * i];
+    a2 += __shfl_xor(a2, 1, 64); a2 += __shfl_xor(a2, 2, 64);
+    a2 += __shfl_xor(a2, 4, 64); a2 += __shfl_xor(a2, 8, 64);
+    if (l == 0) xs[j0 + p] = a2;
     __syncthreads();
   }
-  for (int i = threadIdx.x; i < nb; i += 256) x[k0 + i] = xs[i];
+  if (threadIdx.x < nb) x[k0 + threadIdx.x] = xs[threadIdx.x];
 }
 __global__ void __launch_bounds__(256) k_back_panel_update(const double* __restrict__ S, int ld, int k0, int nb,
                                                            double* __restrict__ x) {
@@ -937,7 +958,7 @@ int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWor
   int last = ((n_fact - 1) / kPanel) * kPanel;
   for (int k0 = last; k0 >= 0; k0 -= kPanel) {
     int nb = (n_fact - k0 < kPanel) ? (n_fact - k0) : kPanel;
-    hipLaunchKernelGGL(k_back_panel_diag, dim3(1), dim3(256), 0, s, S, ld, k0, nb, w.invLt, x);
+    hipLaunchKernelGGL(k_back_panel_diag, dim3(1), dim3(1024), 0, s, S, ld, k0, nb, w.invLt, x);
     if (k0 > 0) hipLaunchKernelGGL(k_back_panel_update, dim3((k0 + 3) / 4), dim3(256), 0, s, S, ld, k0, nb, x);
   }
   CBA_HIP(hipGetLastError());
