@@ -126,6 +126,11 @@ struct cba_problem {
   // imageset -> position of its 6x6 block / rows of B.  Imagesets are sorted along a Z-order curve of the
   // centre of their observations so that the 16-row K slabs of the Schur product touch few grid tiles.
   std::vector<int> pose_slot_host; int* pose_slot = nullptr;
+  // straggler split of the Jacobian pass (see PassArgs)
+  uint8_t* slow_skip = nullptr; int* slow_list = nullptr; int* slow_count = nullptr;
+  // the side stream is the factorisation's far stream (idle during the Jacobian pass): the process must stay
+  // within four HIP streams -- a fifth shares a hardware queue with another one and serialises the LDL^T streams
+  hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr;
   // control point -> rank in the engine's tiled order of the grid unknowns, per camera (see build_grid_order)
   int* gperm[kMaxCameras] = {};
   std::vector<int> dense_perm_host;   // reference dense column -> engine dense column (identity outside the grids)
@@ -143,6 +148,8 @@ struct cba_problem {
 };
 
 namespace cba {
+
+constexpr int kSlowCap = 16384;   // most observations the side-stream launch takes over
 
 static int timer_begin(cba_problem* p, int which) {
   KernelTimer& t = p->timers[which];
@@ -227,6 +234,7 @@ static PassArgs pass_args(cba_problem* p, int which) {
   a.points = p->st[which].points; a.itg = p->itg; a.cams = p->cams_dev[which];
   a.fd_delta = p->cfg.numerical_diff_delta;
   a.pose_slot = p->pose_slot;
+  a.obs_list = nullptr; a.obs_count = nullptr; a.obs_list_cap = 0; a.skip = nullptr;
   return a;
 }
 
@@ -257,11 +265,25 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   const int w = p->cur;
   for (int c = 0; c < L.n_cameras; ++c)
     CBA_TRY(launch_tangents(p->st[w].grids[c], p->tangents[c], p->cams[c].grid_w * p->cams[c].grid_h, p->stream));
-  CBA_TRY(residual_pass(p, w, p->cost_ref));
+  CBA_TRY(launch_compose_poses(p->st[w], L.n_images, L.n_cameras, p->itg, p->stream));
   PassArgs a = pass_args(p, w);
+  // side stream: the observations that failed in the previous Jacobian pass (long sequential projection
+  // chains) -- base projection and their finite-difference tasks -- underneath the main launches
+  PassArgs as = a;
+  as.obs_list = p->slow_list; as.obs_count = p->slow_count; as.obs_list_cap = kSlowCap;
+  a.skip = p->slow_skip;
+  hipStream_t aux = p->ldlt.far_stream;
+  CBA_HIP(hipEventRecord(p->ev_aux0, p->stream));
+  CBA_HIP(hipStreamWaitEvent(aux, p->ev_aux0, 0));
+  CBA_TRY(launch_base_project(as, p->model_mask, p->cost_ref, p->pixels, p->flags, aux));
+  CBA_TRY(launch_fd_tasks(as, p->model_mask, p->tasks_per_obs, L.localize_only, p->pixels, p->flags, p->fd_out, p->fd_ok, aux));
+  CBA_HIP(hipEventRecord(p->ev_aux1, aux));
+  CBA_TRY(launch_base_project(a, p->model_mask, p->cost_ref, p->pixels, p->flags, p->stream));
   CBA_TRY(timer_begin(p, 3));
   CBA_TRY(launch_fd_tasks(a, p->model_mask, p->tasks_per_obs, L.localize_only, p->pixels, p->flags, p->fd_out, p->fd_ok, p->stream));
   CBA_TRY(timer_end(p, 3, 0, 0, 1));
+  CBA_HIP(hipStreamWaitEvent(p->stream, p->ev_aux1, 0));
+  a.skip = nullptr;
   CBA_TRY(launch_assemble(a, L, p->st[w], p->tasks_per_obs, p->rec_doubles, p->pixels, p->flags, p->fd_out, p->fd_ok,
                           p->jrec, p->cells, p->stream));
   const size_t bs = L.block_size, nb = L.n_blocks;
@@ -283,6 +305,7 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   CBA_TRY(timer_end(p, 2, 0, 0, 1));
   if (t_acc) *t_acc += now_s() - t0;
   CBA_TRY(launch_touch_mask(p->B, p->Kpad, p->n_pad, p->n_pad, p->kmask, p->stream));
+  CBA_TRY(launch_collect_slow(p->flags, p->n_obs, p->slow_skip, p->slow_list, p->slow_count, kSlowCap, p->stream));
   p->have_system = true;
   return CBA_OK;
 }
@@ -380,6 +403,11 @@ int cba_create(const cba_config* config, cba_problem** out) {
   const Layout& L = p->L;
   if (L.total_dof <= 0) { delete p; set_error("empty problem"); return CBA_ERR_ARG; }
   CBA_TRY(make_main_stream(&p->stream));
+  CBA_HIP(hipEventCreateWithFlags(&p->ev_aux0, hipEventDisableTiming));
+  CBA_HIP(hipEventCreateWithFlags(&p->ev_aux1, hipEventDisableTiming));
+  CBA_TRY(dev_alloc(&p->slow_list, (size_t)kSlowCap));
+  CBA_TRY(dev_alloc(&p->slow_count, 1));
+  CBA_HIP(hipMemset(p->slow_count, 0, sizeof(int)));
   for (int c = 0; c < L.n_cameras; ++c) p->model_mask |= (p->cams[c].model_type == CBA_CENTRAL_GENERIC) ? 1 : 2;
   const int maxKg = L.localize_only ? 0 : ((p->model_mask & 2) ? 80 : 32);
   p->tasks_per_obs = 3 + maxKg;
@@ -486,6 +514,9 @@ void cba_destroy(cba_problem* p) {
   F(p->x); F(p->scal); F(p->status); F(p->gemv_ws); F(p->kmask);
   ldlt_workspace_free(p->ldlt);
   for (auto& t : p->timers) { if (t.e0) hipEventDestroy(t.e0); if (t.e1) hipEventDestroy(t.e1); }
+  F(p->slow_skip); F(p->slow_list); F(p->slow_count);
+  if (p->ev_aux0) hipEventDestroy(p->ev_aux0);
+  if (p->ev_aux1) hipEventDestroy(p->ev_aux1);
   if (p->stream) hipStreamDestroy(p->stream);
   delete p;
 }
@@ -515,6 +546,10 @@ int cba_set_observations(cba_problem* p, int64_t n, const float* xy, const int32
   CBA_TRY(dev_alloc(&p->fd_out, 2 * (size_t)n * p->tasks_per_obs)); CBA_TRY(dev_alloc(&p->fd_ok, (size_t)n * p->tasks_per_obs));
   CBA_TRY(dev_alloc(&p->jrec, (size_t)n * p->rec_doubles)); CBA_TRY(dev_alloc(&p->cells, 2 * (size_t)n));
   CBA_TRY(dev_alloc(&p->cell_order, (size_t)n));
+  F(p->slow_skip); p->slow_skip = nullptr;
+  CBA_TRY(dev_alloc(&p->slow_skip, (size_t)(n > 0 ? n : 1)));
+  CBA_HIP(hipMemset(p->slow_skip, 0, (size_t)(n > 0 ? n : 1)));
+  CBA_HIP(hipMemset(p->slow_count, 0, sizeof(int)));
   if (n > 0) {
     CBA_HIP(hipMemcpy(p->obs_xy, xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice));
     CBA_HIP(hipMemcpy(p->obs_point, point_index, sizeof(int) * n, hipMemcpyHostToDevice));

@@ -58,6 +58,12 @@ struct PassArgs {
   const CamDev* cams;       // device array [C]
   double fd_delta;
   const int* pose_slot;     // block position of each imageset (rows of B sorted by image footprint) or null
+  // straggler split (Jacobian pass): observations that failed last time run 100 x 10 projection
+  // iterations again; they are processed from `obs_list` on a side stream while the main launch skips them
+  const int* obs_list;      // null = all observations in order
+  const int* obs_count;     // device: entries in obs_list (clamped to obs_list_cap)
+  int obs_list_cap;
+  const uint8_t* skip;      // main launch: per-observation "handled by the list launch" (or null)
 };
 
 // ---- kernels_obs.hip ----
@@ -67,6 +73,7 @@ int launch_base_project(const PassArgs& a, int model_mask, double* cost_vec, dou
                         hipStream_t s);
 int launch_fd_tasks(const PassArgs& a, int model_mask, int tasks_per_obs, int localize_only, const double* pixels,
                     const uint8_t* flags, double* fd_out, uint8_t* fd_ok, hipStream_t s);
+int launch_collect_slow(const uint8_t* flags, int64_t n, uint8_t* skip, int* list, int* count, int cap, hipStream_t s);
 int launch_assemble(const PassArgs& a, const Layout& L, const DevState& st, int tasks_per_obs, int rec_doubles,
                     const double* pixels, uint8_t* flags, const double* fd_out, const uint8_t* fd_ok, double* jrec,
                     int* cells, hipStream_t s);

@@ -138,7 +138,14 @@ template <int MODEL>
 __global__ void __launch_bounds__(256) k_base_project(PassArgs a, double* __restrict__ cost_vec,
                                                       double* __restrict__ pixels, uint8_t* __restrict__ flags) {
   int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= a.n_obs) return;
+  if (a.obs_list) {
+    const int cnt = min(*a.obs_count, a.obs_list_cap);
+    if (o >= cnt) return;
+    o = a.obs_list[o];
+  } else {
+    if (o >= a.n_obs) return;
+    if (a.skip && a.skip[o]) return;
+  }
   int cam = a.obs_camera[o];
   const CamDev c = a.cams[cam];
   if (c.model_type != MODEL) return;
@@ -168,7 +175,8 @@ __global__ void __launch_bounds__(256) k_base_project(PassArgs a, double* __rest
 int launch_base_project(const PassArgs& a, int model_mask, double* cost_vec, double* pixels, uint8_t* flags,
                         hipStream_t s) {
   if (a.n_obs == 0) return CBA_OK;
-  dim3 grid((unsigned)((a.n_obs + 255) / 256)), block(256);
+  const int64_t items = a.obs_list ? a.obs_list_cap : a.n_obs;
+  dim3 grid((unsigned)((items + 255) / 256)), block(256);
   if (model_mask & 1) hipLaunchKernelGGL(k_base_project<kCentral>, grid, block, 0, s, a, cost_vec, pixels, flags);
   if (model_mask & 2) hipLaunchKernelGGL(k_base_project<kNoncentral>, grid, block, 0, s, a, cost_vec, pixels, flags);
   CBA_HIP(hipGetLastError());
@@ -187,7 +195,15 @@ __global__ void __launch_bounds__(256) k_fd_tasks(PassArgs a, int tasks_per_obs,
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t o = t / tasks_per_obs;
   int k = (int)(t - o * tasks_per_obs);
-  if (o >= a.n_obs) return;
+  if (a.obs_list) {
+    const int cnt = min(*a.obs_count, a.obs_list_cap);
+    if (o >= cnt) return;
+    o = a.obs_list[o];
+    t = o * tasks_per_obs + k;          // results are indexed by (observation, task)
+  } else {
+    if (o >= a.n_obs) return;
+    if (a.skip && a.skip[o]) return;
+  }
   if (!(flags[o] & 1)) return;
   int cam = a.obs_camera[o];
   const CamDev c = a.cams[cam];
@@ -244,12 +260,33 @@ __global__ void __launch_bounds__(256) k_fd_tasks(PassArgs a, int tasks_per_obs,
 int launch_fd_tasks(const PassArgs& a, int model_mask, int tasks_per_obs, int localize_only, const double* pixels,
                     const uint8_t* flags, double* fd_out, uint8_t* fd_ok, hipStream_t s) {
   if (a.n_obs == 0) return CBA_OK;
-  int64_t total = a.n_obs * tasks_per_obs;
+  int64_t total = (a.obs_list ? (int64_t)a.obs_list_cap : a.n_obs) * tasks_per_obs;
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
   if (model_mask & 1)
     hipLaunchKernelGGL(k_fd_tasks<kCentral>, grid, block, 0, s, a, tasks_per_obs, localize_only, pixels, flags, fd_out, fd_ok);
   if (model_mask & 2)
     hipLaunchKernelGGL(k_fd_tasks<kNoncentral>, grid, block, 0, s, a, tasks_per_obs, localize_only, pixels, flags, fd_out, fd_ok);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
+// Observations whose last Jacobian pass did not end with (valid, has-Jacobian) -- failed projections run
+// the full 2 x 100 x 10 iteration budget, ~1 ms for a single lane -- are listed for the side-stream launch.
+__global__ void __launch_bounds__(256) k_collect_slow(const uint8_t* __restrict__ flags, int64_t n, uint8_t* __restrict__ skip,
+                                                      int* __restrict__ list, int* __restrict__ count, int cap) {
+  int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n) return;
+  uint8_t sk = 0;
+  if (flags[o] != 3) {
+    const int idx = atomicAdd(count, 1);
+    if (idx < cap) { list[idx] = (int)o; sk = 1; }
+  }
+  skip[o] = sk;
+}
+int launch_collect_slow(const uint8_t* flags, int64_t n, uint8_t* skip, int* list, int* count, int cap, hipStream_t s) {
+  if (n == 0) return CBA_OK;
+  CBA_HIP(hipMemsetAsync(count, 0, sizeof(int), s));
+  hipLaunchKernelGGL(k_collect_slow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, flags, n, skip, list, count, cap);
   CBA_HIP(hipGetLastError());
   return CBA_OK;
 }

@@ -75,6 +75,9 @@ def load() -> C.CDLL:
     # torch bundles its own copy of the HIP runtime (same SONAME libamdhip64.so.7).  Importing it first
     # makes the dynamic loader resolve our NEEDED entry to that copy, so that device pointers and
     # streams are shared by one runtime when torch.distributed does the all-reduce.
+    # four concurrent engine streams + RCCL's own: ask the runtime for more than its default of four
+    # hardware queues (only effective if HIP has not been initialised yet)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     try:
         import torch  # noqa: F401
     except Exception:
