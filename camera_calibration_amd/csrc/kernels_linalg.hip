@@ -618,6 +618,139 @@ __global__ void __launch_bounds__(256) k_ldlt_diag(double* __restrict__ M, int l
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Panel row right of the look-ahead columns: forward substitution through the whole panel, fused.
+// One workgroup per 64-column tile walks the panel's 64-blocks top to bottom,
+//   X_j = invL_jj (U_j - sum_{e<j} L_je X_e),
+// reading U once and writing X (panel buffer) and L = X / d (in place) once.  The per-block launches
+// this replaces (a K = 64 solve and a K = 64 update over all remaining columns per block) were
+// latency-bound at ~1 TFLOP/s and, in the leading panels, took longer than the bulk update they fed.
+// ------------------------------------------------------------------------------------------------
+constexpr int TS = kInner + 16;   // LDS row stride (doubles) of a staged K-slab / 64x64 tile
+
+// loads that must observe global stores made earlier by this same launch go to L2 (agent scope)
+template <bool COH>
+__device__ __forceinline__ double ldg(const double* p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+
+// acc (64x64 tile, 4 waves x 32x32) += sum_{k<K} A[k][m] B[k][n];  A, B K-major in global memory, or B
+// already in LDS as Bl[k][TS].  K multiple of 16.  Register-staged double buffering; ends with a barrier.
+template <bool COH_A, bool COH_B, bool B_LDS>
+__device__ __forceinline__ void tile_mma(v4f64 (&acc)[2][2], const double* __restrict__ A, int lda,
+                                         const double* __restrict__ B, int ldb, int K, double* sA, double* sB,
+                                         const double* Bl) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
+  const int r = tid >> 5, c2 = 2 * (tid & 31);
+  const int nk = K / KT;
+  double ra[2][2], rb[2][2];
+#define CBA_TLOAD(k0_)                                                                           \
+  {                                                                                              \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                              \
+      const double* pa = A + (size_t)((k0_) + r + 8 * h) * lda + c2;                             \
+      ra[h][0] = ldg<COH_A>(pa); ra[h][1] = ldg<COH_A>(pa + 1);                                  \
+      if constexpr (!B_LDS) {                                                                    \
+        const double* pb = B + (size_t)((k0_) + r + 8 * h) * ldb + c2;                           \
+        rb[h][0] = ldg<COH_B>(pb); rb[h][1] = ldg<COH_B>(pb + 1);                                \
+      }                                                                                          \
+    }                                                                                            \
+  }
+#define CBA_TSTORE(buf_)                                                                         \
+  {                                                                                              \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                              \
+      double* qa = sA + (buf_) * KT * TS + (r + 8 * h) * TS + c2;                                \
+      qa[0] = ra[h][0]; qa[1] = ra[h][1];                                                        \
+      if constexpr (!B_LDS) {                                                                    \
+        double* qb = sB + (buf_) * KT * TS + (r + 8 * h) * TS + c2;                              \
+        qb[0] = rb[h][0]; qb[1] = rb[h][1];                                                      \
+      }                                                                                          \
+    }                                                                                            \
+  }
+  CBA_TLOAD(0);
+  CBA_TSTORE(0);
+  __syncthreads();
+  for (int kb = 0; kb < nk; ++kb) {
+    const int buf = kb & 1;
+    if (kb + 1 < nk) CBA_TLOAD((kb + 1) * KT);
+    const double* a_s = sA + buf * KT * TS;
+    const double* b_s = B_LDS ? Bl + kb * KT * TS : sB + buf * KT * TS;
+#pragma unroll
+    for (int kk = 0; kk < KT; kk += 4) {
+      double af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = a_s[(kk + lk) * TS + wm0 + i * 16 + li];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = b_s[(kk + lk) * TS + wn0 + j * 16 + li];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kb + 1 < nk) CBA_TSTORE(buf ^ 1);
+    __syncthreads();
+  }
+#undef CBA_TLOAD
+#undef CBA_TSTORE
+}
+
+__global__ void __launch_bounds__(256) k_panel_solve(double* __restrict__ S, int ld, int k0, int nb, int col0,
+                                                     double* __restrict__ Xk, int ldx, const double* __restrict__ dvec,
+                                                     const double* __restrict__ invLt_all) {
+  __shared__ double sA[2 * KT * TS];
+  __shared__ double sB[2 * KT * TS];
+  __shared__ double sV[kInner * TS];
+  __builtin_amdgcn_s_setprio(2);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
+  const int n0 = col0 + kInner * (int)blockIdx.x;
+  const int nblk = nb / kInner;
+  for (int j = 0; j < nblk; ++j) {
+    v4f64 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    // sum_{e<j} L_je X_e: rows 0 .. 64 j of the panel are one K range (A = L in place, B = X written above)
+    if (j > 0)
+      tile_mma<false, true, false>(acc, S + (size_t)k0 * ld + (k0 + kInner * j), ld, Xk + n0, ldx, kInner * j, sA, sB, nullptr);
+    double* Urow = S + (size_t)(k0 + kInner * j) * ld + n0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = wm0 + i * 16 + lk + 4 * r, n = wn0 + jj * 16 + li;
+          sV[m * TS + n] = Urow[(size_t)m * ld + n] - acc[i][jj][r];
+        }
+    __syncthreads();
+    v4f64 x[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) x[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    tile_mma<false, false, true>(x, invLt_all + (size_t)((k0 + kInner * j) / kInner) * kInner * kInner, kInner, nullptr, 0,
+                                 kInner, sA, sB, sV);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = wm0 + i * 16 + lk + 4 * r;
+        const double d = dvec[k0 + kInner * j + m];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int n = wn0 + jj * 16 + li;
+          const double v = x[i][jj][r];
+          Xk[(size_t)(kInner * j + m) * ldx + n0 + n] = v;
+          Urow[(size_t)m * ld + n] = v / d;
+        }
+      }
+    __syncthreads();   // the stores are acknowledged by L2 (vmcnt) before any lane re-reads X with agent-scope loads
+  }
+}
+
 int panel_cu_count() {
   static int n = -1;
   if (n < 0) {
@@ -716,8 +849,8 @@ void ldlt_workspace_free(LdltWorkspace& w) {
 //           block it also solves that block for the next panel's columns and applies (a'), the update of
 //           the next panel's diagonal block, so that the next panel starts without a stream hop;
 //   mid   : the same solve / update for the next panel's 256 columns (what (a') needs);
-//   far   : ... and for everything right of that, plus (a''), the update of the rest of the next
-//           panel's rows;
+//   far   : after the panel's chain: the fused forward substitution of everything right of that
+//           (k_panel_solve), plus (a''), the update of the rest of the next panel's rows;
 //   main  : (b) the bulk trailing update with K = 256 on the MFMA GEMM.  The next panel is factored
 //           underneath (b) (look-ahead).
 static int trsm_cols(double* S, int ld, int j0, int k0, int col_begin, int col_end, double* Xk, LdltWorkspace& w, hipStream_t s) {
@@ -822,12 +955,13 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
         if ((rc = update_block(S, ld, j0, k0, c0, e0, e0, nx, /*upper*/ 0, Xk, s4))) return rc;
         CBA_HIP(hipEventRecord(w.ev_mid, s4));
       }
-      // ---- far: everything right of that ----
-      CBA_HIP(hipStreamWaitEvent(s3, w.ev_chain, 0));
-      if ((rc = trsm_cols(S, ld, j0, k0, nx, n_pad, Xk, w, s3))) return rc;
-      if ((rc = update_block(S, ld, j0, k0, c0, e0, nx, n_pad, /*upper*/ 0, Xk, s3))) return rc;
     }
-    CBA_HIP(hipEventRecord(w.ev_panel, s3));     // far is queued behind every chain event of this panel
+    // ---- far: everything right of the look-ahead columns, one fused forward substitution per 64-column tile ----
+    CBA_HIP(hipStreamWaitEvent(s3, w.ev_chain, 0));          // the panel's last block is factored
+    if (n_pad > nx)
+      hipLaunchKernelGGL(k_panel_solve, dim3((n_pad - nx) / kInner), dim3(256), 0, s3, S, ld, k0, nb, nx, Xk, n_pad,
+                         w.dvec, w.invLt);
+    CBA_HIP(hipEventRecord(w.ev_panel, s3));
     CBA_HIP(hipStreamWaitEvent(s, w.ev_panel, 0));
     if (more && r0 < n_pad) {
       if (la) {
