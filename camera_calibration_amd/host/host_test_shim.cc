@@ -2,6 +2,7 @@
 // CameraModel objects from packed arrays, calls vis::OptimizeJointly with the reference's signature
 // (as APP/test/util.h:452-469 does) and copies the result back.
 #include "joint_optimization.h"
+#include "calibration_report.h"
 
 using namespace vis;
 
@@ -77,5 +78,54 @@ extern "C" int cba_host_optimize_jointly(
   Vec2d px;
   Vec3d probe = state.camera_tr_rig[0] * (state.rig_tr_global[0] * state.points[0]);
   (void)state.intrinsics[0]->Project(probe, &px);
+  return 0;
+}
+
+
+// Drives vis::ComputeAllReprojectionErrors / ComputeReprojectionErrorHistogram (calibration_report.h) from packed
+// arrays.  errors_out: 2 per observation of `camera` (capacity n_obs), returns the count through *count.
+extern "C" int cba_host_reprojection_report(
+    int n_cameras, const cba_camera* cams, const double* const* grids, int camera,
+    int n_imagesets, const double* rig_tr_global, const double* camera_tr_rig, int n_points, const double* points,
+    int64_t n_obs, const float* xy, const int32_t* point_index, const int32_t* imageset_index, const int32_t* camera_index,
+    int64_t* count, double* sum, double* max, double* errors_out, float* features_out,
+    int hist_resolution, double hist_extent, double* hist_out) {
+  Dataset dataset(n_cameras);
+  BAState state;
+  for (int c = 0; c < n_cameras; ++c) {
+    const cba_camera& k = cams[c];
+    std::shared_ptr<CameraModel> m;
+    if (k.model_type == CBA_CENTRAL_GENERIC)
+      m.reset(new CentralGenericModel(k.grid_w, k.grid_h, k.calib_min_x, k.calib_min_y, k.calib_max_x, k.calib_max_y, k.width, k.height));
+    else
+      m.reset(new NoncentralGenericModel(k.grid_w, k.grid_h, k.calib_min_x, k.calib_min_y, k.calib_max_x, k.calib_max_y, k.width, k.height));
+    m->set_abi_grid(grids[c]);
+    state.intrinsics.push_back(m);
+    const double* p = camera_tr_rig + 7 * c;
+    state.camera_tr_rig.push_back(SE3d(Quaterniond(p[0], p[1], p[2], p[3]), Vec3d(p[4], p[5], p[6])));
+  }
+  for (int i = 0; i < n_imagesets; ++i) {
+    dataset.NewImageset();
+    const double* p = rig_tr_global + 7 * (size_t)i;
+    state.rig_tr_global.push_back(SE3d(Quaterniond(p[0], p[1], p[2], p[3]), Vec3d(p[4], p[5], p[6])));
+    state.image_used.push_back(true);
+  }
+  for (int p = 0; p < n_points; ++p) state.points.push_back(Vec3d(points[3 * p], points[3 * p + 1], points[3 * p + 2]));
+  for (int64_t o = 0; o < n_obs; ++o) {
+    auto& feats = dataset.GetImageset(imageset_index[o])->FeaturesOfCamera(camera_index[o]);
+    feats.emplace_back(Vec2f(xy[2 * o], xy[2 * o + 1]), point_index[o]);
+    feats.back().index = point_index[o];
+  }
+  usize n = 0; double s = 0, mx = 0;
+  std::vector<Vec2d> errors; std::vector<Vec2f> feats;
+  ComputeAllReprojectionErrors(camera, dataset, state, &n, &s, &mx, &errors, &feats);
+  *count = (int64_t)n; *sum = s; *max = mx;
+  for (size_t i = 0; i < errors.size(); ++i) {
+    errors_out[2 * i] = errors[i].x(); errors_out[2 * i + 1] = errors[i].y();
+    features_out[2 * i] = feats[i].x(); features_out[2 * i + 1] = feats[i].y();
+  }
+  Image<double> hist;
+  ComputeReprojectionErrorHistogram(hist_resolution, hist_extent, errors, &hist);
+  for (int i = 0; i < hist_resolution * hist_resolution; ++i) hist_out[i] = hist.data()[i];
   return 0;
 }

@@ -268,3 +268,46 @@ def se3_exp(t):
     o = np.zeros(7)
     lib().orc_se3_exp(_dp(t), _dp(o))
     return o
+
+
+# ---------------------------------------------------------------------------------------------------
+# calibration report statistics -- restated per observation, scalar loops
+# ---------------------------------------------------------------------------------------------------
+def all_reprojection_errors(camera_index: int, pb, st):
+    """ComputeAllReprojectionErrors, APP/calibration_report.cc:101-148: per feature of one camera
+    local = R(image_tr_global) * point + t, Project() from the centre, error = pixel - xy; failures skipped."""
+    cam = pb.cameras[camera_index]
+    grid = st.grids[camera_index]
+    count, esum, emax = 0, 0.0, 0.0
+    errors, feats = [], []
+    for o in range(pb.n_obs):
+        if pb.obs_camera[o] != camera_index:
+            continue
+        itg = se3_mul(st.camera_tr_rig[camera_index], st.rig_tr_global[pb.obs_image[o]])
+        q = itg[:4]
+        w, x, y, z = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        local = R @ st.points[pb.obs_point[o]] + itg[4:]
+        px, ok = project(cam, grid, local[None, :])
+        if not ok[0]:
+            continue
+        e = px[0] - pb.obs_xy[o].astype(np.float64)
+        m = float(np.sqrt(e[0] * e[0] + e[1] * e[1]))
+        count += 1; esum += m; emax = max(emax, m)
+        errors.append(e); feats.append(pb.obs_xy[o])
+    return dict(count=count, sum=esum, max=emax, errors=np.array(errors).reshape(-1, 2), features=np.array(feats).reshape(-1, 2))
+
+
+def reprojection_error_histogram(resolution: int, extent_in_px: float, errors):
+    """ComputeReprojectionErrorHistogram, APP/calibration_report.cc:151-168 (scalar loop)."""
+    hist = np.zeros((resolution, resolution))
+    for ex, ey in np.asarray(errors).reshape(-1, 2):
+        hx_f = resolution * 0.5 * ((ex / extent_in_px) + 1.0)
+        hx = int(hx_f) - (1 if hx_f < 0 else 0)
+        hy_f = resolution * 0.5 * ((ey / extent_in_px) + 1.0)
+        hy = int(hy_f) - (1 if hy_f < 0 else 0)
+        if 0 <= hx < resolution and 0 <= hy < resolution:
+            hist[hy, hx] += 1.0
+    return hist
