@@ -18,4 +18,11 @@ void ComputeAllReprojectionErrors(int camera_index, const Dataset& dataset, cons
 void ComputeReprojectionErrorHistogram(int resolution, double extent_in_px, const std::vector<Vec2d>& reprojection_errors,
                                        Image<double>* hist_image);
 
+// APP/calibration.cc:62-184.  The window / visualisation arguments of the reference are
+// accepted and ignored (calibration_window must be null: there is no UI here).
+class CalibrationWindow;
+void DeleteOutlierFeatures(int camera_index, Dataset* dataset, BAState* state, float outlier_removal_factor,
+                           CalibrationWindow* calibration_window = nullptr, bool step_by_step = false,
+                           const char* outlier_visualization_path = nullptr);
+
 }  // namespace vis

@@ -89,7 +89,8 @@ extern "C" int cba_host_reprojection_report(
     int n_imagesets, const double* rig_tr_global, const double* camera_tr_rig, int n_points, const double* points,
     int64_t n_obs, const float* xy, const int32_t* point_index, const int32_t* imageset_index, const int32_t* camera_index,
     int64_t* count, double* sum, double* max, double* errors_out, float* features_out,
-    int hist_resolution, double hist_extent, double* hist_out) {
+    int hist_resolution, double hist_extent, double* hist_out,
+    float outlier_removal_factor, uint8_t* keep_out /*n_obs or NULL*/, uint8_t* used_out /*n_imagesets*/) {
   Dataset dataset(n_cameras);
   BAState state;
   for (int c = 0; c < n_cameras; ++c) {
@@ -127,5 +128,21 @@ extern "C" int cba_host_reprojection_report(
   Image<double> hist;
   ComputeReprojectionErrorHistogram(hist_resolution, hist_extent, errors, &hist);
   for (int i = 0; i < hist_resolution * hist_resolution; ++i) hist_out[i] = hist.data()[i];
+  // DeleteOutlierFeatures on the same objects: report which observations survive and which imagesets stay used
+  if (keep_out) {
+    for (int64_t o = 0; o < n_obs; ++o) keep_out[o] = 0;
+    // tag every feature with its observation index through the (otherwise unused) id field
+    std::vector<size_t> cursor((size_t)n_imagesets * n_cameras, 0);
+    for (int64_t o = 0; o < n_obs; ++o) {
+      size_t key = (size_t)imageset_index[o] * n_cameras + camera_index[o];
+      dataset.GetImageset(imageset_index[o])->FeaturesOfCamera(camera_index[o])[cursor[key]++].id = (int)o;
+    }
+    DeleteOutlierFeatures(camera, &dataset, &state, outlier_removal_factor);
+    for (int i = 0; i < n_imagesets; ++i) {
+      used_out[i] = state.image_used[i] ? 1 : 0;
+      for (int c = 0; c < n_cameras; ++c)
+        for (const PointFeature& f : dataset.GetImageset(i)->FeaturesOfCamera(c)) keep_out[f.id] = 1;
+    }
+  }
   return 0;
 }

@@ -311,3 +311,48 @@ def reprojection_error_histogram(resolution: int, extent_in_px: float, errors):
         if 0 <= hx < resolution and 0 <= hy < resolution:
             hist[hy, hx] += 1.0
     return hist
+
+
+def delete_outlier_features(camera_index: int, pb, st, outlier_removal_factor: float, image_used=None):
+    """DeleteOutlierFeatures, APP/calibration.cc:62-184 restated with scalar loops.
+    Returns (keep mask, image_used, threshold or None)."""
+    used = np.ones(pb.n_images, dtype=bool) if image_used is None else np.array(image_used, dtype=bool)
+    cam = pb.cameras[camera_index]
+    grid = st.grids[camera_index]
+
+    def project_obs(o):
+        itg = se3_mul(st.camera_tr_rig[camera_index], st.rig_tr_global[pb.obs_image[o]])
+        w, x, y, z = itg[:4]
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        local = R @ st.points[pb.obs_point[o]] + itg[4:]
+        px, ok = project(cam, grid, local[None, :])
+        if not ok[0]:
+            return None
+        e = px[0] - pb.obs_xy[o].astype(np.float64)
+        return float(np.sqrt(e[0] * e[0] + e[1] * e[1]))
+
+    obs = [o for o in range(pb.n_obs) if pb.obs_camera[o] == camera_index and used[pb.obs_image[o]]]
+    mags = {o: project_obs(o) for o in obs}
+    errs = sorted(m for m in mags.values() if m is not None)
+    keep = np.ones(pb.n_obs, dtype=bool)
+    if len(errs) < 8:
+        return keep, used, None
+    n = len(errs)
+    q1 = errs[int(np.float32(0.25) * np.float32(n) + np.float32(0.5))]
+    q3 = errs[int(np.float32(0.75) * np.float32(n) + np.float32(0.5))]
+    thr = q3 + float(np.float32(outlier_removal_factor)) * (q3 - q1)
+    for i in range(pb.n_images):
+        if not used[i]:
+            continue
+        feats = [o for o in obs if pb.obs_image[o] == i]
+        left = 0
+        for o in feats:
+            if mags[o] is None or mags[o] > thr:
+                keep[o] = False
+            else:
+                left += 1
+        if left < 3:
+            used[i] = False
+    return keep, used, thr
