@@ -1,9 +1,17 @@
 // Host mirror of PointFeature / Imageset / Dataset (APP/dataset.h:57-212 in the reference tree) and
 // BAState (APP/bundle_adjustment/ba_state.h:46-97, ba_state.cc:78-91).
 #pragma once
+#include <string>
+#include <unordered_map>
 #include "camera_model.h"
 
 namespace vis {
+
+// APP/dataset.h:49-55
+struct KnownGeometry {
+  std::unordered_map<int, Vec2i> feature_id_to_position;   // feature id -> integer position on the pattern
+  float cell_length_in_meters = 0.f;
+};
 
 struct PointFeature {
   PointFeature() = default;
@@ -40,7 +48,12 @@ class Dataset {
   std::shared_ptr<Imageset> GetImageset(int i) { return m_imagesets[i]; }
   int ImagesetCount() const { return (int)m_imagesets.size(); }
   int num_cameras() const { return m_num_cameras; }
+  void SetKnownGeometriesCount(int n) { m_known_geometries.resize(n); }
+  int KnownGeometriesCount() const { return (int)m_known_geometries.size(); }
+  KnownGeometry& GetKnownGeometry(int i) { return m_known_geometries[i]; }
+  const KnownGeometry& GetKnownGeometry(int i) const { return m_known_geometries[i]; }
  private:
+  std::vector<KnownGeometry> m_known_geometries;
   int m_num_cameras;
   std::vector<Vec2i> image_sizes;
   std::vector<std::shared_ptr<Imageset>> m_imagesets;

@@ -3,6 +3,7 @@
 // (as APP/test/util.h:452-469 does) and copies the result back.
 #include "joint_optimization.h"
 #include "calibration_report.h"
+#include "calibration_io.h"
 
 using namespace vis;
 
@@ -144,5 +145,24 @@ extern "C" int cba_host_reprojection_report(
         for (const PointFeature& f : dataset.GetImageset(i)->FeaturesOfCamera(c)) keep_out[f.id] = 1;
     }
   }
+  return 0;
+}
+
+
+// F2 round trip through the C++ mirror: load dataset.bin + BAState directory, write both back elsewhere.
+extern "C" int cba_host_io_roundtrip(const char* dataset_in, const char* state_in, const char* dataset_out, const char* state_out,
+                                     int* n_imagesets, int* n_cameras, int64_t* n_features, int* n_points, int* n_unindexed) {
+  Dataset dataset;
+  if (!LoadDataset(dataset_in, &dataset)) return -1;
+  BAState state;
+  if (!LoadBAState(state_in, &state, &dataset)) return -2;
+  *n_imagesets = dataset.ImagesetCount(); *n_cameras = dataset.num_cameras(); *n_points = (int)state.points.size();
+  int64_t nf = 0; int bad = 0;
+  for (int i = 0; i < dataset.ImagesetCount(); ++i)
+    for (int c = 0; c < dataset.num_cameras(); ++c)
+      for (const PointFeature& f : dataset.GetImageset(i)->FeaturesOfCamera(c)) { ++nf; if (f.index < 0) ++bad; }
+  *n_features = nf; *n_unindexed = bad;
+  if (!SaveDataset(dataset_out, dataset)) return -3;
+  if (!SaveBAState(state_out, state)) return -4;
   return 0;
 }
