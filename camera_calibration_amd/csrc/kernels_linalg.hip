@@ -751,6 +751,109 @@ __global__ void __launch_bounds__(256) k_panel_solve(double* __restrict__ S, int
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Chain step of a 256-panel, fused: the solve of the block row inside the panel and its update of the
+// rest of the panel's diagonal block in ONE launch (was: a K = 64 solve launch followed by a K = 64
+// update launch, ~12 + ~9 us of mostly launch and pipeline-fill latency on the critical path).
+// One workgroup per upper 64x64 tile (r, c) of the remaining diagonal block; it recomputes the two
+// solved tiles it needs, X_r = invL_jj U_j[:, r] and X_c, and applies T_rc -= (X_r / d)^T X_c.  The
+// diagonal tiles also publish X_c.  U_j is only read here: L = X / d is written in place by
+// k_scale_rows on the mid stream, off the critical path.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tile_mma_lds(v4f64 (&acc)[2][2], const double* Al, const double* Bl) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < kInner; kk += 4) {
+    double af[2], bf[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) af[i] = Al[(kk + lk) * TS + wm0 + i * 16 + li];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bf[j] = Bl[(kk + lk) * TS + wn0 + j * 16 + li];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_near_fused(double* __restrict__ S, int ld, int k0, int j0, int e0,
+                                                    double* __restrict__ Xk, int ldx, const double* __restrict__ dvec,
+                                                    const double* __restrict__ invLt_all) {
+  __shared__ double sA[2 * KT * TS];
+  __shared__ double sB[2 * KT * TS];
+  __shared__ double sV[kInner * TS];    // X_c           [p][n]
+  __shared__ double sL[kInner * TS];    // X_r / d = L^T [p][m]
+  __builtin_amdgcn_s_setprio(3);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
+  const int c0 = j0 + kInner, nblk = (e0 - c0) / kInner;
+  int t = blockIdx.x, r = 0;
+  for (; r < nblk; ++r) { const int cnt = nblk - r; if (t < cnt) break; t -= cnt; }
+  const int c = r + t;
+  const int colr = c0 + kInner * r, colc = c0 + kInner * c;
+  const double* invLt = invLt_all + (size_t)(j0 / kInner) * kInner * kInner;
+  const double* Uj = S + (size_t)j0 * ld;
+  v4f64 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  tile_mma<false, false, false>(acc, invLt, kInner, Uj + colr, ld, kInner, sA, sB, nullptr);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int p = wm0 + i * 16 + lk + 4 * r4;
+      const double d = dvec[j0 + p];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int n = wn0 + jj * 16 + li;
+        const double v = acc[i][jj][r4];
+        sL[p * TS + n] = v / d;
+        if (r == c) { sV[p * TS + n] = v; Xk[(size_t)(j0 - k0 + p) * ldx + colr + n] = v; }
+      }
+    }
+  if (r != c) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    tile_mma<false, false, false>(acc, invLt, kInner, Uj + colc, ld, kInner, sA, sB, nullptr);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) sV[(wm0 + i * 16 + lk + 4 * r4) * TS + wn0 + jj * 16 + li] = acc[i][jj][r4];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  tile_mma_lds(acc, sL, sV);
+  double* T = S + (size_t)colr * ld + colc;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
+        T[(size_t)m * ld + n] -= acc[i][jj][r4];
+      }
+}
+
+// L = X / d in place for the panel-internal columns [c0, e0) of block row j0 (see k_near_fused)
+__global__ void __launch_bounds__(256) k_scale_rows(double* __restrict__ S, int ld, int k0, int j0, int c0, int e0,
+                                                    const double* __restrict__ Xk, int ldx, const double* __restrict__ dvec) {
+  const int p = blockIdx.x;
+  const double d = dvec[j0 + p];
+  for (int col = c0 + threadIdx.x; col < e0; col += blockDim.x)
+    S[(size_t)(j0 + p) * ld + col] = Xk[(size_t)(j0 - k0 + p) * ldx + col] / d;
+}
+
 int panel_cu_count() {
   static int n = -1;
   if (n < 0) {
@@ -933,9 +1036,20 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
       const bool last = (c0 == e0);
       // ---- chain: factor the diagonal block, near solve, near update ----
       hipLaunchKernelGGL(k_ldlt_diag<kInner>, dim3(1), dim3(256), 0, s2, S, ld, j0, w.dvec, w.invLt, w.status);
-      if ((rc = trsm_cols(S, ld, j0, k0, c0, e0, Xk, w, s2))) return rc;
-      if ((rc = update_block(S, ld, j0, k0, c0, e0, c0, e0, /*upper*/ 1, Xk, s2))) return rc;
+      const bool fused_near = (pw == kPanel) && (c0 < e0);
+      if (fused_near) {
+        const int nbk = (e0 - c0) / kInner;
+        hipLaunchKernelGGL(k_near_fused, dim3(nbk * (nbk + 1) / 2), dim3(256), 0, s2, S, ld, k0, j0, e0, Xk, n_pad, w.dvec, w.invLt);
+      } else {
+        if ((rc = trsm_cols(S, ld, j0, k0, c0, e0, Xk, w, s2))) return rc;
+        if ((rc = update_block(S, ld, j0, k0, c0, e0, c0, e0, /*upper*/ 1, Xk, s2))) return rc;
+      }
       CBA_HIP(hipEventRecord(w.ev_chain, s2));
+      if (fused_near) {      // L in place for the panel-internal columns, off the critical path
+        CBA_HIP(hipStreamWaitEvent(s4, w.ev_chain, 0));
+        hipLaunchKernelGGL(k_scale_rows, dim3(kInner), dim3(256), 0, s4, S, ld, k0, j0, c0, e0, Xk, n_pad, w.dvec);
+        if (last || nx <= e0) CBA_HIP(hipEventRecord(w.ev_mid, s4));
+      }
       if (last && la) {
         // the last block's solve on the next panel's columns and (a') stay on the chain stream
         CBA_HIP(hipStreamWaitEvent(s2, w.ev_mid, 0));      // mid updates of the earlier blocks
@@ -958,6 +1072,7 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
     }
     // ---- far: everything right of the look-ahead columns, one fused forward substitution per 64-column tile ----
     CBA_HIP(hipStreamWaitEvent(s3, w.ev_chain, 0));          // the panel's last block is factored
+    CBA_HIP(hipStreamWaitEvent(s3, w.ev_mid, 0));            // ... and L is in place inside the panel
     if (n_pad > nx)
       hipLaunchKernelGGL(k_panel_solve, dim3((n_pad - nx) / kInner), dim3(256), 0, s3, S, ld, k0, nb, nx, Xk, n_pad,
                          w.dvec, w.invLt);
@@ -971,12 +1086,22 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
         CBA_HIP(hipStreamWaitEvent(s3, w.ev_strip, 0));    // the chain's solve on the next panel's columns
         if (mt > head) {
           CBA_HIP(hipStreamWaitEvent(s3, w.ev_bulk, 0));
+          // first the block the next panel's mid stream reads (its own next-panel columns), in small tiles,
+          // then the rest of the strip: the mid stream is released ~50 us earlier in the chain-bound tail
+          const int h2 = (mt - head) < head ? (mt - head) : head;
           GemmArgs v = u;
-          v.upper = 0; v.m_off = r0; v.m_tiles = head; v.n_off = r0 + head * 128; v.n_tiles = mt - head;
-          if ((rc = launch_gemm<128, 128, 64, 64, true>(v, s3))) return rc;
+          v.upper = 0; v.m_off = r0; v.m_tiles = head * 2; v.n_off = r0 + head * 128; v.n_tiles = h2 * 2;
+          if ((rc = launch_gemm<64, 64, 32, 32, true>(v, s3))) return rc;
+          CBA_HIP(hipEventRecord(w.ev_aa, s3));
+          CBA_HIP(hipStreamWaitEvent(s4, w.ev_aa, 0));
+          if (mt - head > h2) {
+            v.m_tiles = head; v.n_off = r0 + (head + h2) * 128; v.n_tiles = mt - head - h2;
+            if ((rc = launch_gemm<128, 128, 64, 64, true>(v, s3))) return rc;
+          }
+        } else {
+          CBA_HIP(hipEventRecord(w.ev_aa, s3));
+          CBA_HIP(hipStreamWaitEvent(s4, w.ev_aa, 0));
         }
-        CBA_HIP(hipEventRecord(w.ev_aa, s3));
-        CBA_HIP(hipStreamWaitEvent(s4, w.ev_aa, 0));
         // (b) bulk
         if (mt > head) {
           u.upper = 1; u.m_off = r0 + head * 128; u.m_tiles = mt - head; u.n_off = r0 + head * 128; u.n_tiles = mt - head;
