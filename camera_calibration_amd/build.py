@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcalib_ba_hip.so")
-SOURCES = ["cba_api.hip", "kernels_obs.hip", "kernels_linalg.hip"]
+SOURCES = ["cba_api.hip", "kernels_obs.hip", "kernels_linalg.hip", "kernels_fit.hip"]
 HEADERS = ["cba_internal.h", "model.hip.h", os.path.join("..", "..", "include", "cba.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
          "-mllvm", "-amdgpu-mfma-vgpr-form"]  # keep MFMA accumulators in VGPRs: no AGPR<->VGPR copies in the K loop
@@ -59,7 +59,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 HOST_DIR = os.path.join(HERE, "host")
 HOST_LIB = os.path.join(HERE, "libcalib_ba_host.so")
-HOST_SOURCES = ["joint_optimization_hip.cc", "calibration_report_hip.cc", "calibration_io.cc", "host_test_shim.cc"]
+HOST_SOURCES = ["joint_optimization_hip.cc", "calibration_report_hip.cc", "calibration_io.cc", "central_generic_fit_hip.cc", "host_test_shim.cc"]
 HOST_HEADERS = ["vis_types.h", "camera_model.h", "dataset.h", "joint_optimization.h"]
 
 

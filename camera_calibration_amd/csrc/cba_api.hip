@@ -961,4 +961,107 @@ int cba_schur_solve(int32_t block_size, int32_t n_blocks, int32_t dense_dof, con
   return CBA_OK;
 }
 
+int cba_fit_grid_to_directions(const cba_camera* camera, double* grid, int64_t n, const double* grid_points,
+                               const double* directions, int32_t max_iteration_count, cba_fit_report* report, int32_t device) {
+  if (!camera || !grid || n < 0 || (n > 0 && (!grid_points || !directions)) || max_iteration_count < 0 || !camera_ok(*camera) ||
+      camera->model_type != CBA_CENTRAL_GENERIC) { set_error("cba_fit_grid_to_directions: bad argument"); return CBA_ERR_ARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device available (the engine has no CPU fallback)"); return CBA_ERR_HIP; }
+  if (device < 0 || device >= ndev) { set_error("bad device ordinal"); return CBA_ERR_ARG; }
+  CBA_HIP(hipSetDevice(device));
+  const int gw = camera->grid_w, gh = camera->grid_h, G = gw * gh, dof = 2 * G;
+  int n_pad, n_fact; padded_dims(dof, &n_pad, &n_fact);
+  const int ld = n_pad;
+  cba_fit_report rep{};
+  double *g[2] = {nullptr, nullptr}, *tang, *gp, *dirs, *cost_ref, *cost_test, *rec, *H, *b, *S, *x, *partials, *red8, *scal;
+  int *keys, *count, *start, *fill, *order, *status;
+  const size_t nn = (size_t)(n > 0 ? n : 1);
+  CBA_TRY(dev_alloc(&g[0], 3 * (size_t)G)); CBA_TRY(dev_alloc(&g[1], 3 * (size_t)G)); CBA_TRY(dev_alloc(&tang, 6 * (size_t)G));
+  CBA_TRY(dev_alloc(&gp, 2 * nn)); CBA_TRY(dev_alloc(&dirs, 3 * nn)); CBA_TRY(dev_alloc(&cost_ref, 3 * nn)); CBA_TRY(dev_alloc(&cost_test, 3 * nn));
+  CBA_TRY(dev_alloc(&rec, nn * 99)); CBA_TRY(dev_alloc(&keys, nn)); CBA_TRY(dev_alloc(&order, nn));
+  CBA_TRY(dev_alloc(&count, (size_t)G + 1)); CBA_TRY(dev_alloc(&start, (size_t)G + 1)); CBA_TRY(dev_alloc(&fill, (size_t)G + 1));
+  CBA_TRY(dev_alloc(&H, (size_t)ld * ld)); CBA_TRY(dev_alloc(&b, (size_t)ld)); CBA_TRY(dev_alloc(&S, (size_t)ld * ld)); CBA_TRY(dev_alloc(&x, (size_t)ld));
+  CBA_TRY(dev_alloc(&partials, 256 * 8)); CBA_TRY(dev_alloc(&red8, 8)); CBA_TRY(dev_alloc(&scal, 8)); CBA_TRY(dev_alloc(&status, 1));
+  CBA_HIP(hipMemcpy(g[0], grid, sizeof(double) * 3 * G, hipMemcpyHostToDevice));
+  if (n) {
+    CBA_HIP(hipMemcpy(gp, grid_points, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+    CBA_HIP(hipMemcpy(dirs, directions, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+  }
+  CBA_HIP(hipMemset(status, 0, sizeof(int)));
+  LdltWorkspace w;
+  CBA_TRY(ldlt_workspace_alloc(w, n_pad));
+  hipStream_t s = nullptr;
+  CBA_TRY(make_main_stream(&s));
+  auto cleanup = [&]() {
+    ldlt_workspace_free(w);
+    if (s) hipStreamDestroy(s);
+    void* ptrs[] = {g[0], g[1], tang, gp, dirs, cost_ref, cost_test, rec, keys, order, count, start, fill, H, b, S, x, partials, red8, scal, status};
+    for (void* q : ptrs) hipFree(q);
+  };
+  auto read = [&](const double* dev, double* host, int k) -> int {
+    CBA_HIP(hipMemcpyAsync(host, dev, sizeof(double) * k, hipMemcpyDeviceToHost, s));
+    CBA_HIP(hipStreamSynchronize(s));
+    return CBA_OK;
+  };
+  int cur = 0, rc = CBA_OK;
+  double lambda = -1.0, last_cost = 0.0;
+  const double init_lambda_factor = (double)0.001f;
+  for (int iteration = 0; iteration < max_iteration_count && rc == CBA_OK; ++iteration) {
+    double t0 = now_s();
+    if ((rc = launch_tangents(g[cur], tang, G, s))) break;
+    if ((rc = launch_fit_pass(true, gw, gh, g[cur], tang, n, gp, dirs, cost_ref, rec, keys, status, s))) break;
+    CBA_HIP(hipMemsetAsync(H, 0, sizeof(double) * (size_t)ld * ld, s));
+    CBA_HIP(hipMemsetAsync(b, 0, sizeof(double) * (size_t)ld, s));
+    if ((rc = launch_fit_accumulate(gw, gh, n, rec, keys, count, start, fill, order, H, ld, b, s))) break;
+    if ((rc = launch_reduce_costs(cost_ref, nullptr, nullptr, 3 * n, partials, red8, s))) break;
+    if ((rc = launch_fit_diag_sum(H, ld, dof, scal, s))) break;
+    double h8[8], hsum = 0; int st = 0;
+    if ((rc = read(red8, h8, 8)) || (rc = read(scal, &hsum, 1))) break;
+    CBA_HIP(hipMemcpy(&st, status, sizeof(int), hipMemcpyDeviceToHost));
+    rep.t_pass += now_s() - t0;
+    if (st == 3) { set_error("cba_fit_grid_to_directions: a grid point lies outside the grid's 4x4 patches"); rc = CBA_ERR_ARG; break; }
+    last_cost = h8[0];
+    if (iteration == 0) { rep.initial_cost = last_cost; lambda = init_lambda_factor * hsum / dof; }
+    if (last_cost == 0) break;
+    bool applied = false;
+    for (int lm = 0; lm < 10 && rc == CBA_OK; ++lm) {
+      rep.lm_attempts += 1;
+      t0 = now_s();
+      CBA_HIP(hipMemcpyAsync(S, H, sizeof(double) * (size_t)ld * ld, hipMemcpyDeviceToDevice, s));
+      if ((rc = launch_finish_diag(S, ld, dof, n_pad, lambda, s))) break;
+      if ((rc = launch_fit_set_rhs(S, ld, b, dof, s))) break;
+      CBA_HIP(hipMemsetAsync(w.status, 0, sizeof(int), s));
+      if ((rc = ldlt_factor(S, n_fact, ld, w, s, nullptr))) break;
+      if ((rc = ldlt_back_solve(S, n_fact, ld, ld - 1, w, x, s))) break;
+      CBA_HIP(hipMemcpyAsync(&st, w.status, sizeof(int), hipMemcpyDeviceToHost, s));
+      CBA_HIP(hipStreamSynchronize(s));
+      rep.t_solve += now_s() - t0;
+      if (st != 0) { lambda = 2.f * lambda; continue; }     // zero pivot: treated like the reference's NaN update
+      t0 = now_s();
+      if ((rc = launch_update_direction_grid(g[cur], x, G, g[cur ^ 1], s))) break;
+      if ((rc = launch_fit_pass(false, gw, gh, g[cur ^ 1], tang, n, gp, dirs, cost_test, nullptr, nullptr, status, s))) break;
+      if ((rc = launch_reduce_costs(cost_ref, cost_test, nullptr, 3 * n, partials, red8, s))) break;
+      if ((rc = read(red8, h8, 8))) break;
+      rep.t_pass += now_s() - t0;
+      if (h8[4] > 0 && h8[3] < h8[2]) {                       // CostIsSmallerThan
+        cur ^= 1;
+        lambda = 0.5f * lambda;
+        applied = true;
+        rep.iterations_performed += 1;
+        last_cost = h8[1];
+        break;
+      }
+      lambda = 2.f * lambda;
+    }
+    if (!applied || last_cost == 0) break;
+  }
+  if (rc == CBA_OK) {
+    rep.final_cost = last_cost; rep.lambda = lambda;
+    if (hipMemcpy(grid, g[cur], sizeof(double) * 3 * G, hipMemcpyDeviceToHost) != hipSuccess) { set_error("cba_fit_grid_to_directions: copy back failed"); rc = CBA_ERR_HIP; }
+    if (report) *report = rep;
+  }
+  cleanup();
+  return rc;
+}
+
 }  // extern "C"

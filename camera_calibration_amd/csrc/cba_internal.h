@@ -92,6 +92,14 @@ int launch_reduce_costs(const double* ref, const double* test, const uint8_t* fl
                         double* out8, hipStream_t s);
 int launch_apply_update(const Layout& L, const std::vector<cba_camera>& cams, const DevState& in, const double* x,
                         DevState& out, const int* pose_slot, int* const* gperm, hipStream_t s);
+int launch_update_direction_grid(const double* in, const double* x, int G, double* out, hipStream_t s);
+// ---- kernels_fit.hip (grid-only LM) ----
+int launch_fit_pass(bool jac, int gw, int gh, const double* grid, const double* tang, int64_t n, const double* gp,
+                    const double* dirs, double* cost_vec, double* rec, int* keys, int* status, hipStream_t s);
+int launch_fit_accumulate(int gw, int gh, int64_t n, const double* rec, const int* keys, int* count, int* start, int* fill,
+                          int* order, double* H, int ld, double* b, hipStream_t s);
+int launch_fit_set_rhs(double* S, int ld, const double* b, int n, hipStream_t s);
+int launch_fit_diag_sum(const double* H, int ld, int n, double* out, hipStream_t s);
 int launch_project_points(const CamDev* cam_dev, int model, int64_t n, const double* local, const double* init,
                           double* pixels, uint8_t* ok, hipStream_t s);
 int launch_unproject(const CamDev* cam_dev, int model, int64_t n, const double* pixels, double* lines, double* jac,

@@ -818,6 +818,15 @@ int launch_apply_update(const Layout& L, const std::vector<cba_camera>& cams, co
   return CBA_OK;
 }
 
+// direction grid -= x in its local parametrisation (DirectionGridStateWithLocalUpdates::operator-=,
+// central_generic.cc:65-80: the same tangent-plane update as SubtractDelta)
+int launch_update_direction_grid(const double* in, const double* x, int G, double* out, hipStream_t s) {
+  if (G == 0) return CBA_OK;
+  hipLaunchKernelGGL(k_update_grid, dim3((G + 255) / 256), dim3(256), 0, s, in, x, G, 2, 1, (const int*)nullptr, out);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // stateless model-level kernels (cba_project / cba_unproject)
 // ------------------------------------------------------------------------------------------------

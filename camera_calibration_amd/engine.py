@@ -43,6 +43,11 @@ class CbaConfig(C.Structure):
                 ("reduce_buffer", C.c_void_p), ("reduce_buffer_doubles", C.c_int64)]
 
 
+class CbaFitReport(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("lambda_", C.c_double),
+                ("iterations_performed", C.c_int32), ("lm_attempts", C.c_int32), ("t_pass", C.c_double), ("t_solve", C.c_double)]
+
+
 class CbaReport(C.Structure):
     _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("lambda_", C.c_double),
                 ("accepted", C.c_int32), ("lm_attempts", C.c_int32),
@@ -57,7 +62,7 @@ EXPORTED_SYMBOLS = [
     "cba_get_state", "cba_get_last_projection", "cba_step", "cba_cost", "cba_project", "cba_unproject",
     "cba_schur_solve", "cba_debug_dump", "cba_debug_accumulate", "cba_debug_solve", "cba_debug_apply_update",
     "cba_total_dof", "cba_dense_dof", "cba_jacobian_record_doubles", "cba_reduce_buffer_doubles",
-    "cba_kernel_stats",
+    "cba_kernel_stats", "cba_fit_grid_to_directions",
 ]
 
 DUMP_COST_VECTOR, DUMP_PIXELS, DUMP_FLAGS, DUMP_JACOBIANS = 1, 2, 3, 4
@@ -103,6 +108,7 @@ def load() -> C.CDLL:
     L.cba_project.argtypes = [C.POINTER(CbaCamera), dp, C.c_int64, dp, dp, dp, C.POINTER(C.c_uint8), C.c_int32]
     L.cba_unproject.argtypes = [C.POINTER(CbaCamera), dp, C.c_int64, dp, dp, dp, C.POINTER(C.c_uint8), C.c_int32]
     L.cba_schur_solve.argtypes = [C.c_int32, C.c_int32, C.c_int32, dp, dp, dp, dp, dp, dp, C.c_int32]
+    L.cba_fit_grid_to_directions.argtypes = [C.POINTER(CbaCamera), dp, C.c_int64, dp, dp, C.c_int32, C.POINTER(CbaFitReport), C.c_int32]
     L.cba_debug_dump.argtypes = [vp, C.c_int32, vp, C.c_size_t]
     L.cba_debug_accumulate.argtypes = [vp, dp]
     L.cba_debug_solve.argtypes = [vp, C.c_double]
@@ -318,6 +324,23 @@ def schur_solve(block_diag_H: np.ndarray, off_diag_H: np.ndarray, dense_H: np.nd
 
 
 # ---- host mirror of the reference entry point ---------------------------------------------------------
+def fit_grid_to_directions(cam: Camera, grid: np.ndarray, grid_points: np.ndarray, directions: np.ndarray,
+                           max_iteration_count: int, device: int = 0):
+    """cba_fit_grid_to_directions (CentralGenericModel::FitToPixelDirectionsImpl).  Returns (new grid (G,3), report dict)."""
+    L = load()
+    g = np.ascontiguousarray(grid, dtype=np.float64).reshape(-1, 3).copy()
+    gp = np.ascontiguousarray(grid_points, dtype=np.float64).reshape(-1, 2)
+    d = np.ascontiguousarray(directions, dtype=np.float64).reshape(-1, 3)
+    assert gp.shape[0] == d.shape[0] and g.shape[0] == cam.grid_points
+    cs = _cam_struct(cam)
+    rep = CbaFitReport()
+    _check(L.cba_fit_grid_to_directions(C.byref(cs), _dp(g), gp.shape[0], _dp(gp) if gp.size else None,
+                                        _dp(d) if d.size else None, max_iteration_count, C.byref(rep), device),
+           "cba_fit_grid_to_directions")
+    return g, dict(initial_cost=rep.initial_cost, final_cost=rep.final_cost, final_lambda=rep.lambda_,
+                   iterations=rep.iterations_performed, lm_attempts=rep.lm_attempts, t_pass=rep.t_pass, t_solve=rep.t_solve)
+
+
 def optimize_jointly(problem: Problem, state: State, max_iteration_count: int, init_lambda: float = -1.0,
                      device: int = 0, engine: Optional[Engine] = None, print_progress: bool = False):
     """Python mirror of ``vis::OptimizeJointly`` (APP/bundle_adjustment/joint_optimization.h:53-70).

@@ -53,6 +53,19 @@ class CentralGenericModel : public CameraModel {
   CameraModel* duplicate() override { return new CentralGenericModel(*this); }
   int update_parameter_count() const override { return 2 * m_grid.width() * m_grid.height(); }
   bool GetGridResolution(int* rx, int* ry) const override { *rx = m_grid.width(); *ry = m_grid.height(); return true; }
+  // Grid-only fitting (APP/models/central_generic.cc:267-431, 551-568), LM on the GPU through
+  // cba_fit_grid_to_directions.  Defined in host/central_generic_fit_hip.cc.
+  bool FitToDenseModel(const Image<Vec3d>& dense_model, int subsample_step, int max_iteration_count = 10);
+  void FitToPixelDirections(const std::vector<Vec2d>& pixels, const std::vector<Vec3d>& directions, int max_iteration_count);
+  // central_grid.h:127-131 (evaluated in float) and :150-154
+  Vec2d GridPointToPixelCornerConv(int x, int y) const {
+    return Vec2d(m_calibration_min_x + ((x - 1.f) / (m_grid.width() - 3.f)) * (m_calibration_max_x + 1 - m_calibration_min_x),
+                 m_calibration_min_y + ((y - 1.f) / (m_grid.height() - 3.f)) * (m_calibration_max_y + 1 - m_calibration_min_y));
+  }
+  Vec2d PixelCornerConvToGridPoint(double x, double y) const {
+    return Vec2d(1.f + (m_grid.width() - 3.f) * (x - m_calibration_min_x) / (m_calibration_max_x + 1 - m_calibration_min_x),
+                 1.f + (m_grid.height() - 3.f) * (y - m_calibration_min_y) / (m_calibration_max_y + 1 - m_calibration_min_y));
+  }
   void SetGrid(const Image<Vec3d>& g) { m_grid = g; }
   const Image<Vec3d>& grid() const { return m_grid; }
   Image<Vec3d>& grid() { return m_grid; }

@@ -4,6 +4,7 @@
 #include "joint_optimization.h"
 #include "calibration_report.h"
 #include "calibration_io.h"
+#include "calibration_fit.h"
 
 using namespace vis;
 
@@ -164,5 +165,26 @@ extern "C" int cba_host_io_roundtrip(const char* dataset_in, const char* state_i
   *n_features = nf; *n_unindexed = bad;
   if (!SaveDataset(dataset_out, dataset)) return -3;
   if (!SaveBAState(state_out, state)) return -4;
+  return 0;
+}
+
+
+// F3 through the C++ mirror: FitToDenseModel on a dense direction image, then ResampleModel to a finer grid.
+extern "C" int cba_host_fit_and_resample(const cba_camera* cam, int dense_w, int dense_h, const double* dense /*3 per pixel, NaN = invalid*/,
+                                         int subsample_step, int max_iteration_count, double* grid_out /*3G*/,
+                                         int target_w, int target_h, double* resampled_out /*3 * target_w * target_h*/) {
+  CentralGenericModel model(cam->grid_w, cam->grid_h, cam->calib_min_x, cam->calib_min_y, cam->calib_max_x, cam->calib_max_y, cam->width, cam->height);
+  Image<Vec3d> dm(dense_w, dense_h);
+  for (size_t i = 0; i < (size_t)dense_w * dense_h; ++i) dm.data()[i] = Vec3d(dense[3 * i], dense[3 * i + 1], dense[3 * i + 2]);
+  if (!model.FitToDenseModel(dm, subsample_step, max_iteration_count)) return -1;
+  std::vector<double> g = model.abi_grid();
+  for (size_t i = 0; i < g.size(); ++i) grid_out[i] = g[i];
+  if (target_w > 0) {
+    std::shared_ptr<CameraModel> m(new CentralGenericModel(model));
+    SE3d dummy;
+    if (!ResampleModel(m, &dummy, cam->calib_min_x, cam->calib_min_y, cam->calib_max_x, cam->calib_max_y, CameraModel::Type::CentralGeneric, target_w, target_h)) return -2;
+    std::vector<double> g2 = m->abi_grid();
+    for (size_t i = 0; i < g2.size(); ++i) resampled_out[i] = g2[i];
+  }
   return 0;
 }

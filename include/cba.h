@@ -144,6 +144,27 @@ int cba_schur_solve(int32_t block_size, int32_t n_blocks, int32_t dense_dof, con
                     const double* off_diag_H, const double* dense_H, const double* block_diag_b,
                     const double* dense_b, double* x, int32_t device);
 
+/* ---- grid-only LM ---- */
+/* OptimizationReport of the fit + the optimizer's final lambda */
+typedef struct {
+  double initial_cost;          /* cost of the first residual+Jacobian pass */
+  double final_cost;            /* report.final_cost */
+  double lambda;                /* lambda after the last attempt */
+  int32_t iterations_performed; /* report.num_iterations_performed */
+  int32_t lm_attempts;          /* dense solves */
+  double t_pass;                /* residual / Jacobian / cost passes incl. accumulation [s] */
+  double t_solve;               /* dense solves [s] */
+} cba_fit_report;
+/* CentralGenericModel::FitToPixelDirectionsImpl (APP/models/central_generic.cc:551-568): LM over the 2G local grid
+ * updates minimising sum_i 0.5 |normalize(spline(grid_point_i)) - direction_i|^2 (cost function :153-225, residual
+ * and Jacobian :86-150, state update :65-80), LMOptimizer::Optimize(max_iteration_count, max_lm_attempts = 10,
+ * init_lambda = -1, init_lambda_factor = 0.001f), dense solve (LV/lm_optimizer.h).  grid: 3G doubles, row-major,
+ * unit directions, updated in place.  grid_points: 2n, in grid coordinates (PixelCornerConvToGridPoint already
+ * applied, as FitToPixelDirections / FitToDenseModel do, central_generic.cc:413-431); they must address a full 4x4
+ * patch (CBA_ERR_ARG otherwise, the reference CHECK-aborts).  Central-generic model only. */
+int cba_fit_grid_to_directions(const cba_camera* camera, double* grid, int64_t n, const double* grid_points,
+                               const double* directions, int32_t max_iteration_count, cba_fit_report* report, int32_t device);
+
 /* ---- parity/debug access (read-only views of the last cba_step / cba_debug_* call) ---- */
 enum {
   CBA_DUMP_COST_VECTOR = 1,      /* n doubles: Jacobian-pass residual costs (-1 invalid) */

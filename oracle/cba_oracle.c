@@ -1213,3 +1213,150 @@ double orc_optimize_jointly(orc_problem* pb, orc_state* st, int max_iteration_co
   free(cost_vec); free(test_vec); free(orig_diag); free(x);
   return final_cost;
 }
+
+
+/* =============================================================================================
+ * grid-only LM, CentralGenericModel::FitToPixelDirections
+ * (APP/models/central_generic.cc:44-83 state, :86-150 residual + Jacobian w.r.t. the local grid
+ * updates, :153-225 cost function, :551-568 driver).  Residual of sample i (3 scalar residuals with
+ * QuadraticLoss, LV/loss_functions.h:68-89): r = normalize(sum_c w_c P_c) - measurement; the
+ * Jacobian pass evaluates the weights with the generated code's 15-digit literals
+ * (central_generic_jacobians.cc:34-57), the cost-only pass goes through UnprojectFromGrid
+ * (exact fractions, b_spline.h:49-60).  The derivative is restated analytically instead of through
+ * the generated common-subexpression code:
+ *     d r / d P_c = w_c (I - d d^T) / |v| ,    d P_c / d(update) = [t1_c t2_c]
+ * (DirectionJacobianWrtLocalUpdate, direction_parametrization.h:57-70).
+ * ============================================================================================= */
+static void fit_residual_and_jacobian(int gw, const double* grid, const double* tang /*6 per grid point*/,
+                                      double gpx, double gpy, const double* meas, double* r, int* idx /*32*/,
+                                      double* J /*3 x 32 row-major*/) {
+  int ix = (int)floor(gpx + 2), iy = (int)floor(gpy + 2);
+  double fx = gpx + 2 - (ix - 3), fy = gpy + 2 - (iy - 3);
+  axis_weights ax, ay;
+  axis_weights_generated(fx, &ax);
+  axis_weights_generated(fy, &ay);
+  double wx[4] = {ax.a5 * ax.a3, ax.b, ax.c, ax.d8 * ax.d7};
+  double wy[4] = {ay.a5 * ay.a3, ay.b, ay.c, ay.d8 * ay.d7};
+  double v[3] = {0, 0, 0};
+  double w[16];
+  for (int y = 0; y < 4; ++y) {
+    double row[3] = {0, 0, 0};
+    for (int x = 0; x < 4; ++x) {
+      int seq = (ix - 3 + x) + (iy - 3 + y) * gw;
+      const double* P = grid + 3 * (size_t)seq;
+      row[0] += wx[x] * P[0]; row[1] += wx[x] * P[1]; row[2] += wx[x] * P[2];
+      w[x + 4 * y] = wx[x] * wy[y];
+      idx[2 * (x + 4 * y)] = 2 * seq; idx[2 * (x + 4 * y) + 1] = 2 * seq + 1;
+    }
+    v[0] += wy[y] * row[0]; v[1] += wy[y] * row[1]; v[2] += wy[y] * row[2];
+  }
+  double inv = 1. / sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  double d[3] = {v[0] * inv, v[1] * inv, v[2] * inv};
+  r[0] = d[0] - meas[0]; r[1] = d[1] - meas[1]; r[2] = d[2] - meas[2];
+  for (int c = 0; c < 16; ++c) {
+    int seq = idx[2 * c] / 2;
+    const double* t1 = tang + 6 * (size_t)seq;
+    const double* t2 = t1 + 3;
+    double s = w[c] * inv;
+    double dt1 = dot3(d, t1), dt2 = dot3(d, t2);
+    for (int a = 0; a < 3; ++a) {
+      J[a * 32 + 2 * c] = s * (t1[a] - d[a] * dt1);
+      J[a * 32 + 2 * c + 1] = s * (t2[a] - d[a] * dt2);
+    }
+  }
+}
+
+/* Compute<compute_jacobians>: returns the cost; cost_vec (3n) gets 0.5 r^2 per scalar residual;
+ * H (dof x dof row-major, upper triangle written) and b (dof) are zeroed and filled when H != NULL. */
+double orc_fit_grid_pass(int32_t gw, int32_t gh, const double* grid, int64_t n, const double* grid_points,
+                         const double* directions, double* H, double* b, double* cost_vec) {
+  const int dof = 2 * gw * gh;
+  double cost = 0;
+  double* tang = NULL;
+  if (H) {
+    memset(H, 0, (size_t)dof * dof * sizeof(double));
+    memset(b, 0, (size_t)dof * sizeof(double));
+    tang = (double*)malloc(6 * (size_t)gw * gh * sizeof(double));
+    for (int g = 0; g < gw * gh; ++g) orc_tangents(grid + 3 * (size_t)g, tang + 6 * (size_t)g, tang + 6 * (size_t)g + 3);
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    double r[3];
+    if (H) {
+      int idx[32]; double J[96];
+      fit_residual_and_jacobian(gw, grid, tang, grid_points[2 * i], grid_points[2 * i + 1], directions + 3 * i, r, idx, J);
+      for (int a = 0; a < 3; ++a) {   /* AddResidualWithJacobian(scalar residual, indices, row): H += J^T J (upper), b += J^T r */
+        const double* Ja = J + a * 32;
+        for (int p = 0; p < 32; ++p) {
+          b[idx[p]] += Ja[p] * r[a];
+          for (int q = p; q < 32; ++q) H[(size_t)idx[p] * dof + idx[q]] += Ja[p] * Ja[q];
+        }
+      }
+    } else {
+      double d[3];
+      orc_bspline_surface(grid, gw, gh, 3, grid_points[2 * i], grid_points[2 * i + 1], d);   /* UnprojectFromGrid */
+      double nrm = sqrt(dot3(d, d));
+      for (int a = 0; a < 3; ++a) r[a] = d[a] / nrm - directions[3 * i + a];
+    }
+    for (int a = 0; a < 3; ++a) { double c = 0.5 * r[a] * r[a]; cost += c; if (cost_vec) cost_vec[3 * i + a] = c; }
+  }
+  free(tang);
+  return cost;
+}
+
+/* DirectionGridStateWithLocalUpdates::operator-= (central_generic.cc:65-80) */
+void orc_fit_grid_apply_update(int32_t gw, int32_t gh, const double* grid_in, const double* x, double* grid_out) {
+  for (int g = 0; g < gw * gh; ++g) {
+    double t1[3], t2[3], d[3] = {grid_in[3 * g], grid_in[3 * g + 1], grid_in[3 * g + 2]};
+    orc_tangents(d, t1, t2);
+    apply_local_update_to_direction(d, t1, t2, -x[2 * g], -x[2 * g + 1]);
+    grid_out[3 * g] = d[0]; grid_out[3 * g + 1] = d[1]; grid_out[3 * g + 2] = d[2];
+  }
+}
+
+/* FitToPixelDirectionsImpl (:551-568): LMOptimizer::Optimize(max_iteration_count, max_lm_attempts = 10,
+ * init_lambda = -1, init_lambda_factor = 0.001f) on the dense system (LV/lm_optimizer.h:629-991, dense
+ * solve x = H.selfadjointView<Upper>().ldlt().solve(b)).  report4 = {initial cost, final cost,
+ * iterations performed, final lambda}. */
+void orc_fit_grid_to_points(int32_t gw, int32_t gh, double* grid, int64_t n, const double* grid_points,
+                            const double* directions, int32_t max_iteration_count, double* report4) {
+  const int dof = 2 * gw * gh, max_lm_attempts = 10;
+  const double init_lambda_factor = (double)0.001f;
+  double* H = (double*)malloc((size_t)dof * dof * sizeof(double));
+  double* b = (double*)malloc((size_t)dof * sizeof(double));
+  double* x = (double*)malloc((size_t)dof * sizeof(double));
+  double* diag = (double*)malloc((size_t)dof * sizeof(double));
+  double* cv = (double*)malloc(3 * (size_t)n * sizeof(double));
+  double* tv = (double*)malloc(3 * (size_t)n * sizeof(double));
+  double* test_grid = (double*)malloc(3 * (size_t)gw * gh * sizeof(double));
+  double lambda = -1, last_cost = 0, initial = 0;
+  int performed = 0;
+  for (int iteration = 0; iteration < max_iteration_count; ++iteration) {
+    last_cost = orc_fit_grid_pass(gw, gh, grid, n, grid_points, directions, H, b, cv);
+    if (iteration == 0) initial = last_cost;
+    if (last_cost == 0) break;
+    if (iteration == 0) {
+      double s = 0;
+      for (int i = 0; i < dof; ++i) s += H[(size_t)i * dof + i];
+      lambda = init_lambda_factor * s / dof;
+    }
+    for (int i = 0; i < dof; ++i) diag[i] = H[(size_t)i * dof + i];
+    int applied = 0;
+    for (int lm = 0; lm < max_lm_attempts; ++lm) {
+      for (int i = 0; i < dof; ++i) H[(size_t)i * dof + i] = diag[i] + lambda;
+      orc_ldlt_solve_upper(H, dof, b, x);
+      if (x[0] != x[0]) { lambda = 2.f * lambda; continue; }
+      orc_fit_grid_apply_update(gw, gh, grid, x, test_grid);
+      double test_cost = orc_fit_grid_pass(gw, gh, test_grid, n, grid_points, directions, NULL, NULL, tv);
+      if (cost_is_smaller_than(tv, cv, 3 * n)) {
+        memcpy(grid, test_grid, 3 * (size_t)gw * gh * sizeof(double));
+        lambda = 0.5f * lambda;
+        applied = 1; performed += 1; last_cost = test_cost;
+        break;
+      }
+      lambda = 2.f * lambda;
+    }
+    if (!applied || last_cost == 0) break;
+  }
+  if (report4) { report4[0] = initial; report4[1] = last_cost; report4[2] = performed; report4[3] = lambda; }
+  free(H); free(b); free(x); free(diag); free(cv); free(tv); free(test_grid);
+}

@@ -134,6 +134,13 @@ double orc_optimize_jointly(orc_problem* pb, orc_state* st, int max_iteration_co
                             double* timings3 /* t_jac, t_solve, t_cost; may be NULL */,
                             int32_t* lm_attempts /* may be NULL */);
 
+/* ---- grid-only LM (CentralGenericModel::FitToPixelDirections) ---- */
+double orc_fit_grid_pass(int32_t gw, int32_t gh, const double* grid, int64_t n, const double* grid_points,
+                         const double* directions, double* H /*dof x dof or NULL*/, double* b, double* cost_vec);
+void orc_fit_grid_apply_update(int32_t gw, int32_t gh, const double* grid_in, const double* x, double* grid_out);
+void orc_fit_grid_to_points(int32_t gw, int32_t gh, double* grid, int64_t n, const double* grid_points,
+                            const double* directions, int32_t max_iteration_count, double* report4);
+
 #ifdef __cplusplus
 }
 #endif

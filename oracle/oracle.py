@@ -356,3 +356,78 @@ def delete_outlier_features(camera_index: int, pb, st, outlier_removal_factor: f
         if left < 3:
             used[i] = False
     return keep, used, thr
+
+
+# ---------------------------------------------------------------------------------------------------
+# grid-only LM (CentralGenericModel::FitToPixelDirections / FitToDenseModel)
+# ---------------------------------------------------------------------------------------------------
+def _fit_sigs():
+    L = lib()
+    if getattr(L, "_fit_sigs_done", False):
+        return L
+    dp = C.POINTER(C.c_double)
+    L.orc_fit_grid_pass.restype = C.c_double
+    L.orc_fit_grid_pass.argtypes = [C.c_int32, C.c_int32, dp, C.c_int64, dp, dp, dp, dp, dp]
+    L.orc_fit_grid_apply_update.restype = None
+    L.orc_fit_grid_apply_update.argtypes = [C.c_int32, C.c_int32, dp, dp, dp]
+    L.orc_fit_grid_to_points.restype = None
+    L.orc_fit_grid_to_points.argtypes = [C.c_int32, C.c_int32, dp, C.c_int64, dp, dp, C.c_int32, dp]
+    L.orc_grid_point_to_pixel.restype = None
+    L.orc_pixel_to_grid_point.restype = None
+    L._fit_sigs_done = True
+    return L
+
+
+def fit_grid_pass(gw: int, gh: int, grid, grid_points, directions, with_jacobian: bool):
+    """One Compute<compute_jacobians> of CentralGenericBSplineDirectionCostFunction (central_generic.cc:153-225).
+    Returns (cost, cost_vector[3n], H (dof x dof upper) or None, b or None)."""
+    L = _fit_sigs()
+    g = np.ascontiguousarray(grid, dtype=np.float64).reshape(-1, 3)
+    gp = np.ascontiguousarray(grid_points, dtype=np.float64).reshape(-1, 2)
+    d = np.ascontiguousarray(directions, dtype=np.float64).reshape(-1, 3)
+    n = gp.shape[0]
+    cv = np.zeros(3 * n)
+    dof = 2 * gw * gh
+    H = np.zeros((dof, dof)) if with_jacobian else None
+    b = np.zeros(dof) if with_jacobian else None
+    cost = L.orc_fit_grid_pass(gw, gh, _dp(g), n, _dp(gp), _dp(d), _dp(H) if with_jacobian else None,
+                               _dp(b) if with_jacobian else None, _dp(cv))
+    return cost, cv, H, b
+
+
+def fit_grid_apply_update(gw: int, gh: int, grid, x):
+    L = _fit_sigs()
+    g = np.ascontiguousarray(grid, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros_like(g)
+    xx = np.ascontiguousarray(x, dtype=np.float64)
+    L.orc_fit_grid_apply_update(gw, gh, _dp(g), _dp(xx), _dp(out))
+    return out
+
+
+def fit_grid_to_points(gw: int, gh: int, grid, grid_points, directions, max_iteration_count: int):
+    """FitToPixelDirectionsImpl (central_generic.cc:551-568).  Returns (new grid, report dict)."""
+    L = _fit_sigs()
+    g = np.ascontiguousarray(grid, dtype=np.float64).reshape(-1, 3).copy()
+    gp = np.ascontiguousarray(grid_points, dtype=np.float64).reshape(-1, 2)
+    d = np.ascontiguousarray(directions, dtype=np.float64).reshape(-1, 3)
+    rep = np.zeros(4)
+    L.orc_fit_grid_to_points(gw, gh, _dp(g), gp.shape[0], _dp(gp), _dp(d), max_iteration_count, _dp(rep))
+    return g, dict(initial_cost=rep[0], final_cost=rep[1], iterations=int(rep[2]), final_lambda=rep[3])
+
+
+def pixel_to_grid_point(cam, pixels):
+    L = _fit_sigs()
+    cs = camera_struct(cam)
+    px = np.ascontiguousarray(pixels, dtype=np.float64).reshape(-1, 2)
+    out = np.zeros_like(px)
+    for i in range(px.shape[0]):
+        L.orc_pixel_to_grid_point(C.byref(cs), C.c_double(px[i, 0]), C.c_double(px[i, 1]), _dp(out[i]))
+    return out
+
+
+def grid_point_to_pixel(cam, gx: int, gy: int):
+    L = _fit_sigs()
+    cs = camera_struct(cam)
+    out = np.zeros(2)
+    L.orc_grid_point_to_pixel(C.byref(cs), C.c_double(float(gx)), C.c_double(float(gy)), _dp(out))
+    return out
