@@ -431,3 +431,54 @@ def grid_point_to_pixel(cam, gx: int, gy: int):
     out = np.zeros(2)
     L.orc_grid_point_to_pixel(C.byref(cs), C.c_double(float(gx)), C.c_double(float(gy)), _dp(out))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# ChooseNiceCameraOrientation / ScaleToMetric, scalar restatements
+# ---------------------------------------------------------------------------------------------------
+def choose_nice_camera_orientation(cam, grid):
+    """CentralGenericModel::ChooseNiceCameraOrientation, APP/models/central_generic.cc:570-621 (per-pixel loops)."""
+    g = np.ascontiguousarray(grid, dtype=np.float64).reshape(-1, 3)
+    w, h = cam.width, cam.height
+    line, ok = unproject(cam, g, np.array([[0.5 * w, 0.5 * h]]))
+    forward = line[0, :3] if ok[0] else np.array([0.0, 0.0, 1.0])
+    # Quaterniond::FromTwoVectors(forward, (0,0,1)).toRotationMatrix()
+    v0 = forward / np.linalg.norm(forward); v1 = np.array([0.0, 0.0, 1.0])
+    c = float(v1 @ v0)
+    axis = np.cross(v0, v1); s_ = np.sqrt((1 + c) * 2)
+    qw = s_ * 0.5; qx, qy, qz = axis / s_
+    fr = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy)],
+                   [2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx)],
+                   [2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)]])
+    right_sum = np.zeros(3); right_count = 0
+    for y in range(max(0, h // 2 - 10), min(h - 1, h // 2 + 10) + 1):
+        for x in range(min(w - 1, w // 2 + 11), w):
+            l, o = unproject(cam, g, np.array([[x + 0.5, y + 0.5]]))
+            if not o[0]:
+                continue
+            right_sum += l[0, :3]; right_count += 1
+    if right_count > 0:
+        r = fr @ (right_sum / right_count)
+        a = np.arctan2(-r[1], r[0])
+        rr = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+    else:
+        rr = np.eye(3)
+    rot = rr @ fr
+    return rot, np.array([rot @ v for v in g])
+
+
+def scale_to_metric_factor(known_geometries, points, feature_id_to_points_index):
+    """ScaleToMetric, APP/calibration.cc:307-370: exp(mean log(ideal / actual neighbour distance))."""
+    log_sum, count = 0.0, 0
+    for cell, id_to_pos in known_geometries:
+        pos_to_idx = {tuple(p): feature_id_to_points_index[f] for f, p in id_to_pos.items() if f in feature_id_to_points_index}
+        for f, p in id_to_pos.items():
+            if tuple(p) not in pos_to_idx:
+                continue
+            i = pos_to_idx[tuple(p)]
+            for n in ((1, 0), (0, 1)):
+                q = (p[0] + n[0], p[1] + n[1])
+                if q not in pos_to_idx:
+                    continue
+                log_sum += np.log(cell / np.linalg.norm(points[i] - points[pos_to_idx[q]])); count += 1
+    return float(np.exp(log_sum / count))
