@@ -59,7 +59,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 HOST_DIR = os.path.join(HERE, "host")
 HOST_LIB = os.path.join(HERE, "libcalib_ba_host.so")
-HOST_SOURCES = ["joint_optimization_hip.cc", "calibration_report_hip.cc", "calibration_io.cc", "central_generic_fit_hip.cc", "host_test_shim.cc"]
+HOST_SOURCES = ["joint_optimization_hip.cc", "calibration_report_hip.cc", "calibration_io.cc", "central_generic_fit_hip.cc", "calibration_hip.cc", "host_test_shim.cc"]
 HOST_HEADERS = ["vis_types.h", "camera_model.h", "dataset.h", "joint_optimization.h"]
 
 

@@ -5,6 +5,7 @@
 #include "calibration_report.h"
 #include "calibration_io.h"
 #include "calibration_fit.h"
+#include "calibration.h"
 
 using namespace vis;
 
@@ -186,5 +187,36 @@ extern "C" int cba_host_fit_and_resample(const cba_camera* cam, int dense_w, int
     std::vector<double> g2 = m->abi_grid();
     for (size_t i = 0; i < g2.size(); ++i) resampled_out[i] = g2[i];
   }
+  return 0;
+}
+
+
+// F1 through the C++ mirror: ChooseNiceCameraOrientation on a central-generic grid (rotation 9 doubles row-major,
+// grid rotated in place) and ScaleToMetric on a one-geometry lattice (returns the scaled points).
+extern "C" int cba_host_nice_orientation(const cba_camera* cam, double* grid /*3G in/out*/, double* rotation9) {
+  CentralGenericModel model(cam->grid_w, cam->grid_h, cam->calib_min_x, cam->calib_min_y, cam->calib_max_x, cam->calib_max_y, cam->width, cam->height);
+  model.set_abi_grid(grid);
+  const Mat3d r = ChooseNiceCameraOrientation(&model);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) rotation9[3 * i + j] = r.m[i][j];
+  std::vector<double> g = model.abi_grid();
+  for (size_t i = 0; i < g.size(); ++i) grid[i] = g[i];
+  return 0;
+}
+extern "C" int cba_host_scale_to_metric(float cell_length, int n, const int32_t* feature_id, const int32_t* pos_xy, double* points /*3n in/out*/,
+                                        double* pose7 /*one rig pose, in/out*/) {
+  Dataset dataset(1);
+  dataset.SetKnownGeometriesCount(1);
+  KnownGeometry& g = dataset.GetKnownGeometry(0);
+  g.cell_length_in_meters = cell_length;
+  BAState state;
+  for (int i = 0; i < n; ++i) {
+    g.feature_id_to_position[feature_id[i]] = Vec2i(pos_xy[2 * i], pos_xy[2 * i + 1]);
+    state.feature_id_to_points_index[feature_id[i]] = i;
+    state.points.push_back(Vec3d(points[3 * i], points[3 * i + 1], points[3 * i + 2]));
+  }
+  state.rig_tr_global.push_back(SE3d(Quaterniond(pose7[0], pose7[1], pose7[2], pose7[3]), Vec3d(pose7[4], pose7[5], pose7[6])));
+  ScaleToMetric(&dataset, &state);
+  for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) points[3 * i + k] = state.points[i].v[k];
+  for (int k = 0; k < 3; ++k) pose7[4 + k] = state.rig_tr_global[0].translation().v[k];
   return 0;
 }

@@ -72,3 +72,51 @@ def test_run_bundle_adjustment_loop_converges_like_the_reference_gtest():
     assert costs[-1] <= 1e-6 and all(b <= a * (1 + 1e-9) + 1e-9 for a, b in zip(costs, costs[1:]))
     centre = orc.unproject(pb.cameras[0], st.grids[0], np.array([[0.5 * pb.cameras[0].width, 0.5 * pb.cameras[0].height]]))[0][0, :3]
     np.testing.assert_allclose(centre, [0, 0, 1], atol=1e-6)
+
+
+def _host_lib():
+    import ctypes as C
+    import os
+    from camera_calibration_amd import engine as eng
+    lib_dir = os.path.dirname(os.path.abspath(cal.__file__))
+    C.CDLL(os.path.join(lib_dir, "libcalib_ba_hip.so"), mode=C.RTLD_GLOBAL)
+    return C.CDLL(os.path.join(lib_dir, "libcalib_ba_host.so"))
+
+
+def test_cpp_scale_to_metric_matches_oracle():
+    import ctypes as C
+    try:
+        L = _host_lib()
+    except OSError as e:
+        pytest.skip(f"cannot load host library here: {e}")
+    rng = np.random.default_rng(6)
+    fid, pos, pts = [], [], []
+    for y in range(3):
+        for x in range(5):
+            fid.append(200 + len(pts)); pos.append((x, y)); pts.append(np.array([x, y, 0.0]) * 0.015 * 2.2 + rng.normal(0, 1e-4, 3))
+    pts = np.ascontiguousarray(np.array(pts)); pts_in = pts.copy()
+    fid_a = np.array(fid, dtype=np.int32); pos_a = np.ascontiguousarray(np.array(pos, dtype=np.int32))
+    pose = np.array([1.0, 0, 0, 0, 0.3, -0.2, 0.9])
+    dp = C.POINTER(C.c_double); ip = C.POINTER(C.c_int32)
+    rc = L.cba_host_scale_to_metric(C.c_float(0.015), C.c_int(len(fid)), fid_a.ctypes.data_as(ip), pos_a.ctypes.data_as(ip),
+                                    pts.ctypes.data_as(dp), pose.ctypes.data_as(dp))
+    assert rc == 0
+    f_ref = orc.scale_to_metric_factor([(np.float32(0.015), dict(zip(fid, pos)))], pts_in, {f: i for i, f in enumerate(fid)})
+    np.testing.assert_allclose(pts, pts_in * f_ref, rtol=1e-13)
+    np.testing.assert_allclose(pose[4:], np.array([0.3, -0.2, 0.9]) * f_ref, rtol=1e-13)
+
+
+@pytest.mark.gpu
+def test_cpp_choose_nice_camera_orientation_on_gpu():
+    import ctypes as C
+    from camera_calibration_amd import engine as eng
+    pb, st, cam, g = _rotated_model(43)
+    L = _host_lib()
+    cs = eng._cam_struct(cam)
+    grid = np.ascontiguousarray(g, dtype=np.float64).copy()
+    R = np.zeros(9)
+    dp = C.POINTER(C.c_double)
+    assert L.cba_host_nice_orientation(C.byref(cs), grid.ctypes.data_as(dp), R.ctypes.data_as(dp)) == 0
+    R_ref, g_ref = orc.choose_nice_camera_orientation(cam, g)
+    np.testing.assert_allclose(R.reshape(3, 3), R_ref, atol=1e-10)
+    np.testing.assert_allclose(grid, g_ref, atol=1e-10)
