@@ -211,6 +211,35 @@ def test_first_iteration_parity_eliminate_points():
     _compare_pass(pb, st)
 
 
+@pytest.mark.parametrize("num_cameras", [1, 2])
+def test_first_iteration_parity_localize_only(num_cameras):
+    """localize_only = true (OptimizeJointly argument; intrinsics held fixed, joint_optimization.cc:451-593):
+    no intrinsics block in the state, the dense part is points (+ rig poses)."""
+    pb, st, gt = syn.reference_test_problem(num_cameras, oracle_project, seed=6, num_points=60, num_poses=20)
+    pb.localize_only = True
+    _compare_pass(pb, st)
+
+
+def test_localize_only_trajectory_matches_oracle():
+    pb, st0, gt = syn.reference_test_problem(1, oracle_project, seed=8, num_points=50, num_poses=12)
+    pb.localize_only = True
+    op = orc.OracleProblem(pb)
+    st_ref = st0.copy()
+    e = eng.Engine(pb)
+    e.set_state(st0)
+    lam_ref, lam = -1.0, -1.0
+    for it in range(4):
+        r = op.optimize_jointly(st_ref, 1, lam_ref); lam_ref = r["final_lambda"]
+        rep = e.step(lam); lam = rep.final_lambda
+        assert rep.accepted == int(r["performed"])
+        assert abs(rep.final_cost - r["cost"]) <= 1e-5 * max(1.0, abs(r["cost"]))
+    st = e.get_state(st0)
+    for g, g0 in zip(st.grids, st0.grids):
+        np.testing.assert_array_equal(g, g0)          # the intrinsics are not touched
+    np.testing.assert_allclose(st.points, st_ref.points, atol=1e-5)
+    e.close()
+
+
 def test_cost_pass_matches_oracle_and_invalid_residuals():
     pb, st, gt = syn.reference_test_problem(1, oracle_project, seed=1, num_points=80, num_poses=30)
     # push some points behind / far outside so that projections fail
