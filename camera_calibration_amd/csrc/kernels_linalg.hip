@@ -149,6 +149,7 @@ struct GemmArgs {
   const unsigned long long* kmask;  // optional block-sparsity mask [column tile][kmask_words], bit = K slab of 16 rows
   int kmask_words;
   int epi_mode;                 // developer switch (bench harness): 0 normal, 1 no Cin read, 2 no store
+  int strips;                   // set by launch_gemm: strip-blocked tile order (square upper dense launches)
 };
 
 template <int TM, int TN, int WM, int WN, bool SUB>
@@ -171,7 +172,29 @@ __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
   long long t = (cq * 8 + (b & 7)) * g.chunk + (q - cq * g.chunk);
   if (t >= g.total_tiles) return;
   int tm, tn;
-  if (g.upper) {
+  if (g.strips) {
+    // Square upper-triangular launch, dense: tiles are enumerated strip by strip (kStripW tile columns), row by
+    // row inside a strip, so that the ~64 workgroups in flight on an XCD form an 8 x 8 block sharing 8 A and
+    // 8 B panels (row-major order: 1 A panel and 64 different B panels -- 4x the operand traffic).
+    constexpr int kStripW = 8;
+    long long rem = t;
+    int s = 0, w = 0;
+    for (;; ++s) {
+      const int c0 = s * kStripW;
+      w = g.n_tiles - c0 < kStripW ? g.n_tiles - c0 : kStripW;
+      const long long cnt = (long long)c0 * w + (long long)w * (w + 1) / 2;   // full rows above + triangle
+      if (rem < cnt) break;
+      rem -= cnt;
+    }
+    const int c0 = s * kStripW;
+    if (rem < (long long)c0 * w) { tm = (int)(rem / w); tn = c0 + (int)(rem - (long long)tm * w); }
+    else {
+      rem -= (long long)c0 * w;
+      int i = 0;
+      while (rem >= w - i) { rem -= w - i; ++i; }
+      tm = c0 + i; tn = c0 + i + (int)rem;
+    }
+  } else if (g.upper) {
     // enumerate tile rows; row tm owns tiles tn in [first(tm), n_tiles)
     // first(tm) = smallest tn with n_off + tn*TN + TN - 1 >= m_off + tm*TM
     long long rem = t;
@@ -198,27 +221,32 @@ __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
   // operand slab (and the co-resident workgroup's MFMAs) instead of sitting in the epilogue; the
   // result is C = -acc.  (Measured: the epilogue read cost 0.44 ms per 1.2 GB trailing update.)
   v4f64 acc[MI][NJ];
-  if (SUB && g.epi_mode != 1) {
-    double dadd0 = 0.0;
-    if (g.diag) dadd0 = g.diag_add_ptr ? *g.diag_add_ptr : g.diag_add;
+  // SUB: the accumulators start as -(Cin + diag) (see below); in the LDS-DMA variant the tile is loaded AFTER the
+  // first operand slab has been put in flight so that the two HBM round trips overlap.
+  auto preload_c = [&]() {
+    if (SUB && g.epi_mode != 1) {
+      double dadd0 = 0.0;
+      if (g.diag) dadd0 = g.diag_add_ptr ? *g.diag_add_ptr : g.diag_add;
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = m0 + wm0 + i * 16 + lk + 4 * r;
-          const int n = n0 + wn0 + j * 16 + li;
-          double cin = g.Cin[(size_t)m * g.ldcin + n];
-          if (g.diag && m == n) cin += (m < g.n_real) ? dadd0 : 1.0;
-          acc[i][j][r] = -cin;
-        }
-  } else {
+          for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm0 + i * 16 + lk + 4 * r;
+            const int n = n0 + wn0 + j * 16 + li;
+            double cin = g.Cin[(size_t)m * g.ldcin + n];
+            if (g.diag && m == n) cin += (m < g.n_real) ? dadd0 : 1.0;
+            acc[i][j][r] = -cin;
+          }
+    } else {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
-  }
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    }
+  };
+  if constexpr (!(TM == 128 && TN == 128)) preload_c();
 
 
   const double* Ag = g.A + m0;
@@ -262,6 +290,7 @@ __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
     };
     int kb = next_slab(-1);
     if (kb < nk) CBA_DMA_STAGE(0, kb * KT);
+    preload_c();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int buf = 0;
@@ -377,6 +406,9 @@ static int launch_gemm(GemmArgs g, hipStream_t s) {
   // dense launches: one contiguous range per XCD (best L2 reuse); block-sparse launches: chunks of 64
   // interleaved over the XCDs so that dense and sparse regions of the matrix are spread evenly
   g.chunk = (int)((g.kmask && per > 64) ? 64 : (per < 1 ? 1 : per));
+  static const int use_strips = getenv("CBA_NO_STRIPS") ? 0 : 1;
+  g.strips = (use_strips && TM == 128 && TN == 128 && g.upper && !g.kmask && g.m_off == g.n_off && g.m_tiles == g.n_tiles &&
+              g.total_tiles >= 512) ? 1 : 0;
   long long chunks = (g.total_tiles + g.chunk - 1) / g.chunk;
   long long blocks = ((chunks + 7) / 8) * 8 * g.chunk;
   hipLaunchKernelGGL((k_gemm_atb<TM, TN, WM, WN, SUB>), dim3((unsigned)blocks), dim3(256), 0, s, g);
