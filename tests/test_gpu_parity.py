@@ -355,3 +355,27 @@ def test_full_size_config2_properties():
     both = (v_ref >= 0) & (v_new >= 0)
     assert v_new[both].sum() < v_ref[both].sum()
     e.close()
+
+
+def test_baseline_config1_end_to_end_against_oracle():
+    """BASELINE configs[0] (30 imagesets, 16x12 grid, 343 pattern points, D = 1 413): the reference's CPU-runnable
+    case, end to end through the C-ABI against the oracle -- three OptimizeJointly(1) calls on the same start:
+    accept decisions and attempt counts identical, costs to 1e-5 relative (finite-difference Jacobians of iterative
+    projections), lambda to 1e-4."""
+    pb, st0, gt = syn.baseline_config(1, oracle_project)
+    assert pb.dense_dof == 1413 and pb.n_images == 30
+    op = orc.OracleProblem(pb)
+    st_ref = st0.copy()
+    e = eng.Engine(pb)
+    e.set_state(st0)
+    lam_ref, lam = -1.0, -1.0
+    for it in range(3):
+        r = op.optimize_jointly(st_ref, 1, lam_ref); lam_ref = r["final_lambda"]
+        rep = e.step(lam); lam = rep.final_lambda
+        assert rep.accepted == int(r["performed"]) and rep.lm_attempts == r["lm_attempts"]
+        assert abs(rep.final_cost - r["cost"]) <= 1e-5 * max(1.0, abs(r["cost"]))
+        assert abs(lam - lam_ref) <= 1e-4 * lam_ref
+    st = e.get_state(st0)
+    np.testing.assert_allclose(st.points, st_ref.points, atol=1e-6)
+    np.testing.assert_allclose(st.grids[0], st_ref.grids[0], atol=1e-6)
+    e.close()
