@@ -12,6 +12,11 @@ Host mirror of (APP = applications/camera_calibration/src/camera_calibration):
   dense model by un-projecting every pixel centre (``cba_unproject``), then ``fit_to_dense_model`` with at most
   300 x 300 samples and 3 iterations.
 
+* ``initialize_noncentral_from_central`` -- NoncentralGenericModel::InitializeFromCentralGenericModel,
+  APP/models/noncentral_generic.cc:136-146; ``resample_noncentral_model`` -- the non-central -> non-central branch of
+  ResampleModel (calibration.cc:386-425): bilinear re-gridding of both grids (libvis InterpolateBilinear, float
+  weights), no optimisation.
+
 `fit_fn(cam, grid, grid_points, directions, max_iteration_count) -> (grid, report)` is injectable so that the tests
 can run the host logic against the oracle; the default is the HIP engine (no CPU fallback).
 """
@@ -156,3 +161,42 @@ def resample_model(cam: Camera, grid: np.ndarray, target_resolution_x: int, targ
     step = max(1, min(int(round(aw // 300)), int(round(ah // 300))))
     new_grid, rep = fit_to_dense_model(new_cam, dense, step, 3, fit_fn)
     return new_cam, new_grid, rep
+
+
+def initialize_noncentral_from_central(cam: Camera, grid: np.ndarray):
+    """Returns (non-central Camera, grids (2,G,3) = direction grid, zero point grid)."""
+    from .problem import NONCENTRAL_GENERIC
+    g = np.asarray(grid, dtype=np.float64).reshape(-1, 3)
+    nc = Camera(NONCENTRAL_GENERIC, cam.width, cam.height, cam.calib_min_x, cam.calib_min_y, cam.calib_max_x, cam.calib_max_y,
+                cam.grid_w, cam.grid_h)
+    return nc, np.stack([g, np.zeros_like(g)])
+
+
+def _interpolate_bilinear(img: np.ndarray, x: float, y: float) -> np.ndarray:
+    """libvis Image::InterpolateBilinear for Vec3d pixels (LV/image.h:152-176): the fractions are floats."""
+    ix, iy = int(x), int(y)
+    fx = np.float32(x - ix); fy = np.float32(y - iy)
+    fxi = np.float32(1.0) - fx; fyi = np.float32(1.0) - fy
+    return (float(fxi * fyi) * img[iy, ix] + float(fx * fyi) * img[iy, ix + 1] +
+            float(fxi * fy) * img[iy + 1, ix] + float(fx * fy) * img[iy + 1, ix + 1])
+
+
+def resample_noncentral_model(cam: Camera, grids: np.ndarray, target_resolution_x: int, target_resolution_y: int):
+    """ResampleModel, non-central generic -> non-central generic (calibration.cc:386-425).  Returns (Camera, grids)."""
+    from .problem import NONCENTRAL_GENERIC
+    assert cam.model_type == NONCENTRAL_GENERIC
+    g = np.asarray(grids, dtype=np.float64).reshape(2, cam.grid_h, cam.grid_w, 3)
+    new_cam = Camera(NONCENTRAL_GENERIC, cam.width, cam.height, cam.calib_min_x, cam.calib_min_y, cam.calib_max_x, cam.calib_max_y,
+                     target_resolution_x, target_resolution_y)
+    out = np.zeros((2, target_resolution_y, target_resolution_x, 3))
+    f = np.float32
+    for y in range(target_resolution_y):
+        for x in range(target_resolution_x):
+            # static GridPointToPixelCornerConv (central_grid.h:132-140): evaluated in float
+            px = float(f(cam.calib_min_x) + ((f(x) - f(1.0)) / (f(target_resolution_x) - f(3.0))) * f(cam.calib_max_x + 1 - cam.calib_min_x))
+            py = float(f(cam.calib_min_y) + ((f(y) - f(1.0)) / (f(target_resolution_y) - f(3.0))) * f(cam.calib_max_y + 1 - cam.calib_min_y))
+            ogx, ogy = pixel_corner_conv_to_grid_point(cam, px, py)      # same formula in the non-central model
+            ogx = min(max(float(ogx), 0.0), cam.grid_w - 1.001); ogy = min(max(float(ogy), 0.0), cam.grid_h - 1.001)
+            out[1, y, x] = _interpolate_bilinear(g[1], ogx, ogy)          # point grid
+            out[0, y, x] = _interpolate_bilinear(g[0], ogx, ogy)          # direction grid (not re-normalised, as in the reference)
+    return new_cam, out.reshape(2, -1, 3)

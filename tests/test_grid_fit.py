@@ -172,3 +172,28 @@ def test_cpp_mirror_fit_and_resample_match_python_mirror():
     np.testing.assert_allclose(g_out, g_py, atol=1e-12)
     new_cam, r_py, _ = grid_fit.resample_model(cam, g_py, 13, 10)
     np.testing.assert_allclose(r_out, r_py, atol=1e-10)
+
+
+def test_noncentral_resampling_and_initialisation():
+    from camera_calibration_amd.problem import NONCENTRAL_GENERIC
+    cam = Camera(0, W, H, 0, 0, W - 1, H - 1, 8, 6)
+    grid = grid_fit.initialize_grid_from_dense_model(cam, dense_pinhole(240, 240, 320, 240))
+    nc, grids = grid_fit.initialize_noncentral_from_central(cam, grid)
+    assert nc.model_type == NONCENTRAL_GENERIC and grids.shape == (2, 48, 3) and not grids[1].any()
+    np.testing.assert_array_equal(grids[0], grid)
+    rng = np.random.default_rng(2)
+    grids[1] = rng.normal(0, 1e-3, grids[1].shape)
+    new_cam, g2 = grid_fit.resample_noncentral_model(nc, grids, 12, 9)
+    assert (new_cam.grid_w, new_cam.grid_h) == (12, 9) and g2.shape == (2, 108, 3)
+    # scalar restatement of one interior and one clamped grid point (calibration.cc:392-412, LV/image.h:152-176)
+    f = np.float32
+    for (x, y) in [(5, 4), (0, 0), (11, 8)]:
+        px = float(f(0) + ((f(x) - f(1)) / (f(12) - f(3))) * f(W)); py = float(f(0) + ((f(y) - f(1)) / (f(9) - f(3))) * f(H))
+        ogx = 1.0 + float(f(8) - f(3)) * px / W; ogy = 1.0 + float(f(6) - f(3)) * py / H
+        ogx = min(max(ogx, 0.0), 8 - 1.001); ogy = min(max(ogy, 0.0), 6 - 1.001)
+        ix, iy = int(ogx), int(ogy)
+        fx, fy = f(ogx - ix), f(ogy - iy)
+        G = grids[1].reshape(6, 8, 3)
+        ref = (float((f(1) - fx) * (f(1) - fy)) * G[iy, ix] + float(fx * (f(1) - fy)) * G[iy, ix + 1] +
+               float((f(1) - fx) * fy) * G[iy + 1, ix] + float(fx * fy) * G[iy + 1, ix + 1])
+        np.testing.assert_allclose(g2[1].reshape(9, 12, 3)[y, x], ref, rtol=1e-15, atol=1e-18)
