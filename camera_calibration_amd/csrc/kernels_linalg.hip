@@ -540,45 +540,56 @@ template <int SA, int SAN>
 __device__ __forceinline__ void ldlt_diag_step(double (&T)[4][4], double (&X)[4][4], double (*colbuf)[kInner],
                                                double (*rowbuf)[kInner], int ti, int tj, int sr, int nsr, bool& bad) {
   const int s = 16 * SA + sr, pb = s & 1;
-  // all LDS reads of the step are issued back to back (one round trip), masks are applied afterwards
+  // Only part of the cyclic sub-grid is still live in segment SA (s in [16 SA, 16 SA + 16)): rows and columns of
+  // T in groups a, b < SA are eliminated (their l_i / d l_j are zero), and row s of X = L^-1 is zero right of column
+  // s, i.e. in groups b > SA.  The dead groups are skipped statically: on average 12.5 of the 32 FMAs and 8.5 of the
+  // 13 LDS reads per step remain -- the step is instruction-issue bound, so this is where its time goes.
   const double d = colbuf[pb][s];
   double li[4], lj[4], xr[4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) li[a] = colbuf[pb][ti + 16 * a];
+  for (int a = 0; a < 4; ++a) if (a >= SA) li[a] = colbuf[pb][ti + 16 * a];
 #pragma unroll
-  for (int b = 0; b < 4; ++b) { lj[b] = colbuf[pb][tj + 16 * b]; xr[b] = rowbuf[pb][tj + 16 * b]; }
+  for (int b = 0; b < 4; ++b) {
+    if (b >= SA) lj[b] = colbuf[pb][tj + 16 * b];
+    if (b <= SA) xr[b] = rowbuf[pb][tj + 16 * b];
+  }
   if (!(fabs(d) > 0.0)) bad = true;
   const double invd = pivot_rcp(d);
 #pragma unroll
-  for (int a = 0; a < 4; ++a) li[a] = (ti + 16 * a > s) ? li[a] * invd : 0.0;
+  for (int a = 0; a < 4; ++a) {
+    if (a == SA) li[a] = (ti + 16 * a > s) ? li[a] * invd : 0.0;      // the group that contains row s needs the mask
+    else if (a > SA) li[a] = li[a] * invd;
+  }
 #pragma unroll
-  for (int b = 0; b < 4; ++b) lj[b] = (tj + 16 * b > s) ? lj[b] : 0.0;
+  for (int b = 0; b < 4; ++b) if (b == SA) lj[b] = (tj + 16 * b > s) ? lj[b] : 0.0;
   if constexpr (SAN < 4) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a) T[a][SAN] -= li[a] * lj[SAN];
+    for (int a = 0; a < 4; ++a) if (a >= SA) T[a][SAN] -= li[a] * lj[SAN];
+    if constexpr (SAN >= SA) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) X[SAN][b] -= li[SAN] * xr[b];
-    if (tj == nsr) {
-#pragma unroll
-      for (int a = 0; a < 4; ++a) colbuf[pb ^ 1][ti + 16 * a] = T[a][SAN];
+      for (int b = 0; b < 4; ++b) if (b <= SA) X[SAN][b] -= li[SAN] * xr[b];
     }
-    if (ti == nsr) {
+    // branch-free publish: non-owners write to a scratch row behind the buffers (an exec-masked branch per
+    // publish costs a VALU -> SALU -> branch round trip on the critical path of every step)
+    {
+      double* cdst = (tj == nsr) ? &colbuf[pb ^ 1][ti] : &colbuf[2][ti];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) rowbuf[pb ^ 1][tj + 16 * b] = X[SAN][b];
+      for (int a = 0; a < 4; ++a) cdst[16 * a] = T[a][SAN];
+      double* rdst = (ti == nsr) ? &rowbuf[pb ^ 1][tj] : &rowbuf[2][tj];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) rdst[16 * b] = X[SAN][b];
     }
   }
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      if (b != SAN) T[a][b] -= li[a] * lj[b];               // l_i d l_j with lj holding d*l_j
-      if (a != SAN) X[a][b] -= li[a] * xr[b];
+      if (a >= SA && b >= SA && b != SAN) T[a][b] -= li[a] * lj[b];               // l_i d l_j with lj holding d*l_j
+      if (a >= SA && b <= SA && a != SAN) X[a][b] -= li[a] * xr[b];
     }
-  if (tj == sr) {                                           // store column s of L in place of T[:,s]
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-      if (ti + 16 * a > s) T[a][SA] = li[a];
-  }
+  for (int a = 0; a < 4; ++a)                               // store column s of L in place of T[:,s] (select, no branch)
+    if (a >= SA) T[a][SA] = (tj == sr && ti + 16 * a > s) ? li[a] : T[a][SA];
   __syncthreads();
 }
 
@@ -608,8 +619,8 @@ __device__ __forceinline__ void ldlt_diag_segment(double (&T)[4][4], double (&X)
 template <int NSTEPS = kInner>
 __global__ void __launch_bounds__(256) k_ldlt_diag(double* __restrict__ M, int ld, int j0, double* __restrict__ dvec,
                                                    double* __restrict__ invLt_all, int* __restrict__ status) {
-  __shared__ double colbuf[2][kInner];
-  __shared__ double rowbuf[2][kInner];
+  __shared__ double colbuf[3][kInner];   // [2] = scratch row for the branch-free publish
+  __shared__ double rowbuf[3][kInner];
   __builtin_amdgcn_s_setprio(3);   // latency-critical: runs underneath the bulk trailing-update GEMM
   const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
   double T[4][4], X[4][4];
