@@ -128,6 +128,8 @@ struct cba_problem {
   std::vector<int> pose_slot_host; int* pose_slot = nullptr;
   // straggler split of the Jacobian pass (see PassArgs)
   uint8_t* slow_skip = nullptr; int* slow_list = nullptr; int* slow_count = nullptr;
+  int64_t* img_start = nullptr;          // first observation of every imageset (+ end), for the strip accumulation
+  unsigned* band_mask = nullptr;         // per observation: column bands of B it touches
   // the side stream is the factorisation's far stream (idle during the Jacobian pass): the process must stay
   // within four HIP streams -- a fifth shares a hardware queue with another one and serialises the LDL^T streams
   hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr;
@@ -289,7 +291,10 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   const size_t bs = L.block_size, nb = L.n_blocks;
   CBA_HIP(hipMemsetAsync(p->Dblk, 0, sizeof(double) * nb * bs * bs, p->stream));
   CBA_HIP(hipMemsetAsync(p->bblk, 0, sizeof(double) * nb * bs, p->stream));
-  CBA_HIP(hipMemsetAsync(p->B, 0, sizeof(double) * (size_t)p->Kpad * p->n_pad, p->stream));
+  if (L.eliminate_points)
+    CBA_HIP(hipMemsetAsync(p->B, 0, sizeof(double) * (size_t)p->Kpad * p->n_pad, p->stream));
+  else if (p->Kpad > L.block_dof)     // padding rows of B (the strips below overwrite everything else, zeros included)
+    CBA_HIP(hipMemsetAsync(p->B + (size_t)L.block_dof * p->n_pad, 0, sizeof(double) * (size_t)(p->Kpad - L.block_dof) * p->n_pad, p->stream));
   CBA_HIP(hipMemsetAsync(p->Hdd, 0, sizeof(double) * (size_t)p->n_pad * p->n_pad, p->stream));
   CBA_HIP(hipMemsetAsync(p->bd, 0, sizeof(double) * (size_t)p->n_pad, p->stream));
   double t0 = now_s();
@@ -298,6 +303,8 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   // Hdd/B use the padded leading dimension
   Layout Lp = L;
   Lp.dense_dof = p->n_pad;  // row stride used by the kernel
+  if (!L.eliminate_points)   // B strips first (plain stores), the remaining terms are added on top atomically
+    CBA_TRY(launch_accumulate_strips(a, Lp, L.n_images, p->rec_doubles, p->flags, p->jrec, p->cells, p->band_mask, p->img_start, p->B, p->n_pad, p->stream));
   CBA_TRY(launch_accumulate(a, Lp, p->rec_doubles, p->flags, p->jrec, p->cells, p->pair_tables, p->pair_counts, T, p->stream));
   if (!L.localize_only)
     CBA_TRY(launch_accumulate_cells(a, p->cams, p->cell_base_host, p->rec_doubles, p->n_pad, p->flags, p->jrec, p->cells, p->cell_base,
@@ -436,7 +443,9 @@ int cba_create(const cba_config* config, cba_problem** out) {
         for (int k = i; k < K; ++k) {
           const bool hot = i >= h0 && i < h0 + nh && k >= h0 && k < h0 + nh;
           const bool grid_grid = i >= K - Kg && k >= K - Kg;   // summed per grid cell by k_accumulate_cells
-          if (!hot && !grid_grid) tab[slot * stride + e++] = ((uint32_t)i << 16) | (uint32_t)k;
+          // pose x (point | grid) goes through k_accumulate_strips when the poses are the Schur blocks
+          const bool strip = !L.eliminate_points && i < 6 && k >= nh;
+          if (!hot && !grid_grid && !strip) tab[slot * stride + e++] = ((uint32_t)i << 16) | (uint32_t)k;
         }
       counts[slot] = e;
     }
@@ -514,7 +523,7 @@ void cba_destroy(cba_problem* p) {
   F(p->x); F(p->scal); F(p->status); F(p->gemv_ws); F(p->kmask);
   ldlt_workspace_free(p->ldlt);
   for (auto& t : p->timers) { if (t.e0) hipEventDestroy(t.e0); if (t.e1) hipEventDestroy(t.e1); }
-  F(p->slow_skip); F(p->slow_list); F(p->slow_count);
+  F(p->slow_skip); F(p->slow_list); F(p->slow_count); F(p->img_start); F(p->band_mask);
   if (p->ev_aux0) hipEventDestroy(p->ev_aux0);
   if (p->ev_aux1) hipEventDestroy(p->ev_aux1);
   if (p->stream) hipStreamDestroy(p->stream);
@@ -546,6 +555,16 @@ int cba_set_observations(cba_problem* p, int64_t n, const float* xy, const int32
   CBA_TRY(dev_alloc(&p->fd_out, 2 * (size_t)n * p->tasks_per_obs)); CBA_TRY(dev_alloc(&p->fd_ok, (size_t)n * p->tasks_per_obs));
   CBA_TRY(dev_alloc(&p->jrec, (size_t)n * p->rec_doubles)); CBA_TRY(dev_alloc(&p->cells, 2 * (size_t)n));
   CBA_TRY(dev_alloc(&p->cell_order, (size_t)n));
+  F(p->img_start); p->img_start = nullptr;
+  F(p->band_mask); p->band_mask = nullptr;
+  CBA_TRY(dev_alloc(&p->band_mask, (size_t)(n > 0 ? n : 1)));
+  {
+    std::vector<int64_t> is((size_t)L.n_images + 1, 0);
+    for (int64_t i = 0; i < n; ++i) is[image_index[i] + 1] += 1;
+    for (int i = 0; i < L.n_images; ++i) is[i + 1] += is[i];
+    CBA_TRY(dev_alloc(&p->img_start, is.size()));
+    CBA_HIP(hipMemcpy(p->img_start, is.data(), sizeof(int64_t) * is.size(), hipMemcpyHostToDevice));
+  }
   F(p->slow_skip); p->slow_skip = nullptr;
   CBA_TRY(dev_alloc(&p->slow_skip, (size_t)(n > 0 ? n : 1)));
   CBA_HIP(hipMemset(p->slow_skip, 0, (size_t)(n > 0 ? n : 1)));

@@ -83,6 +83,8 @@ struct AccumTargets {
 int launch_accumulate(const PassArgs& a, const Layout& L, int rec_doubles, const uint8_t* flags, const double* jrec,
                       const int* cells, const uint32_t* pair_tables, const int* pair_counts, AccumTargets t,
                       hipStream_t s);
+int launch_accumulate_strips(const PassArgs& a, const Layout& L, int n_images, int rec_doubles, const uint8_t* flags, const double* jrec,
+                             const int* cells, unsigned* band_mask, const int64_t* img_start, double* B, int ld, hipStream_t s);
 int launch_accumulate_cells(const PassArgs& a, const std::vector<cba_camera>& cams, const std::vector<int>& cell_base_host,
                             int rec_doubles, int ld, const uint8_t* flags, const double* jrec, const int* cells,
                             const int* cell_base, int* count, int* start, int* fill, int* order, double* Hdd, hipStream_t s);

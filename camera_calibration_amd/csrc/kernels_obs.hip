@@ -678,6 +678,119 @@ int launch_accumulate_cells(const PassArgs& a, const std::vector<cba_camera>& ca
   return CBA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Off-diagonal strips B_i (pose block i x dense columns), eliminate_points = 0.  Every entry of B_i gets
+// ~8 contributions from different observations of imageset i (neighbouring pattern points share grid
+// cells), far apart in the observation order, so per-observation atomics cannot merge them.  Here one
+// workgroup owns (imageset, band of kStripBand dense columns): it scans the imageset's observations,
+// sums the 6 x (3 + K_cell) products that fall into its band in LDS (ds_add_f64) and writes the band of
+// the six rows with plain coalesced stores -- zeros included, so B needs no memset and receives no
+// global atomics from these terms (210 of the ~350 per observation).
+// ------------------------------------------------------------------------------------------------
+constexpr int kStripBand = 1024;
+// bit t of band_mask[o]: observation o couples its pose to a dense column of band t (<= 32 bands = 65 536 columns;
+// wider systems fall back to "all bands")
+__global__ void __launch_bounds__(256) k_strip_band_mask(PassArgs a, AccumLayout L, const uint8_t* __restrict__ flags,
+                                                         const int* __restrict__ cells, unsigned* __restrict__ band_mask, int n_bands) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= a.n_obs) return;
+  if (flags[o] != 3) { band_mask[o] = 0u; return; }
+  if (n_bands > 32) { band_mask[o] = 0xffffffffu; return; }
+  const CamDev cd = a.cams[a.obs_camera[o]];
+  unsigned m = 0u;
+  const int pc = L.first_points - L.block_dof + 3 * a.obs_point[o];
+  m |= 1u << (pc / kStripBand); m |= 1u << ((pc + 2) / kStripBand);
+  if (!L.localize_only) {
+    const int cx0 = cells[2 * o], cy0 = cells[2 * o + 1];
+    for (int c = 0; c < 16; ++c) {
+      const int col = grid_column(cd, (cx0 + (c & 3)) + (cy0 + (c >> 2)) * cd.gw, 0);
+      m |= 1u << (col / kStripBand); m |= 1u << ((col + cd.params_per_point - 1) / kStripBand);
+    }
+  }
+  band_mask[o] = m;
+}
+constexpr int kStripWaves = 8;
+__global__ void __launch_bounds__(64 * kStripWaves) k_accumulate_strips(PassArgs a, AccumLayout L, int rec_doubles, const uint8_t* __restrict__ flags,
+                                                            const double* __restrict__ jrec, const int* __restrict__ cells,
+                                                            const unsigned* __restrict__ band_mask,
+                                                            const int64_t* __restrict__ img_start, double* __restrict__ B, int ld) {
+  __shared__ double acc[6][kStripBand];
+  const int img = blockIdx.x, band = blockIdx.y;
+  const int col_lo = band * kStripBand;
+  const int col_hi = min(col_lo + kStripBand, ld);
+  for (int i = threadIdx.x; i < 6 * kStripBand; i += 64 * kStripWaves) (&acc[0][0])[i] = 0.0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const unsigned bit = 1u << (band & 31);
+  const int64_t o_begin = img_start[img], o_end = img_start[img + 1];
+  // kStripWaves wavefronts.  Pass = 64 * kStripWaves consecutive observations: every wavefront loads the band masks of one group of 64
+  // (one coalesced load instead of a chain of dependent L2 round trips) and publishes its ballot; then the matching
+  // observations of the whole pass are dealt round-robin to the wavefronts (the matches of one band are neighbours
+  // in the observation order, so whole groups would leave most wavefronts idle), all 64 lanes on an observation's
+  // columns.
+  __shared__ unsigned long long gmask[kStripWaves];
+  for (int64_t p0 = o_begin; p0 < o_end; p0 += 64 * kStripWaves) {
+    const int64_t mine = p0 + 64 * wv + lane;
+    const bool hit = mine < o_end && (band_mask[mine] & bit);
+    const unsigned long long bal = __ballot(hit);
+    if (lane == 0) gmask[wv] = bal;
+    __syncthreads();
+    int seen = 0;
+    for (int gidx = 0; gidx < kStripWaves; ++gidx) {
+      unsigned long long todo = gmask[gidx];
+      while (todo) {
+        const int idx = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        if (((seen++) % kStripWaves) != wv) continue;
+        const int64_t o = p0 + 64 * gidx + idx;
+        const CamDev cd = a.cams[a.obs_camera[o]];
+        const int per = cd.params_per_point;
+        const int Kg = L.localize_only ? 0 : per * 16;
+        const int nc = 3 + Kg;                              // dense columns of this observation coupled to the pose
+        const double* rec = jrec + (size_t)o * rec_doubles;
+        const int cx0 = cells[2 * o], cy0 = cells[2 * o + 1];
+        const int point_col = L.first_points - L.block_dof + 3 * a.obs_point[o];
+        const double w = rec[2];
+        for (int c = lane; c < nc; c += 64) {
+          int col; double j0, j1;
+          if (c < 3) { col = point_col + c; j0 = rec[27 + c]; j1 = rec[30 + c]; }
+          else {
+            const int g = c - 3, cell = g / per, d = g - cell * per;
+            col = grid_column(cd, (cx0 + (cell & 3)) + (cy0 + (cell >> 2)) * cd.gw, d);
+            j0 = rec[kRecHeader + g]; j1 = rec[kRecHeader + Kg + g];
+          }
+          if (col < col_lo || col >= col_hi) continue;
+          const double w0 = w * j0, w1 = w * j1;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) unsafeAtomicAdd(&acc[k][col - col_lo], rec[3 + k] * w0 + rec[9 + k] * w1);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  const int slot = a.pose_slot ? a.pose_slot[img] : img;
+  for (int k = 0; k < 6; ++k) {
+    double* row = B + (size_t)(6 * slot + k) * ld + col_lo;
+    for (int c = threadIdx.x; c < col_hi - col_lo; c += 64 * kStripWaves) row[c] = acc[k][c];
+  }
+}
+int launch_accumulate_strips(const PassArgs& a, const Layout& L, int n_images, int rec_doubles, const uint8_t* flags, const double* jrec,
+                             const int* cells, unsigned* band_mask, const int64_t* img_start, double* B, int ld, hipStream_t s) {
+  if (n_images == 0) return CBA_OK;
+  AccumLayout al;
+  al.rig_in_state = L.rig_in_state; al.eliminate_points = L.eliminate_points; al.localize_only = L.localize_only;
+  al.first_rig_tr_global = L.first_rig_tr_global; al.first_camera_tr_rig = L.first_camera_tr_rig;
+  al.first_points = L.first_points; al.block_dof = L.block_dof; al.block_size = L.block_size; al.dense_dof = L.dense_dof;
+  const int bands = (ld + kStripBand - 1) / kStripBand;
+  if (a.n_obs > 0)
+    hipLaunchKernelGGL(k_strip_band_mask, dim3((unsigned)((a.n_obs + 255) / 256)), dim3(256), 0, s, a, al, flags, cells, band_mask, bands);
+  hipLaunchKernelGGL(k_accumulate_strips, dim3((unsigned)n_images, (unsigned)bands), dim3(64 * kStripWaves), 0, s, a, al, rec_doubles, flags, jrec, cells,
+                     band_mask, img_start, B, ld);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
 int launch_accumulate(const PassArgs& a, const Layout& L, int rec_doubles, const uint8_t* flags, const double* jrec,
                       const int* cells, const uint32_t* pair_tables, const int* pair_counts, AccumTargets t,
                       hipStream_t s) {
