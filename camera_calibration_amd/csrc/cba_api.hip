@@ -308,7 +308,8 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   CBA_TRY(launch_accumulate(a, Lp, p->rec_doubles, p->flags, p->jrec, p->cells, p->pair_tables, p->pair_counts, T, p->stream));
   if (!L.localize_only)
     CBA_TRY(launch_accumulate_cells(a, p->cams, p->cell_base_host, p->rec_doubles, p->n_pad, p->flags, p->jrec, p->cells, p->cell_base,
-                                    p->cell_count, p->cell_start, p->cell_fill, p->cell_order, p->Hdd, p->stream));
+                                    p->cell_count, p->cell_start, p->cell_fill, p->cell_order, p->Hdd,
+                                    (!L.eliminate_points && L.rig_in_state) ? L.first_camera_tr_rig - L.block_dof : -1, p->stream));
   CBA_TRY(timer_end(p, 2, 0, 0, 1));
   if (t_acc) *t_acc += now_s() - t0;
   CBA_TRY(launch_touch_mask(p->B, p->Kpad, p->n_pad, p->n_pad, p->kmask, p->stream));
@@ -445,7 +446,9 @@ int cba_create(const cba_config* config, cba_problem** out) {
           const bool grid_grid = i >= K - Kg && k >= K - Kg;   // summed per grid cell by k_accumulate_cells
           // pose x (point | grid) goes through k_accumulate_strips when the poses are the Schur blocks
           const bool strip = !L.eliminate_points && i < 6 && k >= nh;
-          if (!hot && !grid_grid && !strip) tab[slot * stride + e++] = ((uint32_t)i << 16) | (uint32_t)k;
+          // rig pose x grid is summed per grid cell by k_accumulate_cells as well (several cameras, poses eliminated)
+          const bool rig_grid = !L.eliminate_points && L.rig_in_state && i >= 6 && i < 12 && k >= K - Kg;
+          if (!hot && !grid_grid && !strip && !rig_grid) tab[slot * stride + e++] = ((uint32_t)i << 16) | (uint32_t)k;
         }
       counts[slot] = e;
     }

@@ -602,15 +602,19 @@ __global__ void __launch_bounds__(256) k_cell_fill(PassArgs a, const uint8_t* __
   const int key = cell_base[cam] + cells[2 * o + 1] * a.cams[cam].gw + cells[2 * o];
   order[start[key] + atomicAdd(fill + key, 1)] = (int)o;
 }
+// rig_row0 >= 0 (several cameras, poses eliminated): the bucket also sums the camera's rig-pose x grid block
+// (6 x K_g entries of H_dd that EVERY observation of the camera would otherwise hit with atomics).
 template <int PER>
 __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, int key0, int n_cells, int rec_doubles, int ld,
                                                           const double* __restrict__ jrec, const int* __restrict__ start,
-                                                          const int* __restrict__ order, double* __restrict__ Hdd) {
+                                                          const int* __restrict__ order, double* __restrict__ Hdd, int rig_row0) {
   constexpr int KG = PER * 16;
   constexpr int NPAIR = KG * (KG + 1) / 2;
   constexpr int NE = (NPAIR + 63) / 64;
+  constexpr int NR = (6 * KG + 63) / 64;
   __shared__ double sJ0[4][KG];
   __shared__ double sJ1[4][KG];
+  __shared__ double sRig[4][12];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int cell = blockIdx.x * 4 + wv;
   if (cell >= n_cells) return;
@@ -628,18 +632,29 @@ __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, i
   double acc[NE];
 #pragma unroll
   for (int t = 0; t < NE; ++t) acc[t] = 0.0;
+  double racc[NR];
+#pragma unroll
+  for (int t = 0; t < NR; ++t) racc[t] = 0.0;
   for (int idx = o_begin; idx < o_end; ++idx) {
     const int o = order[idx];
     const double* rec = jrec + (size_t)o * rec_doubles;
     const double w = rec[2];
     __builtin_amdgcn_wave_barrier();
     for (int k = lane; k < KG; k += 64) { sJ0[wv][k] = rec[kRecHeader + k]; sJ1[wv][k] = rec[kRecHeader + KG + k]; }
+    if (rig_row0 >= 0 && lane < 12) sRig[wv][lane] = rec[15 + lane];
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
     for (int t = 0; t < NE; ++t) {
       const int i = pi[t], k = pk[t];
       acc[t] += w * (sJ0[wv][i] * sJ0[wv][k] + sJ1[wv][i] * sJ1[wv][k]);
+    }
+    if (rig_row0 >= 0) {
+#pragma unroll
+      for (int t = 0; t < NR; ++t) {
+        const int e = lane + 64 * t;
+        if (e < 6 * KG) { const int r = e / KG, k = e - r * KG; racc[t] += w * (sRig[wv][r] * sJ0[wv][k] + sRig[wv][6 + r] * sJ1[wv][k]); }
+      }
     }
   }
   const CamDev cd = a.cams[cam];
@@ -654,10 +669,21 @@ __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, i
     if (row > col) { const int t2 = row; row = col; col = t2; }   // tiled order is not monotone in the patch order
     unsafeAtomicAdd(Hdd + (size_t)row * ld + col, acc[t]);
   }
+  if (rig_row0 >= 0) {
+#pragma unroll
+    for (int t = 0; t < NR; ++t) {
+      const int e = lane + 64 * t;
+      if (e >= 6 * KG) continue;
+      const int r = e / KG, k = e - r * KG, ck = k / PER, dk = k - ck * PER;
+      const int col = grid_column(cd, (cx0 + (ck & 3)) + (cy0 + (ck >> 2)) * cd.gw, dk);
+      unsafeAtomicAdd(Hdd + (size_t)(rig_row0 + r) * ld + col, racc[t]);      // rig rows precede the grid columns
+    }
+  }
 }
 int launch_accumulate_cells(const PassArgs& a, const std::vector<cba_camera>& cams, const std::vector<int>& cell_base_host,
                             int rec_doubles, int ld, const uint8_t* flags, const double* jrec, const int* cells,
-                            const int* cell_base, int* count, int* start, int* fill, int* order, double* Hdd, hipStream_t s) {
+                            const int* cell_base, int* count, int* start, int* fill, int* order, double* Hdd,
+                            int rig_row_first /* dense row of camera 0's rig block, or -1 */, hipStream_t s) {
   if (a.n_obs == 0) return CBA_OK;
   const int n_keys = cell_base_host.back();
   CBA_HIP(hipMemsetAsync(count, 0, sizeof(int) * (size_t)n_keys, s));
@@ -670,9 +696,11 @@ int launch_accumulate_cells(const PassArgs& a, const std::vector<cba_camera>& ca
     const int n_cells = cams[c].grid_w * cams[c].grid_h;
     dim3 g2((unsigned)((n_cells + 3) / 4));
     if (cams[c].model_type == CBA_CENTRAL_GENERIC)
-      hipLaunchKernelGGL(k_accumulate_cells<2>, g2, block, 0, s, a, (int)c, cell_base_host[c], n_cells, rec_doubles, ld, jrec, start, order, Hdd);
+      hipLaunchKernelGGL(k_accumulate_cells<2>, g2, block, 0, s, a, (int)c, cell_base_host[c], n_cells, rec_doubles, ld, jrec, start, order, Hdd,
+                         rig_row_first >= 0 ? rig_row_first + 6 * (int)c : -1);
     else
-      hipLaunchKernelGGL(k_accumulate_cells<5>, g2, block, 0, s, a, (int)c, cell_base_host[c], n_cells, rec_doubles, ld, jrec, start, order, Hdd);
+      hipLaunchKernelGGL(k_accumulate_cells<5>, g2, block, 0, s, a, (int)c, cell_base_host[c], n_cells, rec_doubles, ld, jrec, start, order, Hdd,
+                         rig_row_first >= 0 ? rig_row_first + 6 * (int)c : -1);
   }
   CBA_HIP(hipGetLastError());
   return CBA_OK;
