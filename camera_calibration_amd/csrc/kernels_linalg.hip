@@ -150,7 +150,26 @@ struct GemmArgs {
   int kmask_words;
   int epi_mode;                 // developer switch (bench harness): 0 normal, 1 no Cin read, 2 no store
   int strips;                   // set by launch_gemm: strip-blocked tile order (square upper dense launches)
+  int tlog_tag;                 // developer timeline (tools/bench_linalg.hip, -DCBA_TLOG): tag + 1, 0 = none
 };
+
+// Developer timeline of the factorisation schedule: with -DCBA_TLOG (tools/bench_linalg.hip only) every kernel of
+// ldlt_factor stamps the 100 MHz wall clock at its first workgroup's start and its last workgroup's end into
+// g_tlog[tag], without a profiler attached (rocprofv3's queue interception stretches the cross-stream hops).
+#ifdef CBA_TLOG
+__device__ unsigned long long* g_tlog = nullptr;
+__device__ __forceinline__ void tlog_begin(int tag) {
+  if (g_tlog && tag >= 0 && threadIdx.x == 0) atomicMin(&g_tlog[2 * tag], (unsigned long long)wall_clock64());
+}
+__device__ __forceinline__ void tlog_end(int tag) {
+  if (g_tlog && tag >= 0 && threadIdx.x == 0) atomicMax(&g_tlog[2 * tag + 1], (unsigned long long)wall_clock64());
+}
+#else
+__device__ __forceinline__ void tlog_begin(int) {}
+__device__ __forceinline__ void tlog_end(int) {}
+#endif
+enum { kTlDiag = 0, kTlNear, kTlScale, kTlMidTrsm, kTlMidUpd, kTlChainTrsm, kTlChainUpd, kTlAPrime, kTlPanelSolve,
+       kTlAA_n, kTlAA_rest, kTlBulk, kTlXn, kTlKinds = 16 };
 
 template <int TM, int TN, int WM, int WN, bool SUB>
 __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
@@ -171,6 +190,7 @@ __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
   const long long cq = q / g.chunk;
   long long t = (cq * 8 + (b & 7)) * g.chunk + (q - cq * g.chunk);
   if (t >= g.total_tiles) return;
+  tlog_begin(g.tlog_tag - 1);
   int tm, tn;
   if (g.strips) {
     // Square upper-triangular launch, dense: tiles are enumerated strip by strip (kStripW tile columns), row by
@@ -246,7 +266,16 @@ __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
         for (int j = 0; j < NJ; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
     }
   };
-  if constexpr (!(TM == 128 && TN == 128)) preload_c();
+  // The panel-sized variants keep the C tile in its own registers instead (loaded behind the first operand slabs, never
+  // waited for before the epilogue): C = Cin - sum.
+  constexpr bool kSmall = !(TM == 128 && TN == 128);
+  v4f64 cin[MI][NJ];
+  if constexpr (kSmall) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) { acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0}; cin[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0}; }
+  }
 
 
   const double* Ag = g.A + m0;
@@ -319,53 +348,85 @@ __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
     }
 #undef CBA_DMA_STAGE
   } else {
-    // small-tile variant (panel operations): register-staged double buffering
+    // small-tile variant (panel operations): register-staged, with kDepth slabs in flight.  These launches are a
+    // handful of workgroups on the critical path of the factorisation; with one slab in flight every K step paid a
+    // full L2 / HBM round trip (~1.5 us per 16-row slab against 0.4 us of MFMA work).
+    constexpr int kDepth = 3;
     constexpr int A_PER = KT * TM / 2 / 256, B_PER = KT * TN / 2 / 256;
     constexpr int A_ROWSTEP = 256 / (TM / 2), B_ROWSTEP = 256 / (TN / 2);
     const int a_row = tid / (TM / 2), a_c2 = tid % (TM / 2);
     const int b_row = tid / (TN / 2), b_c2 = tid % (TN / 2);
-    double2 ra[A_PER], rb[B_PER];
-#define CBA_GLOAD(k0_)                                                                                          \
+    static_assert(A_PER == 2 && (B_PER == 2 || B_PER == 4), "staging registers below are written out for these shapes");
+    // staging registers, written out as scalars: one set per slot (arrays here end up in scratch memory)
+    double2 ra0_0, ra0_1, ra1_0, ra1_1, ra2_0, ra2_1;
+    double2 rb0_0, rb0_1, rb0_2, rb0_3, rb1_0, rb1_1, rb1_2, rb1_3, rb2_0, rb2_1, rb2_2, rb2_3;
+#define CBA_LDA(j_, k0_) (*reinterpret_cast<const double2*>(Ag + (size_t)((k0_) + a_row + (j_) * A_ROWSTEP) * g.lda + 2 * a_c2))
+#define CBA_LDB(j_, k0_) (*reinterpret_cast<const double2*>(Bg + (size_t)((k0_) + b_row + (j_) * B_ROWSTEP) * g.ldb + 2 * b_c2))
+#define CBA_STA(buf_, j_) (*reinterpret_cast<double2*>(&sA[(buf_)][(a_row + (j_) * A_ROWSTEP) * LDA_S + 2 * a_c2]))
+#define CBA_STB(buf_, j_) (*reinterpret_cast<double2*>(&sB[(buf_)][(b_row + (j_) * B_ROWSTEP) * LDB_S + 2 * b_c2]))
+#define CBA_GLOAD(slot_, k0_)                                                                                   \
   {                                                                                                             \
-    _Pragma("unroll") for (int j = 0; j < A_PER; ++j)                                                           \
-        ra[j] = *reinterpret_cast<const double2*>(Ag + (size_t)((k0_) + a_row + j * A_ROWSTEP) * g.lda + 2 * a_c2); \
-    _Pragma("unroll") for (int j = 0; j < B_PER; ++j)                                                           \
-        rb[j] = *reinterpret_cast<const double2*>(Bg + (size_t)((k0_) + b_row + j * B_ROWSTEP) * g.ldb + 2 * b_c2); \
+    const int kq = (k0_);                                                                                       \
+    ra##slot_##_0 = CBA_LDA(0, kq); ra##slot_##_1 = CBA_LDA(1, kq);                                             \
+    rb##slot_##_0 = CBA_LDB(0, kq); rb##slot_##_1 = CBA_LDB(1, kq);                                             \
+    if constexpr (B_PER == 4) { rb##slot_##_2 = CBA_LDB(2, kq); rb##slot_##_3 = CBA_LDB(3, kq); }               \
   }
-#define CBA_SSTORE(buf_)                                                                                        \
+#define CBA_SSTORE(buf_, slot_)                                                                                 \
   {                                                                                                             \
-    _Pragma("unroll") for (int j = 0; j < A_PER; ++j)                                                           \
-        *reinterpret_cast<double2*>(&sA[(buf_)][(a_row + j * A_ROWSTEP) * LDA_S + 2 * a_c2]) = ra[j];           \
-    _Pragma("unroll") for (int j = 0; j < B_PER; ++j)                                                           \
-        *reinterpret_cast<double2*>(&sB[(buf_)][(b_row + j * B_ROWSTEP) * LDB_S + 2 * b_c2]) = rb[j];           \
+    const int bq = (buf_);                                                                                      \
+    CBA_STA(bq, 0) = ra##slot_##_0; CBA_STA(bq, 1) = ra##slot_##_1;                                             \
+    CBA_STB(bq, 0) = rb##slot_##_0; CBA_STB(bq, 1) = rb##slot_##_1;                                             \
+    if constexpr (B_PER == 4) { CBA_STB(bq, 2) = rb##slot_##_2; CBA_STB(bq, 3) = rb##slot_##_3; }               \
   }
-    CBA_GLOAD(0);
-    CBA_SSTORE(0);
-    __syncthreads();
-    for (int kb = 0; kb < nk; ++kb) {
-      const int buf = kb & 1;
-      // the slab after the last one is a re-read of the last slab (stays in bounds, result unused)
-      const int knext = (kb + 1 < nk) ? (kb + 1) * KT : kb * KT;
-      CBA_GLOAD(knext);
-      const double* a_s = &sA[buf][0];
-      const double* b_s = &sB[buf][0];
+    // slabs past the last one are re-reads of the last slab (in bounds, never stored to LDS)
+    CBA_GLOAD(0, 0);
+    CBA_GLOAD(1, (1 < nk ? 1 : nk - 1) * KT);
+    CBA_GLOAD(2, (2 < nk ? 2 : nk - 1) * KT);
+    if (SUB && g.epi_mode != 1) {       // raw tile only: touching the values here would wait for the loads
 #pragma unroll
-      for (int kk = 0; kk < KT; kk += 4) {
-        double af[MI], bf[NJ];
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int i = 0; i < MI; ++i) af[i] = a_s[(kk + lk) * LDA_S + wm0 + i * 16 + li];
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) bf[j] = b_s[(kk + lk) * LDB_S + wn0 + j * 16 + li];
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
-      }
-      CBA_SSTORE(buf ^ 1);
-      __syncthreads();
+          for (int r = 0; r < 4; ++r)
+            cin[i][j][r] = g.Cin[(size_t)(m0 + wm0 + i * 16 + lk + 4 * r) * g.ldcin + n0 + wn0 + j * 16 + li];
     }
+    CBA_SSTORE(0, 0);
+    __syncthreads();
+    // one K slab: the register slot that held slab kb (in LDS by now) is refilled with slab kb + kDepth.  The slot
+    // numbers are literals (a run-time slot index would put the staging registers into scratch memory).
+#define CBA_KSTEP(slot_, next_slot_)                                                                            \
+  if (kb0 + (slot_) < nk) {                                                                                     \
+    const int kb = kb0 + (slot_);                                                                               \
+    const int buf = kb & 1;                                                                                     \
+    CBA_GLOAD(slot_, (kb + kDepth < nk ? kb + kDepth : nk - 1) * KT);                                           \
+    const double* a_s = &sA[buf][0];                                                                            \
+    const double* b_s = &sB[buf][0];                                                                            \
+    _Pragma("unroll") for (int kk = 0; kk < KT; kk += 4) {                                                      \
+      double af[MI], bf[NJ];                                                                                    \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i) af[i] = a_s[(kk + lk) * LDA_S + wm0 + i * 16 + li];        \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j) bf[j] = b_s[(kk + lk) * LDB_S + wn0 + j * 16 + li];        \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                            \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                          \
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);                   \
+    }                                                                                                           \
+    CBA_SSTORE(buf ^ 1, next_slot_);                                                                            \
+    __syncthreads();                                                                                            \
+  }
+    static_assert(kDepth == 3, "CBA_KSTEP sequence below is written for three slots");
+#pragma nounroll
+    for (int kb0 = 0; kb0 < nk; kb0 += kDepth) {
+      CBA_KSTEP(0, 1)
+      CBA_KSTEP(1, 2)
+      CBA_KSTEP(2, 0)
+    }
+#undef CBA_KSTEP
 #undef CBA_GLOAD
 #undef CBA_SSTORE
+#undef CBA_LDA
+#undef CBA_LDB
+#undef CBA_STA
+#undef CBA_STB
   }
 
   // ---- epilogue ----
@@ -379,10 +440,18 @@ __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
         const int n = n0 + wn0 + j * 16 + li;
         double v = acc[i][j][r];
         if (g.epi_mode == 2) { if (v == 1.2345e300) g.C[(size_t)m * g.ldc + n] = v; continue; }
-        if (SUB) v = -v;
+        if constexpr (kSmall) {
+          if (SUB) {
+            double c = cin[i][j][r];
+            if (g.diag && m == n && g.epi_mode != 1) c += (m < g.n_real) ? (g.diag_add_ptr ? *g.diag_add_ptr : g.diag_add) : 1.0;
+            v = c - v;
+          }
+        }
+        else if (SUB) v = -v;
         g.C[(size_t)m * g.ldc + n] = v;
         if (g.C2) g.C2[(size_t)m * g.ldc2 + n] = v / g.rowscale_inv[m];
       }
+  tlog_end(g.tlog_tag - 1);
 }
 
 static long long count_upper_tiles(int m_off, int n_off, int m_tiles, int n_tiles, int TM, int TN) {
@@ -622,6 +691,7 @@ __global__ void __launch_bounds__(256) k_ldlt_diag(double* __restrict__ M, int l
   __shared__ double colbuf[3][kInner];   // [2] = scratch row for the branch-free publish
   __shared__ double rowbuf[3][kInner];
   __builtin_amdgcn_s_setprio(3);   // latency-critical: runs underneath the bulk trailing-update GEMM
+  tlog_begin((j0 / kInner) * kTlKinds + kTlDiag);
   const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
   double T[4][4], X[4][4];
 #pragma unroll
@@ -659,6 +729,7 @@ __global__ void __launch_bounds__(256) k_ldlt_diag(double* __restrict__ M, int l
       invLt[j * kInner + i] = (i >= j) ? X[a][b] : 0.0;     // invLt[q][p] = invL(p,q)
       if (i == j) dvec[j0 + i] = T[a][b];
     }
+  tlog_end((j0 / kInner) * kTlKinds + kTlDiag);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -679,7 +750,7 @@ __device__ __forceinline__ double ldg(const double* p) {
 }
 
 // acc (64x64 tile, 4 waves x 32x32) += sum_{k<K} A[k][m] B[k][n];  A, B K-major in global memory, or B
-// already in LDS as Bl[k][TS].  K multiple of 16.  Register-staged double buffering; ends with a barrier.
+// already in LDS as Bl[k][TS].  K multiple of 16.  Register-staged, three slabs in flight; ends with a barrier.
 template <bool COH_A, bool COH_B, bool B_LDS>
 __device__ __forceinline__ void tile_mma(v4f64 (&acc)[2][2], const double* __restrict__ A, int lda,
                                          const double* __restrict__ B, int ldb, int K, double* sA, double* sB,
@@ -688,52 +759,61 @@ __device__ __forceinline__ void tile_mma(v4f64 (&acc)[2][2], const double* __res
   const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
   const int r = tid >> 5, c2 = 2 * (tid & 31);
   const int nk = K / KT;
-  double ra[2][2], rb[2][2];
-#define CBA_TLOAD(k0_)                                                                           \
+  constexpr int kDepth = 3;     // K slabs in flight (see the small-tile variant of k_gemm_atb)
+  // staging registers written out as scalars, one set per slot (arrays here end up in scratch memory)
+  double ra0_00, ra0_01, ra0_10, ra0_11, ra1_00, ra1_01, ra1_10, ra1_11, ra2_00, ra2_01, ra2_10, ra2_11;
+  double rb0_00, rb0_01, rb0_10, rb0_11, rb1_00, rb1_01, rb1_10, rb1_11, rb2_00, rb2_01, rb2_10, rb2_11;
+#define CBA_TLOAD(slot_, k0_)                                                                    \
   {                                                                                              \
-    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                              \
-      const double* pa = A + (size_t)((k0_) + r + 8 * h) * lda + c2;                             \
-      ra[h][0] = ldg<COH_A>(pa); ra[h][1] = ldg<COH_A>(pa + 1);                                  \
-      if constexpr (!B_LDS) {                                                                    \
-        const double* pb = B + (size_t)((k0_) + r + 8 * h) * ldb + c2;                           \
-        rb[h][0] = ldg<COH_B>(pb); rb[h][1] = ldg<COH_B>(pb + 1);                                \
-      }                                                                                          \
+    const double* pa = A + (size_t)((k0_) + r) * lda + c2;                                       \
+    ra##slot_##_00 = ldg<COH_A>(pa); ra##slot_##_01 = ldg<COH_A>(pa + 1);                        \
+    ra##slot_##_10 = ldg<COH_A>(pa + (size_t)8 * lda); ra##slot_##_11 = ldg<COH_A>(pa + (size_t)8 * lda + 1); \
+    if constexpr (!B_LDS) {                                                                      \
+      const double* pb = B + (size_t)((k0_) + r) * ldb + c2;                                     \
+      rb##slot_##_00 = ldg<COH_B>(pb); rb##slot_##_01 = ldg<COH_B>(pb + 1);                      \
+      rb##slot_##_10 = ldg<COH_B>(pb + (size_t)8 * ldb); rb##slot_##_11 = ldg<COH_B>(pb + (size_t)8 * ldb + 1); \
     }                                                                                            \
   }
-#define CBA_TSTORE(buf_)                                                                         \
+#define CBA_TSTORE(buf_, slot_)                                                                  \
   {                                                                                              \
-    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                              \
-      double* qa = sA + (buf_) * KT * TS + (r + 8 * h) * TS + c2;                                \
-      qa[0] = ra[h][0]; qa[1] = ra[h][1];                                                        \
-      if constexpr (!B_LDS) {                                                                    \
-        double* qb = sB + (buf_) * KT * TS + (r + 8 * h) * TS + c2;                              \
-        qb[0] = rb[h][0]; qb[1] = rb[h][1];                                                      \
-      }                                                                                          \
+    double* qa = sA + (buf_) * KT * TS + r * TS + c2;                                            \
+    qa[0] = ra##slot_##_00; qa[1] = ra##slot_##_01; qa[8 * TS] = ra##slot_##_10; qa[8 * TS + 1] = ra##slot_##_11; \
+    if constexpr (!B_LDS) {                                                                      \
+      double* qb = sB + (buf_) * KT * TS + r * TS + c2;                                          \
+      qb[0] = rb##slot_##_00; qb[1] = rb##slot_##_01; qb[8 * TS] = rb##slot_##_10; qb[8 * TS + 1] = rb##slot_##_11; \
     }                                                                                            \
   }
-  CBA_TLOAD(0);
-  CBA_TSTORE(0);
+  CBA_TLOAD(0, 0);
+  CBA_TLOAD(1, (1 < nk ? 1 : nk - 1) * KT);
+  CBA_TLOAD(2, (2 < nk ? 2 : nk - 1) * KT);
+  CBA_TSTORE(0, 0);
   __syncthreads();
-  for (int kb = 0; kb < nk; ++kb) {
-    const int buf = kb & 1;
-    if (kb + 1 < nk) CBA_TLOAD((kb + 1) * KT);
-    const double* a_s = sA + buf * KT * TS;
-    const double* b_s = B_LDS ? Bl + kb * KT * TS : sB + buf * KT * TS;
-#pragma unroll
-    for (int kk = 0; kk < KT; kk += 4) {
-      double af[2], bf[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = a_s[(kk + lk) * TS + wm0 + i * 16 + li];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) bf[j] = b_s[(kk + lk) * TS + wn0 + j * 16 + li];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
-    if (kb + 1 < nk) CBA_TSTORE(buf ^ 1);
-    __syncthreads();
+#define CBA_TSTEP(slot_, next_slot_)                                                                       \
+  if (kb0 + (slot_) < nk) {                                                                                  \
+    const int kb = kb0 + (slot_);                                                                            \
+    const int buf = kb & 1;                                                                                  \
+    CBA_TLOAD(slot_, (kb + kDepth < nk ? kb + kDepth : nk - 1) * KT);                                        \
+    const double* a_s = sA + buf * KT * TS;                                                                  \
+    const double* b_s = B_LDS ? Bl + kb * KT * TS : sB + buf * KT * TS;                                      \
+    _Pragma("unroll") for (int kk = 0; kk < KT; kk += 4) {                                                   \
+      double af[2], bf[2];                                                                                   \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) af[i] = a_s[(kk + lk) * TS + wm0 + i * 16 + li];         \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) bf[j] = b_s[(kk + lk) * TS + wn0 + j * 16 + li];         \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);                \
+    }                                                                                                        \
+    CBA_TSTORE(buf ^ 1, next_slot_);                                                                         \
+    __syncthreads();                                                                                         \
   }
+  static_assert(kDepth == 3, "CBA_TSTEP sequence below is written for three slots");
+#pragma nounroll
+  for (int kb0 = 0; kb0 < nk; kb0 += kDepth) {
+    CBA_TSTEP(0, 1)
+    CBA_TSTEP(1, 2)
+    CBA_TSTEP(2, 0)
+  }
+#undef CBA_TSTEP
 #undef CBA_TLOAD
 #undef CBA_TSTORE
 }
@@ -745,6 +825,7 @@ __global__ void __launch_bounds__(256) k_panel_solve(double* __restrict__ S, int
   __shared__ double sB[2 * KT * TS];
   __shared__ double sV[kInner * TS];
   __builtin_amdgcn_s_setprio(2);
+  tlog_begin((k0 / kInner) * kTlKinds + kTlPanelSolve);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
   const int n0 = col0 + kInner * (int)blockIdx.x;
@@ -792,6 +873,7 @@ __global__ void __launch_bounds__(256) k_panel_solve(double* __restrict__ S, int
       }
     __syncthreads();   // the stores are acknowledged by L2 (vmcnt) before any lane re-reads X with agent-scope loads
   }
+  tlog_end((k0 / kInner) * kTlKinds + kTlPanelSolve);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -828,6 +910,7 @@ __global__ void __launch_bounds__(256) k_near_fused(double* __restrict__ S, int 
   __shared__ double sV[kInner * TS];    // X_c           [p][n]
   __shared__ double sL[kInner * TS];    // X_r / d = L^T [p][m]
   __builtin_amdgcn_s_setprio(3);
+  tlog_begin((j0 / kInner) * kTlKinds + kTlNear);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
   const int c0 = j0 + kInner, nblk = (e0 - c0) / kInner;
@@ -886,15 +969,18 @@ __global__ void __launch_bounds__(256) k_near_fused(double* __restrict__ S, int 
         const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
         T[(size_t)m * ld + n] -= acc[i][jj][r4];
       }
+  tlog_end((j0 / kInner) * kTlKinds + kTlNear);
 }
 
 // L = X / d in place for the panel-internal columns [c0, e0) of block row j0 (see k_near_fused)
 __global__ void __launch_bounds__(256) k_scale_rows(double* __restrict__ S, int ld, int k0, int j0, int c0, int e0,
                                                     const double* __restrict__ Xk, int ldx, const double* __restrict__ dvec) {
   const int p = blockIdx.x;
+  tlog_begin((j0 / kInner) * kTlKinds + kTlScale);
   const double d = dvec[j0 + p];
   for (int col = c0 + threadIdx.x; col < e0; col += blockDim.x)
     S[(size_t)(j0 + p) * ld + col] = Xk[(size_t)(j0 - k0 + p) * ldx + col] / d;
+  tlog_end((j0 / kInner) * kTlKinds + kTlScale);
 }
 
 int panel_cu_count() {
@@ -962,6 +1048,7 @@ int ldlt_workspace_alloc(LdltWorkspace& w, int n_pad) {
   CBA_HIP(hipEventCreateWithFlags(&w.ev_panel, hipEventDisableTiming | hipEventDisableSystemFence));
   CBA_HIP(hipEventCreateWithFlags(&w.ev_strip, hipEventDisableTiming | hipEventDisableSystemFence));
   CBA_HIP(hipEventCreateWithFlags(&w.ev_mid, hipEventDisableTiming | hipEventDisableSystemFence));
+  CBA_HIP(hipEventCreateWithFlags(&w.ev_diag, hipEventDisableTiming | hipEventDisableSystemFence));
   CBA_HIP(hipEventCreateWithFlags(&w.ev_aa, hipEventDisableTiming | hipEventDisableSystemFence));
   CBA_HIP(hipEventCreateWithFlags(&w.ev_chain, hipEventDisableTiming | hipEventDisableSystemFence));
   CBA_HIP(hipEventCreateWithFlags(&w.ev_bulk, hipEventDisableTiming | hipEventDisableSystemFence));
@@ -979,6 +1066,7 @@ void ldlt_workspace_free(LdltWorkspace& w) {
   if (w.ev_panel) hipEventDestroy(w.ev_panel);
   if (w.ev_strip) hipEventDestroy(w.ev_strip);
   if (w.ev_mid) hipEventDestroy(w.ev_mid);
+  if (w.ev_diag) hipEventDestroy(w.ev_diag);
   if (w.ev_aa) hipEventDestroy(w.ev_aa);
   if (w.ev_chain) hipEventDestroy(w.ev_chain);
   if (w.ev_bulk) hipEventDestroy(w.ev_bulk);
@@ -999,7 +1087,8 @@ void ldlt_workspace_free(LdltWorkspace& w) {
 //           (k_panel_solve), plus (a''), the update of the rest of the next panel's rows;
 //   main  : (b) the bulk trailing update with K = 256 on the MFMA GEMM.  The next panel is factored
 //           underneath (b) (look-ahead).
-static int trsm_cols(double* S, int ld, int j0, int k0, int col_begin, int col_end, double* Xk, LdltWorkspace& w, hipStream_t s) {
+static int trsm_cols(double* S, int ld, int j0, int k0, int col_begin, int col_end, double* Xk, LdltWorkspace& w, hipStream_t s,
+                     int tl_kind) {
   // X[p][i] = sum_q invLt[q][p] * S[j0+q][i], i in [col_begin, col_end); L = X / d written in place
   if (col_begin >= col_end) return CBA_OK;
   GemmArgs g{};
@@ -1009,6 +1098,7 @@ static int trsm_cols(double* S, int ld, int j0, int k0, int col_begin, int col_e
   g.m_tiles = 1; g.m_off = 0; g.upper = 0; g.diag = 0;
   g.rowscale_inv = w.dvec + j0;
   g.C2 = S + (size_t)j0 * ld; g.ldc2 = ld;
+  g.tlog_tag = (j0 / kInner) * kTlKinds + tl_kind + 1;
   int c = col_begin;
   if (c % 128 != 0) {  // unaligned 64-column head
     GemmArgs h = g; h.n_tiles = 1; h.n_off = c;
@@ -1032,7 +1122,7 @@ static int trsm_cols(double* S, int ld, int j0, int k0, int col_begin, int col_e
 }
 // S[m][n] -= sum_p L[p][m] X[p][n] for rows m in [m_begin, m_end), cols n in [n_begin, n_end) (64-tiles)
 static int update_block(double* S, int ld, int j0, int k0, int m_begin, int m_end, int n_begin, int n_end, int upper,
-                        double* Xk, hipStream_t s) {
+                        double* Xk, hipStream_t s, int tl_kind) {
   if (m_begin >= m_end || n_begin >= n_end) return CBA_OK;
   GemmArgs u{};
   u.A = S + (size_t)j0 * ld; u.lda = ld;       // L values (rows j0..j0+63)
@@ -1041,6 +1131,7 @@ static int update_block(double* S, int ld, int j0, int k0, int m_begin, int m_en
   u.m_off = m_begin; u.m_tiles = (m_end - m_begin) / 64;
   u.n_off = n_begin; u.n_tiles = (n_end - n_begin) / 64;
   u.upper = upper; u.diag = 0;
+  u.tlog_tag = (j0 / kInner) * kTlKinds + tl_kind + 1;
   return launch_gemm<64, 64, 32, 32, true>(u, s);
 }
 
@@ -1079,13 +1170,21 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
       const bool last = (c0 == e0);
       // ---- chain: factor the diagonal block, near solve, near update ----
       hipLaunchKernelGGL(k_ldlt_diag<kInner>, dim3(1), dim3(256), 0, s2, S, ld, j0, w.dvec, w.invLt, w.status);
+      const bool mid_work = !last && nx > e0;
+      if (mid_work) {
+        // mid: the block row's solve on the next panel's columns needs only the diagonal factor, so it runs next to
+        // the chain's near step instead of behind it (the mid stream's tail is what the last block's solve waits for)
+        CBA_HIP(hipEventRecord(w.ev_diag, s2));
+        CBA_HIP(hipStreamWaitEvent(s4, w.ev_diag, 0));
+        if ((rc = trsm_cols(S, ld, j0, k0, e0, nx, Xk, w, s4, kTlMidTrsm))) return rc;
+      }
       const bool fused_near = (pw == kPanel) && (c0 < e0);
       if (fused_near) {
         const int nbk = (e0 - c0) / kInner;
         hipLaunchKernelGGL(k_near_fused, dim3(nbk * (nbk + 1) / 2), dim3(256), 0, s2, S, ld, k0, j0, e0, Xk, n_pad, w.dvec, w.invLt);
       } else {
-        if ((rc = trsm_cols(S, ld, j0, k0, c0, e0, Xk, w, s2))) return rc;
-        if ((rc = update_block(S, ld, j0, k0, c0, e0, c0, e0, /*upper*/ 1, Xk, s2))) return rc;
+        if ((rc = trsm_cols(S, ld, j0, k0, c0, e0, Xk, w, s2, kTlChainTrsm))) return rc;
+        if ((rc = update_block(S, ld, j0, k0, c0, e0, c0, e0, /*upper*/ 1, Xk, s2, kTlChainUpd))) return rc;
       }
       CBA_HIP(hipEventRecord(w.ev_chain, s2));
       if (fused_near) {      // L in place for the panel-internal columns, off the critical path
@@ -1096,20 +1195,20 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
       if (last && la) {
         // the last block's solve on the next panel's columns and (a') stay on the chain stream
         CBA_HIP(hipStreamWaitEvent(s2, w.ev_mid, 0));      // mid updates of the earlier blocks
-        if ((rc = trsm_cols(S, ld, j0, k0, e0, nx, Xk, w, s2))) return rc;
+        if ((rc = trsm_cols(S, ld, j0, k0, e0, nx, Xk, w, s2, kTlXn))) return rc;
         CBA_HIP(hipStreamWaitEvent(s2, w.ev_bulk, 0));     // the previous bulk update wrote the same block
         // (a') diagonal block of the next panel.  64x64 tiles: ten small tiles on ten CUs finish several
         // times sooner than three 128x128 tiles, and this launch is on the critical path.
         GemmArgs v = u;
         v.upper = 1; v.m_off = r0; v.m_tiles = head * 2; v.n_off = r0; v.n_tiles = head * 2;
+        v.tlog_tag = (k0 / kInner) * kTlKinds + kTlAPrime + 1;
         if ((rc = launch_gemm<64, 64, 32, 32, true>(v, s2))) return rc;
         CBA_HIP(hipEventRecord(w.ev_strip, s2));
       }
       // ---- mid: the next panel's columns ----
-      if (!last && nx > e0) {
-        CBA_HIP(hipStreamWaitEvent(s4, w.ev_chain, 0));
-        if ((rc = trsm_cols(S, ld, j0, k0, e0, nx, Xk, w, s4))) return rc;
-        if ((rc = update_block(S, ld, j0, k0, c0, e0, e0, nx, /*upper*/ 0, Xk, s4))) return rc;
+      if (mid_work) {
+        CBA_HIP(hipStreamWaitEvent(s4, w.ev_chain, 0));    // L of the panel-internal columns (near step / k_scale_rows)
+        if ((rc = update_block(S, ld, j0, k0, c0, e0, e0, nx, /*upper*/ 0, Xk, s4, kTlMidUpd))) return rc;
         CBA_HIP(hipEventRecord(w.ev_mid, s4));
       }
     }
@@ -1134,11 +1233,13 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
           const int h2 = (mt - head) < head ? (mt - head) : head;
           GemmArgs v = u;
           v.upper = 0; v.m_off = r0; v.m_tiles = head * 2; v.n_off = r0 + head * 128; v.n_tiles = h2 * 2;
+          v.tlog_tag = (k0 / kInner) * kTlKinds + kTlAA_n + 1;
           if ((rc = launch_gemm<64, 64, 32, 32, true>(v, s3))) return rc;
           CBA_HIP(hipEventRecord(w.ev_aa, s3));
           CBA_HIP(hipStreamWaitEvent(s4, w.ev_aa, 0));
           if (mt - head > h2) {
             v.m_tiles = head; v.n_off = r0 + (head + h2) * 128; v.n_tiles = mt - head - h2;
+            v.tlog_tag = (k0 / kInner) * kTlKinds + kTlAA_rest + 1;
             if ((rc = launch_gemm<128, 128, 64, 64, true>(v, s3))) return rc;
           }
         } else {
@@ -1148,6 +1249,7 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
         // (b) bulk
         if (mt > head) {
           u.upper = 1; u.m_off = r0 + head * 128; u.m_tiles = mt - head; u.n_off = r0 + head * 128; u.n_tiles = mt - head;
+          u.tlog_tag = (k0 / kInner) * kTlKinds + kTlBulk + 1;
           if ((rc = launch_gemm<128, 128, 64, 64, true>(u, s))) return rc;
         }
         CBA_HIP(hipEventRecord(w.ev_bulk, s));

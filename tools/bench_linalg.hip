@@ -5,6 +5,7 @@
 #include <chrono>
 #include <vector>
 #include <cmath>
+#include <algorithm>
 namespace cba { void set_error(const std::string& m) { fprintf(stderr, "error: %s\n", m.c_str()); } }
 using namespace cba;
 namespace cba {
@@ -76,6 +77,16 @@ int main(int argc, char** argv) {
     hipDeviceSynchronize();
     GemmStats gs;
     hipMemset(w.status, 0, 4);
+#ifdef CBA_TLOG
+    const int n_tags = (n / 64 + 1) * kTlKinds;
+    static unsigned long long* tl = nullptr;
+    if (!tl) { hipMalloc(&tl, sizeof(unsigned long long) * 2 * n_tags); hipMemcpyToSymbol(HIP_SYMBOL(g_tlog), &tl, sizeof(tl)); }
+    {
+      std::vector<unsigned long long> init(2 * n_tags);
+      for (int i = 0; i < n_tags; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0; }
+      hipMemcpy(tl, init.data(), sizeof(unsigned long long) * 2 * n_tags, hipMemcpyHostToDevice);
+    }
+#endif
     hipEventRecord(e0, ms);
     auto h0 = std::chrono::steady_clock::now();
     ldlt_factor(S, n_fact, n, w, ms, &gs);
@@ -84,6 +95,46 @@ int main(int argc, char** argv) {
     float ms_ = timeit(e0, e1);
     printf("host enqueue time of ldlt_factor: %.3f ms\n", std::chrono::duration<double, std::milli>(h1 - h0).count());
     printf("ldlt_factor n_fact=%d: %.3f ms  (trailing %.3f TFLOP -> %.2f TFLOP/s overall)\n", n_fact, ms_, gs.flops / 1e12, gs.flops / ms_ / 1e9);
+#ifdef CBA_TLOG
+    if (rep == 1) {
+      std::vector<unsigned long long> lg(2 * n_tags);
+      hipMemcpy(lg.data(), tl, sizeof(unsigned long long) * 2 * n_tags, hipMemcpyDeviceToHost);
+      static const char* names[kTlKinds] = {"diag", "near", "scale", "mid_trsm", "mid_upd", "chain_trsm", "chain_upd", "a'", "panel_solve",
+                                            "a''n", "a''rest", "bulk", "Xn", "", "", ""};
+      const char* pe = getenv("TL_PANELS");       // e.g. "0,6656,9216,11776": first column of the panels to print
+      std::vector<int> want;
+      if (pe) { for (const char* c = pe; *c;) { want.push_back(atoi(c)); while (*c && *c != ',') ++c; if (*c) ++c; } }
+      else want = {0, 4096, 6656, 9216, 11776};
+      // panel spans (diag of the panel's first block to the next panel's first diag)
+      printf("panel starts (us since first diag), width, span:\n");
+      const double t00 = (double)lg[0];
+      for (int k0 = 0; k0 < n_fact;) {
+        const int pw = panel_width_at(k0, n_fact);
+        const int nxt = k0 + pw;
+        const double a = (lg[2 * ((k0 / 64) * kTlKinds)] - t00) / 100.0;
+        const double b = nxt < n_fact ? (lg[2 * ((nxt / 64) * kTlKinds)] - t00) / 100.0 : NAN;
+        printf("  panel %6d w %3d start %9.1f span %8.1f\n", k0, pw, a, b - a);
+        k0 = nxt;
+      }
+      for (int k0 : want) {
+        if (k0 >= n_fact) continue;
+        const int pw = panel_width_at(k0, n_fact);
+        struct Ev { double a, b; int blk, kind; };
+        std::vector<Ev> evs;
+        const double t0 = (double)lg[2 * ((k0 / 64) * kTlKinds)];
+        for (int blk = k0 / 64; blk < (k0 + pw) / 64 + 1 && blk * kTlKinds < n_tags; ++blk)
+          for (int kd = 0; kd < kTlKinds; ++kd) {
+            const unsigned long long a = lg[2 * (blk * kTlKinds + kd)], b = lg[2 * (blk * kTlKinds + kd) + 1];
+            if (a == ~0ull || b == 0) continue;
+            if (blk == (k0 + pw) / 64 && kd != kTlDiag) continue;
+            evs.push_back({(a - t0) / 100.0, (b - t0) / 100.0, blk, kd});
+          }
+        std::sort(evs.begin(), evs.end(), [](const Ev& x, const Ev& y) { return x.a < y.a; });
+        printf("timeline of panel at column %d (width %d), us relative to its first diag:\n", k0, pw);
+        for (const Ev& e : evs) printf("  %8.1f %8.1f  dur %7.1f  blk %3d  %s\n", e.a, e.b, e.b - e.a, e.blk, names[e.kind]);
+      }
+    }
+#endif
     double* x; hipMalloc(&x, sizeof(double) * n);
     hipEventRecord(e0);
     ldlt_back_solve(S, n_fact, n, n - 1, w, x, nullptr);
