@@ -126,7 +126,7 @@ struct LdltWorkspace {
   hipStream_t mid_stream = nullptr;     // panel solves / updates on the next panel's columns
   hipStream_t far_stream = nullptr;     // panel solves / updates right of the next panel
   hipEvent_t ev_panel = nullptr, ev_strip = nullptr, ev_mid = nullptr, ev_aa = nullptr, ev_chain = nullptr, ev_bulk = nullptr,
-             ev_diag = nullptr;
+             ev_diag = nullptr, ev_xn = nullptr;
   size_t n_alloc = 0;
 };
 int ldlt_workspace_alloc(LdltWorkspace& w, int n);

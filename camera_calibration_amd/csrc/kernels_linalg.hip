@@ -685,13 +685,13 @@ __device__ __forceinline__ void ldlt_diag_segment(double (&T)[4][4], double (&X)
 // through LDS and applies the two rank-1 updates
 //     T[i][j] -= l_i d l_j   (i,j > s),        X[i][c] -= l_i X[s][c]   (i > s, c <= s)
 // -- the second is the product form L^-1 = (I - l_62 e_62^T) ... (I - l_0 e_0^T).  One barrier per step.
-template <int NSTEPS = kInner>
-__global__ void __launch_bounds__(256) k_ldlt_diag(double* __restrict__ M, int ld, int j0, double* __restrict__ dvec,
-                                                   double* __restrict__ invLt_all, int* __restrict__ status) {
-  __shared__ double colbuf[3][kInner];   // [2] = scratch row for the branch-free publish
-  __shared__ double rowbuf[3][kInner];
-  __builtin_amdgcn_s_setprio(3);   // latency-critical: runs underneath the bulk trailing-update GEMM
-  tlog_begin((j0 / kInner) * kTlKinds + kTlDiag);
+// `tile` == nullptr: T is read from the stored upper triangle of M; otherwise from a 64 x 64 tile in LDS (row stride
+// tile_ld, upper triangle valid) -- the fused chain kernel hands over the block it has just updated.
+template <int NSTEPS>
+__device__ __forceinline__ void ldlt_diag_body(double* __restrict__ M, int ld, int j0, double* __restrict__ dvec,
+                                               double* __restrict__ invLt_all, int* __restrict__ status,
+                                               const double* tile, int tile_ld, double (*colbuf)[kInner],
+                                               double (*rowbuf)[kInner]) {
   const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
   double T[4][4], X[4][4];
 #pragma unroll
@@ -699,8 +699,8 @@ __global__ void __launch_bounds__(256) k_ldlt_diag(double* __restrict__ M, int l
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       int i = ti + 16 * a, j = tj + 16 * b;
-      int lo = i < j ? i : j, hi = i < j ? j : i;           // symmetric fill from the stored upper triangle
-      T[a][b] = M[(size_t)(j0 + lo) * ld + j0 + hi];
+      int lo = i < j ? i : j, hi = i < j ? j : i;           // symmetric fill from the upper triangle
+      T[a][b] = tile ? tile[lo * tile_ld + hi] : M[(size_t)(j0 + lo) * ld + j0 + hi];
       X[a][b] = (i == j) ? 1.0 : 0.0;
     }
   if (tj == 0) {
@@ -729,6 +729,16 @@ __global__ void __launch_bounds__(256) k_ldlt_diag(double* __restrict__ M, int l
       invLt[j * kInner + i] = (i >= j) ? X[a][b] : 0.0;     // invLt[q][p] = invL(p,q)
       if (i == j) dvec[j0 + i] = T[a][b];
     }
+}
+
+template <int NSTEPS = kInner>
+__global__ void __launch_bounds__(256) k_ldlt_diag(double* __restrict__ M, int ld, int j0, double* __restrict__ dvec,
+                                                   double* __restrict__ invLt_all, int* __restrict__ status) {
+  __shared__ double colbuf[3][kInner];   // [2] = scratch row for the branch-free publish
+  __shared__ double rowbuf[3][kInner];
+  __builtin_amdgcn_s_setprio(3);   // latency-critical: runs underneath the bulk trailing-update GEMM
+  tlog_begin((j0 / kInner) * kTlKinds + kTlDiag);
+  ldlt_diag_body<NSTEPS>(M, ld, j0, dvec, invLt_all, status, nullptr, 0, colbuf, rowbuf);
   tlog_end((j0 / kInner) * kTlKinds + kTlDiag);
 }
 
@@ -902,9 +912,19 @@ __device__ __forceinline__ void tile_mma_lds(v4f64 (&acc)[2][2], const double* A
   }
 }
 
-__global__ void __launch_bounds__(256) k_near_fused(double* __restrict__ S, int ld, int k0, int j0, int e0,
-                                                    double* __restrict__ Xk, int ldx, const double* __restrict__ dvec,
-                                                    const double* __restrict__ invLt_all) {
+//
+// Tiles: first the nblk (nblk + 1) / 2 upper tiles (r, c) of the panel's remaining diagonal block, then -- when the
+// caller passes nx > e0 -- the nblk x ncn tiles (r, cn) of the panel's remaining rows in the NEXT panel's columns
+// [e0, nx), which keeps the whole look-ahead of a 256-panel on the chain stream (no second stream, no cross-stream
+// hops of ~17 us each).  X of the next panel's columns is published by the tiles of row r = 0.
+//
+// FUSE_DIAG: workgroup 0 owns tile (0, 0), the next diagonal block.  Instead of writing it back it factors it
+// right away (same code as k_ldlt_diag, fed from LDS) while the other workgroups finish their tiles: the chain is
+// one launch per 64-block instead of two, and the near step hides behind the 64 pivot steps.
+template <bool FUSE_DIAG>
+__global__ void __launch_bounds__(256) k_near_fused(double* __restrict__ S, int ld, int k0, int j0, int e0, int nx,
+                                                    double* __restrict__ Xk, int ldx, double* __restrict__ dvec,
+                                                    double* __restrict__ invLt_all, int* __restrict__ status) {
   __shared__ double sA[2 * KT * TS];
   __shared__ double sB[2 * KT * TS];
   __shared__ double sV[kInner * TS];    // X_c           [p][n]
@@ -914,10 +934,32 @@ __global__ void __launch_bounds__(256) k_near_fused(double* __restrict__ S, int 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
   const int c0 = j0 + kInner, nblk = (e0 - c0) / kInner;
-  int t = blockIdx.x, r = 0;
-  for (; r < nblk; ++r) { const int cnt = nblk - r; if (t < cnt) break; t -= cnt; }
-  const int c = r + t;
-  const int colr = c0 + kInner * r, colc = c0 + kInner * c;
+  const int n_tri = nblk * (nblk + 1) / 2;
+  int r, colc;
+  bool publish, same;
+  // Workgroup b is dispatched to XCD b % 8 and the chain stream owns one CU per XCD (a workgroup fills the CU's
+  // LDS), so with FUSE_DIAG the slots 8, 16, ... stay empty: nothing queues behind workgroup 0's pivot steps.
+  int tile = blockIdx.x;
+  if (FUSE_DIAG && tile > 0) {
+    if ((tile & 7) == 0) return;
+    tile -= tile >> 3;
+  }
+  const int ncn = (nx - e0) / kInner;
+  if (tile >= n_tri + nblk * ncn) return;
+  if (tile < n_tri) {
+    int t = tile;
+    for (r = 0; r < nblk; ++r) { const int cnt = nblk - r; if (t < cnt) break; t -= cnt; }
+    colc = c0 + kInner * (r + t);
+    same = (t == 0);
+    publish = same;
+  } else {
+    const int u = tile - n_tri;
+    r = u / ncn;
+    colc = e0 + kInner * (u - r * ncn);
+    same = false;
+    publish = (r == 0);
+  }
+  const int colr = c0 + kInner * r;
   const double* invLt = invLt_all + (size_t)(j0 / kInner) * kInner * kInner;
   const double* Uj = S + (size_t)j0 * ld;
   v4f64 acc[2][2];
@@ -937,10 +979,10 @@ __global__ void __launch_bounds__(256) k_near_fused(double* __restrict__ S, int 
         const int n = wn0 + jj * 16 + li;
         const double v = acc[i][jj][r4];
         sL[p * TS + n] = v / d;
-        if (r == c) { sV[p * TS + n] = v; Xk[(size_t)(j0 - k0 + p) * ldx + colr + n] = v; }
+        if (same) { sV[p * TS + n] = v; Xk[(size_t)(j0 - k0 + p) * ldx + colr + n] = v; }
       }
     }
-  if (r != c) {
+  if (!same) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -951,7 +993,11 @@ __global__ void __launch_bounds__(256) k_near_fused(double* __restrict__ S, int 
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) sV[(wm0 + i * 16 + lk + 4 * r4) * TS + wn0 + jj * 16 + li] = acc[i][jj][r4];
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int p = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
+          sV[p * TS + n] = acc[i][jj][r4];
+          if (publish) Xk[(size_t)(j0 - k0 + p) * ldx + colc + n] = acc[i][jj][r4];
+        }
   }
   __syncthreads();
 #pragma unroll
@@ -960,25 +1006,46 @@ __global__ void __launch_bounds__(256) k_near_fused(double* __restrict__ S, int 
     for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
   tile_mma_lds(acc, sL, sV);
   double* T = S + (size_t)colr * ld + colc;
+  if (FUSE_DIAG && tile == 0) {
+    // tile (0, 0): updated block -> LDS -> factor it (block j0 + 64) without a round trip through memory
+    __syncthreads();                       // every wave is done reading sV / sL
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
+      for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
-        T[(size_t)m * ld + n] -= acc[i][jj][r4];
-      }
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
+          sV[m * TS + n] = T[(size_t)m * ld + n] - acc[i][jj][r4];
+        }
+    __syncthreads();
+    tlog_begin((c0 / kInner) * kTlKinds + kTlDiag);
+    double (*colbuf)[kInner] = reinterpret_cast<double (*)[kInner]>(sA);
+    double (*rowbuf)[kInner] = reinterpret_cast<double (*)[kInner]>(sA + 3 * kInner);
+    ldlt_diag_body<kInner>(S, ld, c0, dvec, invLt_all, status, sV, TS, colbuf, rowbuf);
+    tlog_end((c0 / kInner) * kTlKinds + kTlDiag);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
+          T[(size_t)m * ld + n] -= acc[i][jj][r4];
+        }
+  }
   tlog_end((j0 / kInner) * kTlKinds + kTlNear);
 }
 
 // L = X / d in place for the panel-internal columns [c0, e0) of block row j0 (see k_near_fused)
 __global__ void __launch_bounds__(256) k_scale_rows(double* __restrict__ S, int ld, int k0, int j0, int c0, int e0,
                                                     const double* __restrict__ Xk, int ldx, const double* __restrict__ dvec) {
-  const int p = blockIdx.x;
+  const int p = blockIdx.x;                 // row j0 + p; the launch may span several 64-blocks of the panel
   tlog_begin((j0 / kInner) * kTlKinds + kTlScale);
   const double d = dvec[j0 + p];
-  for (int col = c0 + threadIdx.x; col < e0; col += blockDim.x)
+  const int own = j0 + kInner * (p / kInner + 1);        // first column right of the row's own diagonal block
+  for (int col = (c0 > own ? c0 : own) + threadIdx.x; col < e0; col += blockDim.x)
     S[(size_t)(j0 + p) * ld + col] = Xk[(size_t)(j0 - k0 + p) * ldx + col] / d;
   tlog_end((j0 / kInner) * kTlKinds + kTlScale);
 }
@@ -1049,6 +1116,7 @@ int ldlt_workspace_alloc(LdltWorkspace& w, int n_pad) {
   CBA_HIP(hipEventCreateWithFlags(&w.ev_strip, hipEventDisableTiming | hipEventDisableSystemFence));
   CBA_HIP(hipEventCreateWithFlags(&w.ev_mid, hipEventDisableTiming | hipEventDisableSystemFence));
   CBA_HIP(hipEventCreateWithFlags(&w.ev_diag, hipEventDisableTiming | hipEventDisableSystemFence));
+  CBA_HIP(hipEventCreateWithFlags(&w.ev_xn, hipEventDisableTiming | hipEventDisableSystemFence));
   CBA_HIP(hipEventCreateWithFlags(&w.ev_aa, hipEventDisableTiming | hipEventDisableSystemFence));
   CBA_HIP(hipEventCreateWithFlags(&w.ev_chain, hipEventDisableTiming | hipEventDisableSystemFence));
   CBA_HIP(hipEventCreateWithFlags(&w.ev_bulk, hipEventDisableTiming | hipEventDisableSystemFence));
@@ -1067,6 +1135,7 @@ void ldlt_workspace_free(LdltWorkspace& w) {
   if (w.ev_strip) hipEventDestroy(w.ev_strip);
   if (w.ev_mid) hipEventDestroy(w.ev_mid);
   if (w.ev_diag) hipEventDestroy(w.ev_diag);
+  if (w.ev_xn) hipEventDestroy(w.ev_xn);
   if (w.ev_aa) hipEventDestroy(w.ev_aa);
   if (w.ev_chain) hipEventDestroy(w.ev_chain);
   if (w.ev_bulk) hipEventDestroy(w.ev_bulk);
@@ -1165,6 +1234,71 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
     u.B = Xk; u.ldb = n_pad; u.K = nb;
     u.C = S; u.ldc = ld; u.Cin = S; u.ldcin = ld;
     u.diag = 0;
+    // A full 256-panel with look-ahead runs its whole chain on the chain stream: one launch per 64-block (near step
+    // on the panel's own AND the next panel's columns + the next diagonal factor, k_near_fused<true>).
+    static const bool no_chain_only = getenv("CBA_NO_CHAIN_ONLY") != nullptr;      // developer switch
+    const bool chain_only = !no_chain_only && pw == kPanel && nb == kPanel && la && nx > e0;
+    if (chain_only) {
+      const int ncn = (nx - e0) / kInner, nblocks = kPanel / kInner;
+      hipLaunchKernelGGL(k_ldlt_diag<kInner>, dim3(1), dim3(256), 0, s2, S, ld, k0, w.dvec, w.invLt, w.status);
+      // the near steps also update this panel's rows in the next panel's columns, which (a''n) of the previous panel
+      // (far stream) wrote last
+      CBA_HIP(hipStreamWaitEvent(s2, w.ev_aa, 0));
+      for (int b = 0; b + 1 < nblocks; ++b) {
+        const int nbk = nblocks - 1 - b;
+        const int tiles = nbk * (nbk + 1) / 2 + nbk * ncn;
+        hipLaunchKernelGGL(k_near_fused<true>, dim3(tiles + (tiles + 5) / 7), dim3(256), 0, s2, S, ld, k0, k0 + kInner * b, e0,
+                           nx, Xk, n_pad, w.dvec, w.invLt, w.status);
+      }
+      CBA_HIP(hipEventRecord(w.ev_chain, s2));
+      // chain: the last block's solve on the next panel's columns, L of those columns for the earlier blocks, (a')
+      if ((rc = trsm_cols(S, ld, e0 - kInner, k0, e0, nx, Xk, w, s2, kTlXn))) return rc;
+      hipLaunchKernelGGL(k_scale_rows, dim3(kPanel - kInner), dim3(256), 0, s2, S, ld, k0, k0, e0, nx, Xk, n_pad, w.dvec);
+      CBA_HIP(hipEventRecord(w.ev_xn, s2));
+      CBA_HIP(hipStreamWaitEvent(s2, w.ev_bulk, 0));     // the previous bulk update wrote the same block
+      GemmArgs v = u;
+      v.upper = 1; v.m_off = r0; v.m_tiles = head * 2; v.n_off = r0; v.n_tiles = head * 2;
+      v.tlog_tag = (k0 / kInner) * kTlKinds + kTlAPrime + 1;
+      if ((rc = launch_gemm<64, 64, 32, 32, true>(v, s2))) return rc;
+      CBA_HIP(hipEventRecord(w.ev_strip, s2));
+      // far: L in place inside the panel, then the fused forward substitution of the columns (a''n) needs, (a''n)
+      // itself -- the next panel's chain waits for it -- and only then the rest of the forward substitution
+      const int h2 = (mt - head) < head ? (mt - head) : head;
+      CBA_HIP(hipStreamWaitEvent(s3, w.ev_chain, 0));
+      hipLaunchKernelGGL(k_scale_rows, dim3(kPanel - kInner), dim3(256), 0, s3, S, ld, k0, k0, k0 + kInner, e0, Xk, n_pad, w.dvec);
+      if (mt > head) {
+        hipLaunchKernelGGL(k_panel_solve, dim3(h2 * 2), dim3(256), 0, s3, S, ld, k0, nb, nx, Xk, n_pad, w.dvec, w.invLt);
+        CBA_HIP(hipStreamWaitEvent(s3, w.ev_xn, 0));
+        CBA_HIP(hipStreamWaitEvent(s3, w.ev_bulk, 0));
+        v.upper = 0; v.m_off = r0; v.m_tiles = head * 2; v.n_off = r0 + head * 128; v.n_tiles = h2 * 2;
+        v.tlog_tag = (k0 / kInner) * kTlKinds + kTlAA_n + 1;
+        if ((rc = launch_gemm<64, 64, 32, 32, true>(v, s3))) return rc;
+      }
+      CBA_HIP(hipEventRecord(w.ev_aa, s3));
+      CBA_HIP(hipStreamWaitEvent(s4, w.ev_aa, 0));
+      if (n_pad > nx + h2 * 128)
+        hipLaunchKernelGGL(k_panel_solve, dim3((n_pad - nx - h2 * 128) / kInner), dim3(256), 0, s3, S, ld, k0, nb, nx + h2 * 128, Xk,
+                           n_pad, w.dvec, w.invLt);
+      CBA_HIP(hipEventRecord(w.ev_panel, s3));
+      CBA_HIP(hipStreamWaitEvent(s, w.ev_panel, 0));
+      if (mt - head > h2) {
+        v.upper = 0; v.m_off = r0; v.m_tiles = head; v.n_off = r0 + (head + h2) * 128; v.n_tiles = mt - head - h2;
+        v.tlog_tag = (k0 / kInner) * kTlKinds + kTlAA_rest + 1;
+        if ((rc = launch_gemm<128, 128, 64, 64, true>(v, s3))) return rc;
+      }
+      if (mt > head) {
+        u.upper = 1; u.m_off = r0 + head * 128; u.m_tiles = mt - head; u.n_off = r0 + head * 128; u.n_tiles = mt - head;
+        u.tlog_tag = (k0 / kInner) * kTlKinds + kTlBulk + 1;
+        if ((rc = launch_gemm<128, 128, 64, 64, true>(u, s))) return rc;
+      }
+      CBA_HIP(hipEventRecord(w.ev_bulk, s));
+      if (st) {
+        double rows = (double)(n_pad - r0);
+        st->flops += rows * rows * nb;
+        st->launches += 1;
+      }
+      continue;
+    }
     for (int j0 = k0; j0 < e0; j0 += kInner) {
       const int c0 = j0 + kInner;
       const bool last = (c0 == e0);
@@ -1181,7 +1315,8 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
       const bool fused_near = (pw == kPanel) && (c0 < e0);
       if (fused_near) {
         const int nbk = (e0 - c0) / kInner;
-        hipLaunchKernelGGL(k_near_fused, dim3(nbk * (nbk + 1) / 2), dim3(256), 0, s2, S, ld, k0, j0, e0, Xk, n_pad, w.dvec, w.invLt);
+        hipLaunchKernelGGL(k_near_fused<false>, dim3(nbk * (nbk + 1) / 2), dim3(256), 0, s2, S, ld, k0, j0, e0, e0, Xk, n_pad, w.dvec,
+                           w.invLt, w.status);
       } else {
         if ((rc = trsm_cols(S, ld, j0, k0, c0, e0, Xk, w, s2, kTlChainTrsm))) return rc;
         if ((rc = update_block(S, ld, j0, k0, c0, e0, c0, e0, /*upper*/ 1, Xk, s2, kTlChainUpd))) return rc;
