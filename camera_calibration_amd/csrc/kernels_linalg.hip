@@ -150,6 +150,7 @@ struct GemmArgs {
   int kmask_words;
   int epi_mode;                 // developer switch (bench harness): 0 normal, 1 no Cin read, 2 no store
   int strips;                   // set by launch_gemm: strip-blocked tile order (square upper dense launches)
+  const double* a_rowdiv;       // small-tile variants only: A[k][m] is divided by a_rowdiv[k] while staged (L = X / d on the fly)
   int tlog_tag;                 // developer timeline (tools/bench_linalg.hip, -DCBA_TLOG): tag + 1, 0 = none
 };
 
@@ -359,6 +360,7 @@ __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
     static_assert(A_PER == 2 && (B_PER == 2 || B_PER == 4), "staging registers below are written out for these shapes");
     // staging registers, written out as scalars: one set per slot (arrays here end up in scratch memory)
     double2 ra0_0, ra0_1, ra1_0, ra1_1, ra2_0, ra2_1;
+    double rd0_0 = 1.0, rd0_1 = 1.0, rd1_0 = 1.0, rd1_1 = 1.0, rd2_0 = 1.0, rd2_1 = 1.0;    // a_rowdiv values of the slot's two rows
     double2 rb0_0, rb0_1, rb0_2, rb0_3, rb1_0, rb1_1, rb1_2, rb1_3, rb2_0, rb2_1, rb2_2, rb2_3;
 #define CBA_LDA(j_, k0_) (*reinterpret_cast<const double2*>(Ag + (size_t)((k0_) + a_row + (j_) * A_ROWSTEP) * g.lda + 2 * a_c2))
 #define CBA_LDB(j_, k0_) (*reinterpret_cast<const double2*>(Bg + (size_t)((k0_) + b_row + (j_) * B_ROWSTEP) * g.ldb + 2 * b_c2))
@@ -368,12 +370,17 @@ __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
   {                                                                                                             \
     const int kq = (k0_);                                                                                       \
     ra##slot_##_0 = CBA_LDA(0, kq); ra##slot_##_1 = CBA_LDA(1, kq);                                             \
+    if (g.a_rowdiv) { rd##slot_##_0 = g.a_rowdiv[kq + a_row]; rd##slot_##_1 = g.a_rowdiv[kq + a_row + A_ROWSTEP]; } \
     rb##slot_##_0 = CBA_LDB(0, kq); rb##slot_##_1 = CBA_LDB(1, kq);                                             \
     if constexpr (B_PER == 4) { rb##slot_##_2 = CBA_LDB(2, kq); rb##slot_##_3 = CBA_LDB(3, kq); }               \
   }
 #define CBA_SSTORE(buf_, slot_)                                                                                 \
   {                                                                                                             \
     const int bq = (buf_);                                                                                      \
+    if (g.a_rowdiv) {                                                                                           \
+      ra##slot_##_0.x /= rd##slot_##_0; ra##slot_##_0.y /= rd##slot_##_0;                                       \
+      ra##slot_##_1.x /= rd##slot_##_1; ra##slot_##_1.y /= rd##slot_##_1;                                       \
+    }                                                                                                           \
     CBA_STA(bq, 0) = ra##slot_##_0; CBA_STA(bq, 1) = ra##slot_##_1;                                             \
     CBA_STB(bq, 0) = rb##slot_##_0; CBA_STB(bq, 1) = rb##slot_##_1;                                             \
     if constexpr (B_PER == 4) { CBA_STB(bq, 2) = rb##slot_##_2; CBA_STB(bq, 3) = rb##slot_##_3; }               \
@@ -913,10 +920,12 @@ __device__ __forceinline__ void tile_mma_lds(v4f64 (&acc)[2][2], const double* A
 }
 
 //
-// Tiles: first the nblk (nblk + 1) / 2 upper tiles (r, c) of the panel's remaining diagonal block, then -- when the
-// caller passes nx > e0 -- the nblk x ncn tiles (r, cn) of the panel's remaining rows in the NEXT panel's columns
-// [e0, nx), which keeps the whole look-ahead of a 256-panel on the chain stream (no second stream, no cross-stream
-// hops of ~17 us each).  X of the next panel's columns is published by the tiles of row r = 0.
+// Workgroups: first the nblk (nblk + 1) / 2 upper tiles (r, c) of the panel's remaining diagonal block, then -- when
+// the caller passes lag = 1 and nx > e0 -- one workgroup per 64-column block cn of the NEXT panel's columns [e0, nx) that
+// does the look-ahead of the PREVIOUS block row (j0 - 64, factored and published by the previous launch): X_cn =
+// invL U[cn], published, and T[r][cn] -= L_r^T X_cn for every later block row r of the panel, with L_r = X_r / d read
+// from the panel buffer.  This keeps the whole look-ahead of a 256-panel on the chain stream (no second stream, no
+// cross-stream hops of ~17 us each), one block row behind the pivot chain so that it never delays it.
 //
 // FUSE_DIAG: workgroup 0 owns tile (0, 0), the next diagonal block.  Instead of writing it back it factors it
 // right away (same code as k_ldlt_diag, fed from LDS) while the other workgroups finish their tiles: the chain is
@@ -924,7 +933,7 @@ __device__ __forceinline__ void tile_mma_lds(v4f64 (&acc)[2][2], const double* A
 template <bool FUSE_DIAG>
 __global__ void __launch_bounds__(256) k_near_fused(double* __restrict__ S, int ld, int k0, int j0, int e0, int nx,
                                                     double* __restrict__ Xk, int ldx, double* __restrict__ dvec,
-                                                    double* __restrict__ invLt_all, int* __restrict__ status) {
+                                                    double* __restrict__ invLt_all, int* __restrict__ status, int lag) {
   __shared__ double sA[2 * KT * TS];
   __shared__ double sB[2 * KT * TS];
   __shared__ double sV[kInner * TS];    // X_c           [p][n]
@@ -936,7 +945,7 @@ __global__ void __launch_bounds__(256) k_near_fused(double* __restrict__ S, int 
   const int c0 = j0 + kInner, nblk = (e0 - c0) / kInner;
   const int n_tri = nblk * (nblk + 1) / 2;
   int r, colc;
-  bool publish, same;
+  bool same;
   // Workgroup b is dispatched to XCD b % 8 and the chain stream owns one CU per XCD (a workgroup fills the CU's
   // LDS), so with FUSE_DIAG the slots 8, 16, ... stay empty: nothing queues behind workgroup 0's pivot steps.
   int tile = blockIdx.x;
@@ -944,20 +953,59 @@ __global__ void __launch_bounds__(256) k_near_fused(double* __restrict__ S, int 
     if ((tile & 7) == 0) return;
     tile -= tile >> 3;
   }
-  const int ncn = (nx - e0) / kInner;
-  if (tile >= n_tri + nblk * ncn) return;
-  if (tile < n_tri) {
+  const int ncn = lag ? (nx - e0) / kInner : 0;
+  if (tile >= n_tri + ncn) return;
+  if (tile >= n_tri) {
+    // ---- look-ahead of block row j0 - 64 on column block cn of the next panel ----
+    const int pj0 = j0 - kInner, cn0 = e0 + kInner * (tile - n_tri);
+    v4f64 xa[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) xa[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    tile_mma<false, false, false>(xa, invLt_all + (size_t)(pj0 / kInner) * kInner * kInner, kInner, S + (size_t)pj0 * ld + cn0, ld,
+                                  kInner, sA, sB, nullptr);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int p = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
+          sV[p * TS + n] = xa[i][jj][r4];
+          Xk[(size_t)(pj0 - k0 + p) * ldx + cn0 + n] = xa[i][jj][r4];
+        }
+    for (int colr = j0; colr < e0; colr += kInner) {
+      __syncthreads();                     // sV written / the previous block row's reads of sL done
+      for (int e = threadIdx.x; e < kInner * kInner; e += 256) {
+        const int p = e >> 6, m = e & 63;
+        sL[p * TS + m] = Xk[(size_t)(pj0 - k0 + p) * ldx + colr + m] / dvec[pj0 + p];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) xa[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
+      tile_mma_lds(xa, sL, sV);
+      double* Tn = S + (size_t)colr * ld + cn0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
+            Tn[(size_t)m * ld + n] -= xa[i][jj][r4];
+          }
+    }
+    tlog_end((j0 / kInner) * kTlKinds + kTlNear);
+    return;
+  }
+  {
     int t = tile;
     for (r = 0; r < nblk; ++r) { const int cnt = nblk - r; if (t < cnt) break; t -= cnt; }
     colc = c0 + kInner * (r + t);
     same = (t == 0);
-    publish = same;
-  } else {
-    const int u = tile - n_tri;
-    r = u / ncn;
-    colc = e0 + kInner * (u - r * ncn);
-    same = false;
-    publish = (r == 0);
   }
   const int colr = c0 + kInner * r;
   const double* invLt = invLt_all + (size_t)(j0 / kInner) * kInner * kInner;
@@ -996,7 +1044,6 @@ __global__ void __launch_bounds__(256) k_near_fused(double* __restrict__ S, int 
         for (int r4 = 0; r4 < 4; ++r4) {
           const int p = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
           sV[p * TS + n] = acc[i][jj][r4];
-          if (publish) Xk[(size_t)(j0 - k0 + p) * ldx + colc + n] = acc[i][jj][r4];
         }
   }
   __syncthreads();
@@ -1036,6 +1083,78 @@ __global__ void __launch_bounds__(256) k_near_fused(double* __restrict__ S, int 
         }
   }
   tlog_end((j0 / kInner) * kTlKinds + kTlNear);
+}
+
+// Last step of a 256-panel's look-ahead (after the last k_near_fused<true>, which has factored the panel's last block):
+// one workgroup per 64-column block cn of the next panel's columns finishes the second-to-last block row,
+//   X_2 = invL_2 U_2[cn]   (published),        U_3' = U_3[cn] - L_23^T X_2,
+// and solves the last one, X_3 = invL_3 U_3' (published).  S is only read: L = X / d is written in place later, off
+// the chain (k_scale_rows on the far stream), and (a') / (a''n) take L from the panel buffer (GemmArgs::a_rowdiv).
+__global__ void __launch_bounds__(256) k_next_last(const double* __restrict__ S, int ld, int k0, int e0, double* __restrict__ Xk,
+                                                   int ldx, const double* __restrict__ dvec, const double* __restrict__ invLt_all) {
+  __shared__ double sA[2 * KT * TS];
+  __shared__ double sB[2 * KT * TS];
+  __shared__ double sV[kInner * TS];
+  __shared__ double sL[kInner * TS];
+  __builtin_amdgcn_s_setprio(3);
+  const int j2 = e0 - 2 * kInner, j3 = e0 - kInner, cn0 = e0 + kInner * (int)blockIdx.x;
+  tlog_begin((j3 / kInner) * kTlKinds + kTlXn);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
+  v4f64 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  for (int e = threadIdx.x; e < kInner * kInner; e += 256) {     // L_23^T from the panel buffer (published by the near step)
+    const int p = e >> 6, m = e & 63;
+    sL[p * TS + m] = Xk[(size_t)(j2 - k0 + p) * ldx + j3 + m] / dvec[j2 + p];
+  }
+  tile_mma<false, false, false>(acc, invLt_all + (size_t)(j2 / kInner) * kInner * kInner, kInner, S + (size_t)j2 * ld + cn0, ld, kInner,
+                                sA, sB, nullptr);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int p = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
+        sV[p * TS + n] = acc[i][jj][r4];
+        Xk[(size_t)(j2 - k0 + p) * ldx + cn0 + n] = acc[i][jj][r4];
+      }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  tile_mma_lds(acc, sL, sV);
+  __syncthreads();                         // every wave is done reading sV
+  const double* U3 = S + (size_t)j3 * ld + cn0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
+        sV[m * TS + n] = U3[(size_t)m * ld + n] - acc[i][jj][r4];
+      }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  tile_mma<false, false, true>(acc, invLt_all + (size_t)(j3 / kInner) * kInner * kInner, kInner, nullptr, 0, kInner, sA, sB, sV);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
+        Xk[(size_t)(j3 - k0 + m) * ldx + cn0 + n] = acc[i][jj][r4];
+      }
+  tlog_end((j3 / kInner) * kTlKinds + kTlXn);
 }
 
 // L = X / d in place for the panel-internal columns [c0, e0) of block row j0 (see k_near_fused)
@@ -1241,22 +1360,22 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
     if (chain_only) {
       const int ncn = (nx - e0) / kInner, nblocks = kPanel / kInner;
       hipLaunchKernelGGL(k_ldlt_diag<kInner>, dim3(1), dim3(256), 0, s2, S, ld, k0, w.dvec, w.invLt, w.status);
-      // the near steps also update this panel's rows in the next panel's columns, which (a''n) of the previous panel
-      // (far stream) wrote last
-      CBA_HIP(hipStreamWaitEvent(s2, w.ev_aa, 0));
       for (int b = 0; b + 1 < nblocks; ++b) {
         const int nbk = nblocks - 1 - b;
-        const int tiles = nbk * (nbk + 1) / 2 + nbk * ncn;
+        // from the second launch on, the look-ahead workgroups update this panel's rows in the next panel's columns,
+        // which (a''n) of the previous panel (far stream) wrote last
+        if (b == 1) CBA_HIP(hipStreamWaitEvent(s2, w.ev_aa, 0));
+        const int tiles = nbk * (nbk + 1) / 2 + (b > 0 ? ncn : 0);
         hipLaunchKernelGGL(k_near_fused<true>, dim3(tiles + (tiles + 5) / 7), dim3(256), 0, s2, S, ld, k0, k0 + kInner * b, e0,
-                           nx, Xk, n_pad, w.dvec, w.invLt, w.status);
+                           nx, Xk, n_pad, w.dvec, w.invLt, w.status, b > 0 ? 1 : 0);
       }
       CBA_HIP(hipEventRecord(w.ev_chain, s2));
-      // chain: the last block's solve on the next panel's columns, L of those columns for the earlier blocks, (a')
-      if ((rc = trsm_cols(S, ld, e0 - kInner, k0, e0, nx, Xk, w, s2, kTlXn))) return rc;
-      hipLaunchKernelGGL(k_scale_rows, dim3(kPanel - kInner), dim3(256), 0, s2, S, ld, k0, k0, e0, nx, Xk, n_pad, w.dvec);
+      // chain: the look-ahead of the last two block rows, then (a') with L taken from the panel buffer
+      hipLaunchKernelGGL(k_next_last, dim3(ncn), dim3(256), 0, s2, S, ld, k0, e0, Xk, n_pad, w.dvec, w.invLt);
       CBA_HIP(hipEventRecord(w.ev_xn, s2));
       CBA_HIP(hipStreamWaitEvent(s2, w.ev_bulk, 0));     // the previous bulk update wrote the same block
       GemmArgs v = u;
+      v.A = Xk; v.lda = n_pad; v.a_rowdiv = w.dvec + k0;
       v.upper = 1; v.m_off = r0; v.m_tiles = head * 2; v.n_off = r0; v.n_tiles = head * 2;
       v.tlog_tag = (k0 / kInner) * kTlKinds + kTlAPrime + 1;
       if ((rc = launch_gemm<64, 64, 32, 32, true>(v, s2))) return rc;
@@ -1266,21 +1385,36 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
       const int h2 = (mt - head) < head ? (mt - head) : head;
       CBA_HIP(hipStreamWaitEvent(s3, w.ev_chain, 0));
       hipLaunchKernelGGL(k_scale_rows, dim3(kPanel - kInner), dim3(256), 0, s3, S, ld, k0, k0, k0 + kInner, e0, Xk, n_pad, w.dvec);
+      // While the bulk update is long (many rows left) the forward substitution it waits for goes first; near the end
+      // the chain is the bottleneck and (a''n), which the next panel's chain waits for, goes first.
+      static const int ps_first_rows = getenv("CBA_PS_FIRST_ROWS") ? atoi(getenv("CBA_PS_FIRST_ROWS")) : 3072;
+      const bool ps_first = (n_pad - r0) > ps_first_rows;
       if (mt > head) {
-        hipLaunchKernelGGL(k_panel_solve, dim3(h2 * 2), dim3(256), 0, s3, S, ld, k0, nb, nx, Xk, n_pad, w.dvec, w.invLt);
+        hipLaunchKernelGGL(k_panel_solve, dim3(ps_first ? (n_pad - nx) / kInner : h2 * 2), dim3(256), 0, s3, S, ld, k0, nb, nx, Xk,
+                           n_pad, w.dvec, w.invLt);
+        if (ps_first) {
+          CBA_HIP(hipEventRecord(w.ev_panel, s3));
+          CBA_HIP(hipStreamWaitEvent(s, w.ev_panel, 0));
+        }
         CBA_HIP(hipStreamWaitEvent(s3, w.ev_xn, 0));
         CBA_HIP(hipStreamWaitEvent(s3, w.ev_bulk, 0));
         v.upper = 0; v.m_off = r0; v.m_tiles = head * 2; v.n_off = r0 + head * 128; v.n_tiles = h2 * 2;
         v.tlog_tag = (k0 / kInner) * kTlKinds + kTlAA_n + 1;
-        if ((rc = launch_gemm<64, 64, 32, 32, true>(v, s3))) return rc;
+        if ((rc = launch_gemm<64, 64, 32, 32, true>(v, s3))) return rc;       // A = panel buffer / d, like (a')
       }
       CBA_HIP(hipEventRecord(w.ev_aa, s3));
       CBA_HIP(hipStreamWaitEvent(s4, w.ev_aa, 0));
-      if (n_pad > nx + h2 * 128)
-        hipLaunchKernelGGL(k_panel_solve, dim3((n_pad - nx - h2 * 128) / kInner), dim3(256), 0, s3, S, ld, k0, nb, nx + h2 * 128, Xk,
-                           n_pad, w.dvec, w.invLt);
-      CBA_HIP(hipEventRecord(w.ev_panel, s3));
-      CBA_HIP(hipStreamWaitEvent(s, w.ev_panel, 0));
+      // L in place in the next panel's columns (the 128 x 128 launches below and the back substitution read it)
+      CBA_HIP(hipStreamWaitEvent(s3, w.ev_xn, 0));
+      hipLaunchKernelGGL(k_scale_rows, dim3(kPanel), dim3(256), 0, s3, S, ld, k0, k0, e0, nx, Xk, n_pad, w.dvec);
+      v.A = u.A; v.lda = u.lda; v.a_rowdiv = nullptr;
+      if (!(mt > head && ps_first)) {
+        if (n_pad > nx + h2 * 128)
+          hipLaunchKernelGGL(k_panel_solve, dim3((n_pad - nx - h2 * 128) / kInner), dim3(256), 0, s3, S, ld, k0, nb, nx + h2 * 128, Xk,
+                             n_pad, w.dvec, w.invLt);
+        CBA_HIP(hipEventRecord(w.ev_panel, s3));
+        CBA_HIP(hipStreamWaitEvent(s, w.ev_panel, 0));
+      }
       if (mt - head > h2) {
         v.upper = 0; v.m_off = r0; v.m_tiles = head; v.n_off = r0 + (head + h2) * 128; v.n_tiles = mt - head - h2;
         v.tlog_tag = (k0 / kInner) * kTlKinds + kTlAA_rest + 1;
@@ -1316,7 +1450,7 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
       if (fused_near) {
         const int nbk = (e0 - c0) / kInner;
         hipLaunchKernelGGL(k_near_fused<false>, dim3(nbk * (nbk + 1) / 2), dim3(256), 0, s2, S, ld, k0, j0, e0, e0, Xk, n_pad, w.dvec,
-                           w.invLt, w.status);
+                           w.invLt, w.status, 0);
       } else {
         if ((rc = trsm_cols(S, ld, j0, k0, c0, e0, Xk, w, s2, kTlChainTrsm))) return rc;
         if ((rc = update_block(S, ld, j0, k0, c0, e0, c0, e0, /*upper*/ 1, Xk, s2, kTlChainUpd))) return rc;
