@@ -768,10 +768,11 @@ __device__ __forceinline__ double ldg(const double* p) {
 
 // acc (64x64 tile, 4 waves x 32x32) += sum_{k<K} A[k][m] B[k][n];  A, B K-major in global memory, or B
 // already in LDS as Bl[k][TS].  K multiple of 16.  Register-staged, three slabs in flight; ends with a barrier.
-template <bool COH_A, bool COH_B, bool B_LDS>
+// A_DIV: A[k][m] is divided by adiv[k] while staged (L = X / d taken from the panel buffer).
+template <bool COH_A, bool COH_B, bool B_LDS, bool A_DIV = false>
 __device__ __forceinline__ void tile_mma(v4f64 (&acc)[2][2], const double* __restrict__ A, int lda,
                                          const double* __restrict__ B, int ldb, int K, double* sA, double* sB,
-                                         const double* Bl) {
+                                         const double* Bl, const double* __restrict__ adiv = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
   const int r = tid >> 5, c2 = 2 * (tid & 31);
@@ -780,11 +781,13 @@ __device__ __forceinline__ void tile_mma(v4f64 (&acc)[2][2], const double* __res
   // staging registers written out as scalars, one set per slot (arrays here end up in scratch memory)
   double ra0_00, ra0_01, ra0_10, ra0_11, ra1_00, ra1_01, ra1_10, ra1_11, ra2_00, ra2_01, ra2_10, ra2_11;
   double rb0_00, rb0_01, rb0_10, rb0_11, rb1_00, rb1_01, rb1_10, rb1_11, rb2_00, rb2_01, rb2_10, rb2_11;
+  double rd0_0 = 1.0, rd0_1 = 1.0, rd1_0 = 1.0, rd1_1 = 1.0, rd2_0 = 1.0, rd2_1 = 1.0;
 #define CBA_TLOAD(slot_, k0_)                                                                    \
   {                                                                                              \
     const double* pa = A + (size_t)((k0_) + r) * lda + c2;                                       \
     ra##slot_##_00 = ldg<COH_A>(pa); ra##slot_##_01 = ldg<COH_A>(pa + 1);                        \
     ra##slot_##_10 = ldg<COH_A>(pa + (size_t)8 * lda); ra##slot_##_11 = ldg<COH_A>(pa + (size_t)8 * lda + 1); \
+    if constexpr (A_DIV) { rd##slot_##_0 = adiv[(k0_) + r]; rd##slot_##_1 = adiv[(k0_) + r + 8]; }  \
     if constexpr (!B_LDS) {                                                                      \
       const double* pb = B + (size_t)((k0_) + r) * ldb + c2;                                     \
       rb##slot_##_00 = ldg<COH_B>(pb); rb##slot_##_01 = ldg<COH_B>(pb + 1);                      \
@@ -794,6 +797,10 @@ __device__ __forceinline__ void tile_mma(v4f64 (&acc)[2][2], const double* __res
 #define CBA_TSTORE(buf_, slot_)                                                                  \
   {                                                                                              \
     double* qa = sA + (buf_) * KT * TS + r * TS + c2;                                            \
+    if constexpr (A_DIV) {                                                                       \
+      ra##slot_##_00 /= rd##slot_##_0; ra##slot_##_01 /= rd##slot_##_0;                          \
+      ra##slot_##_10 /= rd##slot_##_1; ra##slot_##_11 /= rd##slot_##_1;                          \
+    }                                                                                            \
     qa[0] = ra##slot_##_00; qa[1] = ra##slot_##_01; qa[8 * TS] = ra##slot_##_10; qa[8 * TS + 1] = ra##slot_##_11; \
     if constexpr (!B_LDS) {                                                                      \
       double* qb = sB + (buf_) * KT * TS + r * TS + c2;                                          \
@@ -1157,6 +1164,67 @@ __global__ void __launch_bounds__(256) k_next_last(const double* __restrict__ S,
   tlog_end((j3 / kInner) * kTlKinds + kTlXn);
 }
 
+// (a') of a 256-panel fused with the next panel's first diagonal factor: one workgroup per upper 64x64 tile (r, c)
+// of the next panel's diagonal block [r0, r0 + 64 nt),
+//   T_rc -= sum_{p < nb} (X[p][r] / d_p) X[p][c]        (X = panel buffer, complete after k_next_last),
+// and workgroup 0 (tile (0, 0), the next panel's first diagonal block) factors its tile right away, like
+// k_near_fused<true>: the next panel's chain starts ~20 us before the other tiles are done.
+__global__ void __launch_bounds__(256) k_aprime_fused(double* __restrict__ S, int ld, int k0, int nb, int r0, int nt,
+                                                      const double* __restrict__ Xk, int ldx, double* __restrict__ dvec,
+                                                      double* __restrict__ invLt_all, int* __restrict__ status) {
+  __shared__ double sA[2 * KT * TS];
+  __shared__ double sB[2 * KT * TS];
+  __shared__ double sV[kInner * TS];
+  __builtin_amdgcn_s_setprio(3);
+  int tile = blockIdx.x;
+  if (tile > 0) {                          // slots 8, 16, ... stay empty (see k_near_fused)
+    if ((tile & 7) == 0) return;
+    tile -= tile >> 3;
+  }
+  if (tile >= nt * (nt + 1) / 2) return;
+  tlog_begin((k0 / kInner) * kTlKinds + kTlAPrime);
+  int r = 0, t = tile;
+  for (; r < nt; ++r) { const int cnt = nt - r; if (t < cnt) break; t -= cnt; }
+  const int colr = r0 + kInner * r, colc = r0 + kInner * (r + t);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
+  v4f64 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  tile_mma<false, false, false, true>(acc, Xk + colr, ldx, Xk + colc, ldx, nb, sA, sB, nullptr, dvec + k0);
+  double* T = S + (size_t)colr * ld + colc;
+  if (tile == 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
+          sV[m * TS + n] = T[(size_t)m * ld + n] - acc[i][jj][r4];
+        }
+    __syncthreads();
+    tlog_begin((r0 / kInner) * kTlKinds + kTlDiag);
+    double (*colbuf)[kInner] = reinterpret_cast<double (*)[kInner]>(sA);
+    double (*rowbuf)[kInner] = reinterpret_cast<double (*)[kInner]>(sA + 3 * kInner);
+    ldlt_diag_body<kInner>(S, ld, r0, dvec, invLt_all, status, sV, TS, colbuf, rowbuf);
+    tlog_end((r0 / kInner) * kTlKinds + kTlDiag);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
+          T[(size_t)m * ld + n] -= acc[i][jj][r4];
+        }
+  }
+  tlog_end((k0 / kInner) * kTlKinds + kTlAPrime);
+}
+
 // L = X / d in place for the panel-internal columns [c0, e0) of block row j0 (see k_near_fused)
 __global__ void __launch_bounds__(256) k_scale_rows(double* __restrict__ S, int ld, int k0, int j0, int c0, int e0,
                                                     const double* __restrict__ Xk, int ldx, const double* __restrict__ dvec) {
@@ -1334,6 +1402,7 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
   CBA_HIP(hipStreamWaitEvent(s4, w.ev_strip, 0));
   CBA_HIP(hipEventRecord(w.ev_bulk, s));
   int kidx = 0;
+  int prefactored = -1;          // first column of a diagonal block that the previous panel's (a') launch has already factored
   for (int k0 = 0, pw = 0; k0 < n_fact; k0 += pw, ++kidx) {
     pw = panel_width_at(k0, n_fact);
     const int nb = (n_fact - k0 < pw) ? (n_fact - k0) : pw;
@@ -1359,7 +1428,8 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
     const bool chain_only = !no_chain_only && pw == kPanel && nb == kPanel && la && nx > e0;
     if (chain_only) {
       const int ncn = (nx - e0) / kInner, nblocks = kPanel / kInner;
-      hipLaunchKernelGGL(k_ldlt_diag<kInner>, dim3(1), dim3(256), 0, s2, S, ld, k0, w.dvec, w.invLt, w.status);
+      if (prefactored != k0)
+        hipLaunchKernelGGL(k_ldlt_diag<kInner>, dim3(1), dim3(256), 0, s2, S, ld, k0, w.dvec, w.invLt, w.status);
       for (int b = 0; b + 1 < nblocks; ++b) {
         const int nbk = nblocks - 1 - b;
         // from the second launch on, the look-ahead workgroups update this panel's rows in the next panel's columns,
@@ -1374,11 +1444,15 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
       hipLaunchKernelGGL(k_next_last, dim3(ncn), dim3(256), 0, s2, S, ld, k0, e0, Xk, n_pad, w.dvec, w.invLt);
       CBA_HIP(hipEventRecord(w.ev_xn, s2));
       CBA_HIP(hipStreamWaitEvent(s2, w.ev_bulk, 0));     // the previous bulk update wrote the same block
+      {
+        // (a') + the next panel's first diagonal factor in one launch
+        const int nt = head * 2, tiles = nt * (nt + 1) / 2;
+        hipLaunchKernelGGL(k_aprime_fused, dim3(tiles + (tiles + 5) / 7), dim3(256), 0, s2, S, ld, k0, nb, r0, nt, Xk, n_pad, w.dvec,
+                           w.invLt, w.status);
+        prefactored = r0;
+      }
       GemmArgs v = u;
       v.A = Xk; v.lda = n_pad; v.a_rowdiv = w.dvec + k0;
-      v.upper = 1; v.m_off = r0; v.m_tiles = head * 2; v.n_off = r0; v.n_tiles = head * 2;
-      v.tlog_tag = (k0 / kInner) * kTlKinds + kTlAPrime + 1;
-      if ((rc = launch_gemm<64, 64, 32, 32, true>(v, s2))) return rc;
       CBA_HIP(hipEventRecord(w.ev_strip, s2));
       // far: L in place inside the panel, then the fused forward substitution of the columns (a''n) needs, (a''n)
       // itself -- the next panel's chain waits for it -- and only then the rest of the forward substitution
@@ -1437,7 +1511,8 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
       const int c0 = j0 + kInner;
       const bool last = (c0 == e0);
       // ---- chain: factor the diagonal block, near solve, near update ----
-      hipLaunchKernelGGL(k_ldlt_diag<kInner>, dim3(1), dim3(256), 0, s2, S, ld, j0, w.dvec, w.invLt, w.status);
+      if (prefactored != j0)
+        hipLaunchKernelGGL(k_ldlt_diag<kInner>, dim3(1), dim3(256), 0, s2, S, ld, j0, w.dvec, w.invLt, w.status);
       const bool mid_work = !last && nx > e0;
       if (mid_work) {
         // mid: the block row's solve on the next panel's columns needs only the diagonal factor, so it runs next to
