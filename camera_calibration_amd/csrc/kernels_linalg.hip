@@ -585,6 +585,9 @@ static int wide_rows_threshold() {
 }
 static int panel_width_at(int k0, int n_fact) {
   const int thr = wide_rows_threshold();
+  // nothing overlaps the first panel's chain, and a 256-panel's chain is a third of a 512-panel's
+  static const bool narrow_first = getenv("CBA_WIDE_FIRST") == nullptr;
+  if (k0 == 0 && narrow_first) return kPanel;
   return (thr > 0 && n_fact - k0 > thr && n_fact - k0 >= kPanelWide) ? kPanelWide : kPanel;
 }
 
