@@ -629,9 +629,40 @@ __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, i
     if (e < NPAIR) { int rem = e; while (rem >= KG - i) { rem -= KG - i; ++i; } pi[t] = (unsigned short)i; pk[t] = (unsigned short)(i + rem); }
     else { pi[t] = 0; pk[t] = 0; }
   }
-  double acc[NE];
+  const CamDev cd = a.cams[cam];
+  const int cy0 = cell / cd.gw, cx0 = cell - cy0 * cd.gw;
+  {
+    double acc[NE];
 #pragma unroll
-  for (int t = 0; t < NE; ++t) acc[t] = 0.0;
+    for (int t = 0; t < NE; ++t) acc[t] = 0.0;
+    for (int idx = o_begin; idx < o_end; ++idx) {
+      const int o = order[idx];
+      const double* rec = jrec + (size_t)o * rec_doubles;
+      const double w = rec[2];
+      __builtin_amdgcn_wave_barrier();
+      for (int k = lane; k < KG; k += 64) { sJ0[wv][k] = rec[kRecHeader + k]; sJ1[wv][k] = rec[kRecHeader + KG + k]; }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+      for (int t = 0; t < NE; ++t) {
+        const int i = pi[t], k = pk[t];
+        acc[t] += w * (sJ0[wv][i] * sJ0[wv][k] + sJ1[wv][i] * sJ1[wv][k]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NE; ++t) {
+      if (lane + 64 * t >= NPAIR) continue;
+      const int i = pi[t], k = pk[t];
+      const int ci = i / PER, di = i - ci * PER, ck = k / PER, dk = k - ck * PER;
+      int row = grid_column(cd, (cx0 + (ci & 3)) + (cy0 + (ci >> 2)) * cd.gw, di);
+      int col = grid_column(cd, (cx0 + (ck & 3)) + (cy0 + (ck >> 2)) * cd.gw, dk);
+      if (row > col) { const int t2 = row; row = col; col = t2; }   // tiled order is not monotone in the patch order
+      unsafeAtomicAdd(Hdd + (size_t)row * ld + col, acc[t]);
+    }
+  }
+  if (rig_row0 < 0) return;
+  // second pass over the bucket for the rig rows: a separate loop, so that its accumulators are not live together
+  // with the K_g (K_g + 1) / 2 pair sums above (the non-central instantiation spilled 1.6 KB per lane otherwise)
   double racc[NR];
 #pragma unroll
   for (int t = 0; t < NR; ++t) racc[t] = 0.0;
@@ -641,43 +672,22 @@ __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, i
     const double w = rec[2];
     __builtin_amdgcn_wave_barrier();
     for (int k = lane; k < KG; k += 64) { sJ0[wv][k] = rec[kRecHeader + k]; sJ1[wv][k] = rec[kRecHeader + KG + k]; }
-    if (rig_row0 >= 0 && lane < 12) sRig[wv][lane] = rec[15 + lane];
+    if (lane < 12) sRig[wv][lane] = rec[15 + lane];
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
-    for (int t = 0; t < NE; ++t) {
-      const int i = pi[t], k = pk[t];
-      acc[t] += w * (sJ0[wv][i] * sJ0[wv][k] + sJ1[wv][i] * sJ1[wv][k]);
-    }
-    if (rig_row0 >= 0) {
-#pragma unroll
-      for (int t = 0; t < NR; ++t) {
-        const int e = lane + 64 * t;
-        if (e < 6 * KG) { const int r = e / KG, k = e - r * KG; racc[t] += w * (sRig[wv][r] * sJ0[wv][k] + sRig[wv][6 + r] * sJ1[wv][k]); }
-      }
-    }
-  }
-  const CamDev cd = a.cams[cam];
-  const int cy0 = cell / cd.gw, cx0 = cell - cy0 * cd.gw;
-#pragma unroll
-  for (int t = 0; t < NE; ++t) {
-    if (lane + 64 * t >= NPAIR) continue;
-    const int i = pi[t], k = pk[t];
-    const int ci = i / PER, di = i - ci * PER, ck = k / PER, dk = k - ck * PER;
-    int row = grid_column(cd, (cx0 + (ci & 3)) + (cy0 + (ci >> 2)) * cd.gw, di);
-    int col = grid_column(cd, (cx0 + (ck & 3)) + (cy0 + (ck >> 2)) * cd.gw, dk);
-    if (row > col) { const int t2 = row; row = col; col = t2; }   // tiled order is not monotone in the patch order
-    unsafeAtomicAdd(Hdd + (size_t)row * ld + col, acc[t]);
-  }
-  if (rig_row0 >= 0) {
-#pragma unroll
     for (int t = 0; t < NR; ++t) {
       const int e = lane + 64 * t;
-      if (e >= 6 * KG) continue;
-      const int r = e / KG, k = e - r * KG, ck = k / PER, dk = k - ck * PER;
-      const int col = grid_column(cd, (cx0 + (ck & 3)) + (cy0 + (ck >> 2)) * cd.gw, dk);
-      unsafeAtomicAdd(Hdd + (size_t)(rig_row0 + r) * ld + col, racc[t]);      // rig rows precede the grid columns
+      if (e < 6 * KG) { const int r = e / KG, k = e - r * KG; racc[t] += w * (sRig[wv][r] * sJ0[wv][k] + sRig[wv][6 + r] * sJ1[wv][k]); }
     }
+  }
+#pragma unroll
+  for (int t = 0; t < NR; ++t) {
+    const int e = lane + 64 * t;
+    if (e >= 6 * KG) continue;
+    const int r = e / KG, k = e - r * KG, ck = k / PER, dk = k - ck * PER;
+    const int col = grid_column(cd, (cx0 + (ck & 3)) + (cy0 + (ck >> 2)) * cd.gw, dk);
+    unsafeAtomicAdd(Hdd + (size_t)(rig_row0 + r) * ld + col, racc[t]);      // rig rows precede the grid columns
   }
 }
 int launch_accumulate_cells(const PassArgs& a, const std::vector<cba_camera>& cams, const std::vector<int>& cell_base_host,
