@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -91,11 +92,14 @@ static bool camera_ok(const cba_camera& c) {
 
 using namespace cba;
 
+// Stage timers: HIP events on the stream the kernels run on, read back only at the end of the step (a wait on the
+// host in the middle of a step would keep the next stage's launches from being queued behind the running one).
 struct KernelTimer {
-  hipEvent_t e0 = nullptr, e1 = nullptr;
+  struct Span { hipEvent_t e0 = nullptr, e1 = nullptr; };
+  std::vector<Span> spans;     // event pairs, reused from step to step
+  int used = 0;                // spans recorded since the last collect
   double seconds = 0, flops = 0, bytes = 0;
   int launches = 0;
-  bool pending = false;
 };
 
 struct cba_problem {
@@ -132,6 +136,7 @@ struct cba_problem {
   unsigned* band_mask = nullptr;         // per observation: column bands of B it touches
   // the side stream is the factorisation's far stream (idle during the Jacobian pass): the process must stay
   // within four HIP streams -- a fifth shares a hardware queue with another one and serialises the LDL^T streams
+  // (measured twice, also with GPU_MAX_HW_QUEUES=8)
   hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr;
   // control point -> rank in the engine's tiled order of the grid unknowns, per camera (see build_grid_order)
   int* gperm[kMaxCameras] = {};
@@ -143,6 +148,7 @@ struct cba_problem {
   double* Dinv = nullptr; double* dinvb = nullptr; double* W = nullptr; double* S = nullptr; bool S_owned = true; double* P = nullptr; bool P_owned = true;
   double* x = nullptr; double* scal = nullptr; double* gemv_ws = nullptr;
   unsigned long long* kmask = nullptr;   // block-sparsity of B per (column tile, K slab), rebuilt after every accumulation
+  unsigned long long* kmask_host = nullptr; size_t kmask_host_words = 0;   // pinned copy (flop count of the Schur product)
   int* status = nullptr;
   LdltWorkspace ldlt;
   KernelTimer timers[4];
@@ -153,19 +159,34 @@ namespace cba {
 
 constexpr int kSlowCap = 16384;   // most observations the side-stream launch takes over
 
-static int timer_begin(cba_problem* p, int which) {
+static int timer_begin(cba_problem* p, int which, hipStream_t s = nullptr) {
   KernelTimer& t = p->timers[which];
-  if (!t.e0) { CBA_HIP(hipEventCreate(&t.e0)); CBA_HIP(hipEventCreate(&t.e1)); }
-  CBA_HIP(hipEventRecord(t.e0, p->stream));
+  if (t.used == (int)t.spans.size()) {
+    KernelTimer::Span sp;
+    CBA_HIP(hipEventCreate(&sp.e0)); CBA_HIP(hipEventCreate(&sp.e1));
+    t.spans.push_back(sp);
+  }
+  CBA_HIP(hipEventRecord(t.spans[t.used].e0, s ? s : p->stream));
   return CBA_OK;
 }
-static int timer_end(cba_problem* p, int which, double flops, double bytes, int launches) {
+static int timer_end(cba_problem* p, int which, double flops, double bytes, int launches, hipStream_t s = nullptr) {
   KernelTimer& t = p->timers[which];
-  CBA_HIP(hipEventRecord(t.e1, p->stream));
-  CBA_HIP(hipEventSynchronize(t.e1));
-  float ms = 0;
-  CBA_HIP(hipEventElapsedTime(&ms, t.e0, t.e1));
-  t.seconds += ms * 1e-3; t.flops += flops; t.bytes += bytes; t.launches += launches;
+  CBA_HIP(hipEventRecord(t.spans[t.used].e1, s ? s : p->stream));
+  t.used += 1;
+  t.flops += flops; t.bytes += bytes; t.launches += launches;
+  return CBA_OK;
+}
+// adds the elapsed times of the spans recorded since the last call (waits for them)
+static int timers_collect(cba_problem* p) {
+  for (KernelTimer& t : p->timers) {
+    for (int i = 0; i < t.used; ++i) {
+      CBA_HIP(hipEventSynchronize(t.spans[i].e1));
+      float ms = 0;
+      CBA_HIP(hipEventElapsedTime(&ms, t.spans[i].e0, t.spans[i].e1));
+      t.seconds += ms * 1e-3;
+    }
+    t.used = 0;
+  }
   return CBA_OK;
 }
 
@@ -279,6 +300,16 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   CBA_HIP(hipStreamWaitEvent(aux, p->ev_aux0, 0));
   CBA_TRY(launch_base_project(as, p->model_mask, p->cost_ref, p->pixels, p->flags, aux));
   CBA_TRY(launch_fd_tasks(as, p->model_mask, p->tasks_per_obs, L.localize_only, p->pixels, p->flags, p->fd_out, p->fd_ok, aux));
+  // ... and the accumulation targets are cleared there too (1.3 GB for H_dd at cfg 2), underneath the main launches
+  const size_t bs = L.block_size, nb = L.n_blocks;
+  CBA_HIP(hipMemsetAsync(p->Dblk, 0, sizeof(double) * nb * bs * bs, aux));
+  CBA_HIP(hipMemsetAsync(p->bblk, 0, sizeof(double) * nb * bs, aux));
+  if (L.eliminate_points)
+    CBA_HIP(hipMemsetAsync(p->B, 0, sizeof(double) * (size_t)p->Kpad * p->n_pad, aux));
+  else if (p->Kpad > L.block_dof)     // padding rows of B (the strips below overwrite everything else, zeros included)
+    CBA_HIP(hipMemsetAsync(p->B + (size_t)L.block_dof * p->n_pad, 0, sizeof(double) * (size_t)(p->Kpad - L.block_dof) * p->n_pad, aux));
+  CBA_HIP(hipMemsetAsync(p->Hdd, 0, sizeof(double) * (size_t)p->n_pad * p->n_pad, aux));
+  CBA_HIP(hipMemsetAsync(p->bd, 0, sizeof(double) * (size_t)p->n_pad, aux));
   CBA_HIP(hipEventRecord(p->ev_aux1, aux));
   CBA_TRY(launch_base_project(a, p->model_mask, p->cost_ref, p->pixels, p->flags, p->stream));
   CBA_TRY(timer_begin(p, 3));
@@ -286,25 +317,18 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   CBA_TRY(timer_end(p, 3, 0, 0, 1));
   CBA_HIP(hipStreamWaitEvent(p->stream, p->ev_aux1, 0));
   a.skip = nullptr;
+  // (Running the assembly / accumulation of one chunk of imagesets next to the finite-difference launches of the
+  // next chunk was measured and gained nothing: the two share the same CUs and the sum stayed the same.)
   CBA_TRY(launch_assemble(a, L, p->st[w], p->tasks_per_obs, p->rec_doubles, p->pixels, p->flags, p->fd_out, p->fd_ok,
                           p->jrec, p->cells, p->stream));
-  const size_t bs = L.block_size, nb = L.n_blocks;
-  CBA_HIP(hipMemsetAsync(p->Dblk, 0, sizeof(double) * nb * bs * bs, p->stream));
-  CBA_HIP(hipMemsetAsync(p->bblk, 0, sizeof(double) * nb * bs, p->stream));
-  if (L.eliminate_points)
-    CBA_HIP(hipMemsetAsync(p->B, 0, sizeof(double) * (size_t)p->Kpad * p->n_pad, p->stream));
-  else if (p->Kpad > L.block_dof)     // padding rows of B (the strips below overwrite everything else, zeros included)
-    CBA_HIP(hipMemsetAsync(p->B + (size_t)L.block_dof * p->n_pad, 0, sizeof(double) * (size_t)(p->Kpad - L.block_dof) * p->n_pad, p->stream));
-  CBA_HIP(hipMemsetAsync(p->Hdd, 0, sizeof(double) * (size_t)p->n_pad * p->n_pad, p->stream));
-  CBA_HIP(hipMemsetAsync(p->bd, 0, sizeof(double) * (size_t)p->n_pad, p->stream));
   double t0 = now_s();
   CBA_TRY(timer_begin(p, 2));
   AccumTargets T{p->Dblk, p->bblk, p->B, p->Hdd, p->bd};
-  // Hdd/B use the padded leading dimension
   Layout Lp = L;
-  Lp.dense_dof = p->n_pad;  // row stride used by the kernel
+  Lp.dense_dof = p->n_pad;  // Hdd / B use the padded leading dimension as row stride
   if (!L.eliminate_points)   // B strips first (plain stores), the remaining terms are added on top atomically
-    CBA_TRY(launch_accumulate_strips(a, Lp, L.n_images, p->rec_doubles, p->flags, p->jrec, p->cells, p->band_mask, p->img_start, p->B, p->n_pad, p->stream));
+    CBA_TRY(launch_accumulate_strips(a, Lp, L.n_images, p->rec_doubles, p->flags, p->jrec, p->cells, p->band_mask, p->img_start, p->B,
+                                     p->n_pad, p->stream));
   CBA_TRY(launch_accumulate(a, Lp, p->rec_doubles, p->flags, p->jrec, p->cells, p->pair_tables, p->pair_counts, T, p->stream));
   if (!L.localize_only)
     CBA_TRY(launch_accumulate_cells(a, p->cams, p->cell_base_host, p->rec_doubles, p->n_pad, p->flags, p->jrec, p->cells, p->cell_base,
@@ -327,23 +351,18 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
   CBA_HIP(hipMemsetAsync(p->ldlt.status, 0, sizeof(int), p->stream));
   CBA_TRY(launch_block_inverse(p->Dblk, p->bblk, lambda, bs, nb, p->Dinv, p->dinvb, p->status, p->stream));
   CBA_TRY(launch_dinv_times_B_ld(p->Dinv, p->B, bs, nb, dd, ld, p->W, p->stream));
-  double t0 = now_s();
   CBA_TRY(timer_begin(p, 0));
   CBA_TRY(schur_gemm(p->B, p->W, p->Kpad, ld, p->Hdd, p->S, p->n_pad, ld, dd, multi ? 0 : 1, lambda, p->kmask, p->stream));
-  {
-    // algorithmic flops of this launch = K slabs actually multiplied (block-sparse loop), from the touch masks
-    const int nt = p->n_pad / 128, words = schur_mask_words(p->Kpad);
-    std::vector<unsigned long long> hm((size_t)nt * words);
-    CBA_HIP(hipMemcpyAsync(hm.data(), p->kmask, hm.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, p->stream));
-    CBA_HIP(hipStreamSynchronize(p->stream));
-    double slabs = 0;
-    for (int tm = 0; tm < nt; ++tm)
-      for (int tn = tm; tn < nt; ++tn)
-        for (int w = 0; w < words; ++w) slabs += __builtin_popcountll(hm[(size_t)tm * words + w] & hm[(size_t)tn * words + w]);
-    const double tiles = nt * (nt + 1) / 2.0;
-    CBA_TRY(timer_end(p, 0, slabs * 2.0 * 128 * 128 * 16, tiles * 2.0 * 128 * 128 * 8 + slabs * 2.0 * 16 * 128 * 8, 1));
+  CBA_TRY(timer_end(p, 0, 0, 0, 1));
+  // algorithmic flops of this launch = K slabs actually multiplied (block-sparse loop): the touch masks go to pinned
+  // host memory now and are counted after the solve (no host wait in the middle of the step)
+  const int mask_tiles = p->n_pad / 128, mask_words = schur_mask_words(p->Kpad);
+  if (p->kmask_host_words < (size_t)mask_tiles * mask_words) {
+    if (p->kmask_host) CBA_HIP(hipHostFree(p->kmask_host));
+    p->kmask_host_words = (size_t)mask_tiles * mask_words;
+    CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->kmask_host), p->kmask_host_words * sizeof(unsigned long long)));
   }
-  if (rep) rep->t_gemm += now_s() - t0;
+  CBA_HIP(hipMemcpyAsync(p->kmask_host, p->kmask, (size_t)mask_tiles * mask_words * sizeof(unsigned long long), hipMemcpyDeviceToHost, p->stream));
   // right-hand side: S[j][n_pad-1] = bd[j] - sum_k B[k][j] dinvb[k]
   CBA_TRY(launch_gemv_t_strided(p->B, L.block_dof, dd, ld, p->dinvb, p->bd, p->S + (ld - 1), ld, p->gemv_ws, p->stream));
   if (multi) {
@@ -352,19 +371,27 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
     CBA_TRY(launch_pack_upper(p->S, p->n_pad, p->P, 1, p->stream));
     CBA_TRY(launch_finish_diag(p->S, ld, dd, p->n_pad, lambda, p->stream));
   }
-  t0 = now_s();
   GemmStats gs;
   CBA_TRY(timer_begin(p, 1));
   CBA_TRY(ldlt_factor(p->S, p->n_fact, ld, p->ldlt, p->stream, &gs));
   CBA_TRY(timer_end(p, 1, gs.flops, 0, gs.launches));
   CBA_TRY(ldlt_back_solve(p->S, p->n_fact, ld, ld - 1, p->ldlt, p->x + L.block_dof, p->stream));
-  if (rep) rep->t_factor += now_s() - t0;
   // block part: x_b = D^-1 b - W x_d      (lm_optimizer.h:1366-1367)
   CBA_TRY(launch_gemv_n(p->W, L.block_dof, dd, ld, p->x + L.block_dof, p->dinvb, p->x, p->stream));
   int st[2] = {0, 0};
   CBA_HIP(hipMemcpyAsync(&st[0], p->status, sizeof(int), hipMemcpyDeviceToHost, p->stream));
   CBA_HIP(hipMemcpyAsync(&st[1], p->ldlt.status, sizeof(int), hipMemcpyDeviceToHost, p->stream));
   CBA_HIP(hipStreamSynchronize(p->stream));
+  {
+    double slabs = 0;
+    for (int tm = 0; tm < mask_tiles; ++tm)
+      for (int tn = tm; tn < mask_tiles; ++tn)
+        for (int w = 0; w < mask_words; ++w)
+          slabs += __builtin_popcountll(p->kmask_host[(size_t)tm * mask_words + w] & p->kmask_host[(size_t)tn * mask_words + w]);
+    const double tiles = mask_tiles * (mask_tiles + 1) / 2.0;
+    p->timers[0].flops += slabs * 2.0 * 128 * 128 * 16;
+    p->timers[0].bytes += tiles * 2.0 * 128 * 128 * 8 + slabs * 2.0 * 16 * 128 * 8;
+  }
   if (st[0] || st[1]) return CBA_ERR_NUMERIC;
   return CBA_OK;
 }
@@ -398,6 +425,7 @@ int cba_create(const cba_config* config, cba_problem** out) {
   for (int c = 0; c < config->n_cameras; ++c)
     if (!camera_ok(config->cameras[c])) { set_error("cba_create: bad camera"); return CBA_ERR_ARG; }
   if (config->allreduce && config->eliminate_points) { set_error("image sharding requires eliminate_points = 0"); return CBA_ERR_UNSUPPORTED; }
+  setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);   // read by the HIP runtime when it initialises (see cba_problem)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device available (the engine has no CPU fallback)"); return CBA_ERR_HIP; }
   if (config->device < 0 || config->device >= ndev) { set_error("cba_create: bad device ordinal"); return CBA_ERR_ARG; }
@@ -525,7 +553,8 @@ void cba_destroy(cba_problem* p) {
   if (p->P_owned) F(p->P);
   F(p->x); F(p->scal); F(p->status); F(p->gemv_ws); F(p->kmask);
   ldlt_workspace_free(p->ldlt);
-  for (auto& t : p->timers) { if (t.e0) hipEventDestroy(t.e0); if (t.e1) hipEventDestroy(t.e1); }
+  for (auto& t : p->timers) for (auto& sp : t.spans) { hipEventDestroy(sp.e0); hipEventDestroy(sp.e1); }
+  if (p->kmask_host) hipHostFree(p->kmask_host);
   F(p->slow_skip); F(p->slow_list); F(p->slow_count); F(p->img_start); F(p->band_mask);
   if (p->ev_aux0) hipEventDestroy(p->ev_aux0);
   if (p->ev_aux1) hipEventDestroy(p->ev_aux1);
@@ -712,6 +741,7 @@ int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double
   if (!p->have_obs || !p->have_state) { set_error("cba_step: observations/state missing"); return CBA_ERR_STATE; }
   CBA_HIP(hipSetDevice(p->device));
   std::memset(report, 0, sizeof(*report));
+  CBA_TRY(timers_collect(p));
   for (auto& t : p->timers) { t.seconds = t.flops = t.bytes = 0; t.launches = 0; }
   const Layout& L = p->L;
   const bool multi = p->cfg.allreduce != nullptr;
@@ -780,11 +810,18 @@ int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double
   report->lambda = lambda;
   p->last_lambda = lambda;
   p->have_system = true;
+  // stage times from the device-side spans (HIP events on the streams the kernels ran on)
+  CBA_TRY(timers_collect(p));
+  report->t_gemm = p->timers[0].seconds;
+  report->t_factor = p->timers[1].seconds;
+  report->t_accumulate = p->timers[2].seconds;
   return CBA_OK;
 }
 
 int cba_kernel_stats(cba_problem* p, int32_t which, double* seconds, double* flops, double* bytes, int32_t* launches) {
   if (!p || which < 0 || which > 3) { set_error("cba_kernel_stats: bad argument"); return CBA_ERR_ARG; }
+  CBA_HIP(hipSetDevice(p->device));
+  CBA_TRY(timers_collect(p));
   const KernelTimer& t = p->timers[which];
   if (seconds) *seconds = t.seconds;
   if (flops) *flops = t.flops;
