@@ -294,16 +294,16 @@ int launch_collect_slow(const uint8_t* flags, int64_t n, uint8_t* skip, int* lis
 // ------------------------------------------------------------------------------------------------
 // assemble the Jacobian record of one observation (one lane per observation)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_assemble(PassArgs a, int rig_in_state, int localize_only,
-                                                  const double* __restrict__ rig7, const double* __restrict__ camrig7,
-                                                  int tasks_per_obs, int rec_doubles, const double* __restrict__ pixels,
-                                                  uint8_t* __restrict__ flags, const double* __restrict__ fd_out,
-                                                  const uint8_t* __restrict__ fd_ok, double* __restrict__ jrec,
-                                                  int* __restrict__ cells) {
-  int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= a.n_obs) return;
+// returns true if the observation keeps its Jacobian (the caller then copies the grid part of the record)
+__device__ __forceinline__ bool assemble_header(const PassArgs& a, int64_t o, int rig_in_state, int localize_only,
+                                                     const double* __restrict__ rig7, const double* __restrict__ camrig7,
+                                                     int tasks_per_obs, int rec_doubles, const double* __restrict__ pixels,
+                                                     uint8_t* __restrict__ flags, const double* __restrict__ fd_out,
+                                                     const uint8_t* __restrict__ fd_ok, double* __restrict__ jrec,
+                                                     int* __restrict__ cells) {
+  if (o >= a.n_obs) return false;
   uint8_t f = flags[o];
-  if (!(f & 1)) return;
+  if (!(f & 1)) return false;
   int cam = a.obs_camera[o];
   const CamDev c = a.cams[cam];
   const int per = c.params_per_point;
@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(256) k_assemble(PassArgs a, int rig_in_state, 
   for (int k = 0; k < n_tasks; ++k) all_ok = all_ok && (okp[k] != 0);
   if (!all_ok) {  // residual is kept, Jacobian dropped (joint_optimization.cc:373-376, 446-448)
     flags[o] = 1;
-    return;
+    return false;
   }
   const double* fd = fd_out + 2 * (size_t)o * tasks_per_obs;
   double pwl[6];  // d pixel / d local point, 2x3
@@ -373,16 +373,36 @@ __global__ void __launch_bounds__(256) k_assemble(PassArgs a, int rig_in_state, 
         Jpt[3 * r + k] = pwl[3 * r] * R[k] + pwl[3 * r + 1] * R[3 + k] + pwl[3 * r + 2] * R[6 + k];
       }
   }
-  double* Jg = rec + kRecHeader;
-  for (int k = 0; k < Kg; ++k) {
-    Jg[k] = fd[2 * (3 + k)];
-    Jg[Kg + k] = fd[2 * (3 + k) + 1];
-  }
   double gx, gy;
   pixel_to_grid(c, px, py, gx, gy);
   cells[2 * o] = (int)floor(gx) - 1;
   cells[2 * o + 1] = (int)floor(gy) - 1;
   flags[o] = 3;
+  return !localize_only;
+}
+__global__ void __launch_bounds__(256) k_assemble(PassArgs a, int rig_in_state, int localize_only,
+                                                  const double* __restrict__ rig7, const double* __restrict__ camrig7,
+                                                  int tasks_per_obs, int rec_doubles, const double* __restrict__ pixels,
+                                                  uint8_t* __restrict__ flags, const double* __restrict__ fd_out,
+                                                  const uint8_t* __restrict__ fd_ok, double* __restrict__ jrec,
+                                                  int* __restrict__ cells) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // the header of a record is one lane's work; the 2 x K_g grid part is copied by the whole wavefront afterwards
+  // (one lane writing its own 0.8 KB record puts 64 uncoalesced streams on the memory system)
+  const bool with_jacobian = assemble_header(a, o, rig_in_state, localize_only, rig7, camrig7, tasks_per_obs, rec_doubles, pixels, flags,
+                                             fd_out, fd_ok, jrec, cells);
+  unsigned long long todo = __ballot(with_jacobian);
+  const int lane = threadIdx.x & 63;
+  const int64_t o0 = o - lane;
+  while (todo) {
+    const int i = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    const int64_t oi = o0 + i;
+    const int Kg = a.cams[a.obs_camera[oi]].params_per_point * 16;
+    const double* fd = fd_out + 2 * (size_t)oi * tasks_per_obs + 6;
+    double* Jg = jrec + (size_t)oi * rec_doubles + kRecHeader;
+    for (int k = lane; k < Kg; k += 64) { Jg[k] = fd[2 * k]; Jg[Kg + k] = fd[2 * k + 1]; }
+  }
 }
 int launch_assemble(const PassArgs& a, const Layout& L, const DevState& st, int tasks_per_obs, int rec_doubles,
                     const double* pixels, uint8_t* flags, const double* fd_out, const uint8_t* fd_ok, double* jrec,
