@@ -151,7 +151,7 @@ struct cba_problem {
   unsigned long long* kmask_host = nullptr; size_t kmask_host_words = 0;   // pinned copy (flop count of the Schur product)
   int* status = nullptr;
   LdltWorkspace ldlt;
-  KernelTimer timers[4];
+  KernelTimer timers[5];     // see cba_kernel_stats
   double last_lambda = 0;
 };
 
@@ -187,6 +187,9 @@ static int timers_collect(cba_problem* p) {
     }
     t.used = 0;
   }
+  GemmStats gs;                       // kernel-only spans of the factorisation's 128 x 128 GEMM launches
+  { int rc = ldlt_collect_spans(p->ldlt, &gs); if (rc != CBA_OK) return rc; }
+  p->timers[4].seconds += gs.seconds; p->timers[4].flops += gs.flops; p->timers[4].launches += gs.launches;
   return CBA_OK;
 }
 
@@ -819,7 +822,7 @@ int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double
 }
 
 int cba_kernel_stats(cba_problem* p, int32_t which, double* seconds, double* flops, double* bytes, int32_t* launches) {
-  if (!p || which < 0 || which > 3) { set_error("cba_kernel_stats: bad argument"); return CBA_ERR_ARG; }
+  if (!p || which < 0 || which > 4) { set_error("cba_kernel_stats: bad argument"); return CBA_ERR_ARG; }
   CBA_HIP(hipSetDevice(p->device));
   CBA_TRY(timers_collect(p));
   const KernelTimer& t = p->timers[which];

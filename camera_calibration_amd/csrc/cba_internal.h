@@ -128,8 +128,15 @@ struct LdltWorkspace {
   hipEvent_t ev_panel = nullptr, ev_strip = nullptr, ev_mid = nullptr, ev_aa = nullptr, ev_chain = nullptr, ev_bulk = nullptr,
              ev_diag = nullptr, ev_xn = nullptr;
   size_t n_alloc = 0;
+  // kernel-only timing of the 128 x 128 GEMM launches of the factorisation (bulk and row-strip updates): event pairs
+  // on the stream of each launch, read back by the caller after the step (ldlt_collect_spans)
+  struct Span { hipEvent_t e0 = nullptr, e1 = nullptr; double flops = 0; };
+  std::vector<Span> spans;
+  int spans_used = 0;
 };
 int ldlt_workspace_alloc(LdltWorkspace& w, int n);
+// adds the GEMM launches timed since the last call to `st` (waits for them)
+int ldlt_collect_spans(LdltWorkspace& w, GemmStats* st);
 void ldlt_workspace_free(LdltWorkspace& w);
 int ldlt_factor(double* S, int n, int ld, LdltWorkspace& w, hipStream_t s, GemmStats* trailing_stats);
 

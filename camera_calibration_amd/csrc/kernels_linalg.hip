@@ -1325,6 +1325,7 @@ void ldlt_workspace_free(LdltWorkspace& w) {
   if (w.ev_strip) hipEventDestroy(w.ev_strip);
   if (w.ev_mid) hipEventDestroy(w.ev_mid);
   if (w.ev_diag) hipEventDestroy(w.ev_diag);
+  for (auto& sp : w.spans) { hipEventDestroy(sp.e0); hipEventDestroy(sp.e1); }
   if (w.ev_xn) hipEventDestroy(w.ev_xn);
   if (w.ev_aa) hipEventDestroy(w.ev_aa);
   if (w.ev_chain) hipEventDestroy(w.ev_chain);
@@ -1392,6 +1393,40 @@ static int update_block(double* S, int ld, int j0, int k0, int m_begin, int m_en
   u.upper = upper; u.diag = 0;
   u.tlog_tag = (j0 / kInner) * kTlKinds + tl_kind + 1;
   return launch_gemm<64, 64, 32, 32, true>(u, s);
+}
+
+static int span_begin(LdltWorkspace& w, hipStream_t s) {
+  if (w.spans_used == (int)w.spans.size()) {
+    LdltWorkspace::Span sp;
+    CBA_HIP(hipEventCreate(&sp.e0)); CBA_HIP(hipEventCreate(&sp.e1));
+    w.spans.push_back(sp);
+  }
+  CBA_HIP(hipEventRecord(w.spans[w.spans_used].e0, s));
+  return CBA_OK;
+}
+static int span_end(LdltWorkspace& w, hipStream_t s, double flops) {
+  CBA_HIP(hipEventRecord(w.spans[w.spans_used].e1, s));
+  w.spans[w.spans_used].flops = flops;
+  w.spans_used += 1;
+  return CBA_OK;
+}
+int ldlt_collect_spans(LdltWorkspace& w, GemmStats* st) {
+  for (int i = 0; i < w.spans_used; ++i) {
+    CBA_HIP(hipEventSynchronize(w.spans[i].e1));
+    float ms = 0;
+    CBA_HIP(hipEventElapsedTime(&ms, w.spans[i].e0, w.spans[i].e1));
+    if (st) { st->seconds += ms * 1e-3; st->flops += w.spans[i].flops; st->launches += 1; }
+  }
+  w.spans_used = 0;
+  return CBA_OK;
+}
+// launch of the 128 x 128 GEMM bracketed by a timing span (only when the caller collects statistics)
+static int timed_gemm128(const GemmArgs& g, hipStream_t s, LdltWorkspace& w, bool timed, double tiles) {
+  int rc;
+  if (timed && (rc = span_begin(w, s))) return rc;
+  if ((rc = launch_gemm<128, 128, 64, 64, true>(g, s))) return rc;
+  if (timed && (rc = span_end(w, s, tiles * 2.0 * 128 * 128 * g.K))) return rc;
+  return CBA_OK;
 }
 
 int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, GemmStats* st) {
@@ -1495,12 +1530,12 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
       if (mt - head > h2) {
         v.upper = 0; v.m_off = r0; v.m_tiles = head; v.n_off = r0 + (head + h2) * 128; v.n_tiles = mt - head - h2;
         v.tlog_tag = (k0 / kInner) * kTlKinds + kTlAA_rest + 1;
-        if ((rc = launch_gemm<128, 128, 64, 64, true>(v, s3))) return rc;
+        if ((rc = timed_gemm128(v, s3, w, st != nullptr, (double)head * (mt - head - h2)))) return rc;
       }
       if (mt > head) {
         u.upper = 1; u.m_off = r0 + head * 128; u.m_tiles = mt - head; u.n_off = r0 + head * 128; u.n_tiles = mt - head;
         u.tlog_tag = (k0 / kInner) * kTlKinds + kTlBulk + 1;
-        if ((rc = launch_gemm<128, 128, 64, 64, true>(u, s))) return rc;
+        if ((rc = timed_gemm128(u, s, w, st != nullptr, (double)(mt - head) * (mt - head + 1) / 2))) return rc;
       }
       CBA_HIP(hipEventRecord(w.ev_bulk, s));
       if (st) {
@@ -1587,7 +1622,7 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
           if (mt - head > h2) {
             v.m_tiles = head; v.n_off = r0 + (head + h2) * 128; v.n_tiles = mt - head - h2;
             v.tlog_tag = (k0 / kInner) * kTlKinds + kTlAA_rest + 1;
-            if ((rc = launch_gemm<128, 128, 64, 64, true>(v, s3))) return rc;
+            if ((rc = timed_gemm128(v, s3, w, st != nullptr, (double)head * (mt - head - h2)))) return rc;
           }
         } else {
           CBA_HIP(hipEventRecord(w.ev_aa, s3));
@@ -1597,7 +1632,7 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
         if (mt > head) {
           u.upper = 1; u.m_off = r0 + head * 128; u.m_tiles = mt - head; u.n_off = r0 + head * 128; u.n_tiles = mt - head;
           u.tlog_tag = (k0 / kInner) * kTlKinds + kTlBulk + 1;
-          if ((rc = launch_gemm<128, 128, 64, 64, true>(u, s))) return rc;
+          if ((rc = timed_gemm128(u, s, w, st != nullptr, (double)(mt - head) * (mt - head + 1) / 2))) return rc;
         }
         CBA_HIP(hipEventRecord(w.ev_bulk, s));
       } else {

@@ -194,8 +194,9 @@ int32_t cba_dense_dof(const cba_problem* p);
 int32_t cba_jacobian_record_doubles(const cba_problem* p);
 int64_t cba_reduce_buffer_doubles(const cba_config* config);
 /* device-side event timing of the dominant kernels of the last cba_step (bench roofline):
- * which: 0 = Schur GEMM, 1 = trailing-update GEMMs of the factorisation, 2 = accumulation,
- * 3 = finite-difference projection kernel. Returns seconds (<0 on error) and flop/byte counts. */
+ * which: 0 = Schur GEMM launch, 1 = the whole factorisation (flops = its trailing updates), 2 = accumulation,
+ * 3 = finite-difference projection kernel, 4 = the 128x128 GEMM launches inside the factorisation, kernel time only
+ * (events on the stream of each launch). Returns seconds and flop/byte counts. */
 int cba_kernel_stats(cba_problem* p, int32_t which, double* seconds, double* flops, double* bytes,
                      int32_t* launches);
 
