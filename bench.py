@@ -108,6 +108,10 @@ def main():
         print("bench.py: no GPU available (the engine has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local_rank)
+    # the engine's streams first, before anything launches a kernel in this process (see cba_prepare_device)
+    from camera_calibration_amd import engine as eng
+    eng.load()
+    eng.prepare(local_rank)
     use_dist = world > 1 or args.force_allreduce
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -116,11 +120,9 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    from camera_calibration_amd import engine as eng
     from camera_calibration_amd import synthetic as syn
     from camera_calibration_amd.distributed import make_allreduce
 
-    eng.load()
     n_default = syn.BASELINE_CONFIGS[args.config][8]
     n_img = args.imagesets or n_default
     proj = lambda cam, grid, pts: eng.project(cam, grid, pts, device=local_rank)

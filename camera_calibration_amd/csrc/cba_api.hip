@@ -30,6 +30,7 @@ int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWor
 int launch_finish_diag(double* S, int ld, int n_real, int n_pad, double lambda, hipStream_t s);
 int launch_diag_sum(const double* Dblk, int bs, int nb, const double* Hdd, int ld, int dd, double* out, hipStream_t s);
 int make_main_stream(hipStream_t* s);
+int prepare_device_streams();
 int64_t packed_upper_doubles(int n_pad);
 int launch_pack_upper(const double* S, int n_pad, double* P, int unpack, hipStream_t s);
 
@@ -420,6 +421,15 @@ int64_t cba_reduce_buffer_doubles(const cba_config* config) {
   return packed_upper_doubles(n_pad);
 }
 
+int cba_prepare_device(int32_t device) {
+  setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);   // read by the HIP runtime when it initialises (see cba_problem)
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device available (the engine has no CPU fallback)"); return CBA_ERR_HIP; }
+  if (device < 0 || device >= ndev) { set_error("cba_prepare_device: bad device ordinal"); return CBA_ERR_ARG; }
+  CBA_HIP(hipSetDevice(device));
+  return prepare_device_streams();
+}
+
 int cba_create(const cba_config* config, cba_problem** out) {
   if (!config || !out || !config->cameras || config->n_cameras < 1 || config->n_cameras > kMaxCameras ||
       config->n_images < 0 || config->n_points < 0 || !(config->numerical_diff_delta > 0)) {
@@ -561,7 +571,6 @@ void cba_destroy(cba_problem* p) {
   F(p->slow_skip); F(p->slow_list); F(p->slow_count); F(p->img_start); F(p->band_mask);
   if (p->ev_aux0) hipEventDestroy(p->ev_aux0);
   if (p->ev_aux1) hipEventDestroy(p->ev_aux1);
-  if (p->stream) hipStreamDestroy(p->stream);
   delete p;
 }
 
@@ -1056,7 +1065,6 @@ int cba_fit_grid_to_directions(const cba_camera* camera, double* grid, int64_t n
   CBA_TRY(make_main_stream(&s));
   auto cleanup = [&]() {
     ldlt_workspace_free(w);
-    if (s) hipStreamDestroy(s);
     void* ptrs[] = {g[0], g[1], tang, gp, dirs, cost_ref, cost_test, rec, keys, order, count, start, fill, H, b, S, x, partials, red8, scal, status};
     for (void* q : ptrs) hipFree(q);
   };

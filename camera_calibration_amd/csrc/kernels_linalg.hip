@@ -16,6 +16,9 @@
 #include <cstdlib>
 
 #include "cba_internal.h"
+#include <algorithm>
+#include <map>
+#include <mutex>
 
 namespace cba {
 
@@ -172,26 +175,29 @@ __device__ __forceinline__ void tlog_end(int) {}
 enum { kTlDiag = 0, kTlNear, kTlScale, kTlMidTrsm, kTlMidUpd, kTlChainTrsm, kTlChainUpd, kTlAPrime, kTlPanelSolve,
        kTlAA_n, kTlAA_rest, kTlBulk, kTlXn, kTlKinds = 16 };
 
+// slot -> position in the launch's tile enumeration (>= total_tiles: no tile)
+__device__ __forceinline__ long long gemm_slot_tile(const GemmArgs& g, long long b) {
+  const long long q = b >> 3;
+  const long long cq = q / g.chunk;
+  return (cq * 8 + (b & 7)) * g.chunk + (q - cq * g.chunk);
+}
+
+// One output tile.  `b` is the linear slot of the tile (= blockIdx.x: workgroup b runs on XCD b % 8, observed dispatch
+// order; only speed depends on it).  Returns false when the slot is past the last tile.
 template <int TM, int TN, int WM, int WN, bool SUB>
-__global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
+__device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
   constexpr int LDA_S = TM + 16, LDB_S = TN + 16;
   __shared__ double sA[2][KT * LDA_S];
   __shared__ double sB[2][KT * LDB_S];
   constexpr int WAVES_N = TN / WN;
   constexpr int MI = WM / 16, NJ = WN / 16;
-  if constexpr (TM < 128) __builtin_amdgcn_s_setprio(2);   // panel-sized products are on the critical path
 
-  // ---- tile decode (XCD-aware permutation of the linear block index) ----
-  // Workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on it).  Tiles are dealt
-  // to the XCDs in chunks of 64 consecutive tiles of the row-major upper-triangle order: the 64
+  // ---- tile decode (XCD-aware permutation of the linear slot) ----
+  // Tiles are dealt to the XCDs in chunks of 64 consecutive tiles of the row-major upper-triangle order: the 64
   // workgroup slots of an XCD share one A panel (and neighbouring B panels) in its L2, and chunks from
   // all parts of the matrix land on every XCD, which balances the block-sparse K loops.
-  long long b = blockIdx.x;
-  const long long q = b >> 3;
-  const long long cq = q / g.chunk;
-  long long t = (cq * 8 + (b & 7)) * g.chunk + (q - cq * g.chunk);
-  if (t >= g.total_tiles) return;
-  tlog_begin(g.tlog_tag - 1);
+  const long long t = gemm_slot_tile(g, b);
+  if (t >= g.total_tiles) return false;
   int tm, tn;
   if (g.strips) {
     // Square upper-triangular launch, dense: tiles are enumerated strip by strip (kStripW tile columns), row by
@@ -289,15 +295,34 @@ __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
     // one vmcnt(0) + barrier per stage.
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* gbl_ptr;
-#define CBA_DMA_STAGE(buf_, k0_)                                                                                   \
+    // Four separate LDS arrays (not one array indexed by the stage parity): the compiler's wait-count insertion
+    // only lets an LDS read run ahead of an LDS-DMA in flight when it can prove that the two touch different LDS
+    // variables; with sA[buf] / sA[buf ^ 1] it put an s_waitcnt vmcnt(0) between the DMA issue and the first
+    // ds_read of EVERY stage, i.e. the next slab was never in flight during the MFMAs of the current one.
+    __shared__ double dA0[KT * LDA_S], dA1[KT * LDA_S], dB0[KT * LDB_S], dB1[KT * LDB_S];
+#define CBA_DMA_STAGE(SA_, SB_, k0_)                                                                               \
   {                                                                                                                \
     _Pragma("unroll") for (int j = 0; j < KT / 4; ++j) {                                                           \
       const int row = wv * (KT / 4) + j;                                                                           \
       __builtin_amdgcn_global_load_lds((gbl_ptr)(Ag + (size_t)((k0_) + row) * g.lda + 2 * lane),                   \
-                                       (lds_ptr)&sA[(buf_)][row * LDA_S], 16, 0, 0);                               \
+                                       (lds_ptr)&SA_[row * LDA_S], 16, 0, 0);                                      \
       __builtin_amdgcn_global_load_lds((gbl_ptr)(Bg + (size_t)((k0_) + row) * g.ldb + 2 * lane),                   \
-                                       (lds_ptr)&sB[(buf_)][row * LDB_S], 16, 0, 0);                               \
+                                       (lds_ptr)&SB_[row * LDB_S], 16, 0, 0);                                      \
     }                                                                                                              \
+  }
+#define CBA_MMA_STAGE(SA_, SB_)                                                                                    \
+  {                                                                                                                \
+    _Pragma("unroll") for (int kk = 0; kk < KT; kk += 4) {                                                         \
+      double af[MI], bf[NJ];                                                                                       \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i) af[i] = SA_[(kk + lk) * LDA_S + wm0 + i * 16 + li];           \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j) bf[j] = SB_[(kk + lk) * LDB_S + wn0 + j * 16 + li];           \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                               \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                             \
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);                      \
+    }                                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                               \
+    __syncthreads();                                                                                               \
   }
     // Block-sparse K loop: `kmask` (optional) holds, per 128-column tile, one bit per 16-row K slab that
     // contains any non-zero.  A slab contributes to tile (tm, tn) only if both column tiles touch it --
@@ -319,34 +344,22 @@ __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
       return nk;
     };
     int kb = next_slab(-1);
-    if (kb < nk) CBA_DMA_STAGE(0, kb * KT);
+    if (kb < nk) CBA_DMA_STAGE(dA0, dB0, kb * KT);
     preload_c();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int buf = 0;
     while (kb < nk) {
-      const int nxt = next_slab(kb);
-      if (nxt < nk) CBA_DMA_STAGE(buf ^ 1, nxt * KT);
-      const double* a_s = &sA[buf][0];
-      const double* b_s = &sB[buf][0];
-#pragma unroll
-      for (int kk = 0; kk < KT; kk += 4) {
-        double af[MI], bf[NJ];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) af[i] = a_s[(kk + lk) * LDA_S + wm0 + i * 16 + li];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) bf[j] = b_s[(kk + lk) * LDB_S + wn0 + j * 16 + li];
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      int nxt = next_slab(kb);                       // slab kb is in dA0 / dB0
+      if (nxt < nk) CBA_DMA_STAGE(dA1, dB1, nxt * KT);
+      CBA_MMA_STAGE(dA0, dB0);
       kb = nxt;
-      buf ^= 1;
+      if (kb >= nk) break;
+      nxt = next_slab(kb);                           // slab kb is in dA1 / dB1
+      if (nxt < nk) CBA_DMA_STAGE(dA0, dB0, nxt * KT);
+      CBA_MMA_STAGE(dA1, dB1);
+      kb = nxt;
     }
+#undef CBA_MMA_STAGE
 #undef CBA_DMA_STAGE
   } else {
     // small-tile variant (panel operations): register-staged, with kDepth slabs in flight.  These launches are a
@@ -458,6 +471,21 @@ __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
         g.C[(size_t)m * g.ldc + n] = v;
         if (g.C2) g.C2[(size_t)m * g.ldc2 + n] = v / g.rowscale_inv[m];
       }
+  return true;
+}
+
+// One tile per workgroup.  Two alternatives to the CU mask on the main stream were measured and dropped (the mask costs
+// the bulk update 13-17 %: the same launch takes 1402 us on the masked stream and 1161 us on an unmasked one,
+// tools/bench_linalg.hip -DCBA_TLOG): (a) drawing the slot from per-XCD counters with an oversubscribed grid on the
+// masked stream changed nothing, so the loss is not an end-of-launch imbalance between shader engines; (b) persistent
+// workgroups on an unmasked stream that exit when they find themselves on a CU reserved for the pivot chain ran the
+// bulk update at the unmasked speed, but two resident workgroups per CU left no LDS for the far stream's launches and
+// the look-ahead collapsed (factorisation 18.0 -> 18.6 ms).
+template <int TM, int TN, int WM, int WN, bool SUB>
+__global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
+  if constexpr (TM < 128) __builtin_amdgcn_s_setprio(2);   // panel-sized products are on the critical path
+  tlog_begin(g.tlog_tag - 1);
+  gemm_tile<TM, TN, WM, WN, SUB>(g, blockIdx.x);
   tlog_end(g.tlog_tag - 1);
 }
 
@@ -1257,14 +1285,55 @@ void panel_cu_mask(uint32_t* mask8, bool panel) {
     if (is_panel == panel) mask8[bit >> 5] |= (1u << (bit & 31));
   }
 }
-int make_main_stream(hipStream_t* s) {
-  if (panel_cu_count() > 0) {
-    uint32_t mask[8];
-    panel_cu_mask(mask, /*panel=*/false);
-    CBA_HIP(hipExtStreamCreateWithCUMask(s, 8, mask));
-  } else {
-    CBA_HIP(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+// The engine's four HIP streams per device are created ONCE, as early as possible in the life of the process, and
+// never destroyed.  Measured on MI355X / ROCm 7.2 (tools/stream_mask_test.hip): the same GEMM launch runs at
+// 60 TFLOP/s on a stream that was created before the process launched its first kernel and at 52-53 TFLOP/s on a
+// stream created afterwards (and that late stream also slows the older ones down).  cba_prepare_device() is the
+// hook for hosts to call first thing; cba_create calls it as a fallback.
+//   main  : bulk work; CU mask without the CUs reserved for the pivot chain
+//   chain : the latency-bound pivot chain of the factorisation.  It ran ~1.5x slower when its small kernels shared
+//           CUs with the bulk GEMM, so it gets CUs of its own: CBA_PANEL_CUS compute units (default 8 = one per
+//           XCD; mask bits are interleaved over the XCDs)
+//   mid   : look-ahead work of the wide panels, on the same reserved CUs
+//   far   : wide launches next to the bulk update (and the Jacobian pass' stragglers); same mask as main
+struct DeviceStreams { hipStream_t main = nullptr, chain = nullptr, mid = nullptr, far = nullptr; };
+static std::mutex g_streams_mutex;
+static std::map<int, DeviceStreams> g_streams;
+static int device_streams(DeviceStreams* out) {
+  int dev = 0;
+  CBA_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_streams_mutex);
+  auto it = g_streams.find(dev);
+  if (it == g_streams.end()) {
+    DeviceStreams d;
+    uint32_t panel[8], rest[8];
+    panel_cu_mask(panel, /*panel=*/true);
+    panel_cu_mask(rest, /*panel=*/false);
+    if (panel_cu_count() > 0) {
+      CBA_HIP(hipExtStreamCreateWithCUMask(&d.main, 8, rest));
+      CBA_HIP(hipExtStreamCreateWithCUMask(&d.chain, 8, panel));
+      CBA_HIP(hipExtStreamCreateWithCUMask(&d.mid, 8, panel));
+      CBA_HIP(hipExtStreamCreateWithCUMask(&d.far, 8, rest));
+    } else {
+      int lo = 0, hi = 0;
+      CBA_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      CBA_HIP(hipStreamCreateWithFlags(&d.main, hipStreamNonBlocking));
+      CBA_HIP(hipStreamCreateWithPriority(&d.chain, hipStreamNonBlocking, hi));
+      CBA_HIP(hipStreamCreateWithFlags(&d.mid, hipStreamNonBlocking));
+      CBA_HIP(hipStreamCreateWithFlags(&d.far, hipStreamNonBlocking));
+    }
+    it = g_streams.emplace(dev, d).first;
   }
+  *out = it->second;
+  return CBA_OK;
+}
+int prepare_device_streams() { DeviceStreams d; return device_streams(&d); }
+
+int make_main_stream(hipStream_t* s) {
+  DeviceStreams d;
+  int rc = device_streams(&d);
+  if (rc != CBA_OK) return rc;
+  *s = d.main;
   return CBA_OK;
 }
 
@@ -1274,33 +1343,11 @@ int ldlt_workspace_alloc(LdltWorkspace& w, int n_pad) {
   CBA_HIP(hipMalloc(&w.invLt, sizeof(double) * (size_t)(n_pad / kInner) * kInner * kInner));
   CBA_HIP(hipMalloc(&w.dvec, sizeof(double) * (size_t)n_pad));
   CBA_HIP(hipMalloc(&w.status, sizeof(int)));
-  // The panel chain is latency-bound and ran ~1.5x slower when its small kernels shared CUs with the
-  // bulk GEMM, so it gets CUs of its own: CBA_PANEL_CUS compute units (default 8 = one per XCD; mask
-  // bits are interleaved over the XCDs), taken out of the main stream's mask by make_main_stream().
   {
-    uint32_t mask[8];
-    panel_cu_mask(mask, /*panel=*/true);
-    if (panel_cu_count() > 0) {
-      CBA_HIP(hipExtStreamCreateWithCUMask(&w.panel_stream, 8, mask));
-    } else {
-      int lo = 0, hi = 0;
-      CBA_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      CBA_HIP(hipStreamCreateWithPriority(&w.panel_stream, hipStreamNonBlocking, hi));
-    }
-  }
-  {
-    uint32_t mask[8];
-    panel_cu_mask(mask, /*panel=*/true);
-    if (panel_cu_count() > 0) CBA_HIP(hipExtStreamCreateWithCUMask(&w.mid_stream, 8, mask));
-    else CBA_HIP(hipStreamCreateWithFlags(&w.mid_stream, hipStreamNonBlocking));
-  }
-  // the far stream carries wide launches; like the main stream it stays off the chain's CUs
-  if (panel_cu_count() > 0) {
-    uint32_t mask[8];
-    panel_cu_mask(mask, /*panel=*/false);
-    CBA_HIP(hipExtStreamCreateWithCUMask(&w.far_stream, 8, mask));
-  } else {
-    CBA_HIP(hipStreamCreateWithFlags(&w.far_stream, hipStreamNonBlocking));
+    DeviceStreams d;
+    int rc = device_streams(&d);
+    if (rc != CBA_OK) return rc;
+    w.panel_stream = d.chain; w.mid_stream = d.mid; w.far_stream = d.far;     // shared, not owned
   }
   CBA_HIP(hipEventCreateWithFlags(&w.ev_panel, hipEventDisableTiming | hipEventDisableSystemFence));
   CBA_HIP(hipEventCreateWithFlags(&w.ev_strip, hipEventDisableTiming | hipEventDisableSystemFence));
@@ -1318,9 +1365,6 @@ void ldlt_workspace_free(LdltWorkspace& w) {
   if (w.invLt) hipFree(w.invLt);
   if (w.dvec) hipFree(w.dvec);
   if (w.status) hipFree(w.status);
-  if (w.panel_stream) hipStreamDestroy(w.panel_stream);
-  if (w.far_stream) hipStreamDestroy(w.far_stream);
-  if (w.mid_stream) hipStreamDestroy(w.mid_stream);
   if (w.ev_panel) hipEventDestroy(w.ev_panel);
   if (w.ev_strip) hipEventDestroy(w.ev_strip);
   if (w.ev_mid) hipEventDestroy(w.ev_mid);

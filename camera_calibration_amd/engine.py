@@ -62,7 +62,7 @@ EXPORTED_SYMBOLS = [
     "cba_get_state", "cba_get_last_projection", "cba_step", "cba_cost", "cba_project", "cba_unproject",
     "cba_schur_solve", "cba_debug_dump", "cba_debug_accumulate", "cba_debug_solve", "cba_debug_apply_update",
     "cba_total_dof", "cba_dense_dof", "cba_jacobian_record_doubles", "cba_reduce_buffer_doubles",
-    "cba_kernel_stats", "cba_fit_grid_to_directions",
+    "cba_kernel_stats", "cba_fit_grid_to_directions", "cba_prepare_device",
 ]
 
 DUMP_COST_VECTOR, DUMP_PIXELS, DUMP_FLAGS, DUMP_JACOBIANS = 1, 2, 3, 4
@@ -119,8 +119,16 @@ def load() -> C.CDLL:
     L.cba_reduce_buffer_doubles.argtypes = [C.POINTER(CbaConfig)]
     L.cba_reduce_buffer_doubles.restype = C.c_int64
     L.cba_kernel_stats.argtypes = [vp, C.c_int32, dp, dp, dp, C.POINTER(C.c_int32)]
+    L.cba_prepare_device.argtypes = [C.c_int32]
     _lib = L
     return L
+
+
+def prepare(device: int = 0) -> None:
+    """Creates the engine's HIP streams for `device` now (cba_prepare_device).  Call it before the process launches
+    its first GPU kernel: streams created that early run the dominant GEMM ~15 % faster than streams created later
+    (measured on MI355X / ROCm 7.2, tools/stream_mask_test.hip).  Optional -- cba_create does it on demand."""
+    _check(load().cba_prepare_device(int(device)), "cba_prepare_device")
 
 
 def _check(rc: int, what: str) -> None:

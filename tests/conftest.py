@@ -27,3 +27,11 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionstart(session):
+    # On the GPU box: create the engine's HIP streams before any test launches a kernel (cba_prepare_device) --
+    # the same order of events as in bench.py, so that the tests exercise the path that is measured.
+    if _has_gpu():
+        from camera_calibration_amd import engine
+        engine.prepare(0)

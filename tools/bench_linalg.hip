@@ -45,6 +45,37 @@ int main(int argc, char** argv) {
     double nt = n / 128.0, tiles = nt * (nt + 1) / 2;
     printf("trailing-shaped gemm mode=%d n=%d K=%d: %.3f ms  %.2f TFLOP/s\n", mode, n, Kt, ms, tiles * 2.0 * 128 * 128 * Kt / ms / 1e9);
   }
+  // the same with distinct operand panels (what the factorisation's updates look like: A = L in place, B = panel buffer)
+  for (int nn : {n, 10880, 8832, 6144}) for (int Kt : {256, 512}) {
+    if (nn > n || K < 1504 + Kt) continue;
+    GemmArgs u{};
+    u.A = A; u.lda = n; u.B = A + (size_t)1504 * n; u.ldb = n; u.K = Kt; u.C = S; u.ldc = n; u.Cin = S; u.ldcin = n;
+    u.m_off = 0; u.m_tiles = nn / 128; u.n_off = 0; u.n_tiles = nn / 128; u.upper = 1; u.diag = 0;
+    launch_gemm<128, 128, 64, 64, true>(u, nullptr);
+    hipEventRecord(e0);
+    for (int r = 0; r < 5; ++r) launch_gemm<128, 128, 64, 64, true>(u, nullptr);
+    hipEventRecord(e1);
+    float ms = timeit(e0, e1) / 5;
+    double nt = nn / 128, tiles = nt * (nt + 1) / 2;
+    printf("distinct-operand gemm n=%d K=%d: %.3f ms  %.2f TFLOP/s\n", nn, Kt, ms, tiles * 2.0 * 128 * 128 * Kt / ms / 1e9);
+  }
+  {  // ... and on the engine's main stream (CU mask without the CUs reserved for the pivot chain)
+    hipStream_t msk; make_main_stream(&msk);
+    for (int nn : {10880, 6144}) for (int Kt : {256, 512}) {
+      if (nn > n || K < 1504 + Kt) continue;
+      GemmArgs u{};
+      u.A = A; u.lda = n; u.B = A + (size_t)1504 * n; u.ldb = n; u.K = Kt; u.C = S; u.ldc = n; u.Cin = S; u.ldcin = n;
+      u.m_off = 0; u.m_tiles = nn / 128; u.n_off = 0; u.n_tiles = nn / 128; u.upper = 1; u.diag = 0;
+      launch_gemm<128, 128, 64, 64, true>(u, msk);
+      hipEventRecord(e0, msk);
+      for (int r = 0; r < 5; ++r) launch_gemm<128, 128, 64, 64, true>(u, msk);
+      hipEventRecord(e1, msk);
+      float ms = timeit(e0, e1) / 5;
+      double nt = nn / 128, tiles = nt * (nt + 1) / 2;
+      printf("distinct-operand gemm on the masked main stream n=%d K=%d: %.3f ms  %.2f TFLOP/s\n", nn, Kt, ms, tiles * 2.0 * 128 * 128 * Kt / ms / 1e9);
+    }
+
+  }
   LdltWorkspace w; ldlt_workspace_alloc(w, n);
   hipMemset(w.status, 0, 4);
   // diag kernel alone, 200 launches on the first block of a scratch copy
