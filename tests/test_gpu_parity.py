@@ -379,3 +379,25 @@ def test_baseline_config1_end_to_end_against_oracle():
     np.testing.assert_allclose(st.points, st_ref.points, atol=1e-6)
     np.testing.assert_allclose(st.grids[0], st_ref.grids[0], atol=1e-6)
     e.close()
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dd", [63, 64, 65, 127, 255, 256, 257, 320, 511, 512, 513, 639, 767, 769, 1023, 1025, 1279, 1281,
+                                1536, 1793, 2049, 2305, 2561])
+def test_schur_solve_sizes_around_the_panel_boundaries(dd):
+    """The blocked LDL^T switches code paths at multiples of 64 / 128 / 256 (last partial panel, width of the look-ahead,
+    whole 256-panels on the chain stream): every size class against a dense solve."""
+    bs, nb = 6, 5
+    rng = np.random.default_rng(1000 + dd)
+    n = bs * nb + dd
+    J = rng.normal(size=(n + 50, n))
+    H = J.T @ J / n + 1e-2 * np.eye(n)
+    for b in range(nb):
+        for b2 in range(nb):
+            if b != b2:
+                H[b * bs:(b + 1) * bs, b2 * bs:(b2 + 1) * bs] = 0
+    rhs = rng.normal(size=n)
+    bD = np.array([np.triu(H[k * bs:(k + 1) * bs, k * bs:(k + 1) * bs]) for k in range(nb)])
+    x = eng.schur_solve(bD, H[:bs * nb, bs * nb:], np.triu(H[bs * nb:, bs * nb:]), rhs[:bs * nb], rhs[bs * nb:])
+    x_ref = np.linalg.solve(H, rhs)
+    np.testing.assert_allclose(x, x_ref, rtol=1e-7, atol=1e-9 * np.abs(x_ref).max())
+
