@@ -1560,15 +1560,24 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
       CBA_HIP(hipStreamWaitEvent(s3, w.ev_xn, 0));
       hipLaunchKernelGGL(k_scale_rows, dim3(kPanel), dim3(256), 0, s3, S, ld, k0, k0, e0, nx, Xk, n_pad, w.dvec);
       v.A = u.A; v.lda = u.lda; v.a_rowdiv = nullptr;
+      // Near the end of the matrix a launch has fewer 128 x 128 tiles than the chip has CUs and its duration is one
+      // tile's K loop (16 slabs, ~30-60 us): 64 x 64 tiles are four times as many and a quarter as long.
+      constexpr long long kFewTiles = 200;
       if (mt - head > h2) {
         v.upper = 0; v.m_off = r0; v.m_tiles = head; v.n_off = r0 + (head + h2) * 128; v.n_tiles = mt - head - h2;
         v.tlog_tag = (k0 / kInner) * kTlKinds + kTlAA_rest + 1;
-        if ((rc = timed_gemm128(v, s3, w, st != nullptr, (double)head * (mt - head - h2)))) return rc;
+        if ((long long)v.m_tiles * v.n_tiles < kFewTiles) {
+          v.m_tiles *= 2; v.n_tiles *= 2;
+          if ((rc = launch_gemm<64, 64, 32, 32, true>(v, s3))) return rc;
+        } else if ((rc = timed_gemm128(v, s3, w, st != nullptr, (double)head * (mt - head - h2)))) return rc;
       }
       if (mt > head) {
         u.upper = 1; u.m_off = r0 + head * 128; u.m_tiles = mt - head; u.n_off = r0 + head * 128; u.n_tiles = mt - head;
         u.tlog_tag = (k0 / kInner) * kTlKinds + kTlBulk + 1;
-        if ((rc = timed_gemm128(u, s, w, st != nullptr, (double)(mt - head) * (mt - head + 1) / 2))) return rc;
+        if ((long long)u.m_tiles * (u.m_tiles + 1) / 2 < kFewTiles) {
+          u.m_tiles *= 2; u.n_tiles *= 2;
+          if ((rc = launch_gemm<64, 64, 32, 32, true>(u, s))) return rc;
+        } else if ((rc = timed_gemm128(u, s, w, st != nullptr, (double)(mt - head) * (mt - head + 1) / 2))) return rc;
       }
       CBA_HIP(hipEventRecord(w.ev_bulk, s));
       if (st) {
