@@ -199,9 +199,10 @@ __device__ bool unproject_jac(const CamDev& c, const Subst& s, double x, double 
     inv = 1.0 / sqrt(sq);
     inv3 = inv * inv * inv;
   } else {
-    // the generated non-central code normalises with sqrtf (noncentral_generic_jacobians.cc:110,158)
+    // the generated non-central code normalises with `1 / sqrtf(term75)` (noncentral_generic_jacobians.cc:110): square
+    // root AND division in fp32 (int / float); :158-159 cubes the fp32 root in fp64
     float sf = __fsqrt_rn((float)sq);
-    inv = 1.0 / (double)sf;
+    inv = (double)__fdiv_rn(1.0f, sf);
     double t = (double)sf;
     inv3 = 1.0 / (t * t * t);
   }

@@ -242,7 +242,9 @@ int orc_unproject_with_jacobian(const orc_camera* cam, const double* grid, doubl
     double invb = 1. / sqrt(sq);        /* :411-412 */
     inv3 = invb * invb * invb;
   } else {
-    inv = 1 / (double)sqrtf((float)sq); /* noncentral_generic_jacobians.cc:110 (float sqrt) */
+    /* noncentral_generic_jacobians.cc:110 is `1 / sqrtf(term75)`: int / float, i.e. the DIVISION is rounded to fp32 as
+     * well (found by running the reference's code, oracle/_ref, tests/test_oracle_vs_ref.py) */
+    inv = (double)(1.0f / sqrtf((float)sq));
     double tmp = (double)sqrtf((float)sq); /* :158-159 */
     inv3 = 1 / (tmp * tmp * tmp);
   }
