@@ -14,7 +14,32 @@
 #include <string.h>
 #include <time.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 #define MAXK 80
+
+/* Number of host threads the oracle may use (default 1: the reference path is single-threaded).
+ * Threads only split work whose per-entry arithmetic and summation order do not depend on the split: results are
+ * bit-identical for every thread count (tests/test_oracle_golden.py::test_threaded_oracle_is_bit_identical). */
+static int g_threads = 1;
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n <= 0) n = omp_get_num_procs();
+  g_threads = n < 1 ? 1 : n;
+#else
+  (void)n; g_threads = 1;
+#endif
+}
+int orc_get_num_threads(void) { return g_threads; }
+int orc_hardware_threads(void) {
+#ifdef _OPENMP
+  return omp_get_num_procs();
+#else
+  return 1;
+#endif
+}
 
 /* ------------------------------------------------------------------------------------------
  * small vector helpers
@@ -724,10 +749,20 @@ static int projection_jacobian_wrt_intrinsics(const orc_camera* cam, double* gri
   return 1;
 }
 
-/* returns cost (>=0) or -1 for an invalid residual; fills rec if non-NULL; accumulates into sys if non-NULL */
+/* what one observation adds to the normal equations (K = 0: nothing) */
+typedef struct {
+  int K;
+  double res[2], weight;
+  int idx[6 + 6 + 3 + MAXK];
+  double J[2 * (6 + 6 + 3 + MAXK)];
+} acc_item;
+
+/* returns cost (>=0) or -1 for an invalid residual; fills rec if non-NULL; if want_acc, `item` receives the
+ * observation's contribution to the normal equations (accumulated by the caller, in observation order) */
 static double add_reprojection_residual(pass_ctx* ctx, int64_t o, const double* image_tr_global /*7*/,
-                                        const double* R /*9*/, int compute_jacobians, orc_system* sys,
+                                        const double* R /*9*/, int compute_jacobians, int want_acc, acc_item* item,
                                         orc_obs_record* rec) {
+  if (item) item->K = 0;
   const orc_problem* pb = ctx->pb;
   const orc_state* st = ctx->st;
   int cam_i = pb->obs_camera[o];
@@ -832,11 +867,11 @@ static double add_reprojection_residual(pass_ctx* ctx, int64_t o, const double* 
     memcpy(rec->point_jac, point_jac, sizeof(point_jac));
     for (int k = 0; k < Kg; ++k) { rec->grid_indices[k] = gidx[k]; rec->grid_jac[k] = gjac[k]; rec->grid_jac[Kg + k] = gjac[Kg + k]; }
   }
-  if (!sys) return cost;
+  if (!want_acc) return cost;
 
   /* assemble the ascending index list / 2xK Jacobian (joint_optimization.cc:479-590) */
-  int idx[6 + 6 + 3 + MAXK];
-  double Jall[2 * (6 + 6 + 3 + MAXK)];
+  int* idx = item->idx;
+  double* Jall = item->J;
   int K = 6 + (ctx->L.rig_in_state ? 6 : 0) + 3 + Kg;
   int pos = 0;
   int pose_idx = ctx->L.first_rig_tr_global + 6 * img;
@@ -855,7 +890,7 @@ static double add_reprojection_residual(pass_ctx* ctx, int64_t o, const double* 
   }
 #undef PUT
   for (int k = 0; k < Kg; ++k) { idx[pos] = ctx->L.intr_offset[cam_i] + gidx[k]; Jall[pos] = gjac[k]; Jall[K + pos] = gjac[Kg + k]; ++pos; }
-  accumulate(sys, ctx->L.block_dof, res, orc_huber_weight_sq(sq, 1.0), K, idx, Jall);
+  item->K = K; item->res[0] = res[0]; item->res[1] = res[1]; item->weight = orc_huber_weight_sq(sq, 1.0);
   return cost;
 }
 
@@ -882,27 +917,52 @@ static void ctx_free(pass_ctx* ctx) {
   free(ctx->tangents); free(ctx->work_grids);
 }
 
+/* Observations are processed in chunks: the per-observation work (projections, finite differences, Jacobian chain)
+ * of a chunk may run on several threads -- each with its own scratch copy of the grids, which M5 / N3 perturb in
+ * place -- and the chunk's contributions are then added to the normal equations and to the cost by ONE thread in
+ * observation order, so sums are bit-identical to the single-threaded loop of the reference
+ * (joint_optimization.cc:273-291). */
 static double run_pass(const orc_problem* pb, const orc_state* st, int compute_jacobians, orc_system* sys,
                        double* cost_vec, orc_obs_record* records, int img_begin, int img_end) {
-  pass_ctx ctx;
-  ctx_init(&ctx, pb, st, compute_jacobians);
+  const int nthreads = g_threads;
+  pass_ctx* ctxs = (pass_ctx*)malloc(nthreads * sizeof(pass_ctx));
+  for (int t = 0; t < nthreads; ++t) ctx_init(&ctxs[t], pb, st, compute_jacobians);
   double cost = 0;
-  int64_t o = 0;
-  /* skip to the first observation of img_begin */
-  while (o < pb->n_obs && pb->obs_image[o] < img_begin) ++o;
-  while (o < pb->n_obs && pb->obs_image[o] < img_end) {
-    int img = pb->obs_image[o], cam_i = pb->obs_camera[o];
-    double itg[7], R[9];
-    orc_se3_mul(st->camera_tr_rig + 7 * (size_t)cam_i, st->rig_tr_global + 7 * (size_t)img, itg); /* :277 */
-    quat_to_matrix(itg, R);
-    while (o < pb->n_obs && pb->obs_image[o] == img && pb->obs_camera[o] == cam_i) {
-      double c = add_reprojection_residual(&ctx, o, itg, R, compute_jacobians, sys, records ? &records[o] : NULL);
+  int64_t o_begin = 0;
+  while (o_begin < pb->n_obs && pb->obs_image[o_begin] < img_begin) ++o_begin;
+  int64_t o_end = o_begin;
+  while (o_end < pb->n_obs && pb->obs_image[o_end] < img_end) ++o_end;
+  const int64_t chunk = nthreads > 1 ? 256 * (int64_t)nthreads : 1;
+  acc_item* items = sys ? (acc_item*)malloc((size_t)chunk * sizeof(acc_item)) : NULL;
+  double* costs = (double*)malloc((size_t)chunk * sizeof(double));
+  const int block_dof = ctxs[0].L.block_dof;
+  for (int64_t c0 = o_begin; c0 < o_end; c0 += chunk) {
+    const int64_t c1 = c0 + chunk < o_end ? c0 + chunk : o_end;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads) if (nthreads > 1)
+    for (int64_t o = c0; o < c1; ++o) {
+#ifdef _OPENMP
+      pass_ctx* ctx = &ctxs[omp_get_thread_num()];
+#else
+      pass_ctx* ctx = &ctxs[0];
+#endif
+      const int img = pb->obs_image[o], cam_i = pb->obs_camera[o];
+      double itg[7], R[9];
+      orc_se3_mul(st->camera_tr_rig + 7 * (size_t)cam_i, st->rig_tr_global + 7 * (size_t)img, itg); /* :277 */
+      quat_to_matrix(itg, R);
+      costs[o - c0] = add_reprojection_residual(ctx, o, itg, R, compute_jacobians, sys != NULL, items ? &items[o - c0] : NULL,
+                                                records ? &records[o] : NULL);
+    }
+    for (int64_t o = c0; o < c1; ++o) {
+      const double c = costs[o - c0];
+      if (sys && items[o - c0].K > 0)
+        accumulate(sys, block_dof, items[o - c0].res, items[o - c0].weight, items[o - c0].K, items[o - c0].idx, items[o - c0].J);
       if (cost_vec) cost_vec[o] = c;
       if (c >= 0) cost += c;
-      ++o;
     }
   }
-  ctx_free(&ctx);
+  free(items); free(costs);
+  for (int t = 0; t < nthreads; ++t) ctx_free(&ctxs[t]);
+  free(ctxs);
   return cost;
 }
 
@@ -931,7 +991,7 @@ double orc_jacobian_pass(const orc_problem* pb, const orc_state* st, orc_system*
  * ---------------------------------------------------------------------------------------- */
 typedef struct { int n; double* m; /* n x n column-major, lower */ int* transp; } ldlt_t;
 #define LM(i, j) m[(size_t)(j) * n + (i)]
-static void ldlt_compute(ldlt_t* f) {
+static void ldlt_compute_unblocked(ldlt_t* f) {
   int n = f->n; double* m = f->m;
   double* temp = (double*)malloc(n * sizeof(double));
   if (n <= 1) { if (n == 1) f->transp[0] = 0; free(temp); return; }
@@ -967,6 +1027,143 @@ static void ldlt_compute(ldlt_t* f) {
   }
   free(temp);
 }
+/* The same factorisation, cache-blocked and (optionally) multi-threaded, with bit-identical results.
+ * Two facts make that possible: (1) the unblocked kernel above is left-looking, so at step k the diagonal entries it
+ * compares for the pivot are still the ORIGINAL ones -- the whole transposition sequence follows from the original
+ * diagonal and the symmetric permutation can be applied up front; (2) every entry is then computed as
+ *   L(i,k) = (A(i,k) - l(i,0) t(k,0) - l(i,1) t(k,1) - ...) / d_k,   t(k,j) = d_j l(k,j),  subtractions in j order,
+ * and the diagonal as A(k,k) - (sum_j l(k,j) t(k,j)), which a panel algorithm can reproduce term by term.
+ * Panel [k0,k1): (a) the terms j < k0 for all panel columns, tiled over rows and j (GEMM-like, parallel over row
+ * blocks); (b) the NB x NB diagonal block, serial; (c) the terms k0 <= j < k for the rows below, parallel over row
+ * blocks.  Used for n >= 256; smaller systems and a zero first pivot take the unblocked kernel. */
+#define LDLT_NB 64
+#define LDLT_RB 256
+static void ldlt_compute(ldlt_t* f) {
+  const int n = f->n; double* m = f->m;
+  if (n < 256) { ldlt_compute_unblocked(f); return; }
+  /* pivot sequence from the original diagonal (selection with "first largest wins", as in the kernel above) */
+  double* dg = (double*)malloc(n * sizeof(double));
+  int* perm = (int*)malloc(n * sizeof(int));       /* perm[new] = old */
+  for (int i = 0; i < n; ++i) { dg[i] = fabs(LM(i, i)); perm[i] = i; }
+  for (int k = 0; k < n; ++k) {
+    int piv = k; double best = -1;
+    for (int i = k; i < n; ++i) if (dg[i] > best) { best = dg[i]; piv = i; }
+    f->transp[k] = piv;
+    if (piv != k) { double t = dg[k]; dg[k] = dg[piv]; dg[piv] = t; int q = perm[k]; perm[k] = perm[piv]; perm[piv] = q; }
+  }
+  if (!(dg[0] > 0)) { free(dg); free(perm); ldlt_compute_unblocked(f); return; }   /* zero matrix: kernel's early exit */
+  free(dg);
+  /* symmetric permutation of the lower triangle */
+  {
+    double* w = (double*)malloc((size_t)n * n * sizeof(double));
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int j = 0; j < n; ++j)
+      for (int i = j; i < n; ++i) {
+        int r = perm[i], c = perm[j];
+        w[(size_t)j * n + i] = r >= c ? LM(r, c) : LM(c, r);
+      }
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int j = 0; j < n; ++j) memcpy(&LM(j, j), &w[(size_t)j * n + j], (size_t)(n - j) * sizeof(double));
+    free(w);
+  }
+  free(perm);
+  double* T = (double*)malloc((size_t)LDLT_NB * n * sizeof(double));     /* T[kk][j] = d_j l(k0+kk, j) */
+  double acc[LDLT_NB];
+  for (int k0 = 0; k0 < n; k0 += LDLT_NB) {
+    const int k1 = k0 + LDLT_NB < n ? k0 + LDLT_NB : n, nbk = k1 - k0;
+    /* (a) terms j < k0 */
+    for (int kk = 0; kk < nbk; ++kk) {
+      double a = 0;
+      double* Tk = T + (size_t)kk * n;
+      for (int j = 0; j < k0; ++j) { Tk[j] = LM(j, j) * LM(k0 + kk, j); a += LM(k0 + kk, j) * Tk[j]; }
+      acc[kk] = a;
+    }
+    if (k0 > 0) {
+      const int nrb = (n - k0 + LDLT_RB - 1) / LDLT_RB;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+      for (int rb = 0; rb < nrb; ++rb) {
+        const int i0 = k0 + rb * LDLT_RB, i1 = i0 + LDLT_RB < n ? i0 + LDLT_RB : n;
+        /* the block L(i0:i1, j0:j1) is packed into a padded thread-local buffer once and reused by all panel
+         * columns (column strides of n doubles alias in the L1 sets for many n) */
+        double Lp[64][LDLT_RB + 8];
+        for (int j0 = 0; j0 < k0; j0 += 64) {
+          const int j1 = j0 + 64 < k0 ? j0 + 64 : k0;
+          for (int j = j0; j < j1; ++j) memcpy(Lp[j - j0], &LM(i0, j), (size_t)(i1 - i0) * sizeof(double));
+          for (int kk = 0; kk < nbk; ++kk) {
+            const int k = k0 + kk;
+            const int ib = i0 > k + 1 ? i0 : k + 1;
+            if (ib >= i1) continue;
+            double* restrict dst = &LM(0, k);
+            const double* Tk = T + (size_t)kk * n;
+            int i = ib;
+            for (; i + 16 <= i1; i += 16) {          /* 16 rows stay in registers while j runs (same order per entry) */
+              double d[16];
+              for (int t = 0; t < 16; ++t) d[t] = dst[i + t];
+              for (int j = j0; j < j1; ++j) {
+                const double tj = Tk[j];
+                const double* restrict col = &Lp[j - j0][i - i0];
+                for (int t = 0; t < 16; ++t) d[t] -= col[t] * tj;
+              }
+              for (int t = 0; t < 16; ++t) dst[i + t] = d[t];
+            }
+            for (; i < i1; ++i) {
+              double d = dst[i];
+              for (int j = j0; j < j1; ++j) d -= Lp[j - j0][i - i0] * Tk[j];
+              dst[i] = d;
+            }
+          }
+        }
+      }
+    }
+    /* (b) diagonal block: rows and columns of the panel */
+    for (int kk = 0; kk < nbk; ++kk) {
+      const int k = k0 + kk;
+      double* Tk = T + (size_t)kk * n;
+      double a = acc[kk];
+      for (int j = k0; j < k; ++j) { Tk[j] = LM(j, j) * LM(k, j); a += LM(k, j) * Tk[j]; }
+      if (k > 0) LM(k, k) -= a;
+      for (int j = k0; j < k; ++j) {
+        const double tj = Tk[j];
+        for (int i = k + 1; i < k1; ++i) LM(i, k) -= LM(i, j) * tj;
+      }
+      const double akk = LM(k, k);
+      if (fabs(akk) > 0) for (int i = k + 1; i < k1; ++i) LM(i, k) /= akk;
+    }
+    /* (c) rows below the panel */
+    if (k1 < n) {
+      const int nrb = (n - k1 + LDLT_RB - 1) / LDLT_RB;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+      for (int rb = 0; rb < nrb; ++rb) {
+        const int i0 = k1 + rb * LDLT_RB, i1 = i0 + LDLT_RB < n ? i0 + LDLT_RB : n;
+        for (int kk = 0; kk < nbk; ++kk) {
+          const int k = k0 + kk;
+          double* restrict dst = &LM(0, k);
+          const double* Tk = T + (size_t)kk * n;
+          const double akk = LM(k, k);
+          const int valid = fabs(akk) > 0;
+          int i = i0;
+          for (; i + 16 <= i1; i += 16) {
+            double d[16];
+            for (int t = 0; t < 16; ++t) d[t] = dst[i + t];
+            for (int j = k0; j < k; ++j) {
+              const double tj = Tk[j];
+              const double* restrict col = &LM(i, j);
+              for (int t = 0; t < 16; ++t) d[t] -= col[t] * tj;
+            }
+            if (valid) for (int t = 0; t < 16; ++t) d[t] /= akk;
+            for (int t = 0; t < 16; ++t) dst[i + t] = d[t];
+          }
+          for (; i < i1; ++i) {
+            double d = dst[i];
+            for (int j = k0; j < k; ++j) d -= LM(i, j) * Tk[j];
+            dst[i] = valid ? d / akk : d;
+          }
+        }
+      }
+    }
+  }
+  free(T);
+}
 static void ldlt_solve(const ldlt_t* f, double* x /* in: b, out: x */) {
   int n = f->n; const double* m = f->m;
   for (int k = 0; k < n; ++k) { int p = f->transp[k]; if (p != k) { double t = x[k]; x[k] = x[p]; x[p] = t; } }
@@ -985,6 +1182,19 @@ void orc_ldlt_solve_upper(const double* A, int n, const double* b, double* x) {
   for (int j = 0; j < n; ++j)
     for (int i = j; i < n; ++i) f.m[(size_t)j * n + i] = A[(size_t)j * n + i];
   ldlt_compute(&f);
+  if (x != b) memcpy(x, b, n * sizeof(double));
+  ldlt_solve(&f, x);
+  free(f.m); free(f.transp);
+}
+
+/* the textbook kernel only (tests compare the blocked kernel with it bit for bit) */
+void orc_ldlt_solve_upper_unblocked(const double* A, int n, const double* b, double* x) {
+  ldlt_t f; f.n = n;
+  f.m = (double*)malloc((size_t)n * n * sizeof(double));
+  f.transp = (int*)malloc(n * sizeof(int));
+  for (int j = 0; j < n; ++j)
+    for (int i = j; i < n; ++i) f.m[(size_t)j * n + i] = A[(size_t)j * n + i];
+  ldlt_compute_unblocked(&f);
   if (x != b) memcpy(x, b, n * sizeof(double));
   ldlt_solve(&f, x);
   free(f.m); free(f.transp);
@@ -1028,16 +1238,29 @@ void orc_schur_solve(const orc_system* s, double* x) {
     if (v != 0) for (int i = 0; i < dd; ++i) schur_b[i] += Brow[i] * v;
   }
   for (int i = 0; i < dd; ++i) schur_b[i] = s->dense_b[i] - schur_b[i];
-  /* B^T D^-1 B, upper triangle, accumulated as rank-1 updates over the block rows */
-  for (size_t k = 0; k < bd; ++k) {
-    const double* Brow = s->off_diag_H + k * dd;
-    const double* Wrow = D_inv_B + k * dd;
-    for (int i = 0; i < dd; ++i) {
-      double bi = Brow[i];
-      if (bi == 0) continue;
-      double* Mrow = schur_M + (size_t)i * dd;
-      for (int j = i; j < dd; ++j) Mrow[j] += bi * Wrow[j];
-    }
+  /* B^T D^-1 B, upper triangle: every entry accumulates its rank-1 terms in block-row order k = 0, 1, ...
+   * (lm_optimizer.h:1325-1329 leaves the order to Eigen's product kernel).  Tiled over (i, j) so that a tile of M
+   * stays in cache while k runs; the per-entry order does not depend on the tiling or on the thread count. */
+  {
+    const int TI = 32, TJ = 512;
+    const int nti = (dd + TI - 1) / TI, ntj = (dd + TJ - 1) / TJ;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1) num_threads(g_threads)
+    for (int ti = 0; ti < nti; ++ti)
+      for (int tj = 0; tj < ntj; ++tj) {
+        const int i0 = ti * TI, i1 = i0 + TI < dd ? i0 + TI : dd;
+        const int j0 = tj * TJ, j1 = j0 + TJ < dd ? j0 + TJ : dd;
+        if (j1 <= i0) continue;                      /* tile entirely below the diagonal */
+        for (size_t k = 0; k < bd; ++k) {
+          const double* Brow = s->off_diag_H + k * dd;
+          const double* restrict Wrow = D_inv_B + k * dd;
+          for (int i = i0; i < i1; ++i) {
+            const double bi = Brow[i];
+            if (bi == 0) continue;
+            double* restrict Mrow = schur_M + (size_t)i * dd;
+            for (int j = (i > j0 ? i : j0); j < j1; ++j) Mrow[j] += bi * Wrow[j];
+          }
+        }
+      }
   }
   for (int i = 0; i < dd; ++i) {
     double* Mrow = schur_M + (size_t)i * dd;
@@ -1046,8 +1269,9 @@ void orc_schur_solve(const orc_system* s, double* x) {
   }
   double* xd = x + bd;
   orc_ldlt_solve_upper(schur_M, dd, schur_b, xd);
-  for (size_t k = 0; k < bd; ++k) {
-    const double* Wrow = D_inv_B + k * dd;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+  for (long long k = 0; k < (long long)bd; ++k) {
+    const double* Wrow = D_inv_B + (size_t)k * dd;
     double acc = 0;
     for (int i = 0; i < dd; ++i) acc += Wrow[i] * xd[i];
     x[k] = D_inv_b1[k] - acc;

@@ -88,6 +88,13 @@ typedef struct {
   double grid_jac[160];       /* 2xK row-major, K = 32 or 80 */
 } orc_obs_record;
 
+/* ---- host threads ----
+ * n <= 0 selects all hardware threads.  Default 1 (the reference path is single-threaded).  Results do not depend on
+ * the thread count (bit-identical): threads split independent per-observation work and cache tiles only. */
+void orc_set_num_threads(int n);
+int orc_get_num_threads(void);
+int orc_hardware_threads(void);
+
 /* ---- model level ---- */
 void orc_bspline_surface(const double* ctrl, int w, int h, int dim, double x, double y, double* out);
 void orc_bspline_surface_slow(const double* ctrl, int w, int h, int dim, double x, double y, double* out);
@@ -126,6 +133,7 @@ double orc_jacobian_pass(const orc_problem* pb, const orc_state* st, orc_system*
 void orc_schur_solve(const orc_system* sys, double* x);
 /* Pivoted LDLT solve of a dense symmetric system given by its upper triangle (row-major). */
 void orc_ldlt_solve_upper(const double* A_upper, int n, const double* b, double* x);
+void orc_ldlt_solve_upper_unblocked(const double* A_upper, int n, const double* b, double* x);
 /* state -= x  (JointOptimizationState::operator-=). */
 void orc_apply_update(const orc_problem* pb, const orc_state* st_in, const double* x, orc_state* st_out);
 /* One OptimizeJointly call (max_iteration_count outer iterations). Returns final cost. */

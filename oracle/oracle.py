@@ -103,12 +103,26 @@ def lib() -> C.CDLL:
         L.orc_jacobian_pass.restype = C.c_double
         L.orc_schur_solve.argtypes = [C.POINTER(OrcSystem), dp]
         L.orc_ldlt_solve_upper.argtypes = [dp, C.c_int, dp, dp]
+        L.orc_ldlt_solve_upper_unblocked.argtypes = [dp, C.c_int, dp, dp]
         L.orc_apply_update.argtypes = [C.POINTER(OrcProblem), C.POINTER(OrcState), dp, C.POINTER(OrcState)]
         L.orc_optimize_jointly.argtypes = [C.POINTER(OrcProblem), C.POINTER(OrcState), C.c_int, C.c_double,
                                            dp, ip, dp, ip]
         L.orc_optimize_jointly.restype = C.c_double
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_get_num_threads.restype = C.c_int
+        L.orc_hardware_threads.restype = C.c_int
         _lib = L
     return _lib
+
+
+def set_num_threads(n: int) -> int:
+    """Host threads the oracle may use (n <= 0: all).  Results are bit-identical for every thread count."""
+    lib().orc_set_num_threads(int(n))
+    return int(lib().orc_get_num_threads())
+
+
+def hardware_threads() -> int:
+    return int(lib().orc_hardware_threads())
 
 
 def _dp(a: np.ndarray):
@@ -212,11 +226,12 @@ def schur_solve(system: System) -> np.ndarray:
     return x
 
 
-def ldlt_solve_upper(A: np.ndarray, b: np.ndarray) -> np.ndarray:
+def ldlt_solve_upper(A: np.ndarray, b: np.ndarray, unblocked: bool = False) -> np.ndarray:
     A = np.ascontiguousarray(A, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)
     x = np.zeros_like(b)
-    lib().orc_ldlt_solve_upper(_dp(A), A.shape[0], _dp(b), _dp(x))
+    f = lib().orc_ldlt_solve_upper_unblocked if unblocked else lib().orc_ldlt_solve_upper
+    f(_dp(A), A.shape[0], _dp(b), _dp(x))
     return x
 
 

@@ -55,6 +55,49 @@ def test_pivoted_ldlt_matches_dense_solve():
     np.testing.assert_allclose(A @ x, b, rtol=1e-6, atol=1e-9)
 
 
+def test_blocked_ldlt_is_bit_identical_to_the_unblocked_kernel():
+    """The cache-blocked / multi-threaded LDLT of the oracle reproduces the textbook left-looking kernel (Eigen's
+    unblocked LDLT with diagonal pivoting) term by term: same pivots, same x bits, for every thread count."""
+    rng = np.random.default_rng(11)
+    try:
+        for n in (256, 300, 449, 777):
+            B = rng.normal(size=(n, n + 3))
+            A = B @ B.T / n + np.diag(rng.uniform(0.0, 2.0, n))          # varied diagonal: non-trivial pivot order
+            if n == 449:
+                A -= 1.5 * np.eye(n)                                       # indefinite
+            b = rng.normal(size=n)
+            want = orc.ldlt_solve_upper(np.triu(A), b, unblocked=True)
+            for nt in (1, 3, 8):
+                orc.set_num_threads(nt)
+                got = orc.ldlt_solve_upper(np.triu(A), b)
+                assert np.array_equal(got, want), (n, nt)
+            np.testing.assert_allclose(A @ want, b, rtol=1e-6, atol=1e-7)
+    finally:
+        orc.set_num_threads(1)
+
+
+def test_threaded_oracle_is_bit_identical():
+    """orc_set_num_threads: the per-observation work is split over threads, sums are formed in observation order."""
+    pb, st0, _ = syn.reference_test_problem(2, oracle_project, seed=4, num_points=80, num_poses=40)
+    out = {}
+    try:
+        for nt in (1, 5):
+            orc.set_num_threads(nt)
+            op = orc.OracleProblem(pb)
+            st = st0.copy()
+            sysm = op.new_system()
+            c, v, _ = op.jacobian_pass(st, sysm)
+            sysm.add_lambda(1e-4)
+            x = orc.schur_solve(sysm)
+            r = op.optimize_jointly(st, 2, -1.0)
+            out[nt] = (c, v, sysm.dense_H.copy(), sysm.off_diag_H.copy(), sysm.block_diag_H.copy(), x, st.points.copy(), r["cost"],
+                       op.last_projection.copy())
+    finally:
+        orc.set_num_threads(1)
+    for a, b in zip(out[1], out[5]):
+        assert np.array_equal(a, b)
+
+
 def test_huber_loss_identities():
     L = orc.lib()
     for r in np.linspace(-3, 3, 61):
