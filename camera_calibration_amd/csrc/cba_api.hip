@@ -153,6 +153,8 @@ struct cba_problem {
   int* status = nullptr;
   LdltWorkspace ldlt;
   KernelTimer timers[5];     // see cba_kernel_stats
+  // deterministic mode (cba_config.deterministic): fixed-point scale of the current pass
+  unsigned long long* det_bits = nullptr; double* det_scale = nullptr;
   double last_lambda = 0;
 };
 
@@ -202,6 +204,18 @@ static int dev_alloc(T** p, size_t n) {
   return CBA_OK;
 }
 #define CBA_TRY(expr) do { int _rc = (expr); if (_rc != CBA_OK) return _rc; } while (0)
+
+// device buffers of one stateless call: freed on every exit path
+struct DevPool {
+  std::vector<void*> ptrs;
+  ~DevPool() { for (void* q : ptrs) if (q) hipFree(q); }
+  template <typename T> int alloc(T** p, size_t n) {
+    int rc = dev_alloc(p, n);
+    if (rc == CBA_OK) ptrs.push_back(*p);
+    return rc;
+  }
+};
+struct LdltGuard { LdltWorkspace* w; ~LdltGuard() { if (w) ldlt_workspace_free(*w); } };
 
 static int alloc_state(cba_problem* p, DevState& s) {
   CBA_TRY(dev_alloc(&s.rig_tr_global, 7 * (size_t)p->L.n_images));
@@ -330,14 +344,23 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   AccumTargets T{p->Dblk, p->bblk, p->B, p->Hdd, p->bd};
   Layout Lp = L;
   Lp.dense_dof = p->n_pad;  // Hdd / B use the padded leading dimension as row stride
+  const double* det = p->cfg.deterministic ? p->det_scale : nullptr;
+  if (det) CBA_TRY(launch_det_scale(p->n_obs, p->rec_doubles, p->rec_doubles, p->flags, p->jrec, p->det_bits, p->det_scale, p->stream));
   if (!L.eliminate_points)   // B strips first (plain stores), the remaining terms are added on top atomically
     CBA_TRY(launch_accumulate_strips(a, Lp, L.n_images, p->rec_doubles, p->flags, p->jrec, p->cells, p->band_mask, p->img_start, p->B,
-                                     p->n_pad, p->stream));
-  CBA_TRY(launch_accumulate(a, Lp, p->rec_doubles, p->flags, p->jrec, p->cells, p->pair_tables, p->pair_counts, T, p->stream));
+                                     p->n_pad, det, p->stream));
+  CBA_TRY(launch_accumulate(a, Lp, p->rec_doubles, p->flags, p->jrec, p->cells, p->pair_tables, p->pair_counts, T, det, p->stream));
   if (!L.localize_only)
     CBA_TRY(launch_accumulate_cells(a, p->cams, p->cell_base_host, p->rec_doubles, p->n_pad, p->flags, p->jrec, p->cells, p->cell_base,
                                     p->cell_count, p->cell_start, p->cell_fill, p->cell_order, p->Hdd,
-                                    (!L.eliminate_points && L.rig_in_state) ? L.first_camera_tr_rig - L.block_dof : -1, p->stream));
+                                    (!L.eliminate_points && L.rig_in_state) ? L.first_camera_tr_rig - L.block_dof : -1, det, p->stream));
+  if (det) {   // fixed point -> fp64, in place (B: only when it received atomics, i.e. when the points are the Schur blocks)
+    CBA_TRY(launch_det_convert(p->Dblk, nb * bs * bs, det, p->stream));
+    CBA_TRY(launch_det_convert(p->bblk, nb * bs, det, p->stream));
+    CBA_TRY(launch_det_convert(p->Hdd, (size_t)L.dense_dof * p->n_pad, det, p->stream));
+    CBA_TRY(launch_det_convert(p->bd, (size_t)p->n_pad, det, p->stream));
+    if (L.eliminate_points) CBA_TRY(launch_det_convert(p->B, (size_t)L.block_dof * p->n_pad, det, p->stream));
+  }
   CBA_TRY(timer_end(p, 2, 0, 0, 1));
   if (t_acc) *t_acc += now_s() - t0;
   CBA_TRY(launch_touch_mask(p->B, p->Kpad, p->n_pad, p->n_pad, p->kmask, p->stream));
@@ -444,13 +467,15 @@ int cba_create(const cba_config* config, cba_problem** out) {
   if (config->device < 0 || config->device >= ndev) { set_error("cba_create: bad device ordinal"); return CBA_ERR_ARG; }
   CBA_HIP(hipSetDevice(config->device));
   cba_problem* p = new cba_problem();
+  // every early return below destroys the half-built problem (device memory, events); released on success
+  struct Guard { cba_problem* q; ~Guard() { if (q) cba_destroy(q); } } guard{p};
   p->cfg = *config;
   p->cams.assign(config->cameras, config->cameras + config->n_cameras);
   p->cfg.cameras = p->cams.data();
   p->device = config->device;
   make_layout(p->cfg, p->L);
   const Layout& L = p->L;
-  if (L.total_dof <= 0) { delete p; set_error("empty problem"); return CBA_ERR_ARG; }
+  if (L.total_dof <= 0) { set_error("empty problem"); return CBA_ERR_ARG; }
   CBA_TRY(make_main_stream(&p->stream));
   CBA_HIP(hipEventCreateWithFlags(&p->ev_aux0, hipEventDisableTiming));
   CBA_HIP(hipEventCreateWithFlags(&p->ev_aux1, hipEventDisableTiming));
@@ -506,6 +531,7 @@ int cba_create(const cba_config* config, cba_problem** out) {
     CBA_HIP(hipMemcpy(p->cell_base, p->cell_base_host.data(), sizeof(int) * p->cell_base_host.size(), hipMemcpyHostToDevice));
     CBA_TRY(dev_alloc(&p->cell_count, nk + 1)); CBA_TRY(dev_alloc(&p->cell_start, nk + 1)); CBA_TRY(dev_alloc(&p->cell_fill, nk + 1));
   }
+  CBA_TRY(dev_alloc(&p->det_bits, 1)); CBA_TRY(dev_alloc(&p->det_scale, 1));
   CBA_TRY(dev_alloc(&p->red_partials, 256 * 8));
   CBA_TRY(dev_alloc(&p->red8, 16));
   // normal equations
@@ -541,6 +567,7 @@ int cba_create(const cba_config* config, cba_problem** out) {
   CBA_TRY(dev_alloc(&p->gemv_ws, (size_t)gemv_t_workspace_doubles(p->n_pad)));
   CBA_TRY(dev_alloc(&p->status, 1));
   CBA_TRY(ldlt_workspace_alloc(p->ldlt, p->n_pad));
+  guard.q = nullptr;
   *out = p;
   return CBA_OK;
 }
@@ -568,7 +595,7 @@ void cba_destroy(cba_problem* p) {
   ldlt_workspace_free(p->ldlt);
   for (auto& t : p->timers) for (auto& sp : t.spans) { hipEventDestroy(sp.e0); hipEventDestroy(sp.e1); }
   if (p->kmask_host) hipHostFree(p->kmask_host);
-  F(p->slow_skip); F(p->slow_list); F(p->slow_count); F(p->img_start); F(p->band_mask);
+  F(p->slow_skip); F(p->slow_list); F(p->slow_count); F(p->img_start); F(p->band_mask); F(p->det_bits); F(p->det_scale);
   if (p->ev_aux0) hipEventDestroy(p->ev_aux0);
   if (p->ev_aux1) hipEventDestroy(p->ev_aux1);
   delete p;
@@ -598,6 +625,7 @@ int cba_set_observations(cba_problem* p, int64_t n, const float* xy, const int32
   CBA_TRY(dev_alloc(&p->pixels, 2 * (size_t)n)); CBA_TRY(dev_alloc(&p->flags, (size_t)n));
   CBA_TRY(dev_alloc(&p->fd_out, 2 * (size_t)n * p->tasks_per_obs)); CBA_TRY(dev_alloc(&p->fd_ok, (size_t)n * p->tasks_per_obs));
   CBA_TRY(dev_alloc(&p->jrec, (size_t)n * p->rec_doubles)); CBA_TRY(dev_alloc(&p->cells, 2 * (size_t)n));
+  CBA_HIP(hipMemset(p->jrec, 0, sizeof(double) * (size_t)(n > 0 ? n : 1) * p->rec_doubles));   // records of mixed-model problems have unused tails
   CBA_TRY(dev_alloc(&p->cell_order, (size_t)n));
   F(p->img_start); p->img_start = nullptr;
   F(p->band_mask); p->band_mask = nullptr;
@@ -793,7 +821,19 @@ int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double
     if (rc != CBA_OK && rc != CBA_ERR_NUMERIC) return rc;
     double x0 = NAN;
     if (rc == CBA_OK) CBA_TRY(read_scalars(p, p->x, &x0, 1));
-    if (rc == CBA_ERR_NUMERIC || std::isnan(x0)) {   // NaN update -> lambda *= 2 (lm_optimizer.h:905-913)
+    bool failed = rc == CBA_ERR_NUMERIC || std::isnan(x0);
+    if (multi) {
+      // Image sharding: the pose-block inverses and x[0] are rank-local, the factorisation is replicated.  Every rank must
+      // take the same accept / reject / NaN branch -- otherwise one rank would enter the next solve's all-reduce of the
+      // packed system while the others wait in the 8-double cost all-reduce -- so the failure flag is summed over ranks.
+      const double f = failed ? 1.0 : 0.0;
+      CBA_HIP(hipMemcpyAsync(p->scal + 8, &f, sizeof(double), hipMemcpyHostToDevice, p->stream));
+      CBA_TRY(allreduce(p, p->scal + 8, 1));
+      double fs = 0.0;
+      CBA_TRY(read_scalars(p, p->scal + 8, &fs, 1));
+      failed = fs != 0.0;
+    }
+    if (failed) {   // NaN update -> lambda *= 2 (lm_optimizer.h:905-913)
       lambda = 2.f * lambda;
       continue;
     }
@@ -918,61 +958,105 @@ int cba_debug_dump(cba_problem* p, int32_t what, void* out, size_t bytes) {
   }
 }
 
-// ---- stateless entry points -----------------------------------------------------------------------
-static int stateless_setup(const cba_camera* camera, const double* grid, int32_t device, double** d_grid, CamDev** d_cam) {
-  if (!camera || !grid || !camera_ok(*camera)) { set_error("bad camera / grid"); return CBA_ERR_ARG; }
+// ---- model-level entry points: device-resident camera model -----------------------------------------
+struct cba_model {
+  cba_camera cam{};
+  int device = 0;
+  double* d_grid = nullptr; CamDev* d_cam = nullptr;
+  // scratch, grown on demand
+  int64_t cap = 0;
+  double *d_a = nullptr, *d_b = nullptr, *d_c = nullptr, *d_j = nullptr; uint8_t* d_ok = nullptr;
+};
+static int model_reserve(cba_model* m, int64_t n) {
+  if (n <= m->cap) return CBA_OK;
+  auto F = [](void* q) { if (q) hipFree(q); };
+  F(m->d_a); F(m->d_b); F(m->d_c); F(m->d_j); F(m->d_ok);
+  m->d_a = m->d_b = m->d_c = m->d_j = nullptr; m->d_ok = nullptr; m->cap = 0;
+  const int64_t cap = n < 256 ? 256 : n;
+  CBA_TRY(dev_alloc(&m->d_a, 3 * (size_t)cap));     // local points / pixels (in)
+  CBA_TRY(dev_alloc(&m->d_b, 6 * (size_t)cap));     // pixels / lines (out)
+  CBA_TRY(dev_alloc(&m->d_c, 2 * (size_t)cap));     // initial pixels
+  CBA_TRY(dev_alloc(&m->d_j, 12 * (size_t)cap));    // un-projection Jacobians
+  CBA_TRY(dev_alloc(&m->d_ok, (size_t)cap));
+  m->cap = cap;
+  return CBA_OK;
+}
+void cba_model_destroy(cba_model* m) {
+  if (!m) return;
+  hipSetDevice(m->device);
+  auto F = [](void* q) { if (q) hipFree(q); };
+  F(m->d_grid); F(m->d_cam); F(m->d_a); F(m->d_b); F(m->d_c); F(m->d_j); F(m->d_ok);
+  delete m;
+}
+int cba_model_set_grid(cba_model* m, const double* grid) {
+  if (!m || !grid) { set_error("cba_model_set_grid: bad argument"); return CBA_ERR_ARG; }
+  CBA_HIP(hipSetDevice(m->device));
+  const size_t G = (size_t)m->cam.grid_w * m->cam.grid_h;
+  CBA_HIP(hipMemcpy(m->d_grid, grid, (m->cam.model_type == CBA_CENTRAL_GENERIC ? 3 : 6) * G * sizeof(double), hipMemcpyHostToDevice));
+  return CBA_OK;
+}
+int cba_model_create(const cba_camera* camera, const double* grid, int32_t device, cba_model** out) {
+  if (!camera || !grid || !out || !camera_ok(*camera)) { set_error("bad camera / grid"); return CBA_ERR_ARG; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device available (the engine has no CPU fallback)"); return CBA_ERR_HIP; }
   if (device < 0 || device >= ndev) { set_error("bad device ordinal"); return CBA_ERR_ARG; }
   CBA_HIP(hipSetDevice(device));
-  size_t G = (size_t)camera->grid_w * camera->grid_h;
-  size_t nd = (camera->model_type == CBA_CENTRAL_GENERIC ? 3 : 6) * G;
-  CBA_TRY(dev_alloc(d_grid, nd));
-  CBA_HIP(hipMemcpy(*d_grid, grid, nd * sizeof(double), hipMemcpyHostToDevice));
-  CamDev h = make_camdev(*camera, *d_grid, nullptr, 0);
-  CBA_TRY(dev_alloc(d_cam, 1));
-  CBA_HIP(hipMemcpy(*d_cam, &h, sizeof(CamDev), hipMemcpyHostToDevice));
+  cba_model* m = new cba_model();
+  struct Guard { cba_model* q; ~Guard() { if (q) cba_model_destroy(q); } } guard{m};
+  m->cam = *camera; m->device = device;
+  const size_t G = (size_t)camera->grid_w * camera->grid_h;
+  CBA_TRY(dev_alloc(&m->d_grid, (camera->model_type == CBA_CENTRAL_GENERIC ? 3 : 6) * G));
+  CBA_TRY(cba_model_set_grid(m, grid));
+  CamDev h = make_camdev(*camera, m->d_grid, nullptr, 0);
+  CBA_TRY(dev_alloc(&m->d_cam, 1));
+  CBA_HIP(hipMemcpy(m->d_cam, &h, sizeof(CamDev), hipMemcpyHostToDevice));
+  guard.q = nullptr;
+  *out = m;
+  return CBA_OK;
+}
+int cba_model_project(cba_model* m, int64_t n, const double* local_points, const double* init_pixels, double* pixels, uint8_t* ok) {
+  if (!m || n < 0 || (n > 0 && (!local_points || !pixels || !ok))) { set_error("cba_model_project: bad argument"); return CBA_ERR_ARG; }
+  if (n == 0) return CBA_OK;
+  CBA_HIP(hipSetDevice(m->device));
+  CBA_TRY(model_reserve(m, n));
+  CBA_HIP(hipMemcpy(m->d_a, local_points, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+  if (init_pixels) CBA_HIP(hipMemcpy(m->d_c, init_pixels, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+  CBA_TRY(launch_project_points(m->d_cam, m->cam.model_type, n, m->d_a, init_pixels ? m->d_c : nullptr, m->d_b, m->d_ok, nullptr));
+  CBA_HIP(hipMemcpy(pixels, m->d_b, sizeof(double) * 2 * n, hipMemcpyDeviceToHost));
+  CBA_HIP(hipMemcpy(ok, m->d_ok, (size_t)n, hipMemcpyDeviceToHost));
+  return CBA_OK;
+}
+int cba_model_unproject(cba_model* m, int64_t n, const double* pixels, double* lines, double* jacobians, uint8_t* ok) {
+  if (!m || n < 0 || (n > 0 && (!pixels || !lines || !ok))) { set_error("cba_model_unproject: bad argument"); return CBA_ERR_ARG; }
+  if (n == 0) return CBA_OK;
+  CBA_HIP(hipSetDevice(m->device));
+  CBA_TRY(model_reserve(m, n));
+  CBA_HIP(hipMemcpy(m->d_a, pixels, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+  CBA_TRY(launch_unproject(m->d_cam, m->cam.model_type, n, m->d_a, m->d_b, jacobians ? m->d_j : nullptr, m->d_ok, nullptr));
+  CBA_HIP(hipMemcpy(lines, m->d_b, sizeof(double) * 6 * n, hipMemcpyDeviceToHost));
+  CBA_HIP(hipMemcpy(ok, m->d_ok, (size_t)n, hipMemcpyDeviceToHost));
+  if (jacobians) CBA_HIP(hipMemcpy(jacobians, m->d_j, sizeof(double) * 12 * n, hipMemcpyDeviceToHost));
   return CBA_OK;
 }
 
+// ---- stateless entry points (one-shot wrappers) ------------------------------------------------------
 int cba_project(const cba_camera* camera, const double* grid, int64_t n, const double* local_points,
                 const double* init_pixels, double* pixels, uint8_t* ok, int32_t device) {
   if (n < 0 || (n > 0 && (!local_points || !pixels || !ok))) { set_error("cba_project: bad argument"); return CBA_ERR_ARG; }
-  double* d_grid = nullptr; CamDev* d_cam = nullptr;
-  CBA_TRY(stateless_setup(camera, grid, device, &d_grid, &d_cam));
-  double *d_local = nullptr, *d_init = nullptr, *d_px = nullptr; uint8_t* d_ok = nullptr;
-  CBA_TRY(dev_alloc(&d_local, 3 * (size_t)n)); CBA_TRY(dev_alloc(&d_px, 2 * (size_t)n)); CBA_TRY(dev_alloc(&d_ok, (size_t)n));
-  if (n) CBA_HIP(hipMemcpy(d_local, local_points, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
-  if (init_pixels) {
-    CBA_TRY(dev_alloc(&d_init, 2 * (size_t)n));
-    if (n) CBA_HIP(hipMemcpy(d_init, init_pixels, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
-  }
-  int rc = launch_project_points(d_cam, camera->model_type, n, d_local, d_init, d_px, d_ok, nullptr);
-  if (rc == CBA_OK && n) {
-    if (hipMemcpy(pixels, d_px, sizeof(double) * 2 * n, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(ok, d_ok, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) { set_error("cba_project: copy back failed"); rc = CBA_ERR_HIP; }
-  }
-  hipFree(d_grid); hipFree(d_cam); hipFree(d_local); hipFree(d_px); hipFree(d_ok); if (d_init) hipFree(d_init);
+  cba_model* m = nullptr;
+  CBA_TRY(cba_model_create(camera, grid, device, &m));
+  const int rc = cba_model_project(m, n, local_points, init_pixels, pixels, ok);
+  cba_model_destroy(m);
   return rc;
 }
 
 int cba_unproject(const cba_camera* camera, const double* grid, int64_t n, const double* pixels, double* lines,
                   double* jacobians, uint8_t* ok, int32_t device) {
   if (n < 0 || (n > 0 && (!pixels || !lines || !ok))) { set_error("cba_unproject: bad argument"); return CBA_ERR_ARG; }
-  double* d_grid = nullptr; CamDev* d_cam = nullptr;
-  CBA_TRY(stateless_setup(camera, grid, device, &d_grid, &d_cam));
-  double *d_px = nullptr, *d_lines = nullptr, *d_jac = nullptr; uint8_t* d_ok = nullptr;
-  CBA_TRY(dev_alloc(&d_px, 2 * (size_t)n)); CBA_TRY(dev_alloc(&d_lines, 6 * (size_t)n)); CBA_TRY(dev_alloc(&d_ok, (size_t)n));
-  if (jacobians) CBA_TRY(dev_alloc(&d_jac, 12 * (size_t)n));
-  if (n) CBA_HIP(hipMemcpy(d_px, pixels, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
-  int rc = launch_unproject(d_cam, camera->model_type, n, d_px, d_lines, d_jac, d_ok, nullptr);
-  if (rc == CBA_OK && n) {
-    bool okc = hipMemcpy(lines, d_lines, sizeof(double) * 6 * n, hipMemcpyDeviceToHost) == hipSuccess &&
-               hipMemcpy(ok, d_ok, (size_t)n, hipMemcpyDeviceToHost) == hipSuccess;
-    if (okc && jacobians) okc = hipMemcpy(jacobians, d_jac, sizeof(double) * 12 * n, hipMemcpyDeviceToHost) == hipSuccess;
-    if (!okc) { set_error("cba_unproject: copy back failed"); rc = CBA_ERR_HIP; }
-  }
-  hipFree(d_grid); hipFree(d_cam); hipFree(d_px); hipFree(d_lines); hipFree(d_ok); if (d_jac) hipFree(d_jac);
+  cba_model* m = nullptr;
+  CBA_TRY(cba_model_create(camera, grid, device, &m));
+  const int rc = cba_model_unproject(m, n, pixels, lines, jacobians, ok);
+  cba_model_destroy(m);
   return rc;
 }
 
@@ -989,11 +1073,12 @@ int cba_schur_solve(int32_t block_size, int32_t n_blocks, int32_t dense_dof, con
   int n_pad, n_fact; padded_dims(dd, &n_pad, &n_fact);
   const int ld = n_pad, Kpad = round_up(bdof, 16);
   double *Dblk, *bblk, *Dinv, *dinvb, *B, *W, *Hdd, *bd, *S, *xd, *gws; int* status;
-  CBA_TRY(dev_alloc(&gws, (size_t)gemv_t_workspace_doubles(dd)));
-  CBA_TRY(dev_alloc(&Dblk, (size_t)nb * bs * bs)); CBA_TRY(dev_alloc(&bblk, (size_t)bdof)); CBA_TRY(dev_alloc(&Dinv, (size_t)nb * bs * bs));
-  CBA_TRY(dev_alloc(&dinvb, (size_t)Kpad)); CBA_TRY(dev_alloc(&B, (size_t)Kpad * ld)); CBA_TRY(dev_alloc(&W, (size_t)Kpad * ld));
-  CBA_TRY(dev_alloc(&Hdd, (size_t)ld * ld)); CBA_TRY(dev_alloc(&bd, (size_t)ld)); CBA_TRY(dev_alloc(&S, (size_t)ld * ld));
-  CBA_TRY(dev_alloc(&xd, (size_t)bdof + ld)); CBA_TRY(dev_alloc(&status, 1));
+  DevPool pool;
+  CBA_TRY(pool.alloc(&gws, (size_t)gemv_t_workspace_doubles(dd)));
+  CBA_TRY(pool.alloc(&Dblk, (size_t)nb * bs * bs)); CBA_TRY(pool.alloc(&bblk, (size_t)bdof)); CBA_TRY(pool.alloc(&Dinv, (size_t)nb * bs * bs));
+  CBA_TRY(pool.alloc(&dinvb, (size_t)Kpad)); CBA_TRY(pool.alloc(&B, (size_t)Kpad * ld)); CBA_TRY(pool.alloc(&W, (size_t)Kpad * ld));
+  CBA_TRY(pool.alloc(&Hdd, (size_t)ld * ld)); CBA_TRY(pool.alloc(&bd, (size_t)ld)); CBA_TRY(pool.alloc(&S, (size_t)ld * ld));
+  CBA_TRY(pool.alloc(&xd, (size_t)bdof + ld)); CBA_TRY(pool.alloc(&status, 1));
   CBA_HIP(hipMemset(B, 0, sizeof(double) * (size_t)Kpad * ld)); CBA_HIP(hipMemset(W, 0, sizeof(double) * (size_t)Kpad * ld));
   CBA_HIP(hipMemset(Hdd, 0, sizeof(double) * (size_t)ld * ld)); CBA_HIP(hipMemset(S, 0, sizeof(double) * (size_t)ld * ld));
   CBA_HIP(hipMemset(bd, 0, sizeof(double) * ld)); CBA_HIP(hipMemset(status, 0, sizeof(int))); CBA_HIP(hipMemset(dinvb, 0, sizeof(double) * Kpad));
@@ -1011,6 +1096,7 @@ int cba_schur_solve(int32_t block_size, int32_t n_blocks, int32_t dense_dof, con
   CBA_HIP(hipMemcpy2D(Hdd, ld * sizeof(double), hH.data(), dd * sizeof(double), dd * sizeof(double), dd, hipMemcpyHostToDevice));
   CBA_HIP(hipMemcpy(bd, dense_b, sizeof(double) * dd, hipMemcpyHostToDevice));
   LdltWorkspace w;
+  LdltGuard wguard{&w};
   CBA_TRY(ldlt_workspace_alloc(w, n_pad));
   CBA_HIP(hipMemset(w.status, 0, sizeof(int)));
   hipStream_t s = nullptr;
@@ -1026,8 +1112,6 @@ int cba_schur_solve(int32_t block_size, int32_t n_blocks, int32_t dense_dof, con
   CBA_HIP(hipMemcpy(&st[0], status, sizeof(int), hipMemcpyDeviceToHost));
   CBA_HIP(hipMemcpy(&st[1], w.status, sizeof(int), hipMemcpyDeviceToHost));
   CBA_HIP(hipMemcpy(x, xd, sizeof(double) * (bdof + dd), hipMemcpyDeviceToHost));
-  ldlt_workspace_free(w);
-  hipFree(Dblk); hipFree(bblk); hipFree(Dinv); hipFree(dinvb); hipFree(B); hipFree(W); hipFree(Hdd); hipFree(bd); hipFree(S); hipFree(xd); hipFree(status); hipFree(gws);
   if (st[0] || st[1]) { set_error("cba_schur_solve: zero pivot"); return CBA_ERR_NUMERIC; }
   return CBA_OK;
 }
@@ -1047,12 +1131,13 @@ int cba_fit_grid_to_directions(const cba_camera* camera, double* grid, int64_t n
   double *g[2] = {nullptr, nullptr}, *tang, *gp, *dirs, *cost_ref, *cost_test, *rec, *H, *b, *S, *x, *partials, *red8, *scal;
   int *keys, *count, *start, *fill, *order, *status;
   const size_t nn = (size_t)(n > 0 ? n : 1);
-  CBA_TRY(dev_alloc(&g[0], 3 * (size_t)G)); CBA_TRY(dev_alloc(&g[1], 3 * (size_t)G)); CBA_TRY(dev_alloc(&tang, 6 * (size_t)G));
-  CBA_TRY(dev_alloc(&gp, 2 * nn)); CBA_TRY(dev_alloc(&dirs, 3 * nn)); CBA_TRY(dev_alloc(&cost_ref, 3 * nn)); CBA_TRY(dev_alloc(&cost_test, 3 * nn));
-  CBA_TRY(dev_alloc(&rec, nn * 99)); CBA_TRY(dev_alloc(&keys, nn)); CBA_TRY(dev_alloc(&order, nn));
-  CBA_TRY(dev_alloc(&count, (size_t)G + 1)); CBA_TRY(dev_alloc(&start, (size_t)G + 1)); CBA_TRY(dev_alloc(&fill, (size_t)G + 1));
-  CBA_TRY(dev_alloc(&H, (size_t)ld * ld)); CBA_TRY(dev_alloc(&b, (size_t)ld)); CBA_TRY(dev_alloc(&S, (size_t)ld * ld)); CBA_TRY(dev_alloc(&x, (size_t)ld));
-  CBA_TRY(dev_alloc(&partials, 256 * 8)); CBA_TRY(dev_alloc(&red8, 8)); CBA_TRY(dev_alloc(&scal, 8)); CBA_TRY(dev_alloc(&status, 1));
+  DevPool pool;
+  CBA_TRY(pool.alloc(&g[0], 3 * (size_t)G)); CBA_TRY(pool.alloc(&g[1], 3 * (size_t)G)); CBA_TRY(pool.alloc(&tang, 6 * (size_t)G));
+  CBA_TRY(pool.alloc(&gp, 2 * nn)); CBA_TRY(pool.alloc(&dirs, 3 * nn)); CBA_TRY(pool.alloc(&cost_ref, 3 * nn)); CBA_TRY(pool.alloc(&cost_test, 3 * nn));
+  CBA_TRY(pool.alloc(&rec, nn * 99)); CBA_TRY(pool.alloc(&keys, nn)); CBA_TRY(pool.alloc(&order, nn));
+  CBA_TRY(pool.alloc(&count, (size_t)G + 1)); CBA_TRY(pool.alloc(&start, (size_t)G + 1)); CBA_TRY(pool.alloc(&fill, (size_t)G + 1));
+  CBA_TRY(pool.alloc(&H, (size_t)ld * ld)); CBA_TRY(pool.alloc(&b, (size_t)ld)); CBA_TRY(pool.alloc(&S, (size_t)ld * ld)); CBA_TRY(pool.alloc(&x, (size_t)ld));
+  CBA_TRY(pool.alloc(&partials, 256 * 8)); CBA_TRY(pool.alloc(&red8, 8)); CBA_TRY(pool.alloc(&scal, 8)); CBA_TRY(pool.alloc(&status, 1));
   CBA_HIP(hipMemcpy(g[0], grid, sizeof(double) * 3 * G, hipMemcpyHostToDevice));
   if (n) {
     CBA_HIP(hipMemcpy(gp, grid_points, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
@@ -1060,14 +1145,10 @@ int cba_fit_grid_to_directions(const cba_camera* camera, double* grid, int64_t n
   }
   CBA_HIP(hipMemset(status, 0, sizeof(int)));
   LdltWorkspace w;
+  LdltGuard wguard{&w};
   CBA_TRY(ldlt_workspace_alloc(w, n_pad));
   hipStream_t s = nullptr;
   CBA_TRY(make_main_stream(&s));
-  auto cleanup = [&]() {
-    ldlt_workspace_free(w);
-    void* ptrs[] = {g[0], g[1], tang, gp, dirs, cost_ref, cost_test, rec, keys, order, count, start, fill, H, b, S, x, partials, red8, scal, status};
-    for (void* q : ptrs) hipFree(q);
-  };
   auto read = [&](const double* dev, double* host, int k) -> int {
     CBA_HIP(hipMemcpyAsync(host, dev, sizeof(double) * k, hipMemcpyDeviceToHost, s));
     CBA_HIP(hipStreamSynchronize(s));
@@ -1130,7 +1211,6 @@ int cba_fit_grid_to_directions(const cba_camera* camera, double* grid, int64_t n
     if (hipMemcpy(grid, g[cur], sizeof(double) * 3 * G, hipMemcpyDeviceToHost) != hipSuccess) { set_error("cba_fit_grid_to_directions: copy back failed"); rc = CBA_ERR_HIP; }
     if (report) *report = rep;
   }
-  cleanup();
   return rc;
 }
 

@@ -82,13 +82,18 @@ struct AccumTargets {
 };
 int launch_accumulate(const PassArgs& a, const Layout& L, int rec_doubles, const uint8_t* flags, const double* jrec,
                       const int* cells, const uint32_t* pair_tables, const int* pair_counts, AccumTargets t,
-                      hipStream_t s);
+                      const double* det_scale, hipStream_t s);
+// deterministic mode (cba_config.deterministic): fixed-point scale of a pass, conversion of an accumulated array
+int launch_det_scale(int64_t n, int rec_doubles, int used_doubles, const uint8_t* flags, const double* jrec, unsigned long long* bits,
+                     double* scale, hipStream_t s);
+int launch_det_convert(double* p, size_t n, const double* det_scale, hipStream_t s);
 int launch_accumulate_strips(const PassArgs& a, const Layout& L, int n_images, int rec_doubles, const uint8_t* flags, const double* jrec,
-                             const int* cells, unsigned* band_mask, const int64_t* img_start, double* B, int ld, hipStream_t s);
+                             const int* cells, unsigned* band_mask, const int64_t* img_start, double* B, int ld, const double* det_scale,
+                             hipStream_t s);
 int launch_accumulate_cells(const PassArgs& a, const std::vector<cba_camera>& cams, const std::vector<int>& cell_base_host,
                             int rec_doubles, int ld, const uint8_t* flags, const double* jrec, const int* cells,
                             const int* cell_base, int* count, int* start, int* fill, int* order, double* Hdd,
-                            int rig_row_first, hipStream_t s);
+                            int rig_row_first, const double* det_scale, hipStream_t s);
 // 8 outputs: [0] sum ref (valid), [1] sum test (valid), [2] masked ref, [3] masked test, [4] count both valid,
 // [5] n valid ref, [6] n valid test, [7] n jac dropped (flags)
 int launch_reduce_costs(const double* ref, const double* test, const uint8_t* flags, int64_t n, double* partials,

@@ -437,28 +437,55 @@ constexpr int kAccChunk = 8;
 constexpr int kHotMax = 12;                       // pose 6 + rig 6
 constexpr int kHotPairs = kHotMax * (kHotMax + 1) / 2;   // 78
 
-__device__ __forceinline__ void acc_add_H(const AccumLayout& L, const AccumTargets& T, int row, int col, double v) {
+// Accumulator policy.  DET = false: hardware fp64 atomics -- sums depend on the order in which wavefronts arrive (last
+// bits differ from run to run).  DET = true (cba_config.deterministic): every contribution is converted to 64-bit fixed
+// point with ONE power-of-two scale per pass (k_det_scale: 2^62 / (n_obs * largest possible |contribution|), so no sum
+// can overflow) and added with integer atomics; integer addition is associative, so registers, LDS and HBM sums are
+// bit-identical for every execution order -- no sorting, no second data layout.  The targets hold the integers during
+// the pass (same 8-byte slots) and k_det_convert turns them into doubles afterwards.  Resolution: about 19 decimal
+// digits below the largest possible sum, i.e. far below the finite-difference noise of the Jacobians.
+template <bool DET> struct Acc;
+template <> struct Acc<false> {
+  typedef double T;
+  static __device__ __forceinline__ T from(double v, double) { return v; }
+  static __device__ __forceinline__ void add(double* p, T v) { unsafeAtomicAdd(p, v); }
+  static __device__ __forceinline__ double to_double(T v, double) { return v; }
+};
+template <> struct Acc<true> {
+  typedef long long T;
+  static __device__ __forceinline__ T from(double v, double scale) { return __double2ll_rn(v * scale); }
+  static __device__ __forceinline__ void add(double* p, T v) { atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); }
+  static __device__ __forceinline__ double to_double(T v, double scale) { return (double)v / scale; }
+};
+
+template <bool DET>
+__device__ __forceinline__ void acc_add_H(const AccumLayout& L, const AccumTargets& T, int row, int col, typename Acc<DET>::T v) {
   if (row < L.block_dof) {
     if (col < L.block_dof) {
       int blk = row / L.block_size;
       int base = blk * L.block_size;
-      unsafeAtomicAdd(T.Dblk + (size_t)blk * L.block_size * L.block_size + (row - base) * L.block_size + (col - base), v);
+      Acc<DET>::add(T.Dblk + (size_t)blk * L.block_size * L.block_size + (row - base) * L.block_size + (col - base), v);
     } else {
-      unsafeAtomicAdd(T.B + (size_t)row * L.dense_dof + (col - L.block_dof), v);
+      Acc<DET>::add(T.B + (size_t)row * L.dense_dof + (col - L.block_dof), v);
     }
   } else {
-    unsafeAtomicAdd(T.Hdd + (size_t)(row - L.block_dof) * L.dense_dof + (col - L.block_dof), v);
+    Acc<DET>::add(T.Hdd + (size_t)(row - L.block_dof) * L.dense_dof + (col - L.block_dof), v);
   }
 }
-__device__ __forceinline__ void acc_add_b(const AccumLayout& L, const AccumTargets& T, int row, double v) {
-  if (row < L.block_dof) unsafeAtomicAdd(T.bblk + row, v);
-  else unsafeAtomicAdd(T.bd + (row - L.block_dof), v);
+template <bool DET>
+__device__ __forceinline__ void acc_add_b(const AccumLayout& L, const AccumTargets& T, int row, typename Acc<DET>::T v) {
+  if (row < L.block_dof) Acc<DET>::add(T.bblk + row, v);
+  else Acc<DET>::add(T.bd + (row - L.block_dof), v);
 }
 
+template <bool DET>
 __global__ void __launch_bounds__(256) k_accumulate(PassArgs a, AccumLayout L, int rec_doubles,
                                                     const uint8_t* __restrict__ flags, const double* __restrict__ jrec,
                                                     const int* __restrict__ cells, const uint32_t* __restrict__ pair_tables,
-                                                    const int* __restrict__ pair_counts, AccumTargets T) {
+                                                    const int* __restrict__ pair_counts, AccumTargets T,
+                                                    const double* __restrict__ det_scale) {
+  typedef typename Acc<DET>::T acc_t;
+  const double scale = DET ? *det_scale : 1.0;
   __shared__ double sJ0[4][kMaxCols];
   __shared__ double sJ1[4][kMaxCols];
   __shared__ double sW0[4][kMaxCols];
@@ -484,7 +511,7 @@ __global__ void __launch_bounds__(256) k_accumulate(PassArgs a, AccumLayout L, i
       hs_i[t] = sidx - nhp; hs_k[t] = -2;        // b entry
     }
   }
-  double hot[2] = {0.0, 0.0};
+  acc_t hot[2] = {0, 0};
   int cur_pose = -1, cur_rig = -1;
   auto flush = [&]() {
     if (cur_pose < 0) return;
@@ -492,9 +519,9 @@ __global__ void __launch_bounds__(256) k_accumulate(PassArgs a, AccumLayout L, i
     for (int t = 0; t < 2; ++t) {
       if (hs_i[t] < 0) continue;
       int row = hs_i[t] < 6 ? cur_pose + hs_i[t] : cur_rig + hs_i[t] - 6;
-      if (hs_k[t] == -2) acc_add_b(L, T, row, hot[t]);
-      else acc_add_H(L, T, row, hs_k[t] < 6 ? cur_pose + hs_k[t] : cur_rig + hs_k[t] - 6, hot[t]);
-      hot[t] = 0.0;
+      if (hs_k[t] == -2) acc_add_b<DET>(L, T, row, hot[t]);
+      else acc_add_H<DET>(L, T, row, hs_k[t] < 6 ? cur_pose + hs_k[t] : cur_rig + hs_k[t] - 6, hot[t]);
+      hot[t] = 0;
     }
   };
   for (int c = 0; c < kAccChunk; ++c) {
@@ -554,13 +581,13 @@ __global__ void __launch_bounds__(256) k_accumulate(PassArgs a, AccumLayout L, i
     for (int t = 0; t < 2; ++t) {
       if (hs_i[t] < 0) continue;
       const int i = h0 + hs_i[t];
-      if (hs_k[t] == -2) hot[t] += r0 * sW0[wv][i] + r1 * sW1[wv][i];
-      else { const int k = h0 + hs_k[t]; hot[t] += sW0[wv][i] * sJ0[wv][k] + sW1[wv][i] * sJ1[wv][k]; }
+      if (hs_k[t] == -2) hot[t] += Acc<DET>::from(r0 * sW0[wv][i] + r1 * sW1[wv][i], scale);
+      else { const int k = h0 + hs_k[t]; hot[t] += Acc<DET>::from(sW0[wv][i] * sJ0[wv][k] + sW1[wv][i] * sJ1[wv][k], scale); }
     }
     // b += Jw^T r (non-hot positions)
     for (int k = lane; k < K; k += 64) {
       if (k >= h0 && k < h0 + nh) continue;
-      acc_add_b(L, T, sIdx[wv][k], r0 * sW0[wv][k] + r1 * sW1[wv][k]);
+      acc_add_b<DET>(L, T, sIdx[wv][k], Acc<DET>::from(r0 * sW0[wv][k] + r1 * sW1[wv][k], scale));
     }
     // remaining upper-triangle products (the pair tables exclude hot-hot pairs)
     const int slot = (per == 2) ? 0 : 1;
@@ -570,7 +597,7 @@ __global__ void __launch_bounds__(256) k_accumulate(PassArgs a, AccumLayout L, i
       uint32_t pr = table[e];
       int i = pr >> 16, k = pr & 0xffff;
       double v = sW0[wv][i] * sJ0[wv][k] + sW1[wv][i] * sJ1[wv][k];
-      acc_add_H(L, T, sIdx[wv][i], sIdx[wv][k], v);
+      acc_add_H<DET>(L, T, sIdx[wv][i], sIdx[wv][k], Acc<DET>::from(v, scale));
     }
   }
   flush();
@@ -624,10 +651,13 @@ __global__ void __launch_bounds__(256) k_cell_fill(PassArgs a, const uint8_t* __
 }
 // rig_row0 >= 0 (several cameras, poses eliminated): the bucket also sums the camera's rig-pose x grid block
 // (6 x K_g entries of H_dd that EVERY observation of the camera would otherwise hit with atomics).
-template <int PER>
+template <int PER, bool DET>
 __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, int key0, int n_cells, int rec_doubles, int ld,
                                                           const double* __restrict__ jrec, const int* __restrict__ start,
-                                                          const int* __restrict__ order, double* __restrict__ Hdd, int rig_row0) {
+                                                          const int* __restrict__ order, double* __restrict__ Hdd, int rig_row0,
+                                                          const double* __restrict__ det_scale) {
+  typedef typename Acc<DET>::T acc_t;
+  const double scale = DET ? *det_scale : 1.0;
   constexpr int KG = PER * 16;
   constexpr int NPAIR = KG * (KG + 1) / 2;
   constexpr int NE = (NPAIR + 63) / 64;
@@ -652,9 +682,9 @@ __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, i
   const CamDev cd = a.cams[cam];
   const int cy0 = cell / cd.gw, cx0 = cell - cy0 * cd.gw;
   {
-    double acc[NE];
+    acc_t acc[NE];
 #pragma unroll
-    for (int t = 0; t < NE; ++t) acc[t] = 0.0;
+    for (int t = 0; t < NE; ++t) acc[t] = 0;
     for (int idx = o_begin; idx < o_end; ++idx) {
       const int o = order[idx];
       const double* rec = jrec + (size_t)o * rec_doubles;
@@ -666,7 +696,7 @@ __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, i
 #pragma unroll
       for (int t = 0; t < NE; ++t) {
         const int i = pi[t], k = pk[t];
-        acc[t] += w * (sJ0[wv][i] * sJ0[wv][k] + sJ1[wv][i] * sJ1[wv][k]);
+        acc[t] += Acc<DET>::from(w * (sJ0[wv][i] * sJ0[wv][k] + sJ1[wv][i] * sJ1[wv][k]), scale);
       }
     }
 #pragma unroll
@@ -677,15 +707,15 @@ __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, i
       int row = grid_column(cd, (cx0 + (ci & 3)) + (cy0 + (ci >> 2)) * cd.gw, di);
       int col = grid_column(cd, (cx0 + (ck & 3)) + (cy0 + (ck >> 2)) * cd.gw, dk);
       if (row > col) { const int t2 = row; row = col; col = t2; }   // tiled order is not monotone in the patch order
-      unsafeAtomicAdd(Hdd + (size_t)row * ld + col, acc[t]);
+      Acc<DET>::add(Hdd + (size_t)row * ld + col, acc[t]);
     }
   }
   if (rig_row0 < 0) return;
   // second pass over the bucket for the rig rows: a separate loop, so that its accumulators are not live together
   // with the K_g (K_g + 1) / 2 pair sums above (the non-central instantiation spilled 1.6 KB per lane otherwise)
-  double racc[NR];
+  acc_t racc[NR];
 #pragma unroll
-  for (int t = 0; t < NR; ++t) racc[t] = 0.0;
+  for (int t = 0; t < NR; ++t) racc[t] = 0;
   for (int idx = o_begin; idx < o_end; ++idx) {
     const int o = order[idx];
     const double* rec = jrec + (size_t)o * rec_doubles;
@@ -698,7 +728,7 @@ __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, i
 #pragma unroll
     for (int t = 0; t < NR; ++t) {
       const int e = lane + 64 * t;
-      if (e < 6 * KG) { const int r = e / KG, k = e - r * KG; racc[t] += w * (sRig[wv][r] * sJ0[wv][k] + sRig[wv][6 + r] * sJ1[wv][k]); }
+      if (e < 6 * KG) { const int r = e / KG, k = e - r * KG; racc[t] += Acc<DET>::from(w * (sRig[wv][r] * sJ0[wv][k] + sRig[wv][6 + r] * sJ1[wv][k]), scale); }
     }
   }
 #pragma unroll
@@ -707,13 +737,13 @@ __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, i
     if (e >= 6 * KG) continue;
     const int r = e / KG, k = e - r * KG, ck = k / PER, dk = k - ck * PER;
     const int col = grid_column(cd, (cx0 + (ck & 3)) + (cy0 + (ck >> 2)) * cd.gw, dk);
-    unsafeAtomicAdd(Hdd + (size_t)(rig_row0 + r) * ld + col, racc[t]);      // rig rows precede the grid columns
+    Acc<DET>::add(Hdd + (size_t)(rig_row0 + r) * ld + col, racc[t]);      // rig rows precede the grid columns
   }
 }
 int launch_accumulate_cells(const PassArgs& a, const std::vector<cba_camera>& cams, const std::vector<int>& cell_base_host,
                             int rec_doubles, int ld, const uint8_t* flags, const double* jrec, const int* cells,
                             const int* cell_base, int* count, int* start, int* fill, int* order, double* Hdd,
-                            int rig_row_first /* dense row of camera 0's rig block, or -1 */, hipStream_t s) {
+                            int rig_row_first /* dense row of camera 0's rig block, or -1 */, const double* det_scale, hipStream_t s) {
   if (a.n_obs == 0) return CBA_OK;
   const int n_keys = cell_base_host.back();
   CBA_HIP(hipMemsetAsync(count, 0, sizeof(int) * (size_t)n_keys, s));
@@ -725,12 +755,13 @@ int launch_accumulate_cells(const PassArgs& a, const std::vector<cba_camera>& ca
   for (size_t c = 0; c < cams.size(); ++c) {
     const int n_cells = cams[c].grid_w * cams[c].grid_h;
     dim3 g2((unsigned)((n_cells + 3) / 4));
-    if (cams[c].model_type == CBA_CENTRAL_GENERIC)
-      hipLaunchKernelGGL(k_accumulate_cells<2>, g2, block, 0, s, a, (int)c, cell_base_host[c], n_cells, rec_doubles, ld, jrec, start, order, Hdd,
-                         rig_row_first >= 0 ? rig_row_first + 6 * (int)c : -1);
-    else
-      hipLaunchKernelGGL(k_accumulate_cells<5>, g2, block, 0, s, a, (int)c, cell_base_host[c], n_cells, rec_doubles, ld, jrec, start, order, Hdd,
-                         rig_row_first >= 0 ? rig_row_first + 6 * (int)c : -1);
+    const int rr = rig_row_first >= 0 ? rig_row_first + 6 * (int)c : -1;
+    const bool central = cams[c].model_type == CBA_CENTRAL_GENERIC;
+#define CBA_CELLS(PER_, DET_) hipLaunchKernelGGL((k_accumulate_cells<PER_, DET_>), g2, block, 0, s, a, (int)c, cell_base_host[c], n_cells, \
+                                                 rec_doubles, ld, jrec, start, order, Hdd, rr, det_scale)
+    if (central) { if (det_scale) CBA_CELLS(2, true); else CBA_CELLS(2, false); }
+    else { if (det_scale) CBA_CELLS(5, true); else CBA_CELLS(5, false); }
+#undef CBA_CELLS
   }
   CBA_HIP(hipGetLastError());
   return CBA_OK;
@@ -768,11 +799,14 @@ __global__ void __launch_bounds__(256) k_strip_band_mask(PassArgs a, AccumLayout
   band_mask[o] = m;
 }
 constexpr int kStripWaves = 8;
+template <bool DET>
 __global__ void __launch_bounds__(64 * kStripWaves) k_accumulate_strips(PassArgs a, AccumLayout L, int rec_doubles, const uint8_t* __restrict__ flags,
                                                             const double* __restrict__ jrec, const int* __restrict__ cells,
                                                             const unsigned* __restrict__ band_mask,
-                                                            const int64_t* __restrict__ img_start, double* __restrict__ B, int ld) {
-  __shared__ double acc[6][kStripBand];
+                                                            const int64_t* __restrict__ img_start, double* __restrict__ B, int ld,
+                                                            const double* __restrict__ det_scale) {
+  __shared__ double acc[6][kStripBand];      // DET: the same 8-byte slots hold fixed-point integers (zero bits = 0 in both)
+  const double scale = DET ? *det_scale : 1.0;
   const int img = blockIdx.x, band = blockIdx.y;
   const int col_lo = band * kStripBand;
   const int col_hi = min(col_lo + kStripBand, ld);
@@ -820,7 +854,7 @@ __global__ void __launch_bounds__(64 * kStripWaves) k_accumulate_strips(PassArgs
           if (col < col_lo || col >= col_hi) continue;
           const double w0 = w * j0, w1 = w * j1;
 #pragma unroll
-          for (int k = 0; k < 6; ++k) unsafeAtomicAdd(&acc[k][col - col_lo], rec[3 + k] * w0 + rec[9 + k] * w1);
+          for (int k = 0; k < 6; ++k) Acc<DET>::add(&acc[k][col - col_lo], Acc<DET>::from(rec[3 + k] * w0 + rec[9 + k] * w1, scale));
         }
       }
     }
@@ -830,11 +864,13 @@ __global__ void __launch_bounds__(64 * kStripWaves) k_accumulate_strips(PassArgs
   const int slot = a.pose_slot ? a.pose_slot[img] : img;
   for (int k = 0; k < 6; ++k) {
     double* row = B + (size_t)(6 * slot + k) * ld + col_lo;
-    for (int c = threadIdx.x; c < col_hi - col_lo; c += 64 * kStripWaves) row[c] = acc[k][c];
+    for (int c = threadIdx.x; c < col_hi - col_lo; c += 64 * kStripWaves)
+      row[c] = DET ? Acc<true>::to_double(*reinterpret_cast<const long long*>(&acc[k][c]), scale) : acc[k][c];
   }
 }
 int launch_accumulate_strips(const PassArgs& a, const Layout& L, int n_images, int rec_doubles, const uint8_t* flags, const double* jrec,
-                             const int* cells, unsigned* band_mask, const int64_t* img_start, double* B, int ld, hipStream_t s) {
+                             const int* cells, unsigned* band_mask, const int64_t* img_start, double* B, int ld, const double* det_scale,
+                             hipStream_t s) {
   if (n_images == 0) return CBA_OK;
   AccumLayout al;
   al.rig_in_state = L.rig_in_state; al.eliminate_points = L.eliminate_points; al.localize_only = L.localize_only;
@@ -843,22 +879,74 @@ int launch_accumulate_strips(const PassArgs& a, const Layout& L, int n_images, i
   const int bands = (ld + kStripBand - 1) / kStripBand;
   if (a.n_obs > 0)
     hipLaunchKernelGGL(k_strip_band_mask, dim3((unsigned)((a.n_obs + 255) / 256)), dim3(256), 0, s, a, al, flags, cells, band_mask, bands);
-  hipLaunchKernelGGL(k_accumulate_strips, dim3((unsigned)n_images, (unsigned)bands), dim3(64 * kStripWaves), 0, s, a, al, rec_doubles, flags, jrec, cells,
-                     band_mask, img_start, B, ld);
+  if (det_scale)
+    hipLaunchKernelGGL(k_accumulate_strips<true>, dim3((unsigned)n_images, (unsigned)bands), dim3(64 * kStripWaves), 0, s, a, al, rec_doubles, flags,
+                       jrec, cells, band_mask, img_start, B, ld, det_scale);
+  else
+    hipLaunchKernelGGL(k_accumulate_strips<false>, dim3((unsigned)n_images, (unsigned)bands), dim3(64 * kStripWaves), 0, s, a, al, rec_doubles, flags,
+                       jrec, cells, band_mask, img_start, B, ld, det_scale);
   CBA_HIP(hipGetLastError());
   return CBA_OK;
 }
 
 int launch_accumulate(const PassArgs& a, const Layout& L, int rec_doubles, const uint8_t* flags, const double* jrec,
                       const int* cells, const uint32_t* pair_tables, const int* pair_counts, AccumTargets t,
-                      hipStream_t s) {
+                      const double* det_scale, hipStream_t s) {
   if (a.n_obs == 0) return CBA_OK;
   AccumLayout al;
   al.rig_in_state = L.rig_in_state; al.eliminate_points = L.eliminate_points; al.localize_only = L.localize_only;
   al.first_rig_tr_global = L.first_rig_tr_global; al.first_camera_tr_rig = L.first_camera_tr_rig;
   al.first_points = L.first_points; al.block_dof = L.block_dof; al.block_size = L.block_size; al.dense_dof = L.dense_dof;
-  hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((a.n_obs + 4 * kAccChunk - 1) / (4 * kAccChunk))), dim3(256), 0, s, a, al, rec_doubles, flags, jrec,
-                     cells, pair_tables, pair_counts, t);
+  const dim3 grid((unsigned)((a.n_obs + 4 * kAccChunk - 1) / (4 * kAccChunk)));
+  if (det_scale)
+    hipLaunchKernelGGL(k_accumulate<true>, grid, dim3(256), 0, s, a, al, rec_doubles, flags, jrec, cells, pair_tables, pair_counts, t, det_scale);
+  else
+    hipLaunchKernelGGL(k_accumulate<false>, grid, dim3(256), 0, s, a, al, rec_doubles, flags, jrec, cells, pair_tables, pair_counts, t, det_scale);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
+// ---- deterministic mode: scale of the fixed-point accumulation, and the conversion back to doubles ----
+// out_bits: bit pattern of max over the observations with a Jacobian of  2 w (max(|J|, |r|))^2  >= every |contribution|
+// (positive doubles order like their bit patterns, and max is order-independent)
+__global__ void __launch_bounds__(256) k_det_bound(int64_t n, int rec_doubles, int used_doubles, const uint8_t* __restrict__ flags,
+                                                   const double* __restrict__ jrec, unsigned long long* __restrict__ out_bits) {
+  const int lane = threadIdx.x & 63;
+  double m = 0.0;
+  for (int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); o < n; o += (int64_t)gridDim.x * 4) {
+    if (flags[o] != 3) continue;
+    const double* rec = jrec + (size_t)o * rec_doubles;
+    double jm = 0.0;
+    for (int k = lane; k < used_doubles; k += 64) if (k != 2) jm = fmax(jm, fabs(rec[k]));
+    for (int off = 32; off > 0; off >>= 1) jm = fmax(jm, __shfl_xor(jm, off, 64));
+    m = fmax(m, 2.0 * rec[2] * jm * jm);
+  }
+  if (lane == 0 && m > 0.0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(m));
+}
+__global__ void k_det_scale(const unsigned long long* __restrict__ bits, int64_t n_obs, double* __restrict__ scale) {
+  const double m = __longlong_as_double((long long)*bits);
+  const double bound = m * (double)(n_obs > 0 ? n_obs : 1);     // no entry receives more than n_obs contributions
+  int e = 0;
+  if (bound > 0.0) frexp(bound, &e);                            // bound < 2^e
+  *scale = ldexp(1.0, 62 - e);                                  // bound * scale < 2^62
+}
+int launch_det_scale(int64_t n, int rec_doubles, int used_doubles, const uint8_t* flags, const double* jrec, unsigned long long* bits,
+                     double* scale, hipStream_t s) {
+  CBA_HIP(hipMemsetAsync(bits, 0, sizeof(unsigned long long), s));
+  if (n > 0) hipLaunchKernelGGL(k_det_bound, dim3(1024), dim3(256), 0, s, n, rec_doubles, used_doubles, flags, jrec, bits);
+  hipLaunchKernelGGL(k_det_scale, dim3(1), dim3(1), 0, s, bits, n, scale);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+__global__ void __launch_bounds__(256) k_det_convert(double* __restrict__ p, size_t n, const double* __restrict__ det_scale) {
+  const double inv = 1.0 / *det_scale;                          // power of two: exact
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    p[i] = (double)(*reinterpret_cast<const long long*>(p + i)) * inv;
+}
+int launch_det_convert(double* p, size_t n, const double* det_scale, hipStream_t s) {
+  if (n == 0) return CBA_OK;
+  const size_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(k_det_convert, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, p, n, det_scale);
   CBA_HIP(hipGetLastError());
   return CBA_OK;
 }
@@ -976,8 +1064,9 @@ int launch_apply_update(const Layout& L, const std::vector<cba_camera>& cams, co
                        x + L.first_rig_tr_global, N, out.rig_tr_global, 1, pose_slot);
   hipLaunchKernelGGL(k_update_poses, dim3((C + 255) / 256), dim3(256), 0, s, in.camera_tr_rig,
                      x + (L.rig_in_state ? L.first_camera_tr_rig : 0), C, out.camera_tr_rig, L.rig_in_state, (const int*)nullptr);
-  hipLaunchKernelGGL(k_update_points, dim3((3 * P + 255) / 256), dim3(256), 0, s, in.points, x + L.first_points, 3 * P,
-                     out.points);
+  if (P > 0)     // a problem without pattern points (n_points = 0 is accepted by cba_create) must not launch an empty grid
+    hipLaunchKernelGGL(k_update_points, dim3((3 * P + 255) / 256), dim3(256), 0, s, in.points, x + L.first_points, 3 * P,
+                       out.points);
   for (int c = 0; c < C; ++c) {
     int G = cams[c].grid_w * cams[c].grid_h;
     int per = cams[c].model_type == CBA_CENTRAL_GENERIC ? 2 : 5;

@@ -40,7 +40,8 @@ class CbaConfig(C.Structure):
                 ("localize_only", C.c_int32), ("eliminate_points", C.c_int32), ("device", C.c_int32),
                 ("allreduce", ALLREDUCE_FN), ("allreduce_user", C.c_void_p),
                 ("n_images_global", C.c_int32),
-                ("reduce_buffer", C.c_void_p), ("reduce_buffer_doubles", C.c_int64)]
+                ("reduce_buffer", C.c_void_p), ("reduce_buffer_doubles", C.c_int64),
+                ("deterministic", C.c_int32)]
 
 
 class CbaFitReport(C.Structure):
@@ -63,6 +64,7 @@ EXPORTED_SYMBOLS = [
     "cba_schur_solve", "cba_debug_dump", "cba_debug_accumulate", "cba_debug_solve", "cba_debug_apply_update",
     "cba_total_dof", "cba_dense_dof", "cba_jacobian_record_doubles", "cba_reduce_buffer_doubles",
     "cba_kernel_stats", "cba_fit_grid_to_directions", "cba_prepare_device",
+    "cba_model_create", "cba_model_destroy", "cba_model_set_grid", "cba_model_project", "cba_model_unproject",
 ]
 
 DUMP_COST_VECTOR, DUMP_PIXELS, DUMP_FLAGS, DUMP_JACOBIANS = 1, 2, 3, 4
@@ -120,6 +122,12 @@ def load() -> C.CDLL:
     L.cba_reduce_buffer_doubles.restype = C.c_int64
     L.cba_kernel_stats.argtypes = [vp, C.c_int32, dp, dp, dp, C.POINTER(C.c_int32)]
     L.cba_prepare_device.argtypes = [C.c_int32]
+    L.cba_model_create.argtypes = [C.POINTER(CbaCamera), dp, C.c_int32, C.POINTER(vp)]
+    L.cba_model_destroy.argtypes = [vp]
+    L.cba_model_destroy.restype = None
+    L.cba_model_set_grid.argtypes = [vp, dp]
+    L.cba_model_project.argtypes = [vp, C.c_int64, dp, dp, dp, C.POINTER(C.c_uint8)]
+    L.cba_model_unproject.argtypes = [vp, C.c_int64, dp, dp, dp, C.POINTER(C.c_uint8)]
     _lib = L
     return L
 
@@ -169,7 +177,8 @@ class Engine:
     """Device-resident BA problem (cba_problem)."""
 
     def __init__(self, problem: Problem, device: int = 0, allreduce: Optional[Callable[[int, int], int]] = None,
-                 n_images_global: int = 0, reduce_buffer_ptr: int = 0, reduce_buffer_doubles: int = 0):
+                 n_images_global: int = 0, reduce_buffer_ptr: int = 0, reduce_buffer_doubles: int = 0,
+                 last_projection: Optional[np.ndarray] = None, deterministic: bool = False):
         self.L = load()
         self.problem = problem
         self._cams = (CbaCamera * problem.n_cameras)(*[_cam_struct(c) for c in problem.cameras])
@@ -186,7 +195,7 @@ class Engine:
         cfg = CbaConfig(problem.n_cameras, self._cams, problem.n_images, problem.n_points, problem.fd_delta,
                         int(problem.localize_only), int(problem.eliminate_points), device,
                         self._cb if self._cb is not None else ALLREDUCE_FN(0), None, n_images_global,
-                        reduce_buffer_ptr or None, reduce_buffer_doubles)
+                        reduce_buffer_ptr or None, reduce_buffer_doubles, int(deterministic))
         self._cfg = cfg
         self._h = C.c_void_p()
         _check(self.L.cba_create(C.byref(cfg), C.byref(self._h)), "cba_create")
@@ -194,13 +203,15 @@ class Engine:
             self._h, problem.n_obs, problem.obs_xy.ctypes.data_as(C.POINTER(C.c_float)),
             problem.obs_point.ctypes.data_as(C.POINTER(C.c_int32)),
             problem.obs_image.ctypes.data_as(C.POINTER(C.c_int32)),
-            problem.obs_camera.ctypes.data_as(C.POINTER(C.c_int32)), None), "cba_set_observations")
+            problem.obs_camera.ctypes.data_as(C.POINTER(C.c_int32)),
+            None if last_projection is None else _dp(np.ascontiguousarray(last_projection, dtype=np.float64).reshape(-1, 2))),
+            "cba_set_observations")
 
     @staticmethod
     def reduce_buffer_doubles(problem: Problem) -> int:
         cams = (CbaCamera * problem.n_cameras)(*[_cam_struct(c) for c in problem.cameras])
         cfg = CbaConfig(problem.n_cameras, cams, problem.n_images, problem.n_points, problem.fd_delta,
-                        int(problem.localize_only), int(problem.eliminate_points), 0, ALLREDUCE_FN(0), None, 0, None, 0)
+                        int(problem.localize_only), int(problem.eliminate_points), 0, ALLREDUCE_FN(0), None, 0, None, 0, 0)
         return int(load().cba_reduce_buffer_doubles(C.byref(cfg)))
 
     def close(self) -> None:
@@ -284,6 +295,51 @@ class Engine:
         out = np.zeros(shape, dtype=dt)
         _check(self.L.cba_debug_dump(self._h, what, out.ctypes.data_as(C.c_void_p), out.nbytes), "cba_debug_dump")
         return out
+
+
+class DeviceModel:
+    """Device-resident camera model (cba_model): the grid is uploaded once, scratch buffers are kept between calls."""
+
+    def __init__(self, cam: Camera, grid: np.ndarray, device: int = 0):
+        self.L = load()
+        self.cam = cam
+        g = np.ascontiguousarray(grid, dtype=np.float64)
+        cs = _cam_struct(cam)
+        self._h = C.c_void_p()
+        _check(self.L.cba_model_create(C.byref(cs), _dp(g), device, C.byref(self._h)), "cba_model_create")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.cba_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_grid(self, grid: np.ndarray) -> None:
+        g = np.ascontiguousarray(grid, dtype=np.float64)
+        _check(self.L.cba_model_set_grid(self._h, _dp(g)), "cba_model_set_grid")
+
+    def project(self, local_points: np.ndarray, init: Optional[np.ndarray] = None):
+        pts = np.ascontiguousarray(local_points, dtype=np.float64).reshape(-1, 3)
+        n = pts.shape[0]
+        px = np.zeros((n, 2)); ok = np.zeros(n, dtype=np.uint8)
+        ini = None if init is None else np.ascontiguousarray(init, dtype=np.float64).reshape(-1, 2)
+        _check(self.L.cba_model_project(self._h, n, _dp(pts), _dp(ini) if ini is not None else None, _dp(px),
+                                        ok.ctypes.data_as(C.POINTER(C.c_uint8))), "cba_model_project")
+        return px, ok.astype(bool)
+
+    def unproject(self, pixels: np.ndarray, with_jacobian: bool = False):
+        px = np.ascontiguousarray(pixels, dtype=np.float64).reshape(-1, 2)
+        n = px.shape[0]
+        lines = np.zeros((n, 6)); ok = np.zeros(n, dtype=np.uint8)
+        jac = np.zeros((n, 6, 2)) if with_jacobian else None
+        _check(self.L.cba_model_unproject(self._h, n, _dp(px), _dp(lines), _dp(jac) if jac is not None else None,
+                                          ok.ctypes.data_as(C.POINTER(C.c_uint8))), "cba_model_unproject")
+        return (lines, jac, ok.astype(bool)) if with_jacobian else (lines, ok.astype(bool))
 
 
 # ---- stateless model-level API (CameraModel::Project / Unproject) -----------------------------------

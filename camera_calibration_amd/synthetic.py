@@ -145,7 +145,7 @@ def _rig_layout(n_cams: int) -> np.ndarray:
 
 def baseline_config(cfg: int, project_fn: ProjectFn, n_imagesets: int | None = None, noise_px: float = 0.03,
                     seed: int | None = None, grid_perturbation: float = 0.1, pose_perturbation: float = 0.01,
-                    point_perturbation: float = 0.002, image_offset: int = 0):
+                    point_perturbation: float = 0.002, image_offset: int = 0, grid_wh: Tuple[int, int] | None = None):
     """Build BASELINE.json config ``cfg`` (optionally with fewer imagesets). Returns (problem, state, gt).
 
     Perturbations: points +-``point_perturbation`` m, poses exp(``pose_perturbation``*U^6), grid directions
@@ -155,6 +155,8 @@ def baseline_config(cfg: int, project_fn: ProjectFn, n_imagesets: int | None = N
     generated independently (rank r of an N-GPU run passes image_offset = r * n_imagesets).
     """
     n_cams, model, W, H, gw, gh, lx, ly, n_default, fd = BASELINE_CONFIGS[cfg]
+    if grid_wh is not None:      # coarser grid for memory-bound test hosts (the configuration's own grid is the default)
+        gw, gh = grid_wh
     N = n_default if n_imagesets is None else n_imagesets
     seed = 1000 + cfg if seed is None else seed
     rng = np.random.default_rng(seed)

@@ -71,6 +71,11 @@ typedef struct {
   int32_t n_images_global;       /* total imagesets over all ranks (0 = n_images) */
   void* reduce_buffer;           /* optional caller-owned DEVICE buffer for the packed reduced system (all-reduced in place) */
   int64_t reduce_buffer_doubles; /* its size; must be >= cba_reduce_buffer_doubles() */
+  /* 1 = run-to-run reproducible normal equations: JtJ / Jtr terms are accumulated in 64-bit fixed point (integer
+   * atomics are order-independent) instead of fp64 atomics; two runs on the same input then give bit-identical H, b,
+   * x, costs and states.  The reference is single-threaded and therefore reproducible; this is the mode that matches
+   * that property.  Costs about 1 ms per LM iteration at BASELINE configs[1].  0 = fp64 atomics. */
+  int32_t deterministic;
 } cba_config;
 
 /* OptimizationReport (LV/lm_optimizer.h:55-77) + what OptimizeJointly returns through pointers */
@@ -143,6 +148,17 @@ int cba_project(const cba_camera* camera, const double* grid, int64_t n, const d
  * noncentral twins). lines: 6n (direction, origin); jacobians: 12n (6x2 row-major) or NULL. */
 int cba_unproject(const cba_camera* camera, const double* grid, int64_t n, const double* pixels,
                   double* lines, double* jacobians, uint8_t* ok, int32_t device);
+
+/* The same two calls on a DEVICE-RESIDENT camera model: the grid is uploaded once by cba_model_create and scratch buffers
+ * are kept between calls, so a caller that projects point by point (CameraModel::Project in a loop, e.g.
+ * APP/calibration_report.cc:101-148) pays one small launch per call instead of a grid upload and six allocations.
+ * cba_model_set_grid replaces the grid (after an optimisation step changed the intrinsics). */
+typedef struct cba_model cba_model;
+int cba_model_create(const cba_camera* camera, const double* grid, int32_t device, cba_model** out);
+void cba_model_destroy(cba_model* m);
+int cba_model_set_grid(cba_model* m, const double* grid);
+int cba_model_project(cba_model* m, int64_t n, const double* local_points, const double* init_pixels, double* pixels, uint8_t* ok);
+int cba_model_unproject(cba_model* m, int64_t n, const double* pixels, double* lines, double* jacobians, uint8_t* ok);
 
 /* ---- solver-level entry point ---- */
 /* LMOptimizer::SolveWithSchurComplementDenseOffDiag (LV/lm_optimizer.h:1247-1369) on host arrays in

@@ -1,0 +1,48 @@
+"""Records the observed deviation of every parity comparison next to the tolerance it was checked against.
+
+`check(case, quantity, observed, tolerance)` asserts observed <= tolerance and remembers the pair; at interpreter exit the
+table is merged into gpurun_out/parity_deviations.json (scratch, comes back from the GPU box) -- the committed copy is
+profiles/r02_parity_deviations.json.  A tolerance is meant to sit within ~10x of the observed maximum: a looser one hides
+regressions.
+"""
+import atexit
+import json
+import os
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_OUT = os.path.join(_ROOT, "gpurun_out", "parity_deviations.json")
+_rows = {}
+
+
+def check(case: str, quantity: str, observed: float, tolerance: float, exact: bool = False) -> None:
+    observed = float(observed)
+    key = f"{case}/{quantity}"
+    prev = _rows.get(key)
+    _rows[key] = dict(case=case, quantity=quantity, observed=max(observed, prev["observed"]) if prev else observed,
+                      tolerance=float(tolerance), exact=bool(exact))
+    assert observed <= tolerance, f"{key}: observed {observed:.3e} > tolerance {tolerance:.3e}"
+
+
+def check_equal(case: str, quantity: str, mismatches: int) -> None:
+    """bit-exact quantities (masks, flags, indices, decisions): the number of mismatching entries must be 0"""
+    check(case, quantity, float(mismatches), 0.0, exact=True)
+
+
+def _flush():
+    if not _rows:
+        return
+    try:
+        os.makedirs(os.path.dirname(_OUT), exist_ok=True)
+        old = {}
+        if os.path.exists(_OUT):
+            with open(_OUT) as f:
+                old = {f"{r['case']}/{r['quantity']}": r for r in json.load(f).get("rows", [])}
+        old.update(_rows)
+        host = dict(cpu_count=os.cpu_count())
+        with open(_OUT, "w") as f:
+            json.dump(dict(host=host, rows=sorted(old.values(), key=lambda r: (r["case"], r["quantity"]))), f, indent=1)
+    except OSError:
+        pass
+
+
+atexit.register(_flush)

@@ -1,0 +1,98 @@
+"""cba_config.deterministic: normal equations accumulated in 64-bit fixed point (integer atomics are order-independent).
+Two runs on the same input must be bit-identical in H, b, x, cost vectors and the updated state; the default mode (fp64
+atomics) is allowed to differ in the last bits; both agree with the oracle."""
+import numpy as np
+import pytest
+
+from camera_calibration_amd import engine as eng
+from camera_calibration_amd import synthetic as syn
+from camera_calibration_amd.problem import NONCENTRAL_GENERIC
+from oracle import oracle as orc
+from parity_record import check, check_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_project(cam, grid, pts):
+    return eng.project(cam, grid, pts)
+
+
+def _run(pb, st, deterministic, steps):
+    e = eng.Engine(pb, last_projection=pb.obs_xy.astype(np.float64), deterministic=deterministic)
+    e.set_state(st)
+    cost = e.debug_accumulate()
+    out = dict(cost=cost, bD=e.dump(eng.DUMP_BLOCK_DIAG_H), bb=e.dump(eng.DUMP_BLOCK_DIAG_B), B=e.dump(eng.DUMP_OFF_DIAG_H),
+               H=e.dump(eng.DUMP_DENSE_H), b=e.dump(eng.DUMP_DENSE_B))
+    lam = -1.0
+    reps = []
+    for _ in range(steps):
+        r = e.step(lam)
+        lam = r.final_lambda
+        reps.append((r.initial_cost, r.final_cost, r.final_lambda, r.lm_attempts, r.accepted))
+    out["x"] = e.dump(eng.DUMP_X)
+    out["test_cost_vector"] = e.dump(eng.DUMP_TEST_COST_VECTOR)
+    out["reps"] = reps
+    s = e.get_state(st)
+    out["points"], out["poses"], out["grid"], out["rig"] = s.points, s.rig_tr_global, s.grids[0], s.camera_tr_rig
+    e.close()
+    return out
+
+
+@pytest.mark.parametrize("cfg,n", [(2, 120), (3, 40), (4, 40)])
+def test_deterministic_mode_is_bit_reproducible(cfg, n):
+    case = f"deterministic mode, cfg {cfg} ({n} imagesets)"
+    pb, st, _ = syn.baseline_config(cfg, gpu_project, n_imagesets=n)
+    a = _run(pb, st, True, 3)
+    b = _run(pb, st, True, 3)
+    for k in ("cost", "bD", "bb", "B", "H", "b", "x", "test_cost_vector", "points", "poses", "grid", "rig"):
+        check_equal(case, f"run 1 vs run 2: {k}", int(np.count_nonzero(np.asarray(a[k]) != np.asarray(b[k]))))
+    check_equal(case, "run 1 vs run 2: step reports", int(a["reps"] != b["reps"]))
+    # and it is the same problem: against the default mode and the oracle
+    c = _run(pb, st, False, 3)
+    check(case, "dense_H vs default mode / max", np.abs(a["H"] - c["H"]).max() / np.abs(c["H"]).max(), 1e-10)
+    check(case, "off_diag_H vs default mode / max", np.abs(a["B"] - c["B"]).max() / np.abs(c["B"]).max(), 1e-10)
+    check(case, "final cost vs default mode rel", abs(a["reps"][-1][1] - c["reps"][-1][1]) / c["reps"][-1][1], 1e-7)
+    orc.set_num_threads(0)
+    try:
+        op = orc.OracleProblem(pb, last_projection=pb.obs_xy.astype(np.float64))
+        sysm = op.new_system()
+        op.jacobian_pass(st, sysm)
+    finally:
+        orc.set_num_threads(1)
+    check(case, "dense_H vs oracle / max", np.abs(a["H"] - sysm.dense_H).max() / np.abs(sysm.dense_H).max(), 1e-10)
+    check(case, "block_diag_H vs oracle / max",
+          np.abs(np.triu(a["bD"]) - np.triu(sysm.block_diag_H)).max() / np.abs(sysm.block_diag_H).max(), 1e-10)
+    check(case, "dense_b vs oracle / max", np.abs(a["b"] - sysm.dense_b).max() / np.abs(sysm.dense_b).max(), 1e-10)
+
+
+def test_default_mode_differs_only_in_the_last_bits():
+    """The default mode's run-to-run spread (what the deterministic mode removes), recorded for DESIGN.md."""
+    pb, st, _ = syn.baseline_config(2, gpu_project, n_imagesets=120)
+    a = _run(pb, st, False, 2)
+    b = _run(pb, st, False, 2)
+    check("default mode run-to-run", "dense_H / max", np.abs(a["H"] - b["H"]).max() / np.abs(a["H"]).max(), 1e-11)
+    check("default mode run-to-run", "x / max", np.abs(a["x"] - b["x"]).max() / np.abs(a["x"]).max(), 1e-6)
+
+
+def test_device_model_handle_matches_stateless_calls():
+    """cba_model_*: grid uploaded once, per-point calls (CameraModel::Project in a loop) give the batch results."""
+    from camera_calibration_amd.problem import Camera, CENTRAL_GENERIC
+    cam = Camera(CENTRAL_GENERIC, 640, 480, 0, 0, 639, 479, 12, 10)
+    grid = syn.pinhole_direction_grid(cam, 400.0, 400.0, 320.0, 240.0, k1=-0.1)
+    rng = np.random.default_rng(0)
+    px = np.stack([rng.uniform(0, 640, 50), rng.uniform(0, 480, 50)], axis=1)
+    lines, jac, ok = eng.unproject(cam, grid, px, with_jacobian=True)
+    pts = lines[:, :3] * rng.uniform(0.5, 3.0, (50, 1))
+    want, wok = eng.project(cam, grid, pts)
+    m = eng.DeviceModel(cam, grid)
+    l2, j2, ok2 = m.unproject(px, with_jacobian=True)
+    assert np.array_equal(l2, lines) and np.array_equal(j2, jac) and np.array_equal(ok2, ok)
+    for i in range(50):                       # point by point, growing nothing
+        p, o = m.project(pts[i:i + 1])
+        assert o[0] == wok[i] and np.array_equal(p[0], want[i])
+    grid2 = syn.pinhole_direction_grid(cam, 380.0, 380.0, 320.0, 240.0, k1=-0.1)
+    m.set_grid(grid2)
+    p2, _ = m.project(pts)
+    w2, _ = eng.project(cam, grid2, pts)
+    assert np.array_equal(p2, w2)
+    m.close()

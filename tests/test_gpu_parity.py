@@ -11,6 +11,7 @@ from camera_calibration_amd import synthetic as syn
 from camera_calibration_amd.problem import CENTRAL_GENERIC, NONCENTRAL_GENERIC, Camera, Problem, State
 from camera_calibration_amd.se3 import se3_exp, se3_identity, se3_mul
 from oracle import oracle as orc
+from parity_record import check, check_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -128,8 +129,9 @@ def _records_to_arrays(recs, n, Kg):
     return valid, hasj, pix, J
 
 
-def _compare_pass(pb, st, rel_H=1e-9):
-    """Jacobian pass + accumulation + solve + update on identical state: engine vs oracle."""
+def _compare_pass(pb, st, case):
+    """Jacobian pass + accumulation + solve + update on identical state: engine vs oracle.  Tolerances ~10x the maxima
+    observed on MI355X (profiles/r02_parity_deviations.json)."""
     op = orc.OracleProblem(pb)
     sysm = op.new_system()
     cost_ref, vec_ref, recs = op.jacobian_pass(st, sysm, want_records=True)
@@ -141,22 +143,21 @@ def _compare_pass(pb, st, rel_H=1e-9):
     Kg = 0 if pb.localize_only else max(c.params_per_grid_point for c in pb.cameras) * 16
     valid, hasj, pix_ref, J_ref = _records_to_arrays(recs, pb.n_obs, Kg)
     # masks bit-exact
-    assert np.array_equal(flags & 1, valid)
-    assert np.array_equal((flags >> 1) & 1, hasj)
-    assert np.array_equal(vec >= 0, vec_ref >= 0)
+    check_equal(case, "valid mask", int(np.count_nonzero((flags & 1) != valid)))
+    check_equal(case, "has-jacobian mask", int(np.count_nonzero(((flags >> 1) & 1) != hasj)))
+    check_equal(case, "cost-vector sign mask", int(np.count_nonzero((vec >= 0) != (vec_ref >= 0))))
     m = valid.astype(bool)
     pix = e.dump(eng.DUMP_PIXELS)
-    np.testing.assert_allclose(pix[m], pix_ref[m], atol=1e-9)
-    np.testing.assert_allclose(vec[m], vec_ref[m], rtol=1e-9, atol=1e-9)
-    assert abs(cost - cost_ref) <= 1e-9 * max(1.0, abs(cost_ref))
+    check(case, "pixels abs [px]", np.abs(pix[m] - pix_ref[m]).max(), 1e-9)
+    check(case, "cost vector rel", (np.abs(vec[m] - vec_ref[m]) / np.maximum(1e-3, vec_ref[m])).max(), 1e-9)
+    check(case, "total cost rel", abs(cost - cost_ref) / max(1.0, abs(cost_ref)), 1e-11)
     # warm-start cache written back
-    np.testing.assert_allclose(e.get_last_projection()[m], op.last_projection[m], atol=1e-9)
-    # per-observation Jacobians.  Finite differences of two converged projections: agreement is
-    # limited by the projections' own convergence noise / delta
+    check(case, "last_projection abs [px]", np.abs(e.get_last_projection()[m] - op.last_projection[m]).max(), 1e-9)
+    # per-observation Jacobians
     J = e.dump(eng.DUMP_JACOBIANS)
     hj = hasj.astype(bool)
     scale = np.abs(J_ref[hj]).max()
-    np.testing.assert_allclose(J[hj][:, :33 + 2 * Kg], J_ref[hj], atol=2e-5 * scale)
+    check(case, "J records / max", np.abs(J[hj][:, :33 + 2 * Kg] - J_ref[hj]).max() / scale, 1e-8)
     # normal equations
     bD = e.dump(eng.DUMP_BLOCK_DIAG_H)
     for name, a, b in [("block_diag_H", bD, sysm.block_diag_H),
@@ -166,8 +167,7 @@ def _compare_pass(pb, st, rel_H=1e-9):
                        ("dense_b", e.dump(eng.DUMP_DENSE_B), sysm.dense_b)]:
         if name == "block_diag_H":
             a = np.array([np.triu(x) for x in a]); b = np.array([np.triu(x) for x in b])
-        tol = 2e-5 * np.abs(b).max()
-        assert np.abs(a - b).max() <= tol, f"{name}: {np.abs(a - b).max()} > {tol}"
+        check(case, name + " / max", np.abs(a - b).max() / np.abs(b).max(), 1e-8)
     # solve the *oracle's* system on the GPU solver and the engine's own system end-to-end
     lam = 1e-5 * (np.trace(sysm.dense_H) + sum(np.trace(b) for b in sysm.block_diag_H)) / pb.total_dof
     s2 = orc.System(sysm.block_size, sysm.n_blocks, sysm.dense_dof)
@@ -176,39 +176,40 @@ def _compare_pass(pb, st, rel_H=1e-9):
     s2.add_lambda(lam)
     x_ref = orc.schur_solve(s2)
     x_gpu_solver = eng.schur_solve(s2.block_diag_H, s2.off_diag_H, s2.dense_H, s2.block_diag_b, s2.dense_b)
-    np.testing.assert_allclose(x_gpu_solver, x_ref, rtol=1e-8, atol=1e-8 * np.abs(x_ref).max())
+    check(case, "x engine solver vs oracle solver, oracle system / |x|max", np.abs(x_gpu_solver - x_ref).max() / np.abs(x_ref).max(), 1e-8)
     x = e.debug_solve(lam)
-    np.testing.assert_allclose(x, x_ref, atol=5e-4 * np.abs(x_ref).max())
+    check(case, "x engine (own system) vs oracle / |x|max", np.abs(x - x_ref).max() / np.abs(x_ref).max(), 1e-6)
     # state update on the same x
     st_ref = op.apply_update(st, x_ref)
     e.debug_apply_update(x_ref)
     st_gpu = e.get_state(st)
-    np.testing.assert_allclose(st_gpu.points, st_ref.points, atol=1e-15, rtol=1e-15)
+    check(case, "updated points abs", np.abs(st_gpu.points - st_ref.points).max(), 1e-15)
     # quaternion update goes through an fp32 sine/cosine (reference quirk): 1 ulp(fp32) of the update size
-    np.testing.assert_allclose(st_gpu.rig_tr_global, st_ref.rig_tr_global, atol=2e-7 * max(1e-3, np.abs(x_ref[:6 * pb.n_images]).max()) + 1e-15)
-    np.testing.assert_allclose(st_gpu.camera_tr_rig, st_ref.camera_tr_rig, atol=1e-8)
+    check(case, "updated poses abs", np.abs(st_gpu.rig_tr_global - st_ref.rig_tr_global).max(),
+          2e-7 * max(1e-3, np.abs(x_ref[:6 * pb.n_images]).max()) + 1e-15)
+    check(case, "updated camera_tr_rig abs", np.abs(st_gpu.camera_tr_rig - st_ref.camera_tr_rig).max(), 1e-8)
     for g_gpu, g_ref in zip(st_gpu.grids, st_ref.grids):
-        np.testing.assert_allclose(g_gpu, g_ref, atol=1e-14)
+        check(case, "updated grids abs", np.abs(g_gpu - g_ref).max(), 1e-14)
     e.close()
 
 
 @pytest.mark.parametrize("num_cameras", [1, 2])
 def test_first_iteration_parity_reference_fixture(num_cameras):
     pb, st, gt = syn.reference_test_problem(num_cameras, oracle_project, seed=0)
-    _compare_pass(pb, st)
+    _compare_pass(pb, st, f"gtest fixture, {num_cameras} camera(s)")
 
 
 def test_first_iteration_parity_noncentral():
     pb, st, gt = syn.reference_test_problem(1, oracle_project, seed=3, num_points=60, num_poses=25,
                                             model_type=NONCENTRAL_GENERIC)
     pb.fd_delta = 1e-3
-    _compare_pass(pb, st)
+    _compare_pass(pb, st, "gtest fixture, non-central")
 
 
 def test_first_iteration_parity_eliminate_points():
     pb, st, gt = syn.reference_test_problem(1, oracle_project, seed=5, num_points=70, num_poses=30)
     pb.eliminate_points = True
-    _compare_pass(pb, st)
+    _compare_pass(pb, st, "gtest fixture, eliminate_points")
 
 
 @pytest.mark.parametrize("num_cameras", [1, 2])
@@ -217,7 +218,7 @@ def test_first_iteration_parity_localize_only(num_cameras):
     no intrinsics block in the state, the dense part is points (+ rig poses)."""
     pb, st, gt = syn.reference_test_problem(num_cameras, oracle_project, seed=6, num_points=60, num_poses=20)
     pb.localize_only = True
-    _compare_pass(pb, st)
+    _compare_pass(pb, st, f"gtest fixture, localize_only, {num_cameras} camera(s)")
 
 
 def test_localize_only_trajectory_matches_oracle():

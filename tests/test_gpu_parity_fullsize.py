@@ -1,0 +1,278 @@
+"""GPU parity at the sizes that are benchmarked: BASELINE configs 2, 3, 4 and a config-5-shaped 4-camera rig, through the
+C-ABI against the CPU oracle (all host threads; the oracle's results do not depend on the thread count).
+
+Per case, on the same seeded state (warm-start cache = the observed pixels, i.e. the cache as earlier iterations leave it):
+  * validity / has-Jacobian flags and the cost-vector mask bit-exact;
+  * pixels, per-residual costs, total cost, the written-back warm-start cache;
+  * per-observation Jacobian records;
+  * block_diag_H, block_diag_b, off_diag_H, dense_H, dense_b in the REFERENCE's variable order (slot order and tiled
+    grid unknowns are engine-internal);
+  * the engine's update vector against (a) LAPACK on the oracle's system (third solver), (b) the engine's solver on the
+    oracle's system, (c) the residual of the oracle's normal equations.
+Config 2 runs at its full size (500 imagesets); configs 3 / 4 / rig use imageset subsets with the FULL grid so that D,
+the grid tiling, the strip / cell bucket kernels, the 512-wide panels and the straggler side stream are the real ones.
+Also: one full cba_step against the oracle's OptimizeJointly at config-2 grid size, and the reference's non-central
+bundle-adjustment test (APP/test/noncentral_generic_test.cc:111-256) on the GPU.
+
+Every comparison goes through tests/parity_record.py: observed maxima land in profiles/r02_parity_deviations.json and
+each tolerance is kept within ~10x of what was observed on MI355X.
+"""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+import pytest
+
+from camera_calibration_amd import engine as eng
+from camera_calibration_amd import synthetic as syn
+from camera_calibration_amd.problem import CENTRAL_GENERIC, NONCENTRAL_GENERIC, Camera, Problem, State
+from camera_calibration_amd.se3 import se3_exp, se3_identity, se3_mul
+from oracle import oracle as orc
+from parity_record import check, check_equal
+
+pytestmark = pytest.mark.gpu
+
+REC_DTYPE = np.dtype([("valid", np.int32), ("has_jacobian", np.int32), ("pixel", np.float64, 2), ("residual", np.float64, 2),
+                      ("cost", np.float64), ("weight", np.float64), ("pose_jac", np.float64, 12), ("rig_jac", np.float64, 12),
+                      ("point_jac", np.float64, 6), ("grid_indices", np.int32, 80), ("grid_jac", np.float64, 160)], align=True)
+assert REC_DTYPE.itemsize == C.sizeof(orc.OrcObsRecord)
+
+
+def gpu_project(cam, grid, pts):
+    return eng.project(cam, grid, pts)
+
+
+def _maxabs_diff(a, b, rows=256):
+    """max |a - b| and max |b| without n x n temporaries"""
+    worst = scale = 0.0
+    a2 = a.reshape(a.shape[0], -1); b2 = b.reshape(b.shape[0], -1)
+    for r in range(0, a2.shape[0], rows):
+        d = a2[r:r + rows] - b2[r:r + rows]
+        worst = max(worst, float(np.abs(d).max(initial=0.0)))
+        scale = max(scale, float(np.abs(b2[r:r + rows]).max(initial=0.0)))
+    return worst, scale
+
+
+def _sym_matvec_upper(Hu, x):
+    """(Hu + Hu^T - diag) x for a matrix that holds the upper triangle and zeros below it (two BLAS gemv, no n x n temporary)"""
+    return Hu @ x + x @ Hu - np.diagonal(Hu) * x
+
+
+def _full_size_case(case, cfg, n_imagesets, grid_wh=None, lapack=True):
+    t0 = time.time()
+    pb, st, _gt = syn.baseline_config(cfg, gpu_project, n_imagesets=n_imagesets, grid_wh=grid_wh)
+    lp0 = pb.obs_xy.astype(np.float64)
+    orc.set_num_threads(0)
+    try:
+        op = orc.OracleProblem(pb, last_projection=lp0.copy())
+        sysm = op.new_system()
+        recs = (orc.OrcObsRecord * pb.n_obs)()
+        cost_vec_ref = np.zeros(pb.n_obs)
+        cost_ref = orc.lib().orc_jacobian_pass(C.byref(op.c), C.byref(op._state(st)), C.byref(sysm.struct()), orc._dp(cost_vec_ref),
+                                               recs, 0, pb.n_images)
+        R = np.frombuffer(recs, dtype=REC_DTYPE)
+        t_oracle = time.time() - t0
+        e = eng.Engine(pb, last_projection=lp0)
+        e.set_state(st)
+        cost = e.debug_accumulate()
+        # ---- masks, bit-exact ----
+        flags = e.dump(eng.DUMP_FLAGS)
+        vec = e.dump(eng.DUMP_COST_VECTOR)
+        check_equal(case, "valid mask", int(np.count_nonzero((flags & 1) != R["valid"])))
+        check_equal(case, "has-jacobian mask", int(np.count_nonzero(((flags >> 1) & 1) != R["has_jacobian"])))
+        check_equal(case, "cost-vector sign mask", int(np.count_nonzero((vec >= 0) != (cost_vec_ref >= 0))))
+        m = R["valid"].astype(bool)
+        hj = R["has_jacobian"].astype(bool)
+        assert m.mean() > 0.95 and hj.sum() > 0.98 * m.sum()
+        # ---- per-observation values ----
+        pix = e.dump(eng.DUMP_PIXELS)
+        check(case, "pixels abs [px]", np.abs(pix[m] - R["pixel"][m]).max(), 2e-10)
+        check(case, "cost vector rel", (np.abs(vec[m] - cost_vec_ref[m]) / np.maximum(1e-3, cost_vec_ref[m])).max(), 2e-10)
+        check(case, "total cost rel", abs(cost - cost_ref) / cost_ref, 2e-13)
+        check(case, "last_projection abs [px]", np.abs(e.get_last_projection()[m] - op.last_projection[m]).max(), 2e-10)
+        Kg = max(c.params_per_grid_point for c in pb.cameras) * 16
+        J = e.dump(eng.DUMP_JACOBIANS)
+        for name, lo, hi, ref in (("J residual", 0, 2, R["residual"]), ("J pose block", 3, 15, R["pose_jac"]),
+                                  ("J rig block", 15, 27, R["rig_jac"]), ("J point block", 27, 33, R["point_jac"]),
+                                  ("J grid block", 33, 33 + 2 * Kg, R["grid_jac"][:, :2 * Kg])):
+            if name == "J rig block" and pb.n_cameras == 1:
+                continue
+            d = np.abs(J[hj][:, lo:hi] - ref[hj]).max()
+            check(case, name + " / max", d / np.abs(ref[hj]).max(), 4e-10)
+        check(case, "J weight abs", np.abs(J[hj][:, 2] - R["weight"][hj]).max(), 1e-11)
+        del J
+        # ---- normal equations in the reference's variable order ----
+        bD = e.dump(eng.DUMP_BLOCK_DIAG_H)
+        iu = np.triu_indices(pb.block_size)
+        d, s = _maxabs_diff(bD[:, iu[0], iu[1]], sysm.block_diag_H[:, iu[0], iu[1]])
+        check(case, "block_diag_H / max", d / s, 2e-10)
+        d, s = _maxabs_diff(e.dump(eng.DUMP_BLOCK_DIAG_B)[:, None], sysm.block_diag_b[:, None])
+        check(case, "block_diag_b / max", d / s, 2e-10)
+        B = e.dump(eng.DUMP_OFF_DIAG_H)
+        d, s = _maxabs_diff(B, sysm.off_diag_H)
+        check(case, "off_diag_H / max", d / s, 2e-10)
+        Hd = e.dump(eng.DUMP_DENSE_H)                 # upper triangle, zeros below (the oracle leaves its lower part zero too)
+        d, s = _maxabs_diff(Hd, sysm.dense_H)
+        check(case, "dense_H / max", d / s, 2e-10)
+        bd = e.dump(eng.DUMP_DENSE_B)
+        d, s = _maxabs_diff(bd[:, None], sysm.dense_b[:, None])
+        check(case, "dense_b / max", d / s, 2e-10)
+        del Hd
+        # ---- solve ----
+        tr = float(np.trace(sysm.dense_H)) + float(sum(np.trace(b) for b in sysm.block_diag_H))
+        lam = 1e-5 * tr / pb.total_dof
+        x = e.debug_solve(lam)
+        xb, xd = x[:pb.block_dof], x[pb.block_dof:]
+        # (c) residual of the ORACLE's normal equations at the engine's x
+        Ds = np.array([np.triu(b) + np.triu(b, 1).T for b in sysm.block_diag_H])
+        r_block = np.einsum("nij,nj->ni", Ds, xb.reshape(-1, pb.block_size)).ravel() + lam * xb + sysm.off_diag_H @ xd - sysm.block_diag_b
+        r_dense = sysm.off_diag_H.T @ xb + _sym_matvec_upper(sysm.dense_H, xd) + lam * xd - sysm.dense_b
+        check(case, "oracle normal equations residual, block rows / |b|max", np.abs(r_block).max() / np.abs(sysm.block_diag_b).max(), 5e-11)
+        check(case, "oracle normal equations residual, dense rows / |b|max", np.abs(r_dense).max() / np.abs(sysm.dense_b).max(), 1e-10)
+        if lapack:
+            import scipy.linalg as sla
+            Dl = Ds + lam * np.eye(pb.block_size)[None]
+            Dinv = np.linalg.inv(Dl)
+            Bm = sysm.off_diag_H.reshape(pb.n_blocks, pb.block_size, -1)
+            W = np.einsum("nij,njk->nik", Dinv, Bm).reshape(pb.block_dof, -1)
+            S = sysm.off_diag_H.T @ W
+            S *= -1.0
+            S += np.triu(sysm.dense_H)
+            S += np.triu(sysm.dense_H, 1).T
+            S[np.diag_indices_from(S)] += lam
+            rhs = sysm.dense_b - W.T @ sysm.block_diag_b
+            xd_l = sla.solve(S, rhs, assume_a="pos", overwrite_a=True, check_finite=False)
+            del S
+            xb_l = np.einsum("nij,nj->ni", Dinv, sysm.block_diag_b.reshape(-1, pb.block_size)).ravel() - W @ xd_l
+            x_l = np.concatenate([xb_l, xd_l])
+            check(case, "x engine (own system) vs LAPACK (oracle system) / |x|max", np.abs(x - x_l).max() / np.abs(x_l).max(), 1e-8)
+            s2 = orc.System(sysm.block_size, sysm.n_blocks, sysm.dense_dof)
+            for fld in ("block_diag_H", "off_diag_H", "dense_H", "block_diag_b", "dense_b"):
+                getattr(s2, fld)[...] = getattr(sysm, fld)
+            s2.add_lambda(lam)
+            x_g = eng.schur_solve(s2.block_diag_H, s2.off_diag_H, s2.dense_H, s2.block_diag_b, s2.dense_b)
+            check(case, "x engine solver vs LAPACK, both on the oracle system / |x|max", np.abs(x_g - x_l).max() / np.abs(x_l).max(), 1e-10)
+        # ---- state update with the same x: JointOptimizationState::operator-= ----
+        st_ref = op.apply_update(st, x)
+        e.debug_apply_update(x)
+        st_gpu = e.get_state(st)
+        check(case, "updated points abs", np.abs(st_gpu.points - st_ref.points).max(), 1e-15)
+        check(case, "updated poses abs", np.abs(st_gpu.rig_tr_global - st_ref.rig_tr_global).max(), 1e-9)   # one fp32 ulp of sin / cos of the update at most
+        check(case, "updated camera_tr_rig abs", np.abs(st_gpu.camera_tr_rig - st_ref.camera_tr_rig).max(), 1e-8)
+        for g_gpu, g_ref in zip(st_gpu.grids, st_ref.grids):
+            check(case, "updated grids abs", np.abs(g_gpu - g_ref).max(), 1e-14)
+        # ---- cost-only pass on the updated state ----
+        c2_ref, v2_ref = op.cost_pass(st_ref)
+        c2, nv2, v2 = e.cost(want_vector=True)
+        check_equal(case, "cost-pass validity mask", int(np.count_nonzero((v2 >= 0) != (v2_ref >= 0))))
+        both = v2_ref >= 0
+        check(case, "cost-pass cost vector rel", (np.abs(v2[both] - v2_ref[both]) / np.maximum(1e-3, v2_ref[both])).max(), 3e-8)
+        check(case, "cost-pass total rel", abs(c2 - c2_ref) / c2_ref, 2e-13)
+        e.close()
+        print(f"{case}: n_obs {pb.n_obs}, D {pb.dense_dof}, oracle side {t_oracle:.1f} s, total {time.time() - t0:.1f} s")
+    finally:
+        orc.set_num_threads(1)
+
+
+def test_config2_full_size_against_oracle():
+    _full_size_case("cfg2 (500 imagesets, D=12525)", 2, 500)
+
+
+def test_config3_stereo_full_grid_against_oracle():
+    _full_size_case("cfg3 (2 cameras, 200 imagesets, D=22617)", 3, 200, lapack=False)
+
+
+def test_config4_noncentral_full_grid_against_oracle():
+    _full_size_case("cfg4 (non-central, 200 imagesets, D=12845)", 4, 200)
+
+
+def test_config5_shaped_four_camera_rig_against_oracle():
+    """4-camera rig (BASELINE configs[4] shape).  With the configuration's own 84 x 60 grids D = 42 789 and the three host copies
+    of dense_H take 44 GB; hosts with less free memory run the same rig with 44 x 32 grids (D = 13 733)."""
+    import psutil
+    big = psutil.virtual_memory().available > 96 * 2 ** 30
+    if big:
+        _full_size_case("rig4 (4 cameras, 60 imagesets, D=42789)", 5, 60, lapack=False)
+    else:
+        _full_size_case("rig4 (4 cameras, 60 imagesets, 44x32 grids, D=13733)", 5, 60, grid_wh=(44, 32), lapack=False)
+
+
+def test_full_step_at_config2_grid_size_against_oracle_optimize_jointly():
+    """One optimizer.Optimize(max_iteration_count = 1) at D = 12 525 (config-2 grid, 60 imagesets): cba_step against the oracle's
+    OptimizeJointly incl. its own Schur complement and pivoted LDLT -- accept decision, attempt count, lambda, costs, new state."""
+    case = "cfg2 step (60 imagesets, D=12525)"
+    pb, st0, _ = syn.baseline_config(2, gpu_project, n_imagesets=60)
+    lp0 = pb.obs_xy.astype(np.float64)
+    orc.set_num_threads(0)
+    try:
+        op = orc.OracleProblem(pb, last_projection=lp0.copy())
+        st_ref = st0.copy()
+        e = eng.Engine(pb, last_projection=lp0)
+        e.set_state(st0)
+        lam_ref = lam = -1.0
+        for it in range(2):
+            r = op.optimize_jointly(st_ref, 1, lam_ref)
+            rep = e.step(lam)
+            lam_ref, lam = r["final_lambda"], rep.final_lambda
+            check_equal(case, f"iteration {it}: accept decision", int(rep.accepted != bool(r["performed"])))
+            check_equal(case, f"iteration {it}: LM attempts", abs(rep.lm_attempts - r["lm_attempts"]))
+            check(case, f"iteration {it}: final cost rel", abs(rep.final_cost - r["cost"]) / r["cost"], 2e-9)
+            check(case, f"iteration {it}: lambda rel", abs(lam - lam_ref) / lam_ref, 1e-12)
+        st = e.get_state(st0)
+        check(case, "state after 2 iterations: points abs", np.abs(st.points - st_ref.points).max(), 1e-10)
+        check(case, "state after 2 iterations: poses abs", np.abs(st.rig_tr_global - st_ref.rig_tr_global).max(), 2e-10)
+        check(case, "state after 2 iterations: grid abs", np.abs(st.grids[0] - st_ref.grids[0]).max(), 1e-9)
+        e.close()
+    finally:
+        orc.set_num_threads(1)
+
+
+def test_noncentral_bundle_adjustment_trajectory_on_gpu():
+    """NoncentralGenericBSpline.OptimizeJointly (APP/test/noncentral_generic_test.cc:111-256) restated: 8 x 6 non-central
+    grid, 50 points, 20 poses, numerical_diff_delta 1e-3; the reference asserts final cost <= 2e-4.  Same iterates as the
+    oracle while the cost is above the fp32 measurement floor, same converged cost bound."""
+    case = "non-central BA test"
+    rng = np.random.default_rng(7)
+    U = lambda *s: rng.uniform(-1, 1, size=s)
+    W, H = 600, 400
+    cam = Camera(NONCENTRAL_GENERIC, W, H, 0, 0, W - 1, H - 1, 8, 6)
+    d = syn.pinhole_direction_grid(cam, H / 2.0, H / 2.0, W / 2.0, H / 2.0)
+    grid = np.stack([d, 0.01 * U(48, 3)])
+    pts = U(50, 3) * np.array([6.5, 3.5, 1.0])
+    poses = []
+    for _ in range(20):
+        b = np.array([1.0, 0, 0, 0, 0, 0, 5.0]); b[4:] += U(3)
+        poses.append(se3_mul(se3_exp(0.05 * U(6)), b))
+    poses = np.array(poses)
+    xy, pt, im, cm = syn._make_observations([cam], [grid], se3_identity(1), poses, pts, gpu_project, 0.0, rng)
+    pb = Problem([cam], 20, 50, xy, pt, im, cm, fd_delta=1e-3)
+    st0 = State(poses.copy(), se3_identity(1), pts + 0.02 * U(50, 3), [grid.copy()])
+    for i in range(20):
+        st0.rig_tr_global[i] = se3_mul(st0.rig_tr_global[i], se3_exp(0.01 * U(6)))
+    g = st0.grids[0]
+    g[0] += 0.005 * U(48, 3); g[0] /= np.linalg.norm(g[0], axis=1, keepdims=True)
+    g[1] += 0.005 * U(48, 3)
+    op = orc.OracleProblem(pb)
+    st_ref = st0.copy()
+    e = eng.Engine(pb)
+    e.set_state(st0)
+    lam_ref = lam = -1.0
+    cost = cost_ref = np.inf
+    done_ref = False
+    for it in range(50):
+        rep = e.step(lam)
+        lam, cost = rep.final_lambda, rep.final_cost
+        if not done_ref:
+            r = op.optimize_jointly(st_ref, 1, lam_ref)
+            lam_ref, cost_ref = r["final_lambda"], r["cost"]
+            done_ref = not r["performed"]
+            if it < 5:
+                check_equal(case, f"iteration {it}: accept decision", int(rep.accepted != bool(r["performed"])))
+                check_equal(case, f"iteration {it}: LM attempts", abs(rep.lm_attempts - r["lm_attempts"]))
+                check(case, f"iteration {it}: final cost rel", abs(rep.final_cost - r["cost"]) / r["cost"], 5e-8)
+        if not rep.accepted:
+            break
+    check(case, "converged cost (reference bound 2e-4)", cost, 2e-4)
+    check(case, "oracle converged cost (reference bound 2e-4)", cost_ref, 2e-4)
+    e.close()

@@ -1,0 +1,52 @@
+"""HIP kernels against numbers computed by the REFERENCE'S OWN CODE (tests/golden/ref_vectors.npz, produced by oracle/_ref =
+the reference sources compiled by oracle/Makefile; see tests/golden/make_ref_fixtures.py).  No oracle in between:
+CameraModel::Unproject / UnprojectWithJacobian / Project of both generic models through cba_unproject / cba_project on
+the real calibrated 17 x 13 camera the reference ships as a test vector (generic_models/src/main.cc:86-98) and on the
+non-central 8 x 8 camera of its self-test (main.cc:146-160), incl. the reference's own acceptance criterion (round trip
+within 1e-3 px, main.cc:38-84)."""
+import os
+
+import numpy as np
+import pytest
+
+from camera_calibration_amd import calibration_io as cio
+from camera_calibration_amd import engine as eng
+from camera_calibration_amd.problem import NONCENTRAL_GENERIC, Camera
+from parity_record import check, check_equal
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+V = np.load(os.path.join(GOLDEN, "ref_vectors.npz"))
+
+
+def test_central_17x13_reference_camera_on_gpu():
+    case = "GPU vs reference code, central 17x13"
+    cam, grid = cio.load_camera_model(os.path.join(GOLDEN, "ref_generic_models_17x13.yaml"))     # F2 reader
+    grid = np.ascontiguousarray(np.asarray(grid).reshape(-1, 3))
+    lines, jac, ok = eng.unproject(cam, grid, V["c17_px"], with_jacobian=True)
+    check_equal(case, "unproject ok flags", int(np.count_nonzero(~ok)))
+    check(case, "unproject direction abs", np.abs(lines[:, :3] - V["c17_dirs"]).max(), 1e-14)
+    check(case, "unproject jacobian / max", np.abs(jac[:, :3] - V["c17_jac"]).max() / np.abs(V["c17_jac"]).max(), 1e-12)
+    px, pok = eng.project(cam, grid, V["c17_pts"])
+    check_equal(case, "project ok flags", int(np.count_nonzero(pok != V["c17_reproj_ok"].astype(bool))))
+    check(case, "project pixel abs [px]", np.abs(px[pok] - V["c17_reproj"][pok]).max(), 1e-9)
+    check(case, "round trip [px] (reference criterion 1e-3)", np.linalg.norm(px[pok] - V["c17_px"][pok], axis=1).max(), 1e-3)
+    px2, pok2 = eng.project(cam, grid, V["c17_pts"], init=V["c17_init"])
+    check_equal(case, "project-with-initial-estimate ok flags", int(np.count_nonzero(pok2 != V["c17_reproj_init_ok"].astype(bool))))
+    check(case, "project-with-initial-estimate pixel abs [px]", np.abs(px2[pok2] - V["c17_reproj_init"][pok2]).max(), 1e-9)
+    _, okb = eng.project(cam, grid, V["c17_bad_pts"])
+    check_equal(case, "unreachable points flagged", int(np.count_nonzero(okb != V["c17_bad_ok"].astype(bool))))
+
+
+def test_noncentral_8x8_reference_camera_on_gpu():
+    case = "GPU vs reference code, non-central 8x8"
+    cam = Camera(NONCENTRAL_GENERIC, 640, 480, 0, 0, 639, 479, 8, 8)
+    grid = np.ascontiguousarray(V["n8_grid"])
+    lines, jac, ok = eng.unproject(cam, grid, V["n8_px"], with_jacobian=True)
+    check_equal(case, "unproject ok flags", int(np.count_nonzero(~ok)))
+    check(case, "unproject line abs", np.abs(lines - V["n8_lines"]).max(), 1e-13)
+    check(case, "unproject jacobian / max", np.abs(jac - V["n8_jac"]).max() / np.abs(V["n8_jac"]).max(), 1e-12)
+    px, pok = eng.project(cam, grid, V["n8_pts"])
+    check_equal(case, "project ok flags", int(np.count_nonzero(pok != V["n8_reproj_ok"].astype(bool))))
+    check(case, "project pixel abs [px]", np.abs(px[pok] - V["n8_reproj"][pok]).max(), 1e-9)
+    check(case, "round trip [px] (reference criterion 1e-3)", np.linalg.norm(px[pok] - V["n8_px"][pok], axis=1).max(), 1e-3)
