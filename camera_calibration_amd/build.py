@@ -59,7 +59,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 HOST_DIR = os.path.join(HERE, "host")
 HOST_LIB = os.path.join(HERE, "libcalib_ba_host.so")
-HOST_SOURCES = ["joint_optimization_hip.cc", "calibration_report_hip.cc", "calibration_io.cc", "central_generic_fit_hip.cc", "calibration_hip.cc", "host_test_shim.cc"]
+HOST_SOURCES = ["joint_optimization_hip.cc", "calibration_report_hip.cc", "calibration_io.cc", "central_generic_fit_hip.cc", "calibration_hip.cc"]
+# test scaffolding (extern "C" entry points that build Dataset / BAState objects from packed arrays for the Python tests):
+# its own library, NOT part of the product library
+HOST_TEST_LIB = os.path.join(HERE, "libcalib_ba_host_test.so")
+HOST_TEST_SOURCES = ["host_test_shim.cc"]
 HOST_HEADERS = ["vis_types.h", "camera_model.h", "dataset.h", "joint_optimization.h"]
 
 
@@ -74,6 +78,19 @@ def build_host(force: bool = False) -> str:
     return HOST_LIB
 
 
+def build_host_test(force: bool = False) -> str:
+    """Test-only shim over the C++ host adapter (tests/test_gpu_host_adapter.py etc.)."""
+    build_host(force)
+    deps = [os.path.join(HOST_DIR, f) for f in HOST_TEST_SOURCES + HOST_HEADERS] + [HOST_LIB]
+    if not force and os.path.exists(HOST_TEST_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_TEST_LIB) for d in deps):
+        return HOST_TEST_LIB
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", HOST_TEST_LIB,
+           *[os.path.join(HOST_DIR, f) for f in HOST_TEST_SOURCES], "-L" + HERE, "-lcalib_ba_host", "-lcalib_ba_hip", "-Wl,-rpath,$ORIGIN"]
+    subprocess.check_call(cmd)
+    return HOST_TEST_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_host(force="--force" in sys.argv))
+    print(build_host_test(force="--force" in sys.argv))

@@ -151,11 +151,23 @@ struct GemmArgs {
   int chunk;                    // tiles per XCD chunk (set by launch_gemm)
   const unsigned long long* kmask;  // optional block-sparsity mask [column tile][kmask_words], bit = K slab of 16 rows
   int kmask_words;
-  int epi_mode;                 // developer switch (bench harness): 0 normal, 1 no Cin read, 2 no store
+#ifdef CBA_DEV_SWITCHES
+  int epi_mode;                 // bench harness only (tools/bench_linalg.hip): 0 normal, 1 no Cin read, 2 no store
+#endif
   int strips;                   // set by launch_gemm: strip-blocked tile order (square upper dense launches)
   const double* a_rowdiv;       // small-tile variants only: A[k][m] is divided by a_rowdiv[k] while staged (L = X / d on the fly)
   int tlog_tag;                 // developer timeline (tools/bench_linalg.hip, -DCBA_TLOG): tag + 1, 0 = none
 };
+
+// Developer switches are compiled only into the bench harness (tools/bench_linalg.hip defines CBA_DEV_SWITCHES): the
+// product library has no epilogue modes and reads no CBA_* environment variables.
+#ifdef CBA_DEV_SWITCHES
+#define CBA_EPI_MODE(g_) ((g_).epi_mode)
+#define CBA_GETENV(name_) getenv(name_)
+#else
+#define CBA_EPI_MODE(g_) 0
+#define CBA_GETENV(name_) ((const char*)nullptr)
+#endif
 
 // Developer timeline of the factorisation schedule: with -DCBA_TLOG (tools/bench_linalg.hip only) every kernel of
 // ldlt_factor stamps the 100 MHz wall clock at its first workgroup's start and its last workgroup's end into
@@ -251,7 +263,7 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
   // SUB: the accumulators start as -(Cin + diag) (see below); in the LDS-DMA variant the tile is loaded AFTER the
   // first operand slab has been put in flight so that the two HBM round trips overlap.
   auto preload_c = [&]() {
-    if (SUB && g.epi_mode != 1) {
+    if (SUB && CBA_EPI_MODE(g) != 1) {
       double dadd0 = 0.0;
       if (g.diag) dadd0 = g.diag_add_ptr ? *g.diag_add_ptr : g.diag_add;
 #pragma unroll
@@ -402,7 +414,7 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
     CBA_GLOAD(0, 0);
     CBA_GLOAD(1, (1 < nk ? 1 : nk - 1) * KT);
     CBA_GLOAD(2, (2 < nk ? 2 : nk - 1) * KT);
-    if (SUB && g.epi_mode != 1) {       // raw tile only: touching the values here would wait for the loads
+    if (SUB && CBA_EPI_MODE(g) != 1) {       // raw tile only: touching the values here would wait for the loads
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -459,11 +471,11 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
         const int m = m0 + wm0 + i * 16 + lk + 4 * r;
         const int n = n0 + wn0 + j * 16 + li;
         double v = acc[i][j][r];
-        if (g.epi_mode == 2) { if (v == 1.2345e300) g.C[(size_t)m * g.ldc + n] = v; continue; }
+        if (CBA_EPI_MODE(g) == 2) { if (v == 1.2345e300) g.C[(size_t)m * g.ldc + n] = v; continue; }
         if constexpr (kSmall) {
           if (SUB) {
             double c = cin[i][j][r];
-            if (g.diag && m == n && g.epi_mode != 1) c += (m < g.n_real) ? (g.diag_add_ptr ? *g.diag_add_ptr : g.diag_add) : 1.0;
+            if (g.diag && m == n && CBA_EPI_MODE(g) != 1) c += (m < g.n_real) ? (g.diag_add_ptr ? *g.diag_add_ptr : g.diag_add) : 1.0;
             v = c - v;
           }
         }
@@ -510,7 +522,7 @@ static int launch_gemm(GemmArgs g, hipStream_t s) {
   // dense launches: one contiguous range per XCD (best L2 reuse); block-sparse launches: chunks of 64
   // interleaved over the XCDs so that dense and sparse regions of the matrix are spread evenly
   g.chunk = (int)((g.kmask && per > 64) ? 64 : (per < 1 ? 1 : per));
-  static const int use_strips = getenv("CBA_NO_STRIPS") ? 0 : 1;
+  static const int use_strips = CBA_GETENV("CBA_NO_STRIPS") ? 0 : 1;
   g.strips = (use_strips && TM == 128 && TN == 128 && g.upper && !g.kmask && g.m_off == g.n_off && g.m_tiles == g.n_tiles &&
               g.total_tiles >= 512) ? 1 : 0;
   long long chunks = (g.total_tiles + g.chunk - 1) / g.chunk;
@@ -608,13 +620,13 @@ constexpr int kPanelWide = 512;
 // panels are kPanelWide wide while more than this many rows remain (env CBA_WIDE_ROWS overrides; 0 = never)
 static int wide_rows_threshold() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("CBA_WIDE_ROWS"); v = e ? atoi(e) : 6144; if (v < 0) v = 6144; }
+  if (v < 0) { const char* e = CBA_GETENV("CBA_WIDE_ROWS"); v = e ? atoi(e) : 6144; if (v < 0) v = 6144; }
   return v;
 }
 static int panel_width_at(int k0, int n_fact) {
   const int thr = wide_rows_threshold();
   // nothing overlaps the first panel's chain, and a 256-panel's chain is a third of a 512-panel's
-  static const bool narrow_first = getenv("CBA_WIDE_FIRST") == nullptr;
+  static const bool narrow_first = CBA_GETENV("CBA_WIDE_FIRST") == nullptr;
   if (k0 == 0 && narrow_first) return kPanel;
   return (thr > 0 && n_fact - k0 > thr && n_fact - k0 >= kPanelWide) ? kPanelWide : kPanel;
 }
@@ -1271,7 +1283,7 @@ __global__ void __launch_bounds__(256) k_scale_rows(double* __restrict__ S, int 
 int panel_cu_count() {
   static int n = -1;
   if (n < 0) {
-    const char* e = getenv("CBA_PANEL_CUS");
+    const char* e = CBA_GETENV("CBA_PANEL_CUS");
     n = e ? atoi(e) : 8;
     if (n < 0 || n > 128) n = 8;
   }
@@ -1476,7 +1488,7 @@ static int timed_gemm128(const GemmArgs& g, hipStream_t s, LdltWorkspace& w, boo
 int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, GemmStats* st) {
   const int n_pad = ld;
   hipStream_t s2 = w.panel_stream, s3 = w.far_stream, s4 = w.mid_stream;
-  if (getenv("CBA_SERIAL")) { s2 = s; s3 = s; s4 = s; }   // developer switch: one stream (profiling the bulk GEMM alone)
+  if (CBA_GETENV("CBA_SERIAL")) { s2 = s; s3 = s; s4 = s; }   // developer switch: one stream (profiling the bulk GEMM alone)
   // the side streams may start once everything queued on the main stream so far (assembly of S) is done
   CBA_HIP(hipEventRecord(w.ev_strip, s));
   CBA_HIP(hipStreamWaitEvent(s2, w.ev_strip, 0));
@@ -1506,7 +1518,7 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
     u.diag = 0;
     // A full 256-panel with look-ahead runs its whole chain on the chain stream: one launch per 64-block (near step
     // on the panel's own AND the next panel's columns + the next diagonal factor, k_near_fused<true>).
-    static const bool no_chain_only = getenv("CBA_NO_CHAIN_ONLY") != nullptr;      // developer switch
+    static const bool no_chain_only = CBA_GETENV("CBA_NO_CHAIN_ONLY") != nullptr;      // developer switch
     const bool chain_only = !no_chain_only && pw == kPanel && nb == kPanel && la && nx > e0;
     if (chain_only) {
       const int ncn = (nx - e0) / kInner, nblocks = kPanel / kInner;

@@ -11,6 +11,9 @@ namespace vis {
 
 struct Mat3d { double m[3][3]; };   // row-major 3x3
 
+// rotation matrix -> quaternion as SE3d(rotation, translation) does (Eigen's conversion)
+Quaterniond MatrixToQuat(const Mat3d& r);
+
 // Rotates the model's grid in place and returns the rotation (central-generic models only; identity otherwise).
 Mat3d ChooseNiceCameraOrientation(CameraModel* model);
 

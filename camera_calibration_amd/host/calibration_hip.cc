@@ -25,6 +25,8 @@ Mat3d QuatToMatrix(double w, double x, double y, double z) {
                 {2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)},
                 {2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)}}};
 }
+}  // namespace
+
 // Eigen matrix -> quaternion (Shepperd's branches)
 Quaterniond MatrixToQuat(const Mat3d& r) {
   const double t = r.m[0][0] + r.m[1][1] + r.m[2][2];
@@ -42,8 +44,6 @@ Quaterniond MatrixToQuat(const Mat3d& r) {
   }
   return Quaterniond(q[0], q[1], q[2], q[3]);
 }
-
-}  // namespace
 
 Mat3d ChooseNiceCameraOrientation(CameraModel* model) {
   Mat3d identity{{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}};
@@ -97,10 +97,16 @@ void RunBundleAdjustment(bool /*use_cuda*/, SchurMode schur_mode, int max_iterat
   const double numerical_diff_delta = 1e-4;        // numerical_diff_delta_range = {1e-4}, calibration.cc:201
   double lambda = -1;
   double last_cost = std::numeric_limits<double>::infinity();
+  // ONE device-resident problem for the whole loop: the reference calls OptimizeJointly(max_iteration_count = 1) per
+  // iteration (calibration.cc:227-237), which on this backend would re-create the device problem (3 GB of buffers at
+  // BASELINE configs[1]) and re-upload the observations every time.  Per iteration only the state crosses the bus:
+  // down for SaveBAState / the orientation beautification, up again because that beautification edits it.
+  JointOptimizationSession session(*dataset, state, numerical_diff_delta, localize_only, /*eliminate_points*/ false, schur_mode);
+  if (regularization_weight > 0)
+    std::fprintf(stderr, "OptimizeJointly: Regularization is disabled at the moment since it is untested with the current version.\n");
   for (int iteration = 0; iteration < max_iteration_count; ++iteration) {
-    const double cost = OptimizeJointly(*dataset, state, /*max_iteration_count*/ 1, lambda, numerical_diff_delta, regularization_weight,
-                                        localize_only, /*eliminate_points*/ false, schur_mode, &lambda, nullptr, false, false, false, false,
-                                        false, /*print_progress*/ false);
+    const double cost = session.Optimize(/*max_iteration_count*/ 1, lambda, &lambda, nullptr, /*print_progress*/ false);
+    session.ReadBackState();
     if (state_output_path) SaveBAState(state_output_path, *state);
     if (!localize_only) {                          // beautify all camera orientations (:248-254)
       for (int c = 0; c < state->num_cameras(); ++c) {
@@ -108,10 +114,12 @@ void RunBundleAdjustment(bool /*use_cuda*/, SchurMode schur_mode, int max_iterat
         const SE3d rotation_transform(MatrixToQuat(rotation), Vec3d::Zero());
         state->camera_tr_rig[c] = rotation_transform * state->camera_tr_rig[c];
       }
+      session.UploadState();
     }
     if (cost >= last_cost - cost_reduction_threshold) break;
     last_cost = cost;
   }
+  session.ReadBackLastProjections();               // PointFeature::last_projection, mutated in place by the reference
 }
 
 void ScaleToMetric(Dataset* dataset, BAState* state) {

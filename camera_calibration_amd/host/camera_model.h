@@ -16,7 +16,21 @@ class CameraModel {
   CameraModel(int width, int height, int min_x, int min_y, int max_x, int max_y, Type type)
       : m_width(width), m_height(height), m_calibration_min_x(min_x), m_calibration_min_y(min_y),
         m_calibration_max_x(max_x), m_calibration_max_y(max_y), m_type(type) {}
-  virtual ~CameraModel() {}
+  virtual ~CameraModel() { release_device_model(); }
+  // the device-resident copy used by Project / Unproject is per object: copies start without one
+  CameraModel(const CameraModel& o)
+      : device(o.device), m_width(o.m_width), m_height(o.m_height), m_calibration_min_x(o.m_calibration_min_x),
+        m_calibration_min_y(o.m_calibration_min_y), m_calibration_max_x(o.m_calibration_max_x),
+        m_calibration_max_y(o.m_calibration_max_y), m_type(o.m_type) {}
+  CameraModel& operator=(const CameraModel& o) {
+    if (this != &o) {
+      device = o.device; m_width = o.m_width; m_height = o.m_height; m_calibration_min_x = o.m_calibration_min_x;
+      m_calibration_min_y = o.m_calibration_min_y; m_calibration_max_x = o.m_calibration_max_x;
+      m_calibration_max_y = o.m_calibration_max_y; m_type = o.m_type;
+      grid_changed();
+    }
+    return *this;
+  }
   virtual CameraModel* duplicate() = 0;
   virtual int update_parameter_count() const = 0;
   virtual bool GetGridResolution(int* rx, int* ry) const = 0;
@@ -40,7 +54,16 @@ class CameraModel {
   virtual std::vector<double> abi_grid() const = 0;
   virtual void set_abi_grid(const double* g) = 0;
   int device = 0;  // HIP device used by the model-level calls
+  /// Project / Unproject run on a device-resident copy of the model (cba_model, include/cba.h) that is created on first
+  /// use and refreshed when the grid may have changed (any non-const grid access marks it stale), so a caller that
+  /// projects feature by feature (APP/calibration_report.cc:101-148) pays one small kernel launch per call.
+  void grid_changed() const { m_dev_stale = true; }
  protected:
+  cba_model* device_model(int device_ordinal) const;   // joint_optimization_hip.cc
+  void release_device_model() const;
+  mutable cba_model* m_dev = nullptr;
+  mutable int m_dev_device = -1;
+  mutable bool m_dev_stale = true;
   int m_width, m_height, m_calibration_min_x, m_calibration_min_y, m_calibration_max_x, m_calibration_max_y;
   Type m_type;
 };
@@ -66,9 +89,9 @@ class CentralGenericModel : public CameraModel {
     return Vec2d(1.f + (m_grid.width() - 3.f) * (x - m_calibration_min_x) / (m_calibration_max_x + 1 - m_calibration_min_x),
                  1.f + (m_grid.height() - 3.f) * (y - m_calibration_min_y) / (m_calibration_max_y + 1 - m_calibration_min_y));
   }
-  void SetGrid(const Image<Vec3d>& g) { m_grid = g; }
+  void SetGrid(const Image<Vec3d>& g) { m_grid = g; grid_changed(); }
   const Image<Vec3d>& grid() const { return m_grid; }
-  Image<Vec3d>& grid() { return m_grid; }
+  Image<Vec3d>& grid() { grid_changed(); return m_grid; }
   static int exterior_cells_per_side() { return 1; }
   cba_camera abi_camera() const override {
     return cba_camera{CBA_CENTRAL_GENERIC, m_width, m_height, m_calibration_min_x, m_calibration_min_y, m_calibration_max_x,
@@ -83,6 +106,7 @@ class CentralGenericModel : public CameraModel {
   void set_abi_grid(const double* g) override {
     size_t G = (size_t)m_grid.width() * m_grid.height();
     for (size_t i = 0; i < G; ++i) for (int k = 0; k < 3; ++k) m_grid.data()[i].v[k] = g[3 * i + k];
+    grid_changed();
   }
  private:
   Image<Vec3d> m_grid;
@@ -98,12 +122,12 @@ class NoncentralGenericModel : public CameraModel {
   CameraModel* duplicate() override { return new NoncentralGenericModel(*this); }
   int update_parameter_count() const override { return 5 * m_direction_grid.width() * m_direction_grid.height(); }
   bool GetGridResolution(int* rx, int* ry) const override { *rx = m_point_grid.width(); *ry = m_point_grid.height(); return true; }
-  void SetPointGrid(const Image<Vec3d>& g) { m_point_grid = g; }
-  void SetDirectionGrid(const Image<Vec3d>& g) { m_direction_grid = g; }
+  void SetPointGrid(const Image<Vec3d>& g) { m_point_grid = g; grid_changed(); }
+  void SetDirectionGrid(const Image<Vec3d>& g) { m_direction_grid = g; grid_changed(); }
   const Image<Vec3d>& point_grid() const { return m_point_grid; }
   const Image<Vec3d>& direction_grid() const { return m_direction_grid; }
-  Image<Vec3d>& point_grid() { return m_point_grid; }
-  Image<Vec3d>& direction_grid() { return m_direction_grid; }
+  Image<Vec3d>& point_grid() { grid_changed(); return m_point_grid; }
+  Image<Vec3d>& direction_grid() { grid_changed(); return m_direction_grid; }
   cba_camera abi_camera() const override {
     return cba_camera{CBA_NONCENTRAL_GENERIC, m_width, m_height, m_calibration_min_x, m_calibration_min_y, m_calibration_max_x,
                       m_calibration_max_y, (int)m_point_grid.width(), (int)m_point_grid.height()};
@@ -117,6 +141,7 @@ class NoncentralGenericModel : public CameraModel {
   void set_abi_grid(const double* g) override {
     size_t G = (size_t)m_point_grid.width() * m_point_grid.height();
     for (size_t i = 0; i < G; ++i) for (int k = 0; k < 3; ++k) { m_direction_grid.data()[i].v[k] = g[3 * i + k]; m_point_grid.data()[i].v[k] = g[3 * G + 3 * i + k]; }
+    grid_changed();
   }
  private:
   Image<Vec3d> m_point_grid, m_direction_grid;

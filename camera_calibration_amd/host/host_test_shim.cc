@@ -7,7 +7,82 @@
 #include "calibration_fit.h"
 #include "calibration.h"
 
+#include <chrono>
+#include <cmath>
+#include <limits>
+
 using namespace vis;
+
+namespace {
+// Dataset / BAState from packed arrays, and back
+struct PackedProblem {
+  Dataset dataset;
+  BAState state;
+  int n_cameras, n_imagesets_total, n_points;
+  int64_t n_obs;
+  const int32_t* imageset_index; const int32_t* camera_index;
+  PackedProblem(int n_cameras_, const cba_camera* cams, const double* const* grids_in, int n_imagesets_total_, const uint8_t* image_used,
+                const double* rig_tr_global, const double* camera_tr_rig, int n_points_, const double* points, int64_t n_obs_, const float* xy,
+                const int32_t* point_index, const int32_t* imageset_index_, const int32_t* camera_index_)
+      : dataset(n_cameras_), n_cameras(n_cameras_), n_imagesets_total(n_imagesets_total_), n_points(n_points_), n_obs(n_obs_),
+        imageset_index(imageset_index_), camera_index(camera_index_) {
+    for (int c = 0; c < n_cameras; ++c) {
+      const cba_camera& k = cams[c];
+      dataset.SetImageSize(c, Vec2i(k.width, k.height));
+      std::shared_ptr<CameraModel> m;
+      if (k.model_type == CBA_CENTRAL_GENERIC)
+        m.reset(new CentralGenericModel(k.grid_w, k.grid_h, k.calib_min_x, k.calib_min_y, k.calib_max_x, k.calib_max_y, k.width, k.height));
+      else
+        m.reset(new NoncentralGenericModel(k.grid_w, k.grid_h, k.calib_min_x, k.calib_min_y, k.calib_max_x, k.calib_max_y, k.width, k.height));
+      m->set_abi_grid(grids_in[c]);
+      state.intrinsics.push_back(m);
+      const double* p = camera_tr_rig + 7 * c;
+      state.camera_tr_rig.push_back(SE3d(Quaterniond(p[0], p[1], p[2], p[3]), Vec3d(p[4], p[5], p[6])));
+    }
+    for (int i = 0; i < n_imagesets_total; ++i) {
+      dataset.NewImageset();
+      const double* p = rig_tr_global + 7 * (size_t)i;
+      state.rig_tr_global.push_back(SE3d(Quaterniond(p[0], p[1], p[2], p[3]), Vec3d(p[4], p[5], p[6])));
+      state.image_used.push_back(image_used[i] != 0);
+    }
+    for (int p = 0; p < n_points; ++p) {
+      state.points.push_back(Vec3d(points[3 * p], points[3 * p + 1], points[3 * p + 2]));
+      state.feature_id_to_points_index[1000 + p] = p;   // feature id -> point index
+    }
+    for (int64_t o = 0; o < n_obs; ++o) {
+      auto& feats = dataset.GetImageset(imageset_index[o])->FeaturesOfCamera(camera_index[o]);
+      feats.emplace_back(Vec2f(xy[2 * o], xy[2 * o + 1]), 1000 + point_index[o]);
+    }
+    state.ComputeFeatureIdToPointsIndex(&dataset);
+  }
+  void unpack(double* const* grids_out, double* rig_tr_global, double* camera_tr_rig, double* points, double* last_projection_out) {
+    for (int c = 0; c < n_cameras; ++c) {
+      std::vector<double> g = state.intrinsics[c]->abi_grid();
+      for (size_t i = 0; i < g.size(); ++i) grids_out[c][i] = g[i];
+      const Quaterniond& q = state.camera_tr_rig[c].unit_quaternion();
+      double* p = camera_tr_rig + 7 * c;
+      p[0] = q.w(); p[1] = q.x(); p[2] = q.y(); p[3] = q.z();
+      for (int k = 0; k < 3; ++k) p[4 + k] = state.camera_tr_rig[c].translation().v[k];
+    }
+    for (int i = 0; i < n_imagesets_total; ++i) {
+      const Quaterniond& q = state.rig_tr_global[i].unit_quaternion();
+      double* p = rig_tr_global + 7 * (size_t)i;
+      p[0] = q.w(); p[1] = q.x(); p[2] = q.y(); p[3] = q.z();
+      for (int k = 0; k < 3; ++k) p[4 + k] = state.rig_tr_global[i].translation().v[k];
+    }
+    for (int p = 0; p < n_points; ++p) for (int k = 0; k < 3; ++k) points[3 * p + k] = state.points[p].v[k];
+    if (last_projection_out) {
+      // same traversal order as the input arrays were appended in (per imageset/camera feature vectors keep input order)
+      std::vector<size_t> cursor((size_t)n_imagesets_total * n_cameras, 0);
+      for (int64_t o = 0; o < n_obs; ++o) {
+        size_t key = (size_t)imageset_index[o] * n_cameras + camera_index[o];
+        const PointFeature& f = dataset.GetImageset(imageset_index[o])->FeaturesOfCamera(camera_index[o])[cursor[key]++];
+        last_projection_out[2 * o] = f.last_projection.x(); last_projection_out[2 * o + 1] = f.last_projection.y();
+      }
+    }
+  }
+};
+}  // namespace
 
 extern "C" int cba_host_optimize_jointly(
     int n_cameras, const cba_camera* cams, const double* const* grids_in, double* const* grids_out,
@@ -16,71 +91,55 @@ extern "C" int cba_host_optimize_jointly(
     int64_t n_obs, const float* xy, const int32_t* point_index, const int32_t* imageset_index /*original*/, const int32_t* camera_index,
     int max_iteration_count, double init_lambda, double numerical_diff_delta, int localize_only, int eliminate_points,
     double* final_cost, double* final_lambda, int* performed_an_iteration, double* last_projection_out) {
-  Dataset dataset(n_cameras);
-  BAState state;
-  for (int c = 0; c < n_cameras; ++c) {
-    const cba_camera& k = cams[c];
-    dataset.SetImageSize(c, Vec2i(k.width, k.height));
-    std::shared_ptr<CameraModel> m;
-    if (k.model_type == CBA_CENTRAL_GENERIC)
-      m.reset(new CentralGenericModel(k.grid_w, k.grid_h, k.calib_min_x, k.calib_min_y, k.calib_max_x, k.calib_max_y, k.width, k.height));
-    else
-      m.reset(new NoncentralGenericModel(k.grid_w, k.grid_h, k.calib_min_x, k.calib_min_y, k.calib_max_x, k.calib_max_y, k.width, k.height));
-    m->set_abi_grid(grids_in[c]);
-    state.intrinsics.push_back(m);
-    const double* p = camera_tr_rig + 7 * c;
-    state.camera_tr_rig.push_back(SE3d(Quaterniond(p[0], p[1], p[2], p[3]), Vec3d(p[4], p[5], p[6])));
-  }
-  for (int i = 0; i < n_imagesets_total; ++i) {
-    dataset.NewImageset();
-    const double* p = rig_tr_global + 7 * (size_t)i;
-    state.rig_tr_global.push_back(SE3d(Quaterniond(p[0], p[1], p[2], p[3]), Vec3d(p[4], p[5], p[6])));
-    state.image_used.push_back(image_used[i] != 0);
-  }
-  for (int p = 0; p < n_points; ++p) {
-    state.points.push_back(Vec3d(points[3 * p], points[3 * p + 1], points[3 * p + 2]));
-    state.feature_id_to_points_index[1000 + p] = p;   // feature id -> point index
-  }
-  std::vector<PointFeature*> order;
-  for (int64_t o = 0; o < n_obs; ++o) {
-    auto& feats = dataset.GetImageset(imageset_index[o])->FeaturesOfCamera(camera_index[o]);
-    feats.emplace_back(Vec2f(xy[2 * o], xy[2 * o + 1]), 1000 + point_index[o]);
-  }
-  state.ComputeFeatureIdToPointsIndex(&dataset);
+  PackedProblem pp(n_cameras, cams, grids_in, n_imagesets_total, image_used, rig_tr_global, camera_tr_rig, n_points, points, n_obs, xy,
+                   point_index, imageset_index, camera_index);
   bool performed = false;
   double lam = init_lambda;
-  double cost = OptimizeJointly(dataset, &state, max_iteration_count, init_lambda, numerical_diff_delta, /*regularization_weight*/ 0,
+  double cost = OptimizeJointly(pp.dataset, &pp.state, max_iteration_count, init_lambda, numerical_diff_delta, /*regularization_weight*/ 0,
                                 localize_only != 0, eliminate_points != 0, SchurMode::Dense, &lam, &performed,
                                 /*debug_verify_cost*/ true, false, false, false, false, /*print_progress*/ false);
   *final_cost = cost; *final_lambda = lam; *performed_an_iteration = performed ? 1 : 0;
-  for (int c = 0; c < n_cameras; ++c) {
-    std::vector<double> g = state.intrinsics[c]->abi_grid();
-    for (size_t i = 0; i < g.size(); ++i) grids_out[c][i] = g[i];
-    const Quaterniond& q = state.camera_tr_rig[c].unit_quaternion();
-    double* p = camera_tr_rig + 7 * c;
-    p[0] = q.w(); p[1] = q.x(); p[2] = q.y(); p[3] = q.z();
-    for (int k = 0; k < 3; ++k) p[4 + k] = state.camera_tr_rig[c].translation().v[k];
-  }
-  for (int i = 0; i < n_imagesets_total; ++i) {
-    const Quaterniond& q = state.rig_tr_global[i].unit_quaternion();
-    double* p = rig_tr_global + 7 * (size_t)i;
-    p[0] = q.w(); p[1] = q.x(); p[2] = q.y(); p[3] = q.z();
-    for (int k = 0; k < 3; ++k) p[4 + k] = state.rig_tr_global[i].translation().v[k];
-  }
-  for (int p = 0; p < n_points; ++p) for (int k = 0; k < 3; ++k) points[3 * p + k] = state.points[p].v[k];
-  if (last_projection_out) {
-    // same traversal order as the input arrays were appended in (per imageset/camera feature vectors keep input order)
-    std::vector<size_t> cursor((size_t)n_imagesets_total * n_cameras, 0);
-    for (int64_t o = 0; o < n_obs; ++o) {
-      size_t key = (size_t)imageset_index[o] * n_cameras + camera_index[o];
-      const PointFeature& f = dataset.GetImageset(imageset_index[o])->FeaturesOfCamera(camera_index[o])[cursor[key]++];
-      last_projection_out[2 * o] = f.last_projection.x(); last_projection_out[2 * o + 1] = f.last_projection.y();
-    }
-  }
+  pp.unpack(grids_out, rig_tr_global, camera_tr_rig, points, last_projection_out);
   // a model-level call through the mirrored CameraModel API
   Vec2d px;
-  Vec3d probe = state.camera_tr_rig[0] * (state.rig_tr_global[0] * state.points[0]);
-  (void)state.intrinsics[0]->Project(probe, &px);
+  Vec3d probe = pp.state.camera_tr_rig[0] * (pp.state.rig_tr_global[0] * pp.state.points[0]);
+  (void)pp.state.intrinsics[0]->Project(probe, &px);
+  return 0;
+}
+
+// vis::RunBundleAdjustment (host/calibration.h) from packed arrays.  mode 0: the shipped implementation (ONE device-resident
+// JointOptimizationSession for the whole loop); mode 1: the reference's loop literally -- OptimizeJointly(max_iteration_count = 1)
+// per iteration (APP/calibration.cc:227-237), i.e. cba_create + observation upload + cba_destroy every iteration -- to
+// measure what the session saves.  seconds_out: wall time of the loop.
+extern "C" int cba_host_run_bundle_adjustment(
+    int n_cameras, const cba_camera* cams, const double* const* grids_in, double* const* grids_out,
+    int n_imagesets_total, const uint8_t* image_used, double* rig_tr_global, double* camera_tr_rig, int n_points, double* points,
+    int64_t n_obs, const float* xy, const int32_t* point_index, const int32_t* imageset_index, const int32_t* camera_index,
+    int max_iteration_count, double cost_reduction_threshold, int mode, int* iterations_out, double* seconds_out, double* last_projection_out) {
+  PackedProblem pp(n_cameras, cams, grids_in, n_imagesets_total, image_used, rig_tr_global, camera_tr_rig, n_points, points, n_obs, xy,
+                   point_index, imageset_index, camera_index);
+  const auto t0 = std::chrono::steady_clock::now();
+  int iterations = 0;
+  if (mode == 0) {
+    RunBundleAdjustment(false, SchurMode::Dense, max_iteration_count, cost_reduction_threshold, &pp.dataset, &pp.state, 0.0, false);
+    iterations = -1;
+  } else {
+    double lambda = -1, last_cost = std::numeric_limits<double>::infinity();
+    for (int iteration = 0; iteration < max_iteration_count; ++iteration) {
+      const double cost = OptimizeJointly(pp.dataset, &pp.state, 1, lambda, 1e-4, 0.0, false, false, SchurMode::Dense, &lambda, nullptr, false,
+                                          false, false, false, false, false);
+      ++iterations;
+      for (int c = 0; c < pp.state.num_cameras(); ++c) {
+        const Mat3d rotation = ChooseNiceCameraOrientation(pp.state.intrinsics[c].get());
+        pp.state.camera_tr_rig[c] = SE3d(MatrixToQuat(rotation), Vec3d::Zero()) * pp.state.camera_tr_rig[c];
+      }
+      if (cost >= last_cost - cost_reduction_threshold) break;
+      last_cost = cost;
+    }
+  }
+  *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  *iterations_out = iterations;
+  pp.unpack(grids_out, rig_tr_global, camera_tr_rig, points, last_projection_out);
   return 0;
 }
 

@@ -28,4 +28,36 @@ double OptimizeJointly(Dataset& dataset, BAState* state, int max_iteration_count
 /// HIP device ordinal used by OptimizeJointly and the CameraModel calls (default 0 / env CBA_DEVICE).
 void SetHipDevice(int device);
 
+/// What OptimizeJointly does, split so that a caller which runs it in a loop (RunBundleAdjustment, APP/calibration.cc:
+/// 187-304, calls it with max_iteration_count = 1 up to 100 times) keeps ONE device-resident problem alive: the
+/// observations (7.4 MB at BASELINE configs[1]) are marshalled and uploaded once, the 3 GB of device buffers are
+/// allocated once, and only the state (0.3 MB) crosses the bus when the host edits it between iterations
+/// (ChooseNiceCameraOrientation).  OptimizeJointly itself is `Session s(...); s.Optimize(...); s.ReadBack();`.
+/// No counterpart in the reference (its optimizer state lives on the host).
+class JointOptimizationSession {
+ public:
+  JointOptimizationSession(Dataset& dataset, BAState* state, double numerical_diff_delta, bool localize_only,
+                           bool eliminate_points, SchurMode schur_mode);
+  ~JointOptimizationSession();
+  JointOptimizationSession(const JointOptimizationSession&) = delete;
+  JointOptimizationSession& operator=(const JointOptimizationSession&) = delete;
+  /// The loop of OptimizeJointly (joint_optimization.cc:906-940) on the device-resident state.  Returns the final cost.
+  double Optimize(int max_iteration_count, double init_lambda, double* final_lambda, bool* performed_an_iteration,
+                  bool print_progress);
+  /// VerifyCost (joint_optimization.cc:866-877): two cost passes must agree.
+  void VerifyCost();
+  /// device -> *state (poses, points, intrinsics); cheap (0.3 MB).
+  void ReadBackState();
+  /// device -> PointFeature::last_projection of every observation (the warm-start cache the reference mutates in place).
+  void ReadBackLastProjections();
+  /// *state -> device, after the host changed poses / points / intrinsics (same image_used set, same sizes).
+  void UploadState();
+  /// seconds spent creating the device problem and marshalling the observations (measurement aid)
+  double setup_seconds() const { return m_setup_seconds; }
+ private:
+  struct Impl;
+  Impl* m;
+  double m_setup_seconds = 0;
+};
+
 }  // namespace vis

@@ -122,7 +122,7 @@ def test_dataset_to_problem_packs_like_the_host_adapter():
 
 def test_cpp_mirror_reads_and_rewrites_the_files(tmp_path):
     lib_dir = os.path.join(os.path.dirname(os.path.abspath(cio.__file__)))
-    host = os.path.join(lib_dir, "libcalib_ba_host.so")
+    host = os.path.join(lib_dir, "libcalib_ba_host_test.so")
     if not os.path.exists(host):
         pytest.skip("host library not built")
     try:

@@ -80,7 +80,7 @@ def _host_lib():
     from camera_calibration_amd import engine as eng
     lib_dir = os.path.dirname(os.path.abspath(cal.__file__))
     C.CDLL(os.path.join(lib_dir, "libcalib_ba_hip.so"), mode=C.RTLD_GLOBAL)
-    return C.CDLL(os.path.join(lib_dir, "libcalib_ba_host.so"))
+    return C.CDLL(os.path.join(lib_dir, "libcalib_ba_host_test.so"))
 
 
 def test_cpp_scale_to_metric_matches_oracle():

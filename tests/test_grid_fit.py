@@ -160,7 +160,7 @@ def test_cpp_mirror_fit_and_resample_match_python_mirror():
     dense = dense_pinhole(255, 250, 325, 238)
     dense[:30, :] = np.nan
     eng.load()
-    L = C.CDLL(os.path.join(os.path.dirname(eng.LIB_PATH), "libcalib_ba_host.so"))
+    L = C.CDLL(os.path.join(os.path.dirname(eng.LIB_PATH), "libcalib_ba_host_test.so"))
     dp = C.POINTER(C.c_double)
     cs = eng._cam_struct(cam)
     g_out = np.zeros((cam.grid_points, 3)); r_out = np.zeros((13 * 10, 3))

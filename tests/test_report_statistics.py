@@ -71,7 +71,7 @@ def test_cpp_report_mirror_on_gpu():
     from camera_calibration_amd import engine as eng
     pb, st = _problem(2, seed=23)
     eng.load()
-    L = C.CDLL(os.path.join(os.path.dirname(eng.LIB_PATH), "libcalib_ba_host.so"))
+    L = C.CDLL(os.path.join(os.path.dirname(eng.LIB_PATH), "libcalib_ba_host_test.so"))
     dp = C.POINTER(C.c_double)
     cams = (eng.CbaCamera * pb.n_cameras)(*[eng._cam_struct(c) for c in pb.cameras])
     grids = [np.ascontiguousarray(g, dtype=np.float64) for g in st.grids]
@@ -139,7 +139,7 @@ def test_cpp_delete_outlier_features_on_gpu():
     from camera_calibration_amd import engine as eng
     pb, st = _outlier_problem(33)
     eng.load()
-    L = C.CDLL(os.path.join(os.path.dirname(eng.LIB_PATH), "libcalib_ba_host.so"))
+    L = C.CDLL(os.path.join(os.path.dirname(eng.LIB_PATH), "libcalib_ba_host_test.so"))
     dp = C.POINTER(C.c_double)
     cams = (eng.CbaCamera * pb.n_cameras)(*[eng._cam_struct(c) for c in pb.cameras])
     grids = [np.ascontiguousarray(g, dtype=np.float64) for g in st.grids]

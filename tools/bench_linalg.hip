@@ -1,5 +1,6 @@
 // Developer harness (not shipped): times the linear-algebra kernels of the engine in isolation.
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -mllvm -amdgpu-mfma-vgpr-form tools/bench_linalg.hip -o tools/bin/bench_linalg
+#define CBA_DEV_SWITCHES 1   // epilogue modes + CBA_* environment switches exist only in this harness
 #include "../camera_calibration_amd/csrc/kernels_linalg.hip"
 #include <cstdio>
 #include <chrono>
