@@ -78,6 +78,22 @@ def build_host(force: bool = False) -> str:
     return HOST_LIB
 
 
+RCCL_LIB = os.path.join(HERE, "libcalib_ba_rccl.so")
+
+
+def build_rccl(force: bool = False) -> str:
+    """Native RCCL all-reduce callback for C++ hosts (include/cba_rccl.h); links librccl, the engine does not."""
+    src = os.path.join(HOST_DIR, "rccl_allreduce.cc")
+    hdr = os.path.join(HERE, "..", "include", "cba_rccl.h")
+    if not force and os.path.exists(RCCL_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(RCCL_LIB) for d in (src, hdr)):
+        return RCCL_LIB
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [_hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-x", "hip", "--offload-arch=gfx950", src, "-o", RCCL_LIB,
+           "-I" + os.path.join(rocm, "include"), "-L" + os.path.join(rocm, "lib"), "-lrccl", "-Wl,-rpath," + os.path.join(rocm, "lib")]
+    subprocess.check_call(cmd)
+    return RCCL_LIB
+
+
 def build_host_test(force: bool = False) -> str:
     """Test-only shim over the C++ host adapter (tests/test_gpu_host_adapter.py etc.)."""
     build_host(force)
@@ -94,3 +110,4 @@ if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_host(force="--force" in sys.argv))
     print(build_host_test(force="--force" in sys.argv))
+    print(build_rccl(force="--force" in sys.argv))

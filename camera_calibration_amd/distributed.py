@@ -53,21 +53,97 @@ def make_allreduce(big_buffer, local_rank: int):
     big_ptr = big_buffer.data_ptr() if big_buffer is not None else 0
 
     def allreduce(ptr: int, count: int) -> int:
+        # the engine's stream is idle when this is called (include/cba.h); the collective is ordered on torch's current
+        # stream, and only that stream is waited for -- no device-wide synchronisation
         if big_buffer is not None and ptr == big_ptr:
             dist.all_reduce(big_buffer[:count])
-            torch.cuda.synchronize()
+            torch.cuda.current_stream().synchronize()
             return 0
         if count > staging.numel():
             return 1
         if hip.hipMemcpy(staging.data_ptr(), ptr, count * 8, HIP_MEMCPY_D2D) != 0:
             return 1
         dist.all_reduce(staging[:count])
-        torch.cuda.synchronize()
+        torch.cuda.current_stream().synchronize()
         if hip.hipMemcpy(ptr, staging.data_ptr(), count * 8, HIP_MEMCPY_D2D) != 0:
             return 1
         return 0
 
     return allreduce
+
+
+def make_allreduce_host_staged():
+    """callback(ptr, count) that sums a DEVICE fp64 buffer over all ranks through HOST memory with whatever process group is
+    initialised (gloo).  For tests that run several ranks on ONE GPU (RCCL refuses two ranks on one device) and for
+    bring-up on machines without a GPU interconnect; the production path is make_allreduce (RCCL over xGMI) or the native
+    callback of libcalib_ba_rccl.so."""
+    import torch
+    import torch.distributed as dist
+
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipMemcpy.restype = ctypes.c_int
+    D2H, H2D = 2, 1
+
+    def allreduce(ptr: int, count: int) -> int:
+        host = np.empty(count, dtype=np.float64)
+        if hip.hipMemcpy(host.ctypes.data, ptr, count * 8, D2H) != 0:
+            return 1
+        t = torch.from_numpy(host)
+        dist.all_reduce(t)
+        if hip.hipMemcpy(ptr, host.ctypes.data, count * 8, H2D) != 0:
+            return 1
+        return 0
+
+    return allreduce
+
+
+class NativeRccl:
+    """libcalib_ba_rccl.so (include/cba_rccl.h): the all-reduce callback a C++ host uses, bound for Python callers.
+    `fn` / `user` go straight into cba_config.allreduce / allreduce_user -- no Python frame on the reduction path."""
+
+    def __init__(self, rank: int, world: int, id_file: str, device: int):
+        import os
+        here = os.path.dirname(os.path.abspath(__file__))
+        self.lib = ctypes.CDLL(os.path.join(here, "libcalib_ba_rccl.so"))
+        self.lib.cba_rccl_create_via_file.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        self.lib.cba_rccl_destroy.argtypes = [ctypes.c_void_p]
+        self.lib.cba_rccl_last_error.restype = ctypes.c_char_p
+        self.user = ctypes.c_void_p()
+        if self.lib.cba_rccl_create_via_file(rank, world, id_file.encode(), device, ctypes.byref(self.user)) != 0:
+            raise RuntimeError("cba_rccl_create_via_file: " + self.lib.cba_rccl_last_error().decode())
+        self.fn = ctypes.cast(self.lib.cba_rccl_allreduce, ctypes.c_void_p)
+
+    def close(self):
+        if self.user:
+            self.lib.cba_rccl_destroy(self.user)
+            self.user = ctypes.c_void_p()
+
+
+# ---------------------------------------------------------------------------------------------------
+# host mirror of the buffer that crosses ranks (k_pack_upper, csrc/kernels_linalg.hip): the upper 128-row blocks of
+# the n_pad x n_pad reduced system -- block i keeps rows [128 i, 128 i + 128) and columns [128 i, n_pad), rows contiguous;
+# the right-hand side travels in the last padding column (n_pad - 1).
+# ---------------------------------------------------------------------------------------------------
+def packed_upper_doubles(n_pad: int) -> int:
+    return sum(128 * (n_pad - 128 * i) for i in range(n_pad // 128))
+
+
+def pack_upper(S: np.ndarray) -> np.ndarray:
+    n_pad = S.shape[0]
+    assert S.shape == (n_pad, n_pad) and n_pad % 128 == 0
+    return np.concatenate([S[128 * i:128 * i + 128, 128 * i:].ravel() for i in range(n_pad // 128)])
+
+
+def unpack_upper(P: np.ndarray, n_pad: int, out: np.ndarray | None = None) -> np.ndarray:
+    S = np.zeros((n_pad, n_pad)) if out is None else out
+    off = 0
+    for i in range(n_pad // 128):
+        w = n_pad - 128 * i
+        S[128 * i:128 * i + 128, 128 * i:] = P[off:off + 128 * w].reshape(128, w)
+        off += 128 * w
+    assert off == P.size
+    return S
 
 
 # ---------------------------------------------------------------------------------------------------

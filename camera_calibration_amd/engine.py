@@ -178,7 +178,8 @@ class Engine:
 
     def __init__(self, problem: Problem, device: int = 0, allreduce: Optional[Callable[[int, int], int]] = None,
                  n_images_global: int = 0, reduce_buffer_ptr: int = 0, reduce_buffer_doubles: int = 0,
-                 last_projection: Optional[np.ndarray] = None, deterministic: bool = False):
+                 last_projection: Optional[np.ndarray] = None, deterministic: bool = False,
+                 allreduce_native: Optional[tuple] = None):
         self.L = load()
         self.problem = problem
         self._cams = (CbaCamera * problem.n_cameras)(*[_cam_struct(c) for c in problem.cameras])
@@ -192,9 +193,12 @@ class Engine:
                     traceback.print_exc()
                     return 1
             self._cb = ALLREDUCE_FN(_cb)
+        cb, user = (self._cb if self._cb is not None else ALLREDUCE_FN(0)), None
+        if allreduce_native is not None:     # (C function pointer, user pointer), e.g. distributed.NativeRccl.fn / .user
+            cb, user = C.cast(allreduce_native[0], ALLREDUCE_FN), allreduce_native[1]
         cfg = CbaConfig(problem.n_cameras, self._cams, problem.n_images, problem.n_points, problem.fd_delta,
                         int(problem.localize_only), int(problem.eliminate_points), device,
-                        self._cb if self._cb is not None else ALLREDUCE_FN(0), None, n_images_global,
+                        cb, user, n_images_global,
                         reduce_buffer_ptr or None, reduce_buffer_doubles, int(deterministic))
         self._cfg = cfg
         self._h = C.c_void_p()

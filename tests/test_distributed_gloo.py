@@ -97,3 +97,66 @@ def test_two_rank_sharded_step_equals_single_process(tmp_path):
         np.testing.assert_allclose(r[k]["poses"], cand.rig_tr_global[int(r[k]["b"]):int(r[k]["e"])], atol=1e-9)
         np.testing.assert_allclose(r[k]["points"], cand.points, atol=1e-9)
     np.testing.assert_array_equal(r[0]["xd"], r[1]["xd"])   # replicated solve is bit-identical
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the buffer that actually crosses ranks: the packed upper 128-row blocks of the padded reduced system (k_pack_upper)
+# ---------------------------------------------------------------------------------------------------------------------
+def _packed_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pb, st, _ = syn.reference_test_problem(2, _oracle_project, seed=22, num_points=60, num_poses=10)
+    shards = dist_mod.shard_images(np.bincount(pb.obs_image, minlength=pb.n_images), world)
+    b, e = shards[rank]
+    sub, sst = pb.image_slice(b, e), st.image_slice(b, e)
+    op = orc.OracleProblem(sub)
+    sysm = op.new_system()
+    op.jacobian_pass(sst, sysm)
+    lam = 0.37
+    S, s, _, _ = dist_mod.local_reduced_system(sysm.block_diag_H, sysm.off_diag_H, sysm.dense_H, sysm.block_diag_b, sysm.dense_b, lam)
+    D = pb.dense_dof
+    n_pad = -(-(D + 1) // 128) * 128                 # the engine's padding rule (cba_api.hip padded_dims)
+    if -(-D // 64) * 64 >= n_pad:
+        n_pad += 128
+    Sp = np.zeros((n_pad, n_pad))
+    Sp[:D, :D] = np.triu(S)
+    Sp[:D, n_pad - 1] = s                             # right-hand side in the last padding column
+    P = dist_mod.pack_upper(Sp)
+    t = torch.from_numpy(P)
+    dist.all_reduce(t)                                # ONE all-reduce of the packed buffer, as cba_step does
+    Ssum = dist_mod.unpack_upper(t.numpy(), n_pad)
+    np.savez(os.path.join(out_dir, f"packed{rank}.npz"), S=Ssum[:D, :D], s=Ssum[:D, n_pad - 1], n_pad=n_pad, count=P.size)
+    dist.destroy_process_group()
+
+
+def test_packed_upper_layout_sums_over_ranks(tmp_path):
+    world = 2
+    mp.spawn(_packed_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    pb, st, _ = syn.reference_test_problem(2, _oracle_project, seed=22, num_points=60, num_poses=10)
+    op = orc.OracleProblem(pb)
+    sysm = op.new_system()
+    op.jacobian_pass(st, sysm)
+    S, s, _, _ = dist_mod.local_reduced_system(sysm.block_diag_H, sysm.off_diag_H, sysm.dense_H, sysm.block_diag_b, sysm.dense_b, 0.37)
+    r = [np.load(os.path.join(str(tmp_path), f"packed{k}.npz")) for k in range(world)]
+    for k in range(world):
+        np.testing.assert_allclose(np.triu(r[k]["S"]), np.triu(S), rtol=1e-9, atol=1e-9 * np.abs(S).max())
+        np.testing.assert_allclose(r[k]["s"], s, rtol=1e-9, atol=1e-9 * np.abs(s).max())
+    # the size the engine asks its host for (cba_reduce_buffer_doubles, pure host code) is the size of this layout
+    from camera_calibration_amd import engine as eng
+    assert eng.Engine.reduce_buffer_doubles(pb) == int(r[0]["count"]) == dist_mod.packed_upper_doubles(int(r[0]["n_pad"]))
+
+
+def test_pack_unpack_roundtrip_and_block_offsets():
+    n_pad = 640
+    rng = np.random.default_rng(0)
+    S = np.triu(rng.normal(size=(n_pad, n_pad)))
+    P = dist_mod.pack_upper(S)
+    assert P.size == dist_mod.packed_upper_doubles(n_pad)
+    # offset formula of k_pack_upper: block blk starts at 128 * (blk * n_pad - 64 * blk * (blk - 1))
+    for blk in range(n_pad // 128):
+        off = 128 * (blk * n_pad - 64 * blk * (blk - 1))
+        assert P[off] == S[128 * blk, 128 * blk]
+    S2 = dist_mod.unpack_upper(P, n_pad)
+    for blk in range(n_pad // 128):
+        np.testing.assert_array_equal(S2[128 * blk:128 * blk + 128, 128 * blk:], S[128 * blk:128 * blk + 128, 128 * blk:])

@@ -1,0 +1,114 @@
+"""The image-sharded path with REAL sharding on one GPU: two processes share device 0, each owns half of the imagesets,
+and every Gauss-Newton step goes through cba_step's multi-rank control flow (packed-upper all-reduce of the reduced
+system, 8-double scalar reductions, cross-rank failure flag, lambda added after the reduction, replicated factorisation,
+local pose back-substitution).  RCCL refuses two ranks on one device, so the reductions are staged through host memory
+with gloo (camera_calibration_amd.distributed.make_allreduce_host_staged); the engine code under test is identical to
+the RCCL configuration.  Reference for the result: the single-process engine on the whole problem."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+
+from camera_calibration_amd import distributed as dist_mod  # noqa: E402
+from camera_calibration_amd import engine as eng  # noqa: E402
+from camera_calibration_amd import synthetic as syn  # noqa: E402
+from parity_record import check, check_equal  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+STEPS = 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem():
+    return syn.baseline_config(3, lambda cam, grid, pts: eng.project(cam, grid, pts), n_imagesets=24, grid_wh=(20, 16))
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng.prepare(0)
+    pb, st, _ = _problem()
+    shards = dist_mod.shard_images(np.bincount(pb.obs_image, minlength=pb.n_images), world)
+    b, e = shards[rank]
+    sub, sst = pb.image_slice(b, e), st.image_slice(b, e)
+    allreduce = dist_mod.make_allreduce_host_staged()
+    en = eng.Engine(sub, device=0, allreduce=allreduce, n_images_global=pb.n_images, deterministic=True,
+                    last_projection=sub.obs_xy.astype(np.float64))
+    en.set_state(sst)
+    lam = -1.0
+    reps = []
+    for _ in range(STEPS):
+        r = en.step(lam)
+        lam = r.final_lambda
+        reps.append([r.initial_cost, r.final_cost, r.final_lambda, r.lm_attempts, float(r.accepted), r.n_residuals_valid])
+    out = en.get_state(sst)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), b=b, e=e, reps=np.array(reps), poses=out.rig_tr_global, points=out.points,
+             camrig=out.camera_tr_rig, grid0=out.grids[0], grid1=out.grids[1])
+    en.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_the_single_process_engine(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    pb, st, _ = _problem()
+    en = eng.Engine(pb, deterministic=True, last_projection=pb.obs_xy.astype(np.float64))
+    en.set_state(st)
+    lam = -1.0
+    reps = []
+    for _ in range(STEPS):
+        r = en.step(lam)
+        lam = r.final_lambda
+        reps.append([r.initial_cost, r.final_cost, r.final_lambda, r.lm_attempts, float(r.accepted), r.n_residuals_valid])
+    ref = en.get_state(st)
+    en.close()
+    reps = np.array(reps)
+    case = "2 ranks on 1 GPU (cfg-3-shaped, 24 imagesets) vs single process"
+    rk = [np.load(os.path.join(str(tmp_path), f"rank{k}.npz")) for k in range(world)]
+    assert rk[0]["b"] == 0 and rk[1]["e"] == pb.n_images and rk[0]["e"] == rk[1]["b"]
+    for k in range(world):
+        check_equal(case, f"rank {k}: LM attempts / accept decisions / valid counts",
+                    int(np.count_nonzero(rk[k]["reps"][:, 3:] != reps[:, 3:])))
+        check(case, f"rank {k}: costs rel", (np.abs(rk[k]["reps"][:, :2] - reps[:, :2]) / reps[:, :2]).max(), 1e-8)
+        check(case, f"rank {k}: lambda rel", (np.abs(rk[k]["reps"][:, 2] - reps[:, 2]) / reps[:, 2]).max(), 1e-8)
+        b, e = int(rk[k]["b"]), int(rk[k]["e"])
+        check(case, f"rank {k}: own poses abs", np.abs(rk[k]["poses"] - ref.rig_tr_global[b:e]).max(), 1e-8)
+        check(case, f"rank {k}: points abs", np.abs(rk[k]["points"] - ref.points).max(), 1e-8)
+        check(case, f"rank {k}: camera_tr_rig abs", np.abs(rk[k]["camrig"] - ref.camera_tr_rig).max(), 1e-8)
+        check(case, f"rank {k}: grids abs", max(np.abs(rk[k]["grid0"] - ref.grids[0]).max(), np.abs(rk[k]["grid1"] - ref.grids[1]).max()), 1e-8)
+    # the replicated part of the state is bit-identical on both ranks (same reduced system, same factorisation)
+    for key in ("points", "camrig", "grid0", "grid1"):
+        check_equal(case, f"replicated state identical on both ranks: {key}", int(np.count_nonzero(rk[0][key] != rk[1][key])))
+    check_equal(case, "step reports identical on both ranks", int(np.count_nonzero(rk[0]["reps"] != rk[1]["reps"])))
+
+
+def test_native_rccl_callback_world_of_one(tmp_path):
+    """libcalib_ba_rccl.so (include/cba_rccl.h), the callback a C++ host passes to cba_config.allreduce: a communicator of one
+    rank on this GPU must leave every reduction unchanged, i.e. reproduce the plain path."""
+    pb, st, _ = syn.baseline_config(2, lambda cam, grid, pts: eng.project(cam, grid, pts), n_imagesets=20, grid_wh=(24, 18))
+    rc = dist_mod.NativeRccl(0, 1, str(tmp_path / "rccl_id"), 0)
+    e1 = eng.Engine(pb, deterministic=True)
+    e2 = eng.Engine(pb, deterministic=True, allreduce_native=(rc.fn, rc.user), n_images_global=pb.n_images)
+    e1.set_state(st); e2.set_state(st)
+    l1 = l2 = -1.0
+    for _ in range(3):
+        r1 = e1.step(l1); r2 = e2.step(l2)
+        l1, l2 = r1.final_lambda, r2.final_lambda
+        assert r1.accepted == r2.accepted and r1.lm_attempts == r2.lm_attempts
+        check("native RCCL callback, world 1", "final cost rel", abs(r1.final_cost - r2.final_cost) / r1.final_cost, 1e-9)
+    s1, s2 = e1.get_state(st), e2.get_state(st)
+    check("native RCCL callback, world 1", "points abs", np.abs(s1.points - s2.points).max(), 1e-9)
+    e1.close(); e2.close(); rc.close()
