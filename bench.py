@@ -46,47 +46,98 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(pb, st0, n_sample_images, n_obs_total, n_images_total):
-    """Oracle (CPU restatement, 1 thread like the reference) timed on a bounded sample of this workload.
+def _host_description():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model, os.cpu_count()
 
-    Jacobian + cost passes: the first `n_sample_images` imagesets, scaled by observation count.
-    Solve: SolveWithSchurComplementDenseOffDiag restated, timed on a synthetic SPD system of 4608 dense
-    unknowns / 180 pose blocks (about 10 s) and scaled by the flop model  6N*D^2 (Schur product) + D^3/3 (LDLT)."""
+
+def cpu_baseline(pb, st0, n_sample_images, n_obs_total, n_images_total):
+    """Oracle (CPU restatement of the reference path) timed on this box's host cores, on a bounded sample of the workload.
+
+    Primary figure: 1 thread, as the reference's path is single-threaded.  Jacobian + cost passes on the
+    first `n_sample_images` imagesets, scaled by observation count; SolveWithSchurComplementDenseOffDiag restated, timed on
+    a synthetic SPD system of 4608 dense unknowns / 180 pose blocks and scaled by the flop model 6N*D^2 + D^3/3.
+    `all_cores`: the same oracle with every hardware thread (bit-identical results, see oracle/cba_oracle.c): passes on the
+    same sample, and the Schur solve at the FULL size of this workload, measured, not extrapolated."""
     from oracle import oracle as orc
+    host_model, host_cores = _host_description()
+    lp0 = pb.obs_xy.astype(np.float64)          # warm-start cache as later iterations see it
     sub = pb.image_slice(0, n_sample_images)
     sst = st0.image_slice(0, n_sample_images)
-    op = orc.OracleProblem(sub)
-    t0 = time.perf_counter()
-    op.jacobian_pass(sst, None)
-    t_jac = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    op.cost_pass(sst)
-    t_cost = time.perf_counter() - t0
+    sel = pb.obs_image < n_sample_images
     scale_obs = n_obs_total / max(1, sub.n_obs)
-    # solve on a synthetic SPD system of reduced size
-    Ds, Ns = 4608, 180
-    rng = np.random.default_rng(0)
-    s = orc.System(6, Ns, Ds)
-    A = rng.normal(size=(Ds, Ds)); s.dense_H[:] = np.triu(A @ A.T + Ds * np.eye(Ds))
-    s.off_diag_H[:] = rng.normal(size=(6 * Ns, Ds)) * 0.1
-    for b in range(Ns):
-        M = rng.normal(size=(6, 6)); s.block_diag_H[b] = np.triu(M @ M.T + 6 * np.eye(6))
-    s.block_diag_b[:] = rng.normal(size=6 * Ns); s.dense_b[:] = rng.normal(size=Ds)
-    t0 = time.perf_counter()
-    orc.schur_solve(s)
-    t_solve_s = time.perf_counter() - t0
     D, N = pb.dense_dof, n_images_total
-    flops_s = 6 * Ns * Ds ** 2 + Ds ** 3 / 3
-    flops = 6 * N * D ** 2 + D ** 3 / 3
-    t_solve = t_solve_s * flops / flops_s
-    t_iter = t_jac * scale_obs + t_cost * scale_obs + t_solve
-    return {
-        "value": n_obs_total / t_iter / 1e6, "unit": "M obs/s per LM iteration", "cores": 1, "kind": "port",
-        "sample": (f"oracle Jacobian+cost passes on the first {n_sample_images} imagesets ({sub.n_obs} obs, "
-                   f"{t_jac:.2f}s + {t_cost:.2f}s) scaled to {n_obs_total} obs; Schur solve timed at D={Ds},N={Ns} "
-                   f"({t_solve_s:.2f}s) scaled by 6N*D^2 + D^3/3 to D={D},N={N} -> {t_solve:.0f}s"),
-        "t_iter_s_extrapolated": t_iter,
-    }
+
+    def passes(threads):
+        orc.set_num_threads(threads)
+        op = orc.OracleProblem(sub, last_projection=lp0[sel].copy())
+        t0 = time.perf_counter()
+        op.jacobian_pass(sst, None)
+        tj = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        op.cost_pass(sst)
+        return tj, time.perf_counter() - t0
+
+    def synthetic_system(Ds, Ns, seed=0):
+        rng = np.random.default_rng(seed)
+        s = orc.System(6, Ns, Ds)
+        A = rng.normal(size=(Ds, min(Ds, 2048)))
+        s.dense_H[:] = np.triu(A @ A.T + Ds * np.eye(Ds))
+        s.off_diag_H[:] = rng.normal(size=(6 * Ns, Ds)) * 0.1
+        for b in range(Ns):
+            M = rng.normal(size=(6, 6)); s.block_diag_H[b] = np.triu(M @ M.T + 6 * np.eye(6))
+        s.block_diag_b[:] = rng.normal(size=6 * Ns); s.dense_b[:] = rng.normal(size=Ds)
+        return s
+
+    try:
+        # ---- 1 thread ----
+        t_jac, t_cost = passes(1)
+        Ds, Ns = 4608, 180
+        s = synthetic_system(Ds, Ns)
+        t0 = time.perf_counter()
+        orc.schur_solve(s)
+        t_solve_s = time.perf_counter() - t0
+        flops_s = 6 * Ns * Ds ** 2 + Ds ** 3 / 3
+        flops = 6 * N * D ** 2 + D ** 3 / 3
+        t_solve = t_solve_s * flops / flops_s
+        t_iter = t_jac * scale_obs + t_cost * scale_obs + t_solve
+        out = {
+            "value": n_obs_total / t_iter / 1e6, "unit": "M obs/s per LM iteration", "cores": 1, "kind": "port",
+            "host_cpu_model": host_model, "host_cores": host_cores,
+            "sample": (f"oracle Jacobian+cost passes on the first {n_sample_images} imagesets ({sub.n_obs} obs, "
+                       f"{t_jac:.2f}s + {t_cost:.2f}s) scaled to {n_obs_total} obs; Schur solve timed at D={Ds},N={Ns} "
+                       f"({t_solve_s:.2f}s) scaled by 6N*D^2 + D^3/3 to D={D},N={N} -> {t_solve:.0f}s"),
+            "t_iter_s_extrapolated": t_iter,
+        }
+        # ---- all hardware threads ----
+        nthreads = orc.set_num_threads(0)
+        tj_a, tc_a = passes(nthreads)
+        full = D <= 26000                      # the full-size solve needs 2 x D^2 doubles on the host
+        Da, Na = (D, N) if full else (12288, 512)
+        s = synthetic_system(Da, Na, seed=1)
+        orc.set_num_threads(nthreads)
+        t0 = time.perf_counter()
+        orc.schur_solve(s)
+        ts_a = time.perf_counter() - t0
+        if not full:
+            ts_a *= flops / (6 * Na * Da ** 2 + Da ** 3 / 3)
+        ti_a = tj_a * scale_obs + tc_a * scale_obs + ts_a
+        out["all_cores"] = {
+            "value": n_obs_total / ti_a / 1e6, "cores": nthreads, "t_iter_s": ti_a,
+            "sample": (f"same passes with {nthreads} threads ({tj_a:.2f}s + {tc_a:.2f}s on {sub.n_obs} obs); Schur solve "
+                       + (f"measured at the full size D={D},N={N}: {ts_a:.1f}s" if full else f"timed at D={Da},N={Na}, scaled to D={D}: {ts_a:.0f}s")),
+        }
+        return out
+    finally:
+        orc.set_num_threads(1)
 
 
 def main():
@@ -124,7 +175,10 @@ def main():
     from camera_calibration_amd.distributed import make_allreduce
 
     n_default = syn.BASELINE_CONFIGS[args.config][8]
-    n_img = args.imagesets or n_default
+    # BASELINE.json names the GPU count of every config: 4 = 800 imagesets over 2 GPUs, 5 = 4000 imagesets over 8 GPUs.  A
+    # rank always owns n_default / native_gpus imagesets (the config's own size at its native GPU count, weak scaling around it)
+    native_gpus = {1: 1, 2: 1, 3: 1, 4: 2, 5: 8}[args.config]
+    n_img = args.imagesets or (n_default // native_gpus if world > 1 else n_default)
     proj = lambda cam, grid, pts: eng.project(cam, grid, pts, device=local_rank)
     t_gen = time.time()
     pb, st0, gt = syn.baseline_config(args.config, proj, n_imagesets=n_img, image_offset=rank * n_img)
@@ -207,7 +261,9 @@ def main():
         # HBM bytes of the dominant kernel come from PMC passes that cannot run inside the timed region; the last
         # committed measurement (tools/rocprof_pmc.py) is quoted when the workload is the one it was taken on.
         pmc_traffic = {}
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
+        if not os.path.exists(pmc_path):
+            pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
         if args.config == 2 and world == 1 and os.path.exists(pmc_path):
             with open(pmc_path) as fh:
                 pmc_traffic = json.load(fh)
@@ -217,7 +273,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{args.config - 1}]: {pb.n_cameras} cam "
                                    f"{'central' if pb.cameras[0].model_type == 0 else 'non-central'}-generic "
-                                   f"{pb.cameras[0].grid_w}x{pb.cameras[0].grid_h} grid, {n_img} imagesets/GPU x {world} GPU, "
+                                   f"{pb.cameras[0].grid_w}x{pb.cameras[0].grid_h} grid, {n_img} imagesets/GPU x {world} GPU"
+                                   f"{' (= the config as BASELINE.json states it)' if world == native_gpus and n_img * world == n_default else ''}, "
                                    f"{n_obs_total} observations, reduced system D={pb.dense_dof}",
                        "parallelism": f"image-sharded x{world}" if world > 1 else ("single GPU (all-reduce path forced)" if use_dist else "single GPU"),
                        "lm_attempts_per_step": [r.lm_attempts for r in reports],
@@ -272,6 +329,21 @@ def main():
             "iteration_bytes": {"bytes_iter": bytes_iter, "achieved_GBps": bytes_iter / (ms_per_step * 1e-3) / 1e9,
                                 "peak_GBps": 8000.0, "frac": bytes_iter / (ms_per_step * 1e-3) / 8e12},
         }
+        # `roofline` describes the kernel that dominates THIS workload: the fp64 MFMA GEMM at configs 2 / 3 / 5, the
+        # finite-difference projection kernel (fp64 VALU) at the non-central config 4.  The GEMM figures stay available
+        # under roofline_gemm either way.
+        fd_s = agg[3]["seconds"]
+        out["roofline_gemm"] = dict(out["roofline"])
+        if fd_s > dom_s:
+            fd_launches = max(1, agg[3]["launches"])
+            fd_flops = n_loc * (3 + k_cell) * evals_per_projection * flop_per_eval        # per launch (= per step)
+            fd_tflops = fd_flops / (fd_s / fd_launches) / 1e12
+            out["roofline"] = {
+                "bound": "valu_fp64", "achieved": fd_tflops, "peak": 78.6, "unit": "TFLOP/s", "frac": fd_tflops / 78.6, "traffic": None,
+                "kernel": f"k_fd_tasks<{'1' if cam0.model_type == 1 else '0'}> (finite-difference re-projections, lane per (observation, task))",
+                "launches": agg[3]["launches"], "avg_launch_ms": fd_s / fd_launches * 1e3, "flops_per_launch": fd_flops,
+                "model": "algorithmic flops = observations x (3 + K_cell) projections x 3.5 spline evaluations x 0.6 kflop "
+                         "(DESIGN.md section 3); peak = MI355X fp64 vector peak"}
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(pb, st0, min(args.cpu_sample_images, pb.n_images), n_obs_total, n_img)
@@ -294,6 +366,9 @@ def main():
     if rank == 0:
         if conv is not None:
             out["wall_clock_to_convergence"] = conv
+            # the headline value restarts the trajectory every RESTART steps (single-attempt iterations); this is the
+            # average over the WHOLE calibration run incl. the last iterations' rejected LM attempts
+            out["trajectory_avg_mobs"] = n_obs_total * conv["outer_iterations"] / conv["seconds"] / 1e6
         # RCCL prints its version banner through C stdio; flush it first so the JSON line is the last line
         try:
             ctypes.CDLL(None).fflush(None)

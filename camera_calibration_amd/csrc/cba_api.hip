@@ -155,6 +155,8 @@ struct cba_problem {
   KernelTimer timers[5];     // see cba_kernel_stats
   // deterministic mode (cba_config.deterministic): fixed-point scale of the current pass
   unsigned long long* det_bits = nullptr; double* det_scale = nullptr;
+  // finite-difference kernel: work lists of the tasks that leave their staged patch (main launch / side-stream launch)
+  int64_t* fd_redo[2] = {nullptr, nullptr}; int* fd_redo_count = nullptr;
   double last_lambda = 0;
 };
 
@@ -317,7 +319,7 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   CBA_HIP(hipEventRecord(p->ev_aux0, p->stream));
   CBA_HIP(hipStreamWaitEvent(aux, p->ev_aux0, 0));
   CBA_TRY(launch_base_project(as, p->model_mask, p->cost_ref, p->pixels, p->flags, aux));
-  CBA_TRY(launch_fd_tasks(as, p->model_mask, p->tasks_per_obs, L.localize_only, p->pixels, p->flags, p->fd_out, p->fd_ok, aux));
+  CBA_TRY(launch_fd_tasks(as, p->model_mask, p->tasks_per_obs, L.localize_only, p->pixels, p->flags, p->fd_out, p->fd_ok, p->fd_redo[1], p->fd_redo_count + 1, aux));
   // ... and the accumulation targets are cleared there too (1.3 GB for H_dd at cfg 2), underneath the main launches
   const size_t bs = L.block_size, nb = L.n_blocks;
   CBA_HIP(hipMemsetAsync(p->Dblk, 0, sizeof(double) * nb * bs * bs, aux));
@@ -331,7 +333,7 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   CBA_HIP(hipEventRecord(p->ev_aux1, aux));
   CBA_TRY(launch_base_project(a, p->model_mask, p->cost_ref, p->pixels, p->flags, p->stream));
   CBA_TRY(timer_begin(p, 3));
-  CBA_TRY(launch_fd_tasks(a, p->model_mask, p->tasks_per_obs, L.localize_only, p->pixels, p->flags, p->fd_out, p->fd_ok, p->stream));
+  CBA_TRY(launch_fd_tasks(a, p->model_mask, p->tasks_per_obs, L.localize_only, p->pixels, p->flags, p->fd_out, p->fd_ok, p->fd_redo[0], p->fd_redo_count, p->stream));
   CBA_TRY(timer_end(p, 3, 0, 0, 1));
   CBA_HIP(hipStreamWaitEvent(p->stream, p->ev_aux1, 0));
   a.skip = nullptr;
@@ -354,12 +356,12 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
     CBA_TRY(launch_accumulate_cells(a, p->cams, p->cell_base_host, p->rec_doubles, p->n_pad, p->flags, p->jrec, p->cells, p->cell_base,
                                     p->cell_count, p->cell_start, p->cell_fill, p->cell_order, p->Hdd,
                                     (!L.eliminate_points && L.rig_in_state) ? L.first_camera_tr_rig - L.block_dof : -1, det, p->stream));
-  if (det) {   // fixed point -> fp64, in place (B: only when it received atomics, i.e. when the points are the Schur blocks)
+  if (det) {   // fixed point -> fp64, in place
     CBA_TRY(launch_det_convert(p->Dblk, nb * bs * bs, det, p->stream));
     CBA_TRY(launch_det_convert(p->bblk, nb * bs, det, p->stream));
     CBA_TRY(launch_det_convert(p->Hdd, (size_t)L.dense_dof * p->n_pad, det, p->stream));
     CBA_TRY(launch_det_convert(p->bd, (size_t)p->n_pad, det, p->stream));
-    if (L.eliminate_points) CBA_TRY(launch_det_convert(p->B, (size_t)L.block_dof * p->n_pad, det, p->stream));
+    CBA_TRY(launch_det_convert(p->B, (size_t)L.block_dof * p->n_pad, det, p->stream));   // strips store integers, the pose x rig atomics add to them
   }
   CBA_TRY(timer_end(p, 2, 0, 0, 1));
   if (t_acc) *t_acc += now_s() - t0;
@@ -532,6 +534,7 @@ int cba_create(const cba_config* config, cba_problem** out) {
     CBA_TRY(dev_alloc(&p->cell_count, nk + 1)); CBA_TRY(dev_alloc(&p->cell_start, nk + 1)); CBA_TRY(dev_alloc(&p->cell_fill, nk + 1));
   }
   CBA_TRY(dev_alloc(&p->det_bits, 1)); CBA_TRY(dev_alloc(&p->det_scale, 1));
+  CBA_TRY(dev_alloc(&p->fd_redo[0], (size_t)kFdRedoEntries)); CBA_TRY(dev_alloc(&p->fd_redo[1], (size_t)kFdRedoEntries)); CBA_TRY(dev_alloc(&p->fd_redo_count, 2));
   CBA_TRY(dev_alloc(&p->red_partials, 256 * 8));
   CBA_TRY(dev_alloc(&p->red8, 16));
   // normal equations
@@ -595,7 +598,7 @@ void cba_destroy(cba_problem* p) {
   ldlt_workspace_free(p->ldlt);
   for (auto& t : p->timers) for (auto& sp : t.spans) { hipEventDestroy(sp.e0); hipEventDestroy(sp.e1); }
   if (p->kmask_host) hipHostFree(p->kmask_host);
-  F(p->slow_skip); F(p->slow_list); F(p->slow_count); F(p->img_start); F(p->band_mask); F(p->det_bits); F(p->det_scale);
+  F(p->slow_skip); F(p->slow_list); F(p->slow_count); F(p->img_start); F(p->band_mask); F(p->det_bits); F(p->det_scale); F(p->fd_redo[0]); F(p->fd_redo[1]); F(p->fd_redo_count);
   if (p->ev_aux0) hipEventDestroy(p->ev_aux0);
   if (p->ev_aux1) hipEventDestroy(p->ev_aux1);
   delete p;

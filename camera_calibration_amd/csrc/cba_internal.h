@@ -71,8 +71,10 @@ int launch_compose_poses(const DevState& st, int N, int C, double* itg, hipStrea
 int launch_tangents(const double* dir_grid, double* tang, int G, hipStream_t s);
 int launch_base_project(const PassArgs& a, int model_mask, double* cost_vec, double* pixels, uint8_t* flags,
                         hipStream_t s);
+// redo / redo_count: device work list (65 536 entries / one int) for the tasks that leave their staged patch
 int launch_fd_tasks(const PassArgs& a, int model_mask, int tasks_per_obs, int localize_only, const double* pixels,
-                    const uint8_t* flags, double* fd_out, uint8_t* fd_ok, hipStream_t s);
+                    const uint8_t* flags, double* fd_out, uint8_t* fd_ok, int64_t* redo, int* redo_count, hipStream_t s);
+constexpr int kFdRedoEntries = 1 << 16;
 int launch_collect_slow(const uint8_t* flags, int64_t n, uint8_t* skip, int* list, int* count, int cap, hipStream_t s);
 int launch_assemble(const PassArgs& a, const Layout& L, const DevState& st, int tasks_per_obs, int rec_doubles,
                     const double* pixels, uint8_t* flags, const double* fd_out, const uint8_t* fd_ok, double* jrec,

@@ -188,40 +188,36 @@ int launch_base_project(const PassArgs& a, int model_mask, double* cost_vec, dou
 //   task 0..2      : local point component += kDelta                (joint_optimization.cc:357-372)
 //   task 3..3+K-1  : grid parameter (cell, d) += delta in its local parametrisation
 // ------------------------------------------------------------------------------------------------
-template <int MODEL>
-__global__ void __launch_bounds__(256) k_fd_tasks(PassArgs a, int tasks_per_obs, int localize_only,
-                                                  const double* __restrict__ pixels, const uint8_t* __restrict__ flags,
-                                                  double* __restrict__ fd_out, uint8_t* __restrict__ fd_ok) {
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int64_t o = t / tasks_per_obs;
-  int k = (int)(t - o * tasks_per_obs);
-  if (a.obs_list) {
-    const int cnt = min(*a.obs_count, a.obs_list_cap);
-    if (o >= cnt) return;
-    o = a.obs_list[o];
-    t = o * tasks_per_obs + k;          // results are indexed by (observation, task)
-  } else {
-    if (o >= a.n_obs) return;
-    if (a.skip && a.skip[o]) return;
-  }
-  if (!(flags[o] & 1)) return;
-  int cam = a.obs_camera[o];
-  const CamDev c = a.cams[cam];
-  if (c.model_type != MODEL) return;
+// The task lanes of an observation (35 central / 83 non-central) evaluate the B-spline on ONE 4x4 control patch, a few
+// times each (about two LM iterations of one UnprojectWithJacobian + one Unproject).  The workgroup stages the patches of
+// the observations it covers (at most 256 / tasks + 2) in LDS once; every evaluation then reads its 16 control points
+// with ds_read instead of 48 / 96 gathers through L1, and the kernel is built for 4 (central) / 3 (non-central)
+// wavefronts per SIMD instead of 2 / 1 (the gathers of the whole patch in flight cost ~100 / ~190 VGPRs).  A lane whose
+// pixel crosses into a neighbouring cell repeats its projection on the gather path after the staged attempt.
+constexpr int kFdMaxObsPerBlock = 10;
+#ifndef CBA_FD_WAVES_CENTRAL
+#define CBA_FD_WAVES_CENTRAL 3      // wavefronts per SIMD the kernel is register-allocated for
+#endif
+#ifndef CBA_FD_WAVES_NONCENTRAL
+#define CBA_FD_WAVES_NONCENTRAL 2
+#endif
+constexpr int kFdRedoCap = 1 << 16;   // tasks the gather-path follow-up launch can take (a miss needs a pixel within one LM step of a cell boundary)
+
+// One finite-difference task: (observation o, task k) -> fd_out / fd_ok at index t = o * tasks_per_obs + k.
+// STG: spline evaluated on the staged patch `st`; returns false if an iterate left that patch (nothing is written then).
+template <int MODEL, bool STG>
+__device__ __forceinline__ bool fd_task(const PassArgs& a, const CamDev& c, int cam, int64_t o, int k, int64_t t, const double* __restrict__ pixels,
+                                        double* __restrict__ fd_out, uint8_t* __restrict__ fd_ok, StagedPatch<MODEL>* st, double* sub_slot) {
   constexpr int PER = (MODEL == kCentral) ? 2 : 5;
-  const int n_tasks = 3 + (localize_only ? 0 : PER * 16);
-  if (k >= n_tasks) return;
   double local[3];
   local_point_of(a, o, cam, local);
   const double bx = pixels[2 * o], by = pixels[2 * o + 1];
   double px = bx, py = by;
   double delta;
-  bool ok;
   Subst sub; sub.index = -1;
   if (k < 3) {
     delta = a.fd_delta * (MODEL == kCentral ? sqrt(local[0] * local[0] + local[1] * local[1] + local[2] * local[2]) : 0.1);
     local[k] += delta;
-    ok = project_point<MODEL>(c, sub, local, px, py);
   } else {
     delta = a.fd_delta;
     int g = k - 3;
@@ -232,7 +228,7 @@ __global__ void __launch_bounds__(256) k_fd_tasks(PassArgs a, int tasks_per_obs,
     int cx = ix + (cell & 3) - 1, cy = iy + (cell >> 2) - 1;
     if (cx < 0 || cy < 0 || cx >= c.gw || cy >= c.gh) {  // CHECK() in the reference; cannot happen inside the rectangle
       fd_ok[t] = 0;
-      return;
+      return true;
     }
     int seq = cx + cy * c.gw;
     sub.index = seq;
@@ -251,21 +247,159 @@ __global__ void __launch_bounds__(256) k_fd_tasks(PassArgs a, int tasks_per_obs,
       sub.o[1] = go[1] + o3 * tg[1] + o4 * tg[4] + o5 * gd[1];
       sub.o[2] = go[2] + o3 * tg[2] + o4 * tg[5] + o5 * gd[2];
     }
-    ok = project_point<MODEL>(c, sub, local, px, py);
+    if (STG) {
+      sub_slot[0] = sub.d[0]; sub_slot[1] = sub.d[1]; sub_slot[2] = sub.d[2];
+      if (MODEL == kNoncentral) { sub_slot[3] = sub.o[0]; sub_slot[4] = sub.o[1]; sub_slot[5] = sub.o[2]; }
+    }
   }
+  bool miss = false;
+  const bool ok = project_point<MODEL, STG>(c, sub, local, px, py, st, &miss);
+  if (STG && miss) return false;
   fd_out[2 * t] = (px - bx) / delta;
   fd_out[2 * t + 1] = (py - by) / delta;
   fd_ok[t] = ok ? 1 : 0;
+  return true;
+}
+
+// The task lanes of an observation (35 central / 83 non-central) evaluate the B-spline on ONE 4x4 control patch, a few
+// times each (about two LM iterations of one UnprojectWithJacobian + one Unproject).  The workgroup stages the patches of
+// the observations it covers (at most 256 / tasks + 2) in LDS once; every evaluation then reads its 16 control points
+// with ds_read instead of 48 / 96 gathers through L1, which also takes the ~100 / ~190 VGPRs of a whole patch in flight
+// out of the kernel.  A lane whose pixel crosses into a neighbouring cell appends its task to `redo` and the follow-up
+// launch k_fd_redo repeats it on the gather path (the same arithmetic on the same control points).
+template <int MODEL>
+__global__ void __launch_bounds__(256, MODEL == kCentral ? CBA_FD_WAVES_CENTRAL : CBA_FD_WAVES_NONCENTRAL)
+k_fd_tasks(PassArgs a, int tasks_per_obs, int localize_only, const double* __restrict__ pixels, const uint8_t* __restrict__ flags,
+           double* __restrict__ fd_out, uint8_t* __restrict__ fd_ok, int64_t* __restrict__ redo, int* __restrict__ redo_count) {
+  constexpr int PER = (MODEL == kCentral) ? 2 : 5;
+  constexpr int DIM = (MODEL == kCentral) ? 3 : 6;
+  __shared__ double sPatch[kFdMaxObsPerBlock][16 * DIM];
+  __shared__ double sSub[256][DIM];             // per lane: its substituted control point
+  __shared__ int sOrigin[kFdMaxObsPerBlock][2];
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x;
+  const int64_t slot_first = t0 / tasks_per_obs;              // first observation slot of this workgroup
+  // ---- stage the patches ----
+  {
+    const int64_t slot_last = (t0 + blockDim.x - 1) / tasks_per_obs;
+    const int n_slots = (int)(slot_last - slot_first) + 1;    // <= 256 / 35 + 2 = 9 <= kFdMaxObsPerBlock
+    const int64_t limit = a.obs_list ? (int64_t)min(*a.obs_count, a.obs_list_cap) : a.n_obs;
+    for (int e = threadIdx.x; e < n_slots * 16; e += blockDim.x) {
+      const int j = e >> 4, pt = e & 15;
+      const int64_t slot = slot_first + j;
+      bool live = slot < limit;
+      int64_t o = 0;
+      if (live) { o = a.obs_list ? (int64_t)a.obs_list[slot] : slot; live = (flags[o] & 1) != 0; }
+      int fx = -(1 << 20), fy = -(1 << 20);
+      if (live) {
+        const CamDev c = a.cams[a.obs_camera[o]];
+        if (c.model_type == MODEL) {
+          double gx, gy;
+          pixel_to_grid(c, pixels[2 * o], pixels[2 * o + 1], gx, gy);
+          fx = (int)floor(gx + 2) - 3; fy = (int)floor(gy + 2) - 3;      // as unproject_jac places its patch
+          const int cx = fx + (pt & 3), cy = fy + (pt >> 2);
+          if (cx >= 0 && cy >= 0 && cx < c.gw && cy < c.gh) {
+            const double* g = c.grid + 3 * ((size_t)cx + (size_t)cy * c.gw);
+            sPatch[j][pt * DIM + 0] = g[0]; sPatch[j][pt * DIM + 1] = g[1]; sPatch[j][pt * DIM + 2] = g[2];
+            if (MODEL == kNoncentral) {
+              const double* p = g + 3 * (size_t)c.gw * c.gh;
+              sPatch[j][pt * DIM + 3] = p[0]; sPatch[j][pt * DIM + 4] = p[1]; sPatch[j][pt * DIM + 5] = p[2];
+            }
+          } else {
+            fx = -(1 << 20);                                             // never matches: such a patch is never evaluated
+          }
+        }
+      }
+      if (pt == 0) { sOrigin[j][0] = fx; sOrigin[j][1] = fy; }
+    }
+    __syncthreads();
+  }
+  int64_t t = t0 + threadIdx.x;
+  int64_t o = t / tasks_per_obs;
+  int k = (int)(t - o * tasks_per_obs);
+  const int j = (int)(o - slot_first);
+  if (a.obs_list) {
+    const int cnt = min(*a.obs_count, a.obs_list_cap);
+    if (o >= cnt) return;
+    o = a.obs_list[o];
+    t = o * tasks_per_obs + k;          // results are indexed by (observation, task)
+  } else {
+    if (o >= a.n_obs) return;
+    if (a.skip && a.skip[o]) return;
+  }
+  if (!(flags[o] & 1)) return;
+  int cam = a.obs_camera[o];
+  const CamDev c = a.cams[cam];
+  if (c.model_type != MODEL) return;
+  const int n_tasks = 3 + (localize_only ? 0 : PER * 16);
+  if (k >= n_tasks) return;
+  StagedPatch<MODEL> st;
+  st.p = (lds_cdouble_ptr)&sPatch[j][0];
+  st.sub = (lds_cdouble_ptr)&sSub[threadIdx.x][0];
+  st.fx = sOrigin[j][0]; st.fy = sOrigin[j][1];
+  if (!fd_task<MODEL, true>(a, c, cam, o, k, t, pixels, fd_out, fd_ok, &st, &sSub[threadIdx.x][0])) {
+    const int slot = atomicAdd(redo_count, 1);
+    if (slot < kFdRedoCap) redo[slot] = t;
+    else fd_ok[t] = 0;                 // cannot happen in practice (65 536 boundary cases in one pass); dropped Jacobian, as a failed projection
+  }
+}
+// localize_only (3 tasks per observation, no grid tasks): a workgroup would cover 86 observations -- nothing to share, the
+// plain lane-per-task gather kernel
+template <int MODEL>
+__global__ void __launch_bounds__(256) k_fd_tasks_gather(PassArgs a, int tasks_per_obs, int n_tasks, const double* __restrict__ pixels,
+                                                         const uint8_t* __restrict__ flags, double* __restrict__ fd_out, uint8_t* __restrict__ fd_ok) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t o = t / tasks_per_obs;
+  const int k = (int)(t - o * tasks_per_obs);
+  if (a.obs_list) {
+    const int cnt = min(*a.obs_count, a.obs_list_cap);
+    if (o >= cnt) return;
+    o = a.obs_list[o];
+    t = o * tasks_per_obs + k;
+  } else {
+    if (o >= a.n_obs) return;
+    if (a.skip && a.skip[o]) return;
+  }
+  if (!(flags[o] & 1)) return;
+  const int cam = a.obs_camera[o];
+  const CamDev c = a.cams[cam];
+  if (c.model_type != MODEL || k >= n_tasks) return;
+  fd_task<MODEL, false>(a, c, cam, o, k, t, pixels, fd_out, fd_ok, nullptr, nullptr);
+}
+// follow-up: the tasks whose iterates left the staged patch, on the gather path
+template <int MODEL>
+__global__ void __launch_bounds__(256) k_fd_redo(PassArgs a, int tasks_per_obs, const double* __restrict__ pixels, double* __restrict__ fd_out,
+                                                 uint8_t* __restrict__ fd_ok, const int64_t* __restrict__ redo, const int* __restrict__ redo_count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = min(*redo_count, kFdRedoCap);
+  if (i >= n) return;
+  const int64_t t = redo[i];
+  const int64_t o = t / tasks_per_obs;
+  const int k = (int)(t - o * tasks_per_obs);
+  const int cam = a.obs_camera[o];
+  const CamDev c = a.cams[cam];
+  if (c.model_type != MODEL) return;
+  fd_task<MODEL, false>(a, c, cam, o, k, t, pixels, fd_out, fd_ok, nullptr, nullptr);
 }
 int launch_fd_tasks(const PassArgs& a, int model_mask, int tasks_per_obs, int localize_only, const double* pixels,
-                    const uint8_t* flags, double* fd_out, uint8_t* fd_ok, hipStream_t s) {
+                    const uint8_t* flags, double* fd_out, uint8_t* fd_ok, int64_t* redo, int* redo_count, hipStream_t s) {
   if (a.n_obs == 0) return CBA_OK;
   int64_t total = (a.obs_list ? (int64_t)a.obs_list_cap : a.n_obs) * tasks_per_obs;
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (256 / tasks_per_obs + 2 > kFdMaxObsPerBlock) {      // localize_only: 3 tasks per observation
+    if (model_mask & 1) hipLaunchKernelGGL(k_fd_tasks_gather<kCentral>, grid, block, 0, s, a, tasks_per_obs, 3, pixels, flags, fd_out, fd_ok);
+    if (model_mask & 2) hipLaunchKernelGGL(k_fd_tasks_gather<kNoncentral>, grid, block, 0, s, a, tasks_per_obs, 3, pixels, flags, fd_out, fd_ok);
+    CBA_HIP(hipGetLastError());
+    return CBA_OK;
+  }
+  CBA_HIP(hipMemsetAsync(redo_count, 0, sizeof(int), s));
   if (model_mask & 1)
-    hipLaunchKernelGGL(k_fd_tasks<kCentral>, grid, block, 0, s, a, tasks_per_obs, localize_only, pixels, flags, fd_out, fd_ok);
+    hipLaunchKernelGGL(k_fd_tasks<kCentral>, grid, block, 0, s, a, tasks_per_obs, localize_only, pixels, flags, fd_out, fd_ok, redo, redo_count);
   if (model_mask & 2)
-    hipLaunchKernelGGL(k_fd_tasks<kNoncentral>, grid, block, 0, s, a, tasks_per_obs, localize_only, pixels, flags, fd_out, fd_ok);
+    hipLaunchKernelGGL(k_fd_tasks<kNoncentral>, grid, block, 0, s, a, tasks_per_obs, localize_only, pixels, flags, fd_out, fd_ok, redo, redo_count);
+  // gather-path follow-up for the (rare) tasks that left their staged patch: fixed grid over the list capacity, the count
+  // stays on the device (workgroups past it exit at once)
+  if (model_mask & 1) hipLaunchKernelGGL(k_fd_redo<kCentral>, dim3(kFdRedoCap / 256), block, 0, s, a, tasks_per_obs, pixels, fd_out, fd_ok, redo, redo_count);
+  if (model_mask & 2) hipLaunchKernelGGL(k_fd_redo<kNoncentral>, dim3(kFdRedoCap / 256), block, 0, s, a, tasks_per_obs, pixels, fd_out, fd_ok, redo, redo_count);
   CBA_HIP(hipGetLastError());
   return CBA_OK;
 }
@@ -864,8 +998,9 @@ __global__ void __launch_bounds__(64 * kStripWaves) k_accumulate_strips(PassArgs
   const int slot = a.pose_slot ? a.pose_slot[img] : img;
   for (int k = 0; k < 6; ++k) {
     double* row = B + (size_t)(6 * slot + k) * ld + col_lo;
-    for (int c = threadIdx.x; c < col_hi - col_lo; c += 64 * kStripWaves)
-      row[c] = DET ? Acc<true>::to_double(*reinterpret_cast<const long long*>(&acc[k][c]), scale) : acc[k][c];
+    // DET: the fixed-point integers as they are -- k_accumulate adds integer atomics on top (pose x rig-pose entries) and
+    // the whole of B is converted afterwards (launch_det_convert)
+    for (int c = threadIdx.x; c < col_hi - col_lo; c += 64 * kStripWaves) row[c] = acc[k][c];
   }
 }
 int launch_accumulate_strips(const PassArgs& a, const Layout& L, int n_images, int rec_doubles, const uint8_t* flags, const double* jrec,

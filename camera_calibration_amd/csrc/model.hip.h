@@ -124,14 +124,34 @@ __device__ __forceinline__ void load_ctrl(const CamDev& c, const Subst& s, int s
   }
 }
 
-// Unproject: exact-fraction weights, direction normalised in fp64. Returns false outside the rectangle.
+// One 4x4 control patch staged in LDS (finite-difference kernel: the 35 / 83 task lanes of an observation all evaluate the
+// spline on the observation's own patch, a few times each): p[(r * 4 + q) * DIM + k], DIM = 3 (direction) or 6
+// (direction, origin); (fx, fy) = grid coordinates of p[0].  An evaluation whose patch is a different one (the pixel
+// moved across a cell boundary) gathers from global memory as before.
+typedef const __attribute__((address_space(3))) double* lds_cdouble_ptr;   // explicit LDS pointer: ds_read, never a flat load
 template <int MODEL>
-__device__ bool unproject(const CamDev& c, const Subst& s, double x, double y, double* dir, double* org) {
-  if (!in_calibrated_area(c, x, y)) return false;
-  double gx, gy;
-  pixel_to_grid(c, x, y, gx, gy);
-  gx += 2; gy += 2;
-  int ix = (int)gx, iy = (int)gy;
+struct StagedPatch {
+  lds_cdouble_ptr p;      // the observation's patch
+  lds_cdouble_ptr sub;    // this lane's substituted control point (DIM doubles), also in LDS: the substitution is a select
+  int fx, fy;             // on the 32-bit LDS ADDRESS followed by unconditional ds_reads (a select on the loaded values
+};                        // was turned into 16 branches per evaluation by the compiler)
+template <int MODEL, bool LDS>
+__device__ __forceinline__ void ctrl_point(const CamDev& c, const Subst& s, lds_cdouble_ptr stage, lds_cdouble_ptr sub_p, int r, int q, int seq,
+                                           double* d, double* o) {
+  if (LDS) {
+    constexpr int DIM = (MODEL == kCentral) ? 3 : 6;
+    lds_cdouble_ptr g = (seq == s.index) ? sub_p : stage + (r * 4 + q) * DIM;
+    d[0] = g[0]; d[1] = g[1]; d[2] = g[2];
+    if (MODEL == kNoncentral) { o[0] = g[3]; o[1] = g[4]; o[2] = g[5]; }
+  } else {
+    load_ctrl<MODEL>(c, s, seq, d, o);
+  }
+}
+
+// Unproject: exact-fraction weights, direction normalised in fp64. Returns false outside the rectangle.
+template <int MODEL, bool LDS>
+__device__ __forceinline__ void unproject_eval(const CamDev& c, const Subst& s, lds_cdouble_ptr stage, lds_cdouble_ptr sub_p, int ix, int iy, double gx, double gy,
+                                               double* dir, double* org) {
   double wx[4], wy[4];
   weights_value(gx - (ix - 3), wx);
   weights_value(gy - (iy - 3), wy);
@@ -143,7 +163,7 @@ __device__ bool unproject(const CamDev& c, const Subst& s, double x, double y, d
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       double d[3], o[3];
-      load_ctrl<MODEL>(c, s, rowbase + q, d, o);
+      ctrl_point<MODEL, LDS>(c, s, stage, sub_p, r, q, rowbase + q, d, o);
       rd[0] += wx[q] * d[0]; rd[1] += wx[q] * d[1]; rd[2] += wx[q] * d[2];
       if (MODEL == kNoncentral) { ro[0] += wx[q] * o[0]; ro[1] += wx[q] * o[1]; ro[2] += wx[q] * o[2]; }
     }
@@ -153,18 +173,34 @@ __device__ bool unproject(const CamDev& c, const Subst& s, double x, double y, d
   normalize3(vd[0], vd[1], vd[2]);
   dir[0] = vd[0]; dir[1] = vd[1]; dir[2] = vd[2];
   if (MODEL == kNoncentral) { org[0] = vo[0]; org[1] = vo[1]; org[2] = vo[2]; }
-  return true;
 }
-
-// UnprojectWithJacobian. jd = d direction / d pixel (3x2), jo = d origin / d pixel (3x2, non-central).
 template <int MODEL>
-__device__ bool unproject_jac(const CamDev& c, const Subst& s, double x, double y, double* dir, double* org,
-                              double* jd, double* jo) {
+__device__ bool unproject(const CamDev& c, const Subst& s, double x, double y, double* dir, double* org) {
   if (!in_calibrated_area(c, x, y)) return false;
   double gx, gy;
   pixel_to_grid(c, x, y, gx, gy);
   gx += 2; gy += 2;
-  int ix = (int)floor(gx), iy = (int)floor(gy);
+  int ix = (int)gx, iy = (int)gy;
+  unproject_eval<MODEL, false>(c, s, (lds_cdouble_ptr)0, (lds_cdouble_ptr)0, ix, iy, gx, gy, dir, org);
+  return true;
+}
+template <int MODEL>
+__device__ __forceinline__ bool unproject_staged(const CamDev& c, const Subst& s, const StagedPatch<MODEL>& st, double x, double y,
+                                                 double* dir, double* org, bool& miss) {
+  if (!in_calibrated_area(c, x, y)) return false;
+  double gx, gy;
+  pixel_to_grid(c, x, y, gx, gy);
+  gx += 2; gy += 2;
+  int ix = (int)gx, iy = (int)gy;
+  if (ix - 3 != st.fx || iy - 3 != st.fy) { miss = true; return false; }
+  unproject_eval<MODEL, true>(c, s, st.p, st.sub, ix, iy, gx, gy, dir, org);
+  return true;
+}
+
+// UnprojectWithJacobian. jd = d direction / d pixel (3x2), jo = d origin / d pixel (3x2, non-central).
+template <int MODEL, bool LDS>
+__device__ __forceinline__ void unproject_jac_eval(const CamDev& c, const Subst& s, lds_cdouble_ptr stage, lds_cdouble_ptr sub_p, int ix, int iy, double gx, double gy,
+                                                   double* dir, double* org, double* jd, double* jo) {
   double wx[4], dwx[4], wy[4], dwy[4];
   weights_jac(gx - (ix - 3), wx, dwx);
   weights_jac(gy - (iy - 3), wy, dwy);
@@ -177,7 +213,7 @@ __device__ bool unproject_jac(const CamDev& c, const Subst& s, double x, double 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       double d[3], o[3];
-      load_ctrl<MODEL>(c, s, rowbase + q, d, o);
+      ctrl_point<MODEL, LDS>(c, s, stage, sub_p, r, q, rowbase + q, d, o);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         R[k] += wx[q] * d[k];
@@ -221,6 +257,28 @@ __device__ bool unproject_jac(const CamDev& c, const Subst& s, double x, double 
       jo[2 * k + 1] = uy[k] * c.jscale_y;
     }
   }
+}
+template <int MODEL>
+__device__ bool unproject_jac(const CamDev& c, const Subst& s, double x, double y, double* dir, double* org,
+                              double* jd, double* jo) {
+  if (!in_calibrated_area(c, x, y)) return false;
+  double gx, gy;
+  pixel_to_grid(c, x, y, gx, gy);
+  gx += 2; gy += 2;
+  int ix = (int)floor(gx), iy = (int)floor(gy);
+  unproject_jac_eval<MODEL, false>(c, s, (lds_cdouble_ptr)0, (lds_cdouble_ptr)0, ix, iy, gx, gy, dir, org, jd, jo);
+  return true;
+}
+template <int MODEL>
+__device__ __forceinline__ bool unproject_jac_staged(const CamDev& c, const Subst& s, const StagedPatch<MODEL>& st, double x, double y,
+                                                     double* dir, double* org, double* jd, double* jo, bool& miss) {
+  if (!in_calibrated_area(c, x, y)) return false;
+  double gx, gy;
+  pixel_to_grid(c, x, y, gx, gy);
+  gx += 2; gy += 2;
+  int ix = (int)floor(gx), iy = (int)floor(gy);
+  if (ix - 3 != st.fx || iy - 3 != st.fy) { miss = true; return false; }
+  unproject_jac_eval<MODEL, true>(c, s, st.p, st.sub, ix, iy, gx, gy, dir, org, jd, jo);
   return true;
 }
 
@@ -255,14 +313,21 @@ __device__ __forceinline__ void tangent_derivs(const double* d, const double* jd
 // Iterative projection. target = unit direction (central) or local point (non-central).
 // px,py: in = initial estimate (must lie in the calibrated area), out = result.
 // Returns true iff converged (squared error < 1e-12), as the reference does.
-template <int MODEL>
-__device__ bool project_target(const CamDev& c, const Subst& s, const double* target, double& px, double& py) {
+// STG: the spline is evaluated on the patch staged in LDS; if an iterate needs another patch, *miss is set and the call
+// returns false -- the caller then repeats the whole projection on the gather path (rare: a pixel within the last LM
+// step of a cell boundary).
+template <int MODEL, bool STG = false>
+__device__ bool project_target(const CamDev& c, const Subst& s, const double* target, double& px, double& py,
+                               const StagedPatch<MODEL>* st = nullptr, bool* miss = nullptr) {
   constexpr double kEpsilon = 1e-12;
   double lambda = -1.0;
   const double lo_x = (double)c.min_x, hi_x = c.max_x + 0.999, lo_y = (double)c.min_y, hi_y = c.max_y + 0.999;
   for (int it = 0; it < 100; ++it) {
     double dir[3], org[3], jd[6], jo[6];
-    if (!unproject_jac<MODEL>(c, s, px, py, dir, org, jd, jo)) return false;  // CHECK() in the reference
+    bool inside;
+    if (STG) inside = unproject_jac_staged<MODEL>(c, s, *st, px, py, dir, org, jd, jo, *miss);
+    else inside = unproject_jac<MODEL>(c, s, px, py, dir, org, jd, jo);
+    if (!inside) return false;  // CHECK() in the reference
     double cost, H00, H01, H11, b0, b1;
     if (MODEL == kCentral) {
       double dx = dir[0] - target[0], dy = dir[1] - target[1], dz = dir[2] - target[2];
@@ -306,7 +371,10 @@ __device__ bool project_target(const CamDev& c, const Subst& s, const double* ta
       double ty = (lo_y < my) ? my : lo_y;
       double test_cost = INFINITY;
       double td[3], to[3];
-      if (unproject<MODEL>(c, s, tx, ty, td, to)) {
+      bool tin;
+      if (STG) { tin = unproject_staged<MODEL>(c, s, *st, tx, ty, td, to, *miss); if (*miss) return false; }
+      else tin = unproject<MODEL>(c, s, tx, ty, td, to);
+      if (tin) {
         if (MODEL == kCentral) {
           double ex = td[0] - target[0], ey = td[1] - target[1], ez = td[2] - target[2];
           test_cost = ex * ex + ey * ey + ez * ez;
@@ -335,14 +403,15 @@ __device__ bool project_target(const CamDev& c, const Subst& s, const double* ta
 }
 
 // ProjectWithInitialEstimate(local_point): the central model normalises first (central_grid.h:86-88).
-template <int MODEL>
-__device__ __forceinline__ bool project_point(const CamDev& c, const Subst& s, const double* local, double& px, double& py) {
+template <int MODEL, bool STG = false>
+__device__ __forceinline__ bool project_point(const CamDev& c, const Subst& s, const double* local, double& px, double& py,
+                                              const StagedPatch<MODEL>* st = nullptr, bool* miss = nullptr) {
   if (MODEL == kCentral) {
     double d[3] = {local[0], local[1], local[2]};
     normalize3(d[0], d[1], d[2]);
-    return project_target<MODEL>(c, s, d, px, py);
+    return project_target<MODEL, STG>(c, s, d, px, py, st, miss);
   } else {
-    return project_target<MODEL>(c, s, local, px, py);
+    return project_target<MODEL, STG>(c, s, local, px, py, st, miss);
   }
 }
 

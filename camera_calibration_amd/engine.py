@@ -16,7 +16,8 @@ import numpy as np
 from .problem import CENTRAL_GENERIC, Camera, Problem, State
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcalib_ba_hip.so")
+# CBA_HIP_LIB: another build of the same library (kernel A/B measurements, tools/gpu_ab.sh); default = the in-tree build
+LIB_PATH = os.environ.get("CBA_HIP_LIB") or os.path.join(_HERE, "libcalib_ba_hip.so")
 
 
 class EngineError(RuntimeError):

@@ -10,9 +10,15 @@
  * tests (see tests/test_oracle_golden.py): LMOptimizer.SchurComplement2 (H,b -> x),
  * BSpline.SlowFastAlgorithmConsistency, CentralGenericBSpline.ProjectUnproject,
  * NoncentralGenericBSpline.OrthogonalCameraProjectionAndUnprojection, HuberLoss identities,
- * TestOptimizeJointly convergence (cost <= 1e-6 * cameras).  The reference itself cannot be
- * compiled here (needs Eigen/CUDA/Qt/Boost, none present) so converged parameter values are
- * pinned only through those tests -- see DESIGN.md "Oracle".
+ * TestOptimizeJointly convergence (cost <= 1e-6 * cameras), and -- round 2 -- against the reference's OWN CODE where
+ * it compiles from its own source files (oracle/_ref, built by `make ref` from /root/reference against the Eigen /
+ * libvis stand-ins in oracle/ref_shim): generic_models/src (Project / Unproject / UnprojectWithJacobian of both generic
+ * models, the reference's self-test and its 17 x 13 calibrated camera), the generated Jacobian code
+ * (joint_optimization_jacobians.h, *_generic_jacobians.cc), the local parametrisations, b_spline.h and HuberLoss;
+ * tests/test_oracle_vs_ref.py holds the comparison (1e-14 class) and tests/golden/ref_vectors.npz the reference-computed
+ * vectors.  Not compilable here and therefore pinned only through the tests above: joint_optimization.cc (the
+ * per-observation chain and the accumulation order), lm_optimizer.h (LM loop, Schur complement) and Eigen's LDLT --
+ * see DESIGN.md "Oracle".
  *
  * Citations are relative to /root/reference:
  *   APP = applications/camera_calibration/src/camera_calibration, LV = libvis/src/libvis

@@ -49,9 +49,9 @@ def test_deterministic_mode_is_bit_reproducible(cfg, n):
     check_equal(case, "run 1 vs run 2: step reports", int(a["reps"] != b["reps"]))
     # and it is the same problem: against the default mode and the oracle
     c = _run(pb, st, False, 3)
-    check(case, "dense_H vs default mode / max", np.abs(a["H"] - c["H"]).max() / np.abs(c["H"]).max(), 1e-10)
-    check(case, "off_diag_H vs default mode / max", np.abs(a["B"] - c["B"]).max() / np.abs(c["B"]).max(), 1e-10)
-    check(case, "final cost vs default mode rel", abs(a["reps"][-1][1] - c["reps"][-1][1]) / c["reps"][-1][1], 1e-7)
+    check(case, "dense_H vs default mode / max", np.abs(a["H"] - c["H"]).max() / np.abs(c["H"]).max(), 1e-11)
+    check(case, "off_diag_H vs default mode / max", np.abs(a["B"] - c["B"]).max() / np.abs(c["B"]).max(), 1e-11)
+    check(case, "final cost vs default mode rel (after 3 iterations)", abs(a["reps"][-1][1] - c["reps"][-1][1]) / c["reps"][-1][1], 1e-5)
     orc.set_num_threads(0)
     try:
         op = orc.OracleProblem(pb, last_projection=pb.obs_xy.astype(np.float64))
@@ -70,8 +70,8 @@ def test_default_mode_differs_only_in_the_last_bits():
     pb, st, _ = syn.baseline_config(2, gpu_project, n_imagesets=120)
     a = _run(pb, st, False, 2)
     b = _run(pb, st, False, 2)
-    check("default mode run-to-run", "dense_H / max", np.abs(a["H"] - b["H"]).max() / np.abs(a["H"]).max(), 1e-11)
-    check("default mode run-to-run", "x / max", np.abs(a["x"] - b["x"]).max() / np.abs(a["x"]).max(), 1e-6)
+    check("default mode run-to-run", "dense_H / max", np.abs(a["H"] - b["H"]).max() / np.abs(a["H"]).max(), 1e-13)
+    check("default mode run-to-run", "x / max", np.abs(a["x"] - b["x"]).max() / np.abs(a["x"]).max(), 1e-8)
 
 
 def test_device_model_handle_matches_stateless_calls():

@@ -74,7 +74,7 @@ def test_cpp_optimize_jointly_matches_engine_and_oracle(num_cameras):
     assert rc == 0 and performed.value == 1
     case = f"C++ OptimizeJointly adapter, {num_cameras} camera(s)"
     check(case, "final cost rel", abs(cost.value - r["cost"]) / abs(r["cost"]), 1e-6)
-    check(case, "final lambda rel", abs(flam.value - lam) / lam, 1e-9)
+    check(case, "final lambda rel", abs(flam.value - lam) / lam, 1e-10)
     # unused imageset untouched, used ones updated like the oracle's
     np.testing.assert_array_equal(rig[unused], st0.rig_tr_global[unused])
     check(case, "poses abs", np.abs(rig[image_used.astype(bool)] - st_ref.rig_tr_global).max(), 1e-8)
@@ -84,7 +84,7 @@ def test_cpp_optimize_jointly_matches_engine_and_oracle(num_cameras):
         check(case, "grids abs", np.abs(a - b).max(), 1e-8)
     # warm-start cache written back for used imagesets only
     assert np.all(lastp[~keep] == 0)
-    check(case, "last_projection abs [px]", np.abs(lastp[keep] - op.last_projection).max(), 1e-6)
+    check(case, "last_projection abs [px]", np.abs(lastp[keep] - op.last_projection).max(), 1e-8)
 
 
 def test_cpp_run_bundle_adjustment_session_matches_per_call_loop():
@@ -118,8 +118,8 @@ def test_cpp_run_bundle_adjustment_session_matches_per_call_loop():
         assert rc == 0
         out[mode] = dict(rig=rig, camrig=camrig, pts=pts, grid=g_out[0], lastp=lastp, seconds=secs.value, iterations=iters.value)
     case = "C++ RunBundleAdjustment: session vs per-call loop (cfg 2 grid, 120 imagesets, 4 iterations)"
-    check(case, "poses abs", np.abs(out[0]["rig"] - out[1]["rig"]).max(), 1e-9)
-    check(case, "points abs", np.abs(out[0]["pts"] - out[1]["pts"]).max(), 1e-9)
+    check(case, "poses abs", np.abs(out[0]["rig"] - out[1]["rig"]).max(), 5e-10)
+    check(case, "points abs", np.abs(out[0]["pts"] - out[1]["pts"]).max(), 2e-10)
     check(case, "grid abs", np.abs(out[0]["grid"] - out[1]["grid"]).max(), 1e-9)
     check(case, "last_projection abs [px]", np.abs(out[0]["lastp"] - out[1]["lastp"]).max(), 1e-7)
     # measurement, not a bound (recorded in profiles/r02_parity_deviations.json): seconds of the whole loop

@@ -148,16 +148,16 @@ def _compare_pass(pb, st, case):
     check_equal(case, "cost-vector sign mask", int(np.count_nonzero((vec >= 0) != (vec_ref >= 0))))
     m = valid.astype(bool)
     pix = e.dump(eng.DUMP_PIXELS)
-    check(case, "pixels abs [px]", np.abs(pix[m] - pix_ref[m]).max(), 1e-9)
-    check(case, "cost vector rel", (np.abs(vec[m] - vec_ref[m]) / np.maximum(1e-3, vec_ref[m])).max(), 1e-9)
-    check(case, "total cost rel", abs(cost - cost_ref) / max(1.0, abs(cost_ref)), 1e-11)
+    check(case, "pixels abs [px]", np.abs(pix[m] - pix_ref[m]).max(), 2e-10)
+    check(case, "cost vector rel", (np.abs(vec[m] - vec_ref[m]) / np.maximum(1e-3, vec_ref[m])).max(), 5e-10)
+    check(case, "total cost rel", abs(cost - cost_ref) / max(1.0, abs(cost_ref)), 2e-14)
     # warm-start cache written back
-    check(case, "last_projection abs [px]", np.abs(e.get_last_projection()[m] - op.last_projection[m]).max(), 1e-9)
+    check(case, "last_projection abs [px]", np.abs(e.get_last_projection()[m] - op.last_projection[m]).max(), 2e-10)
     # per-observation Jacobians
     J = e.dump(eng.DUMP_JACOBIANS)
     hj = hasj.astype(bool)
     scale = np.abs(J_ref[hj]).max()
-    check(case, "J records / max", np.abs(J[hj][:, :33 + 2 * Kg] - J_ref[hj]).max() / scale, 1e-8)
+    check(case, "J records / max", np.abs(J[hj][:, :33 + 2 * Kg] - J_ref[hj]).max() / scale, 5e-9)
     # normal equations
     bD = e.dump(eng.DUMP_BLOCK_DIAG_H)
     for name, a, b in [("block_diag_H", bD, sysm.block_diag_H),
@@ -167,7 +167,7 @@ def _compare_pass(pb, st, case):
                        ("dense_b", e.dump(eng.DUMP_DENSE_B), sysm.dense_b)]:
         if name == "block_diag_H":
             a = np.array([np.triu(x) for x in a]); b = np.array([np.triu(x) for x in b])
-        check(case, name + " / max", np.abs(a - b).max() / np.abs(b).max(), 1e-8)
+        check(case, name + " / max", np.abs(a - b).max() / np.abs(b).max(), 5e-9)
     # solve the *oracle's* system on the GPU solver and the engine's own system end-to-end
     lam = 1e-5 * (np.trace(sysm.dense_H) + sum(np.trace(b) for b in sysm.block_diag_H)) / pb.total_dof
     s2 = orc.System(sysm.block_size, sysm.n_blocks, sysm.dense_dof)
@@ -176,7 +176,7 @@ def _compare_pass(pb, st, case):
     s2.add_lambda(lam)
     x_ref = orc.schur_solve(s2)
     x_gpu_solver = eng.schur_solve(s2.block_diag_H, s2.off_diag_H, s2.dense_H, s2.block_diag_b, s2.dense_b)
-    check(case, "x engine solver vs oracle solver, oracle system / |x|max", np.abs(x_gpu_solver - x_ref).max() / np.abs(x_ref).max(), 1e-8)
+    check(case, "x engine solver vs oracle solver, oracle system / |x|max", np.abs(x_gpu_solver - x_ref).max() / np.abs(x_ref).max(), 5e-9)
     x = e.debug_solve(lam)
     check(case, "x engine (own system) vs oracle / |x|max", np.abs(x - x_ref).max() / np.abs(x_ref).max(), 1e-6)
     # state update on the same x
@@ -185,11 +185,11 @@ def _compare_pass(pb, st, case):
     st_gpu = e.get_state(st)
     check(case, "updated points abs", np.abs(st_gpu.points - st_ref.points).max(), 1e-15)
     # quaternion update goes through an fp32 sine/cosine (reference quirk): 1 ulp(fp32) of the update size
-    check(case, "updated poses abs", np.abs(st_gpu.rig_tr_global - st_ref.rig_tr_global).max(),
+    check(case, "updated poses abs (bound: 1 fp32 ulp of the update's sin / cos)", np.abs(st_gpu.rig_tr_global - st_ref.rig_tr_global).max(),
           2e-7 * max(1e-3, np.abs(x_ref[:6 * pb.n_images]).max()) + 1e-15)
-    check(case, "updated camera_tr_rig abs", np.abs(st_gpu.camera_tr_rig - st_ref.camera_tr_rig).max(), 1e-8)
+    check(case, "updated camera_tr_rig abs (bound: 1 fp32 ulp of the update's sin / cos)", np.abs(st_gpu.camera_tr_rig - st_ref.camera_tr_rig).max(), 1e-8)
     for g_gpu, g_ref in zip(st_gpu.grids, st_ref.grids):
-        check(case, "updated grids abs", np.abs(g_gpu - g_ref).max(), 1e-14)
+        check(case, "updated grids abs", np.abs(g_gpu - g_ref).max(), 3e-15)
     e.close()
 
 

@@ -87,10 +87,10 @@ def _full_size_case(case, cfg, n_imagesets, grid_wh=None, lapack=True):
         assert m.mean() > 0.95 and hj.sum() > 0.98 * m.sum()
         # ---- per-observation values ----
         pix = e.dump(eng.DUMP_PIXELS)
-        check(case, "pixels abs [px]", np.abs(pix[m] - R["pixel"][m]).max(), 2e-10)
+        check(case, "pixels abs [px]", np.abs(pix[m] - R["pixel"][m]).max(), 3e-11)
         check(case, "cost vector rel", (np.abs(vec[m] - cost_vec_ref[m]) / np.maximum(1e-3, cost_vec_ref[m])).max(), 2e-10)
-        check(case, "total cost rel", abs(cost - cost_ref) / cost_ref, 2e-13)
-        check(case, "last_projection abs [px]", np.abs(e.get_last_projection()[m] - op.last_projection[m]).max(), 2e-10)
+        check(case, "total cost rel", abs(cost - cost_ref) / cost_ref, 5e-14)
+        check(case, "last_projection abs [px]", np.abs(e.get_last_projection()[m] - op.last_projection[m]).max(), 3e-11)
         Kg = max(c.params_per_grid_point for c in pb.cameras) * 16
         J = e.dump(eng.DUMP_JACOBIANS)
         for name, lo, hi, ref in (("J residual", 0, 2, R["residual"]), ("J pose block", 3, 15, R["pose_jac"]),
@@ -99,25 +99,25 @@ def _full_size_case(case, cfg, n_imagesets, grid_wh=None, lapack=True):
             if name == "J rig block" and pb.n_cameras == 1:
                 continue
             d = np.abs(J[hj][:, lo:hi] - ref[hj]).max()
-            check(case, name + " / max", d / np.abs(ref[hj]).max(), 4e-10)
+            check(case, name + " / max", d / np.abs(ref[hj]).max(), 1e-12 if name == "J residual" else 1e-10)
         check(case, "J weight abs", np.abs(J[hj][:, 2] - R["weight"][hj]).max(), 1e-11)
         del J
         # ---- normal equations in the reference's variable order ----
         bD = e.dump(eng.DUMP_BLOCK_DIAG_H)
         iu = np.triu_indices(pb.block_size)
         d, s = _maxabs_diff(bD[:, iu[0], iu[1]], sysm.block_diag_H[:, iu[0], iu[1]])
-        check(case, "block_diag_H / max", d / s, 2e-10)
+        check(case, "block_diag_H / max", d / s, 1e-11)
         d, s = _maxabs_diff(e.dump(eng.DUMP_BLOCK_DIAG_B)[:, None], sysm.block_diag_b[:, None])
-        check(case, "block_diag_b / max", d / s, 2e-10)
+        check(case, "block_diag_b / max", d / s, 1e-11)
         B = e.dump(eng.DUMP_OFF_DIAG_H)
         d, s = _maxabs_diff(B, sysm.off_diag_H)
-        check(case, "off_diag_H / max", d / s, 2e-10)
+        check(case, "off_diag_H / max", d / s, 5e-11)
         Hd = e.dump(eng.DUMP_DENSE_H)                 # upper triangle, zeros below (the oracle leaves its lower part zero too)
         d, s = _maxabs_diff(Hd, sysm.dense_H)
-        check(case, "dense_H / max", d / s, 2e-10)
+        check(case, "dense_H / max", d / s, 2e-11)
         bd = e.dump(eng.DUMP_DENSE_B)
         d, s = _maxabs_diff(bd[:, None], sysm.dense_b[:, None])
-        check(case, "dense_b / max", d / s, 2e-10)
+        check(case, "dense_b / max", d / s, 2e-11)
         del Hd
         # ---- solve ----
         tr = float(np.trace(sysm.dense_H)) + float(sum(np.trace(b) for b in sysm.block_diag_H))
@@ -128,7 +128,7 @@ def _full_size_case(case, cfg, n_imagesets, grid_wh=None, lapack=True):
         Ds = np.array([np.triu(b) + np.triu(b, 1).T for b in sysm.block_diag_H])
         r_block = np.einsum("nij,nj->ni", Ds, xb.reshape(-1, pb.block_size)).ravel() + lam * xb + sysm.off_diag_H @ xd - sysm.block_diag_b
         r_dense = sysm.off_diag_H.T @ xb + _sym_matvec_upper(sysm.dense_H, xd) + lam * xd - sysm.dense_b
-        check(case, "oracle normal equations residual, block rows / |b|max", np.abs(r_block).max() / np.abs(sysm.block_diag_b).max(), 5e-11)
+        check(case, "oracle normal equations residual, block rows / |b|max", np.abs(r_block).max() / np.abs(sysm.block_diag_b).max(), 1e-11)
         check(case, "oracle normal equations residual, dense rows / |b|max", np.abs(r_dense).max() / np.abs(sysm.dense_b).max(), 1e-10)
         if lapack:
             import scipy.linalg as sla
@@ -158,16 +158,16 @@ def _full_size_case(case, cfg, n_imagesets, grid_wh=None, lapack=True):
         e.debug_apply_update(x)
         st_gpu = e.get_state(st)
         check(case, "updated points abs", np.abs(st_gpu.points - st_ref.points).max(), 1e-15)
-        check(case, "updated poses abs", np.abs(st_gpu.rig_tr_global - st_ref.rig_tr_global).max(), 1e-9)   # one fp32 ulp of sin / cos of the update at most
-        check(case, "updated camera_tr_rig abs", np.abs(st_gpu.camera_tr_rig - st_ref.camera_tr_rig).max(), 1e-8)
+        check(case, "updated poses abs (bound: 1 fp32 ulp of the update's sin / cos)", np.abs(st_gpu.rig_tr_global - st_ref.rig_tr_global).max(), 1e-9)
+        check(case, "updated camera_tr_rig abs (bound: 1 fp32 ulp of the update's sin / cos)", np.abs(st_gpu.camera_tr_rig - st_ref.camera_tr_rig).max(), 1e-9)
         for g_gpu, g_ref in zip(st_gpu.grids, st_ref.grids):
-            check(case, "updated grids abs", np.abs(g_gpu - g_ref).max(), 1e-14)
+            check(case, "updated grids abs", np.abs(g_gpu - g_ref).max(), 3e-15)
         # ---- cost-only pass on the updated state ----
         c2_ref, v2_ref = op.cost_pass(st_ref)
         c2, nv2, v2 = e.cost(want_vector=True)
         check_equal(case, "cost-pass validity mask", int(np.count_nonzero((v2 >= 0) != (v2_ref >= 0))))
         both = v2_ref >= 0
-        check(case, "cost-pass cost vector rel", (np.abs(v2[both] - v2_ref[both]) / np.maximum(1e-3, v2_ref[both])).max(), 3e-8)
+        check(case, "cost-pass cost vector rel", (np.abs(v2[both] - v2_ref[both]) / np.maximum(1e-3, v2_ref[both])).max(), 8e-7)
         check(case, "cost-pass total rel", abs(c2 - c2_ref) / c2_ref, 2e-13)
         e.close()
         print(f"{case}: n_obs {pb.n_obs}, D {pb.dense_dof}, oracle side {t_oracle:.1f} s, total {time.time() - t0:.1f} s")
@@ -218,7 +218,7 @@ def test_full_step_at_config2_grid_size_against_oracle_optimize_jointly():
             check_equal(case, f"iteration {it}: accept decision", int(rep.accepted != bool(r["performed"])))
             check_equal(case, f"iteration {it}: LM attempts", abs(rep.lm_attempts - r["lm_attempts"]))
             check(case, f"iteration {it}: final cost rel", abs(rep.final_cost - r["cost"]) / r["cost"], 2e-9)
-            check(case, f"iteration {it}: lambda rel", abs(lam - lam_ref) / lam_ref, 1e-12)
+            check(case, f"iteration {it}: lambda rel", abs(lam - lam_ref) / lam_ref, 5e-13)
         st = e.get_state(st0)
         check(case, "state after 2 iterations: points abs", np.abs(st.points - st_ref.points).max(), 1e-10)
         check(case, "state after 2 iterations: poses abs", np.abs(st.rig_tr_global - st_ref.rig_tr_global).max(), 2e-10)
@@ -270,7 +270,7 @@ def test_noncentral_bundle_adjustment_trajectory_on_gpu():
             if it < 5:
                 check_equal(case, f"iteration {it}: accept decision", int(rep.accepted != bool(r["performed"])))
                 check_equal(case, f"iteration {it}: LM attempts", abs(rep.lm_attempts - r["lm_attempts"]))
-                check(case, f"iteration {it}: final cost rel", abs(rep.final_cost - r["cost"]) / r["cost"], 5e-8)
+                check(case, f"iteration {it}: final cost rel", abs(rep.final_cost - r["cost"]) / r["cost"], 3e-8)
         if not rep.accepted:
             break
     check(case, "converged cost (reference bound 2e-4)", cost, 2e-4)

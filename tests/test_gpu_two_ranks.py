@@ -82,8 +82,8 @@ def test_two_ranks_on_one_gpu_match_the_single_process_engine(tmp_path):
     for k in range(world):
         check_equal(case, f"rank {k}: LM attempts / accept decisions / valid counts",
                     int(np.count_nonzero(rk[k]["reps"][:, 3:] != reps[:, 3:])))
-        check(case, f"rank {k}: costs rel", (np.abs(rk[k]["reps"][:, :2] - reps[:, :2]) / reps[:, :2]).max(), 1e-8)
-        check(case, f"rank {k}: lambda rel", (np.abs(rk[k]["reps"][:, 2] - reps[:, 2]) / reps[:, 2]).max(), 1e-8)
+        check(case, f"rank {k}: costs rel", (np.abs(rk[k]["reps"][:, :2] - reps[:, :2]) / reps[:, :2]).max(), 1e-13)
+        check(case, f"rank {k}: lambda rel", (np.abs(rk[k]["reps"][:, 2] - reps[:, 2]) / reps[:, 2]).max(), 5e-13)
         b, e = int(rk[k]["b"]), int(rk[k]["e"])
         check(case, f"rank {k}: own poses abs", np.abs(rk[k]["poses"] - ref.rig_tr_global[b:e]).max(), 1e-8)
         check(case, f"rank {k}: points abs", np.abs(rk[k]["points"] - ref.points).max(), 1e-8)
@@ -108,7 +108,7 @@ def test_native_rccl_callback_world_of_one(tmp_path):
         r1 = e1.step(l1); r2 = e2.step(l2)
         l1, l2 = r1.final_lambda, r2.final_lambda
         assert r1.accepted == r2.accepted and r1.lm_attempts == r2.lm_attempts
-        check("native RCCL callback, world 1", "final cost rel", abs(r1.final_cost - r2.final_cost) / r1.final_cost, 1e-9)
+        check("native RCCL callback, world 1", "final cost rel", abs(r1.final_cost - r2.final_cost) / r1.final_cost, 5e-8)   # lambda enters before / after the Schur product
     s1, s2 = e1.get_state(st), e2.get_state(st)
     check("native RCCL callback, world 1", "points abs", np.abs(s1.points - s2.points).max(), 1e-9)
     e1.close(); e2.close(); rc.close()

@@ -26,14 +26,14 @@ def test_central_17x13_reference_camera_on_gpu():
     lines, jac, ok = eng.unproject(cam, grid, V["c17_px"], with_jacobian=True)
     check_equal(case, "unproject ok flags", int(np.count_nonzero(~ok)))
     check(case, "unproject direction abs", np.abs(lines[:, :3] - V["c17_dirs"]).max(), 1e-14)
-    check(case, "unproject jacobian / max", np.abs(jac[:, :3] - V["c17_jac"]).max() / np.abs(V["c17_jac"]).max(), 1e-12)
+    check(case, "unproject jacobian / max", np.abs(jac[:, :3] - V["c17_jac"]).max() / np.abs(V["c17_jac"]).max(), 5e-13)
     px, pok = eng.project(cam, grid, V["c17_pts"])
     check_equal(case, "project ok flags", int(np.count_nonzero(pok != V["c17_reproj_ok"].astype(bool))))
-    check(case, "project pixel abs [px]", np.abs(px[pok] - V["c17_reproj"][pok]).max(), 1e-9)
+    check(case, "project pixel abs [px]", np.abs(px[pok] - V["c17_reproj"][pok]).max(), 5e-11)
     check(case, "round trip [px] (reference criterion 1e-3)", np.linalg.norm(px[pok] - V["c17_px"][pok], axis=1).max(), 1e-3)
     px2, pok2 = eng.project(cam, grid, V["c17_pts"], init=V["c17_init"])
     check_equal(case, "project-with-initial-estimate ok flags", int(np.count_nonzero(pok2 != V["c17_reproj_init_ok"].astype(bool))))
-    check(case, "project-with-initial-estimate pixel abs [px]", np.abs(px2[pok2] - V["c17_reproj_init"][pok2]).max(), 1e-9)
+    check(case, "project-with-initial-estimate pixel abs [px]", np.abs(px2[pok2] - V["c17_reproj_init"][pok2]).max(), 5e-11)
     _, okb = eng.project(cam, grid, V["c17_bad_pts"])
     check_equal(case, "unreachable points flagged", int(np.count_nonzero(okb != V["c17_bad_ok"].astype(bool))))
 
@@ -45,8 +45,8 @@ def test_noncentral_8x8_reference_camera_on_gpu():
     lines, jac, ok = eng.unproject(cam, grid, V["n8_px"], with_jacobian=True)
     check_equal(case, "unproject ok flags", int(np.count_nonzero(~ok)))
     check(case, "unproject line abs", np.abs(lines - V["n8_lines"]).max(), 1e-13)
-    check(case, "unproject jacobian / max", np.abs(jac - V["n8_jac"]).max() / np.abs(V["n8_jac"]).max(), 1e-12)
+    check(case, "unproject jacobian / max", np.abs(jac - V["n8_jac"]).max() / np.abs(V["n8_jac"]).max(), 5e-13)
     px, pok = eng.project(cam, grid, V["n8_pts"])
     check_equal(case, "project ok flags", int(np.count_nonzero(pok != V["n8_reproj_ok"].astype(bool))))
-    check(case, "project pixel abs [px]", np.abs(px[pok] - V["n8_reproj"][pok]).max(), 1e-9)
+    check(case, "project pixel abs [px]", np.abs(px[pok] - V["n8_reproj"][pok]).max(), 5e-11)
     check(case, "round trip [px] (reference criterion 1e-3)", np.linalg.norm(px[pok] - V["n8_px"][pok], axis=1).max(), 1e-3)
