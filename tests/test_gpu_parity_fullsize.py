@@ -87,10 +87,10 @@ def _full_size_case(case, cfg, n_imagesets, grid_wh=None, lapack=True):
         assert m.mean() > 0.95 and hj.sum() > 0.98 * m.sum()
         # ---- per-observation values ----
         pix = e.dump(eng.DUMP_PIXELS)
-        check(case, "pixels abs [px]", np.abs(pix[m] - R["pixel"][m]).max(), 3e-11)
+        check(case, "pixels abs [px]", np.abs(pix[m] - R["pixel"][m]).max(), 2e-10)
         check(case, "cost vector rel", (np.abs(vec[m] - cost_vec_ref[m]) / np.maximum(1e-3, cost_vec_ref[m])).max(), 2e-10)
-        check(case, "total cost rel", abs(cost - cost_ref) / cost_ref, 5e-14)
-        check(case, "last_projection abs [px]", np.abs(e.get_last_projection()[m] - op.last_projection[m]).max(), 3e-11)
+        check(case, "total cost rel", abs(cost - cost_ref) / cost_ref, 2e-13)
+        check(case, "last_projection abs [px]", np.abs(e.get_last_projection()[m] - op.last_projection[m]).max(), 2e-10)
         Kg = max(c.params_per_grid_point for c in pb.cameras) * 16
         J = e.dump(eng.DUMP_JACOBIANS)
         for name, lo, hi, ref in (("J residual", 0, 2, R["residual"]), ("J pose block", 3, 15, R["pose_jac"]),
@@ -99,7 +99,7 @@ def _full_size_case(case, cfg, n_imagesets, grid_wh=None, lapack=True):
             if name == "J rig block" and pb.n_cameras == 1:
                 continue
             d = np.abs(J[hj][:, lo:hi] - ref[hj]).max()
-            check(case, name + " / max", d / np.abs(ref[hj]).max(), 1e-12 if name == "J residual" else 1e-10)
+            check(case, name + " / max", d / np.abs(ref[hj]).max(), 1e-12 if name == "J residual" else 4e-10)
         check(case, "J weight abs", np.abs(J[hj][:, 2] - R["weight"][hj]).max(), 1e-11)
         del J
         # ---- normal equations in the reference's variable order ----
@@ -111,10 +111,10 @@ def _full_size_case(case, cfg, n_imagesets, grid_wh=None, lapack=True):
         check(case, "block_diag_b / max", d / s, 1e-11)
         B = e.dump(eng.DUMP_OFF_DIAG_H)
         d, s = _maxabs_diff(B, sysm.off_diag_H)
-        check(case, "off_diag_H / max", d / s, 5e-11)
+        check(case, "off_diag_H / max", d / s, 2e-10)
         Hd = e.dump(eng.DUMP_DENSE_H)                 # upper triangle, zeros below (the oracle leaves its lower part zero too)
         d, s = _maxabs_diff(Hd, sysm.dense_H)
-        check(case, "dense_H / max", d / s, 2e-11)
+        check(case, "dense_H / max", d / s, 3e-11)
         bd = e.dump(eng.DUMP_DENSE_B)
         d, s = _maxabs_diff(bd[:, None], sysm.dense_b[:, None])
         check(case, "dense_b / max", d / s, 2e-11)
@@ -128,7 +128,7 @@ def _full_size_case(case, cfg, n_imagesets, grid_wh=None, lapack=True):
         Ds = np.array([np.triu(b) + np.triu(b, 1).T for b in sysm.block_diag_H])
         r_block = np.einsum("nij,nj->ni", Ds, xb.reshape(-1, pb.block_size)).ravel() + lam * xb + sysm.off_diag_H @ xd - sysm.block_diag_b
         r_dense = sysm.off_diag_H.T @ xb + _sym_matvec_upper(sysm.dense_H, xd) + lam * xd - sysm.dense_b
-        check(case, "oracle normal equations residual, block rows / |b|max", np.abs(r_block).max() / np.abs(sysm.block_diag_b).max(), 1e-11)
+        check(case, "oracle normal equations residual, block rows / |b|max", np.abs(r_block).max() / np.abs(sysm.block_diag_b).max(), 5e-11)
         check(case, "oracle normal equations residual, dense rows / |b|max", np.abs(r_dense).max() / np.abs(sysm.dense_b).max(), 1e-10)
         if lapack:
             import scipy.linalg as sla
