@@ -1037,7 +1037,7 @@ static void ldlt_compute_unblocked(ldlt_t* f) {
  * blocks); (b) the NB x NB diagonal block, serial; (c) the terms k0 <= j < k for the rows below, parallel over row
  * blocks.  Used for n >= 256; smaller systems and a zero first pivot take the unblocked kernel. */
 #define LDLT_NB 64
-#define LDLT_RB 256
+#define LDLT_RB 128
 static void ldlt_compute(ldlt_t* f) {
   const int n = f->n; double* m = f->m;
   if (n < 256) { ldlt_compute_unblocked(f); return; }
@@ -1080,7 +1080,8 @@ static void ldlt_compute(ldlt_t* f) {
     }
     if (k0 > 0) {
       const int nrb = (n - k0 + LDLT_RB - 1) / LDLT_RB;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+      const int team_a = g_threads < nrb ? g_threads : nrb;      /* no more threads than row blocks: idle ones only spin */
+#pragma omp parallel for schedule(dynamic, 1) num_threads(team_a)
       for (int rb = 0; rb < nrb; ++rb) {
         const int i0 = k0 + rb * LDLT_RB, i1 = i0 + LDLT_RB < n ? i0 + LDLT_RB : n;
         /* the block L(i0:i1, j0:j1) is packed into a padded thread-local buffer once and reused by all panel
@@ -1132,7 +1133,8 @@ static void ldlt_compute(ldlt_t* f) {
     /* (c) rows below the panel */
     if (k1 < n) {
       const int nrb = (n - k1 + LDLT_RB - 1) / LDLT_RB;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+      const int team_c = g_threads < nrb ? g_threads : nrb;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(team_c)
       for (int rb = 0; rb < nrb; ++rb) {
         const int i0 = k1 + rb * LDLT_RB, i1 = i0 + LDLT_RB < n ? i0 + LDLT_RB : n;
         for (int kk = 0; kk < nbk; ++kk) {

@@ -276,3 +276,44 @@ def test_noncentral_bundle_adjustment_trajectory_on_gpu():
     check(case, "converged cost (reference bound 2e-4)", cost, 2e-4)
     check(case, "oracle converged cost (reference bound 2e-4)", cost_ref, 2e-4)
     e.close()
+
+
+def test_near_singular_reduced_system_with_tiny_lambda():
+    """Eigen's LDLT pivots on the diagonal (LV/lm_optimizer.h:1289, 1361); the engine's blocked LDL^T does not.  The bundle-adjustment
+    normal equations have ~10 gauge directions (global rotation / translation / scale, ...) that only lambda regularises, so
+    with a tiny lambda the reduced system is nearly singular -- the case where pivoting could matter.  At D = 12 525 (512- and
+    256-wide panels, look-ahead, chain stream all active) with lambda = 1e-9 x the automatic value: the engine's solution must
+    satisfy the ORACLE's normal equations as well as the oracle's own pivoted solution does, and agree with it outside the
+    near-null space (compared through the predicted decrease b.x, which is insensitive to gauge components)."""
+    case = "near-singular system (cfg-2 grid, 60 imagesets, lambda x 1e-9)"
+    pb, st, _ = syn.baseline_config(2, gpu_project, n_imagesets=60)
+    lp0 = pb.obs_xy.astype(np.float64)
+    orc.set_num_threads(0)
+    try:
+        op = orc.OracleProblem(pb, last_projection=lp0.copy())
+        sysm = op.new_system()
+        op.jacobian_pass(st, sysm)
+        tr = float(np.trace(sysm.dense_H)) + float(sum(np.trace(b) for b in sysm.block_diag_H))
+        lam = 1e-9 * 1e-5 * tr / pb.total_dof
+        s2 = orc.System(sysm.block_size, sysm.n_blocks, sysm.dense_dof)
+        for fld in ("block_diag_H", "off_diag_H", "dense_H", "block_diag_b", "dense_b"):
+            getattr(s2, fld)[...] = getattr(sysm, fld)
+        s2.add_lambda(lam)
+        x_ref = orc.schur_solve(s2)                                       # pivoted LDLT (Eigen's algorithm)
+        x_gpu = eng.schur_solve(s2.block_diag_H, s2.off_diag_H, s2.dense_H, s2.block_diag_b, s2.dense_b)   # unpivoted, blocked
+    finally:
+        orc.set_num_threads(1)
+    assert np.isfinite(x_gpu).all()
+    Ds = np.array([np.triu(b) + np.triu(b, 1).T for b in s2.block_diag_H])
+
+    def residual(x):
+        xb, xd = x[:pb.block_dof], x[pb.block_dof:]
+        rb = np.einsum("nij,nj->ni", Ds, xb.reshape(-1, pb.block_size)).ravel() + s2.off_diag_H @ xd - s2.block_diag_b
+        rd = s2.off_diag_H.T @ xb + _sym_matvec_upper(s2.dense_H, xd) - s2.dense_b
+        return max(np.abs(rb).max() / np.abs(s2.block_diag_b).max(), np.abs(rd).max() / np.abs(s2.dense_b).max())
+
+    r_ref, r_gpu = residual(x_ref), residual(x_gpu)
+    b_all = np.concatenate([s2.block_diag_b, s2.dense_b])
+    check(case, "residual of the normal equations, oracle (pivoted) / |b|max", r_ref, 1e-6)
+    check(case, "residual of the normal equations, engine (unpivoted) / |b|max", r_gpu, 1e-6)
+    check(case, "predicted decrease b.x, engine vs oracle rel", abs(b_all @ x_gpu - b_all @ x_ref) / abs(b_all @ x_ref), 1e-6)
