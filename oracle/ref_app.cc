@@ -18,6 +18,7 @@
 
 #include "camera_calibration/b_spline.h"
 #include "camera_calibration/bundle_adjustment/joint_optimization_jacobians.h"
+#include "camera_calibration/io/io_util.h"
 #include "camera_calibration/local_parametrizations/direction_parametrization.h"
 #include "camera_calibration/local_parametrizations/line_parametrization.h"
 #include "camera_calibration/local_parametrizations/quaternion_parametrization.h"
@@ -135,5 +136,28 @@ double ref_huber_cost_sq(double sq, double k) { return HuberLoss<double>(k).Comp
 double ref_huber_weight_sq(double sq, double k) { return HuberLoss<double>(k).ComputeWeightFromSquaredResidual(sq); }
 double ref_huber_cost(double r, double k) { return HuberLoss<double>(k).ComputeCost(r); }
 double ref_huber_weight(double r, double k) { return HuberLoss<double>(k).ComputeWeight(r); }
+
+// The reference's binary serialisation primitives (APP/io/io_util.h:37-125: integers in network byte order, floats raw).
+// `kind`: 0 = u32, 1 = i32, 2 = float.  Appends to `path`; used by the tests to assemble a dataset.bin with the reference's
+// own writers in the order of SaveDataset (APP/io/calibration_io.cc:51-137) and to read one back.
+int ref_io_append(const char* path, int kind, double value) {
+  FILE* f = fopen(path, "ab");
+  if (!f) return -1;
+  if (kind == 0) { u32 v = (u32)value; write_one(&v, f); }
+  else if (kind == 1) { i32 v = (i32)value; write_one(&v, f); }
+  else { float v = (float)value; write_one(&v, f); }
+  fclose(f);
+  return 0;
+}
+int ref_io_read_at(const char* path, long offset, int kind, double* value) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return -1;
+  fseek(f, offset, SEEK_SET);
+  if (kind == 0) { u32 v = 0; read_one(&v, f); *value = v; }
+  else if (kind == 1) { i32 v = 0; read_one(&v, f); *value = v; }
+  else { float v = 0; read_one(&v, f); *value = v; }
+  fclose(f);
+  return 0;
+}
 
 }  // extern "C"

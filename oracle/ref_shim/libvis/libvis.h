@@ -5,7 +5,12 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <iostream>
 #include <vector>
+// LOG(severity) << ...: the real header pulls in the loguru-based logging (LV/logging.h); messages go to stderr here.
+#ifndef LOG
+#define LOG(severity) std::cerr
+#endif
 namespace vis {
 typedef std::size_t usize;
 typedef uint8_t u8; typedef uint16_t u16; typedef uint32_t u32; typedef uint64_t u64;

@@ -34,6 +34,39 @@ def extract_yaml() -> str:
     return central[0]
 
 
+def write_reference_dataset_bin(L, path):
+    """A dataset.bin whose every field is written by the reference's own write_one overloads (APP/io/io_util.h:37-69),
+    called in the order of SaveDataset (APP/io/calibration_io.cc:51-137).  SaveDataset itself cannot be compiled here (Qt,
+    boost, yaml-cpp); the content is the example dataset of tests/test_calibration_io.py."""
+    import ctypes as C
+    L.ref_io_append.argtypes = [C.c_char_p, C.c_int, C.c_double]
+    U32, I32, F32 = 0, 1, 2
+    bp = path.encode()
+    def raw(b):
+        with open(path, "ab") as f:
+            f.write(b)
+    def put(kind, v):
+        assert L.ref_io_append(bp, kind, float(v)) == 0
+    if os.path.exists(path):
+        os.remove(path)
+    raw(b"calib_data"); put(U32, 0)
+    put(U32, 2)
+    for w, h in ((640, 480), (800, 600)):
+        put(U32, w); put(U32, h)
+    f0 = [(1.5, 2.25, 7), (3.0, 4.0, -2)]; f1 = [(10.125, 20.5, 123456)]
+    put(U32, 2)
+    for name, per_camera in ((b"img_000.png", (f0, f1)), (b"", ((), f1))):
+        put(U32, len(name)); raw(name)
+        for feats in per_camera:
+            put(U32, len(feats))
+            for x, y, fid in feats:
+                put(F32, x); put(F32, y); put(I32, fid)
+    put(U32, 1)
+    put(F32, 0.012); put(U32, 2)
+    for fid, (x, y) in ((7, (1, 2)), (-2, (0, -3))):
+        put(I32, fid); put(I32, x); put(I32, y)
+
+
 def main():
     L = ref.lib()
     dp = ref._dp
@@ -156,6 +189,7 @@ def main():
     assert np.abs(fast - slow).max() <= 1e-5          # the reference's own assertion
     out.update(bsp_net=net64, bsp_x=xs, bsp_fast_f32=fast, bsp_slow_f32=slow, bsp_fast=fast64, bsp_slow=slow64)
     np.savez_compressed(os.path.join(HERE, "ref_vectors.npz"), **out)
+    write_reference_dataset_bin(L, os.path.join(HERE, "ref_dataset.bin"))
     print("wrote", yaml_path, "and ref_vectors.npz:", {k_: v.shape for k_, v in out.items()})
 
 

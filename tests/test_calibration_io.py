@@ -60,6 +60,18 @@ def test_dataset_bin_golden_bytes(tmp_path):
     assert ds.known_geometries[0].cell_length_in_meters == np.float32(0.012)
 
 
+def test_dataset_bin_matches_the_file_written_by_the_reference_primitives(tmp_path):
+    """tests/golden/ref_dataset.bin was written field by field by the reference's own write_one overloads (APP/io/io_util.h,
+    compiled into oracle/_ref) in SaveDataset's order (tests/golden/make_ref_fixtures.py): same content, same bytes."""
+    want = open(os.path.join(os.path.dirname(__file__), "golden", "ref_dataset.bin"), "rb").read()
+    assert want == _golden_bytes()
+    p = str(tmp_path / "dataset.bin")
+    cio.save_dataset(p, _example_dataset())
+    assert open(p, "rb").read() == want
+    ds = cio.load_dataset(os.path.join(os.path.dirname(__file__), "golden", "ref_dataset.bin"))
+    assert ds.imagesets[0].features[1]["id"].tolist() == [123456] and ds.imagesets[0].features[0]["y"].tolist() == [2.25, 4.0]
+
+
 def test_dataset_bin_rejects_bad_input(tmp_path):
     p = str(tmp_path / "bad.bin")
     open(p, "wb").write(b"calib_datX" + b"\0" * 16)
