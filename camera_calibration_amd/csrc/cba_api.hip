@@ -133,12 +133,13 @@ struct cba_problem {
   std::vector<int> pose_slot_host; int* pose_slot = nullptr;
   // straggler split of the Jacobian pass (see PassArgs)
   uint8_t* slow_skip = nullptr; int* slow_list = nullptr; int* slow_count = nullptr;
+  int straggler_threshold = 12;   // outer projection iterations before an observation goes to the straggler kernel
   int64_t* img_start = nullptr;          // first observation of every imageset (+ end), for the strip accumulation
   unsigned* band_mask = nullptr;         // per observation: column bands of B it touches
   // the side stream is the factorisation's far stream (idle during the Jacobian pass): the process must stay
   // within four HIP streams -- a fifth shares a hardware queue with another one and serialises the LDL^T streams
   // (measured twice, also with GPU_MAX_HW_QUEUES=8)
-  hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr;
+  hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr, ev_aux2 = nullptr;
   // control point -> rank in the engine's tiled order of the grid unknowns, per camera (see build_grid_order)
   int* gperm[kMaxCameras] = {};
   std::vector<int> dense_perm_host;   // reference dense column -> engine dense column (identity outside the grids)
@@ -299,7 +300,10 @@ static int allreduce(cba_problem* p, double* dev, int64_t count) {
 static int residual_pass(cba_problem* p, int which, double* cost_vec) {
   CBA_TRY(launch_compose_poses(p->st[which], p->L.n_images, p->L.n_cameras, p->itg, p->stream));
   PassArgs a = pass_args(p, which);
-  CBA_TRY(launch_base_project(a, p->model_mask, cost_vec, p->pixels, p->flags, p->stream));
+  CBA_TRY(launch_base_project(a, p->model_mask, cost_vec, p->pixels, p->flags, p->slow_list, p->slow_count, kSlowCap, p->slow_skip, p->straggler_threshold, p->stream));
+  PassArgs as = a;
+  as.obs_list = p->slow_list; as.obs_count = p->slow_count; as.obs_list_cap = kSlowCap;
+  CBA_TRY(launch_base_project_slow(as, p->model_mask, cost_vec, p->pixels, p->flags, p->stream));
   return CBA_OK;
 }
 
@@ -310,17 +314,13 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
     CBA_TRY(launch_tangents(p->st[w].grids[c], p->tangents[c], p->cams[c].grid_w * p->cams[c].grid_h, p->stream));
   CBA_TRY(launch_compose_poses(p->st[w], L.n_images, L.n_cameras, p->itg, p->stream));
   PassArgs a = pass_args(p, w);
-  // side stream: the observations that failed in the previous Jacobian pass (long sequential projection
-  // chains) -- base projection and their finite-difference tasks -- underneath the main launches
+  // side stream: the accumulation targets are cleared there (1.3 GB for H_dd at cfg 2), underneath the main launches ...
   PassArgs as = a;
   as.obs_list = p->slow_list; as.obs_count = p->slow_count; as.obs_list_cap = kSlowCap;
   a.skip = p->slow_skip;
   hipStream_t aux = p->ldlt.far_stream;
   CBA_HIP(hipEventRecord(p->ev_aux0, p->stream));
   CBA_HIP(hipStreamWaitEvent(aux, p->ev_aux0, 0));
-  CBA_TRY(launch_base_project(as, p->model_mask, p->cost_ref, p->pixels, p->flags, aux));
-  CBA_TRY(launch_fd_tasks(as, p->model_mask, p->tasks_per_obs, L.localize_only, p->pixels, p->flags, p->fd_out, p->fd_ok, p->fd_redo[1], p->fd_redo_count + 1, aux));
-  // ... and the accumulation targets are cleared there too (1.3 GB for H_dd at cfg 2), underneath the main launches
   const size_t bs = L.block_size, nb = L.n_blocks;
   CBA_HIP(hipMemsetAsync(p->Dblk, 0, sizeof(double) * nb * bs * bs, aux));
   CBA_HIP(hipMemsetAsync(p->bblk, 0, sizeof(double) * nb * bs, aux));
@@ -330,8 +330,14 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
     CBA_HIP(hipMemsetAsync(p->B + (size_t)L.block_dof * p->n_pad, 0, sizeof(double) * (size_t)(p->Kpad - L.block_dof) * p->n_pad, aux));
   CBA_HIP(hipMemsetAsync(p->Hdd, 0, sizeof(double) * (size_t)p->n_pad * p->n_pad, aux));
   CBA_HIP(hipMemsetAsync(p->bd, 0, sizeof(double) * (size_t)p->n_pad, aux));
+  CBA_TRY(launch_base_project(a, p->model_mask, p->cost_ref, p->pixels, p->flags, p->slow_list, p->slow_count, kSlowCap, p->slow_skip, p->straggler_threshold, p->stream));
+  // ... and the stragglers of the base projection (long projection chains, see k_base_project_slow) are finished there,
+  // followed by their finite-difference tasks, underneath the main finite-difference launch
+  CBA_HIP(hipEventRecord(p->ev_aux2, p->stream));
+  CBA_HIP(hipStreamWaitEvent(aux, p->ev_aux2, 0));
+  CBA_TRY(launch_base_project_slow(as, p->model_mask, p->cost_ref, p->pixels, p->flags, aux));
+  CBA_TRY(launch_fd_tasks(as, p->model_mask, p->tasks_per_obs, L.localize_only, p->pixels, p->flags, p->fd_out, p->fd_ok, p->fd_redo[1], p->fd_redo_count + 1, aux));
   CBA_HIP(hipEventRecord(p->ev_aux1, aux));
-  CBA_TRY(launch_base_project(a, p->model_mask, p->cost_ref, p->pixels, p->flags, p->stream));
   CBA_TRY(timer_begin(p, 3));
   CBA_TRY(launch_fd_tasks(a, p->model_mask, p->tasks_per_obs, L.localize_only, p->pixels, p->flags, p->fd_out, p->fd_ok, p->fd_redo[0], p->fd_redo_count, p->stream));
   CBA_TRY(timer_end(p, 3, 0, 0, 1));
@@ -358,15 +364,14 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
                                     (!L.eliminate_points && L.rig_in_state) ? L.first_camera_tr_rig - L.block_dof : -1, det, p->stream));
   if (det) {   // fixed point -> fp64, in place
     CBA_TRY(launch_det_convert(p->Dblk, nb * bs * bs, det, p->stream));
-    CBA_TRY(launch_det_convert(p->bblk, nb * bs, det, p->stream));
+    CBA_TRY(launch_det_convert(p->bblk, nb * bs, det + 1, p->stream));      // J^T r: second scale
     CBA_TRY(launch_det_convert(p->Hdd, (size_t)L.dense_dof * p->n_pad, det, p->stream));
-    CBA_TRY(launch_det_convert(p->bd, (size_t)p->n_pad, det, p->stream));
+    CBA_TRY(launch_det_convert(p->bd, (size_t)p->n_pad, det + 1, p->stream));
     CBA_TRY(launch_det_convert(p->B, (size_t)L.block_dof * p->n_pad, det, p->stream));   // strips store integers, the pose x rig atomics add to them
   }
   CBA_TRY(timer_end(p, 2, 0, 0, 1));
   if (t_acc) *t_acc += now_s() - t0;
   CBA_TRY(launch_touch_mask(p->B, p->Kpad, p->n_pad, p->n_pad, p->kmask, p->stream));
-  CBA_TRY(launch_collect_slow(p->flags, p->n_obs, p->slow_skip, p->slow_list, p->slow_count, kSlowCap, p->stream));
   p->have_system = true;
   return CBA_OK;
 }
@@ -481,6 +486,7 @@ int cba_create(const cba_config* config, cba_problem** out) {
   CBA_TRY(make_main_stream(&p->stream));
   CBA_HIP(hipEventCreateWithFlags(&p->ev_aux0, hipEventDisableTiming));
   CBA_HIP(hipEventCreateWithFlags(&p->ev_aux1, hipEventDisableTiming));
+  CBA_HIP(hipEventCreateWithFlags(&p->ev_aux2, hipEventDisableTiming));
   CBA_TRY(dev_alloc(&p->slow_list, (size_t)kSlowCap));
   CBA_TRY(dev_alloc(&p->slow_count, 1));
   CBA_HIP(hipMemset(p->slow_count, 0, sizeof(int)));
@@ -533,7 +539,7 @@ int cba_create(const cba_config* config, cba_problem** out) {
     CBA_HIP(hipMemcpy(p->cell_base, p->cell_base_host.data(), sizeof(int) * p->cell_base_host.size(), hipMemcpyHostToDevice));
     CBA_TRY(dev_alloc(&p->cell_count, nk + 1)); CBA_TRY(dev_alloc(&p->cell_start, nk + 1)); CBA_TRY(dev_alloc(&p->cell_fill, nk + 1));
   }
-  CBA_TRY(dev_alloc(&p->det_bits, 1)); CBA_TRY(dev_alloc(&p->det_scale, 1));
+  CBA_TRY(dev_alloc(&p->det_bits, 2)); CBA_TRY(dev_alloc(&p->det_scale, 2));
   CBA_TRY(dev_alloc(&p->fd_redo[0], (size_t)kFdRedoEntries)); CBA_TRY(dev_alloc(&p->fd_redo[1], (size_t)kFdRedoEntries)); CBA_TRY(dev_alloc(&p->fd_redo_count, 2));
   CBA_TRY(dev_alloc(&p->red_partials, 256 * 8));
   CBA_TRY(dev_alloc(&p->red8, 16));
@@ -601,6 +607,7 @@ void cba_destroy(cba_problem* p) {
   F(p->slow_skip); F(p->slow_list); F(p->slow_count); F(p->img_start); F(p->band_mask); F(p->det_bits); F(p->det_scale); F(p->fd_redo[0]); F(p->fd_redo[1]); F(p->fd_redo_count);
   if (p->ev_aux0) hipEventDestroy(p->ev_aux0);
   if (p->ev_aux1) hipEventDestroy(p->ev_aux1);
+  if (p->ev_aux2) hipEventDestroy(p->ev_aux2);
   delete p;
 }
 
@@ -740,6 +747,12 @@ int cba_cost(cba_problem* p, double* cost, int64_t* n_valid, double* cost_vector
   if (cost) *cost = h[1];
   if (n_valid) *n_valid = (int64_t)h[6];
   if (cost_vector && p->n_obs) CBA_HIP(hipMemcpy(cost_vector, p->cost_test, sizeof(double) * p->n_obs, hipMemcpyDeviceToHost));
+  return CBA_OK;
+}
+
+int cba_set_straggler_threshold(cba_problem* p, int32_t outer_iterations) {
+  if (!p || outer_iterations < 0) { set_error("cba_set_straggler_threshold: bad argument"); return CBA_ERR_ARG; }
+  p->straggler_threshold = outer_iterations > 100 ? 100 : outer_iterations;
   return CBA_OK;
 }
 

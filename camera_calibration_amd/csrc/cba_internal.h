@@ -58,8 +58,9 @@ struct PassArgs {
   const CamDev* cams;       // device array [C]
   double fd_delta;
   const int* pose_slot;     // block position of each imageset (rows of B sorted by image footprint) or null
-  // straggler split (Jacobian pass): observations that failed last time run 100 x 10 projection
-  // iterations again; they are processed from `obs_list` on a side stream while the main launch skips them
+  // straggler split: observations whose base projection exceeds the iteration cap of the one-lane kernel are listed by
+  // it and finished by the 16-lanes-per-observation kernel (kernels_obs.hip); in the Jacobian pass that launch and the
+  // finite-difference tasks of the listed observations run on a side stream while the main launch skips them
   const int* obs_list;      // null = all observations in order
   const int* obs_count;     // device: entries in obs_list (clamped to obs_list_cap)
   int obs_list_cap;
@@ -69,13 +70,15 @@ struct PassArgs {
 // ---- kernels_obs.hip ----
 int launch_compose_poses(const DevState& st, int N, int C, double* itg, hipStream_t s);
 int launch_tangents(const double* dir_grid, double* tang, int G, hipStream_t s);
-int launch_base_project(const PassArgs& a, int model_mask, double* cost_vec, double* pixels, uint8_t* flags,
-                        hipStream_t s);
+// base projection of every observation; lanes that exceed the iteration cap are appended to defer_list (and marked in
+// defer_skip) for launch_base_project_slow, which takes the list through PassArgs::obs_list / obs_count / obs_list_cap
+int launch_base_project(const PassArgs& a, int model_mask, double* cost_vec, double* pixels, uint8_t* flags, int* defer_list,
+                        int* defer_count, int defer_cap, uint8_t* defer_skip, int outer_cap, hipStream_t s);
+int launch_base_project_slow(const PassArgs& a, int model_mask, double* cost_vec, double* pixels, uint8_t* flags, hipStream_t s);
 // redo / redo_count: device work list (65 536 entries / one int) for the tasks that leave their staged patch
 int launch_fd_tasks(const PassArgs& a, int model_mask, int tasks_per_obs, int localize_only, const double* pixels,
                     const uint8_t* flags, double* fd_out, uint8_t* fd_ok, int64_t* redo, int* redo_count, hipStream_t s);
 constexpr int kFdRedoEntries = 1 << 16;
-int launch_collect_slow(const uint8_t* flags, int64_t n, uint8_t* skip, int* list, int* count, int cap, hipStream_t s);
 int launch_assemble(const PassArgs& a, const Layout& L, const DevState& st, int tasks_per_obs, int rec_doubles,
                     const double* pixels, uint8_t* flags, const double* fd_out, const uint8_t* fd_ok, double* jrec,
                     int* cells, hipStream_t s);

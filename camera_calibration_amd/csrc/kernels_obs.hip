@@ -134,31 +134,32 @@ __device__ __forceinline__ void local_point_of(const PassArgs& a, int64_t o, int
   local[2] = T[13] * px + T[14] * py + T[15] * pz + T[6];
 }
 
+// One lane per observation runs AddReprojectionResidual's projection: warm start, retry from the centre.  Almost every
+// lane is done after 1-3 outer iterations, but a projection that FAILS runs the reference's whole budget first -- 100 outer
+// iterations with up to 10 damping attempts each, twice (warm start and centre): ~600 B-spline evaluations, 1.5 ms for a
+// single lane, and a pass cannot end before its slowest lane (0.4 % of the observations of the BASELINE configs fail from
+// the perturbed initial state: points whose projection is pinned at the border of the calibrated area, or that settle in a
+// local minimum next to it).  So a lane gives up after `outer_cap` (default 12) outer iterations of either attempt and puts its
+// observation on the straggler list; k_base_project_slow then runs the COMPLETE procedure for the list with 16 lanes per
+// observation.  Nothing of the 100 x 10 semantics is cut short, the long chains are only evaluated faster.
+
 template <int MODEL>
-__global__ void __launch_bounds__(256) k_base_project(PassArgs a, double* __restrict__ cost_vec,
-                                                      double* __restrict__ pixels, uint8_t* __restrict__ flags) {
-  int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (a.obs_list) {
-    const int cnt = min(*a.obs_count, a.obs_list_cap);
-    if (o >= cnt) return;
-    o = a.obs_list[o];
-  } else {
-    if (o >= a.n_obs) return;
-    if (a.skip && a.skip[o]) return;
-  }
-  int cam = a.obs_camera[o];
-  const CamDev c = a.cams[cam];
-  if (c.model_type != MODEL) return;
-  double local[3];
-  local_point_of(a, o, cam, local);
+__device__ __forceinline__ bool base_projection(const PassArgs& a, const CamDev& c, int64_t o, const double* local, int max_outer,
+                                                bool& capped, double& px, double& py) {
   Subst none; none.index = -1;
-  double px = a.last_projection[2 * o], py = a.last_projection[2 * o + 1];
+  px = a.last_projection[2 * o]; py = a.last_projection[2 * o + 1];
   if (!in_calibrated_area(c, px, py) || px != px || py != py) center_pixel(c, px, py);
-  bool ok = project_point<MODEL>(c, none, local, px, py);
-  if (!ok) {
+  capped = false;
+  bool ok = project_point<MODEL>(c, none, local, px, py, nullptr, nullptr, max_outer, &capped);
+  if (!ok && !capped) {
     center_pixel(c, px, py);
-    ok = project_point<MODEL>(c, none, local, px, py);
+    ok = project_point<MODEL>(c, none, local, px, py, nullptr, nullptr, max_outer, &capped);
   }
+  return ok;
+}
+__device__ __forceinline__ void store_base_projection(const PassArgs& a, int64_t o, bool ok, double px, double py,
+                                                      double* __restrict__ cost_vec, double* __restrict__ pixels,
+                                                      uint8_t* __restrict__ flags) {
   if (!ok) {
     cost_vec[o] = -1.0;   // AddInvalidResidual (lm_optimizer_update_accumulator.h:158-160)
     flags[o] = 0;
@@ -172,13 +173,177 @@ __global__ void __launch_bounds__(256) k_base_project(PassArgs a, double* __rest
   cost_vec[o] = huber_cost_sq(rx * rx + ry * ry);
   flags[o] = 1;
 }
-int launch_base_project(const PassArgs& a, int model_mask, double* cost_vec, double* pixels, uint8_t* flags,
-                        hipStream_t s) {
+
+// defer_*: straggler list (device), its fill count, its capacity, and the per-observation "on the list" byte that the
+// finite-difference launch of the same pass reads through PassArgs::skip.
+template <int MODEL>
+__global__ void __launch_bounds__(256) k_base_project(PassArgs a, double* __restrict__ cost_vec,
+                                                      double* __restrict__ pixels, uint8_t* __restrict__ flags,
+                                                      int* __restrict__ defer_list, int* __restrict__ defer_count, int defer_cap,
+                                                      uint8_t* __restrict__ defer_skip, int outer_cap) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= a.n_obs) return;
+  const int cam = a.obs_camera[o];
+  const CamDev c = a.cams[cam];
+  if (c.model_type != MODEL) return;
+  double local[3];
+  local_point_of(a, o, cam, local);
+  double px, py;
+  bool capped;
+  bool ok = base_projection<MODEL>(a, c, o, local, outer_cap, capped, px, py);
+  if (capped) {
+    const int idx = atomicAdd(defer_count, 1);
+    if (idx < defer_cap) { defer_list[idx] = (int)o; defer_skip[o] = 1; return; }
+    ok = base_projection<MODEL>(a, c, o, local, 100, capped, px, py);     // list full: the one-lane path, to the end
+  }
+  defer_skip[o] = 0;
+  store_base_projection(a, o, ok, px, py, cost_vec, pixels, flags);
+}
+
+// The straggler kernel: 16 lanes per listed observation evaluate the SAME procedure speculatively.
+//   lanes 0-7: the warm-start attempt, lanes 8-15: the attempt from the centre of the calibrated area -- the second attempt
+//     does not depend on the first (same target, fixed start), the reference merely skips it when the first succeeds;
+//   within an attempt, lane pair k (k = 0..3) takes damping attempt lm = base + k of the current round (lambda * 2^k): its
+//     even lane evaluates Unproject at the candidate (the test cost), its odd lane UnprojectWithJacobian at the same
+//     candidate (what the NEXT outer iteration needs if this candidate is the first accepted one).  The first accepted
+//     candidate in reference order (lowest lm) wins and its odd lane broadcasts pixel and evaluation to the group.
+// An outer iteration thus costs one evaluation latency instead of 1 + (attempts until acceptance), and both attempts run
+// side by side: ~100 evaluation latencies instead of ~600.  All arithmetic goes through the same device functions as the
+// one-lane loop (project_target), evaluated on identical inputs.
+// Exact shortcut: the loop state is (pixel, lambda); an iteration that maps it to itself (bitwise) will do so 100 times and
+// end in `return false` -- the pinned-at-the-border lanes -- so the attempt stops there with that result.
+template <int MODEL>
+__global__ void __launch_bounds__(256) k_base_project_slow(PassArgs a, double* __restrict__ cost_vec, double* __restrict__ pixels,
+                                                           uint8_t* __restrict__ flags) {
+  constexpr double kEpsilon = 1e-12;
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int cnt = min(*a.obs_count, a.obs_list_cap);
+  if (((tid & ~63) >> 4) >= cnt) return;                    // wave-uniform
+  const int g = tid >> 4;
+  const int64_t o = a.obs_list[g < cnt ? g : cnt - 1];      // idle groups shadow the last entry; they never evaluate or store
+  const int cam = a.obs_camera[o];
+  const CamDev c = a.cams[cam];
+  const bool live = g < cnt && c.model_type == MODEL;
+  const int attempt = (lane >> 3) & 1, cand = (lane >> 1) & 3, kind = lane & 1, gbase = lane & ~7;
+  double target[3];
+  local_point_of(a, o, cam, target);
+  if (MODEL == kCentral) normalize3(target[0], target[1], target[2]);
+  double px = a.last_projection[2 * o], py = a.last_projection[2 * o + 1];
+  if (attempt == 1 || !in_calibrated_area(c, px, py) || px != px || py != py) center_pixel(c, px, py);
+  Subst none; none.index = -1;
+  double dir[3] = {0, 0, 0}, org[3] = {0, 0, 0}, jd[6] = {0, 0, 0, 0, 0, 0}, jo[6] = {0, 0, 0, 0, 0, 0};
+  bool cur_in = false, active = live, result = false;
+  if (active) cur_in = unproject_jac<MODEL>(c, none, px, py, dir, org, jd, jo);
+  double lambda = -1.0;
+  long long prev_px = -1, prev_py = -1, prev_lambda = -1;   // bit patterns of the previous iteration's state (-1 = NaN pattern: none)
+  for (int it = 0; it < 100; ++it) {
+    if (!__any(active)) break;
+    if (active && !cur_in) { result = false; active = false; }          // CHECK() in the reference
+    double cost = 0, H00 = 0, H01 = 0, H11 = 0, b0 = 0, b1 = 0;
+    if (active) {
+      projection_normal_equations<MODEL>(dir, org, jd, jo, target, cost, H00, H01, H11, b0, b1);
+      if (lambda < 0) lambda = 0.01 * 0.5 * (H00 + H11);
+      const long long bx = __double_as_longlong(px), by = __double_as_longlong(py), bl = __double_as_longlong(lambda);
+      if (bx == prev_px && by == prev_py && bl == prev_lambda) { result = false; active = false; }   // fixed point
+      prev_px = bx; prev_py = by; prev_lambda = bl;
+    }
+    bool accepted = false;
+#pragma unroll 1
+    for (int base = 0; base < 10; base += 4) {
+      const int lm = base + cand;
+      const bool mine = active && !accepted && lm < 10;
+      double lam_c = lambda;
+      if (cand >= 1) lam_c *= 2.0;
+      if (cand >= 2) lam_c *= 2.0;
+      if (cand >= 3) lam_c *= 2.0;
+      double tx = px, ty = py, tc = INFINITY;
+      double ndir[3] = {0, 0, 0}, norg[3] = {0, 0, 0}, njd[6] = {0, 0, 0, 0, 0, 0}, njo[6] = {0, 0, 0, 0, 0, 0};
+      bool nin = false;
+      if (mine) {
+        projection_candidate(c, H00, H01, H11, b0, b1, lam_c, px, py, tx, ty);
+        if (kind == 0) {
+          double td[3], to[3];
+          if (unproject<MODEL>(c, none, tx, ty, td, to)) tc = projection_test_cost<MODEL>(td, to, target);
+        } else {
+          nin = unproject_jac<MODEL>(c, none, tx, ty, ndir, norg, njd, njo);
+        }
+      }
+      const double tc_partner = __shfl_xor(tc, 1, 64);
+      const double my_tc = kind == 0 ? tc : tc_partner;
+      const bool acc_c = mine && (my_tc < cost);
+      const unsigned m = (unsigned)((__ballot(acc_c) >> gbase) & 0xffull);
+      const int w = m ? ((__ffs(m) - 1) >> 1) : -1;
+      const int src = gbase + 2 * (w < 0 ? 0 : w) + 1;       // odd lane of the winning pair
+      const double wtx = __shfl(tx, src, 64), wty = __shfl(ty, src, 64);
+      const int w_in = __shfl((int)nin, src, 64);
+      double wdir[3], worg[3], wjd[6], wjo[6];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) wdir[k] = __shfl(ndir[k], src, 64);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) wjd[k] = __shfl(njd[k], src, 64);
+      if (MODEL != kCentral) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) worg[k] = __shfl(norg[k], src, 64);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) wjo[k] = __shfl(njo[k], src, 64);
+      }
+      if (active && !accepted) {
+        if (w >= 0) {
+          double l = lambda;
+          for (int k = 0; k < w; ++k) l *= 2.0;              // the rejected attempts before the accepted one
+          lambda = l * 0.5;
+          px = wtx; py = wty;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) dir[k] = wdir[k];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) jd[k] = wjd[k];
+          if (MODEL != kCentral) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) org[k] = worg[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) jo[k] = wjo[k];
+          }
+          cur_in = w_in != 0;
+          accepted = true;
+        } else {
+          const int tried = 10 - base < 4 ? 10 - base : 4;
+          for (int k = 0; k < tried; ++k) lambda *= 2.0;
+        }
+      }
+    }
+    if (active) {
+      if (!accepted) { result = cost < kEpsilon; active = false; }
+      else if (cost < kEpsilon) { result = true; active = false; }
+    }
+  }
+  // still active after 100 outer iterations: not converged (result stays false)
+  const int first = lane & ~15;
+  const int ok0 = __shfl((int)result, first, 64), ok1 = __shfl((int)result, first + 8, 64);
+  const double px0 = __shfl(px, first, 64), py0 = __shfl(py, first, 64);
+  const double px1 = __shfl(px, first + 8, 64), py1 = __shfl(py, first + 8, 64);
+  if (live && (lane & 15) == 0)
+    store_base_projection(a, o, ok0 || ok1, ok0 ? px0 : px1, ok0 ? py0 : py1, cost_vec, pixels, flags);
+}
+
+// Main launch (one lane per observation, stragglers deferred) followed by the straggler launch on `s_slow` (the same stream
+// in a cost pass; the Jacobian pass passes its side stream and orders it with `ev_main_done`).
+int launch_base_project(const PassArgs& a, int model_mask, double* cost_vec, double* pixels, uint8_t* flags, int* defer_list,
+                        int* defer_count, int defer_cap, uint8_t* defer_skip, int outer_cap, hipStream_t s) {
   if (a.n_obs == 0) return CBA_OK;
-  const int64_t items = a.obs_list ? a.obs_list_cap : a.n_obs;
-  dim3 grid((unsigned)((items + 255) / 256)), block(256);
-  if (model_mask & 1) hipLaunchKernelGGL(k_base_project<kCentral>, grid, block, 0, s, a, cost_vec, pixels, flags);
-  if (model_mask & 2) hipLaunchKernelGGL(k_base_project<kNoncentral>, grid, block, 0, s, a, cost_vec, pixels, flags);
+  CBA_HIP(hipMemsetAsync(defer_count, 0, sizeof(int), s));
+  dim3 grid((unsigned)((a.n_obs + 255) / 256)), block(256);
+  if (model_mask & 1) hipLaunchKernelGGL(k_base_project<kCentral>, grid, block, 0, s, a, cost_vec, pixels, flags, defer_list, defer_count, defer_cap, defer_skip, outer_cap);
+  if (model_mask & 2) hipLaunchKernelGGL(k_base_project<kNoncentral>, grid, block, 0, s, a, cost_vec, pixels, flags, defer_list, defer_count, defer_cap, defer_skip, outer_cap);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+// `a.obs_list / obs_count / obs_list_cap` = the straggler list filled by launch_base_project
+int launch_base_project_slow(const PassArgs& a, int model_mask, double* cost_vec, double* pixels, uint8_t* flags, hipStream_t s) {
+  if (a.n_obs == 0) return CBA_OK;
+  dim3 grid((unsigned)(((int64_t)a.obs_list_cap * 16 + 255) / 256)), block(256);
+  if (model_mask & 1) hipLaunchKernelGGL(k_base_project_slow<kCentral>, grid, block, 0, s, a, cost_vec, pixels, flags);
+  if (model_mask & 2) hipLaunchKernelGGL(k_base_project_slow<kNoncentral>, grid, block, 0, s, a, cost_vec, pixels, flags);
   CBA_HIP(hipGetLastError());
   return CBA_OK;
 }
@@ -404,27 +569,6 @@ int launch_fd_tasks(const PassArgs& a, int model_mask, int tasks_per_obs, int lo
   return CBA_OK;
 }
 
-// Observations whose last Jacobian pass did not end with (valid, has-Jacobian) -- failed projections run
-// the full 2 x 100 x 10 iteration budget, ~1 ms for a single lane -- are listed for the side-stream launch.
-__global__ void __launch_bounds__(256) k_collect_slow(const uint8_t* __restrict__ flags, int64_t n, uint8_t* __restrict__ skip,
-                                                      int* __restrict__ list, int* __restrict__ count, int cap) {
-  int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= n) return;
-  uint8_t sk = 0;
-  if (flags[o] != 3) {
-    const int idx = atomicAdd(count, 1);
-    if (idx < cap) { list[idx] = (int)o; sk = 1; }
-  }
-  skip[o] = sk;
-}
-int launch_collect_slow(const uint8_t* flags, int64_t n, uint8_t* skip, int* list, int* count, int cap, hipStream_t s) {
-  if (n == 0) return CBA_OK;
-  CBA_HIP(hipMemsetAsync(count, 0, sizeof(int), s));
-  hipLaunchKernelGGL(k_collect_slow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, flags, n, skip, list, count, cap);
-  CBA_HIP(hipGetLastError());
-  return CBA_OK;
-}
-
 // ------------------------------------------------------------------------------------------------
 // assemble the Jacobian record of one observation (one lane per observation)
 // ------------------------------------------------------------------------------------------------
@@ -619,7 +763,8 @@ __global__ void __launch_bounds__(256) k_accumulate(PassArgs a, AccumLayout L, i
                                                     const int* __restrict__ pair_counts, AccumTargets T,
                                                     const double* __restrict__ det_scale) {
   typedef typename Acc<DET>::T acc_t;
-  const double scale = DET ? *det_scale : 1.0;
+  const double scale = DET ? det_scale[0] : 1.0;
+  const double scale_b = DET ? det_scale[1] : 1.0;     // the J^T r sums have their own (finer) fixed-point scale
   __shared__ double sJ0[4][kMaxCols];
   __shared__ double sJ1[4][kMaxCols];
   __shared__ double sW0[4][kMaxCols];
@@ -715,13 +860,13 @@ __global__ void __launch_bounds__(256) k_accumulate(PassArgs a, AccumLayout L, i
     for (int t = 0; t < 2; ++t) {
       if (hs_i[t] < 0) continue;
       const int i = h0 + hs_i[t];
-      if (hs_k[t] == -2) hot[t] += Acc<DET>::from(r0 * sW0[wv][i] + r1 * sW1[wv][i], scale);
+      if (hs_k[t] == -2) hot[t] += Acc<DET>::from(r0 * sW0[wv][i] + r1 * sW1[wv][i], scale_b);
       else { const int k = h0 + hs_k[t]; hot[t] += Acc<DET>::from(sW0[wv][i] * sJ0[wv][k] + sW1[wv][i] * sJ1[wv][k], scale); }
     }
     // b += Jw^T r (non-hot positions)
     for (int k = lane; k < K; k += 64) {
       if (k >= h0 && k < h0 + nh) continue;
-      acc_add_b<DET>(L, T, sIdx[wv][k], Acc<DET>::from(r0 * sW0[wv][k] + r1 * sW1[wv][k], scale));
+      acc_add_b<DET>(L, T, sIdx[wv][k], Acc<DET>::from(r0 * sW0[wv][k] + r1 * sW1[wv][k], scale_b));
     }
     // remaining upper-triangle products (the pair tables exclude hot-hot pairs)
     const int slot = (per == 2) ? 0 : 1;
@@ -739,7 +884,7 @@ __global__ void __launch_bounds__(256) k_accumulate(PassArgs a, AccumLayout L, i
 // ------------------------------------------------------------------------------------------------
 // grid x grid block of JtJ, grouped by grid cell.  All observations whose 4x4 control patch starts at
 // the same cell add their K_g x K_g products to the same entries of H_dd, so they are first bucketed by
-// (camera, cell) with a counting sort and then one wavefront per cell sums its bucket in registers
+// (camera, cell) with a counting sort and then one workgroup per cell sums its bucket in registers
 // (528 entries for the central model, 3240 for the non-central one) and issues ONE atomic per entry.
 // This removes 58 % (central) / 81 % (non-central) of the atomics of the per-observation scatter.
 // ------------------------------------------------------------------------------------------------
@@ -785,7 +930,12 @@ __global__ void __launch_bounds__(256) k_cell_fill(PassArgs a, const uint8_t* __
 }
 // rig_row0 >= 0 (several cameras, poses eliminated): the bucket also sums the camera's rig-pose x grid block
 // (6 x K_g entries of H_dd that EVERY observation of the camera would otherwise hit with atomics).
-template <int PER, bool DET>
+// One workgroup per cell.  The K_g (K_g + 1) / 2 pair sums are dealt to the 256 lanes (3 per lane central, 13 non-central),
+// the records of the bucket are staged in LDS eight at a time (all loads of a stage in flight together), and every entry
+// is summed in bucket order and added to H_dd with ONE atomic.  (The first version gave a cell to one wavefront: 51 pair
+// sums per lane = 441 registers, one wavefront per SIMD walking ~200 records with a dependent global load each -- 3.1 ms
+// at BASELINE configs[3].)
+template <int PER, bool DET, bool RIG>
 __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, int key0, int n_cells, int rec_doubles, int ld,
                                                           const double* __restrict__ jrec, const int* __restrict__ start,
                                                           const int* __restrict__ order, double* __restrict__ Hdd, int rig_row0,
@@ -794,84 +944,84 @@ __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, i
   const double scale = DET ? *det_scale : 1.0;
   constexpr int KG = PER * 16;
   constexpr int NPAIR = KG * (KG + 1) / 2;
-  constexpr int NE = (NPAIR + 63) / 64;
-  constexpr int NR = (6 * KG + 63) / 64;
-  __shared__ double sJ0[4][KG];
-  __shared__ double sJ1[4][KG];
-  __shared__ double sRig[4][12];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int cell = blockIdx.x * 4 + wv;
+  constexpr int NE = (NPAIR + 255) / 256;
+  constexpr int NR = (6 * KG + 255) / 256;
+  constexpr int RB = 8;                          // records per stage
+  __shared__ double sJ0[RB][KG];
+  __shared__ double sJ1[RB][KG];
+  __shared__ double sRig[RB][12];
+  __shared__ double sW[RB];
+  const int tid = threadIdx.x;
+  const int cell = blockIdx.x;
   if (cell >= n_cells) return;
   const int o_begin = start[key0 + cell], o_end = start[key0 + cell + 1];
-  if (o_begin == o_end) return;
-  // this lane's pairs (i <= k), enumerated row by row
-  unsigned short pi[NE], pk[NE];
+  if (o_begin == o_end) return;                  // workgroup-uniform
+  // this lane's pairs (i <= k), enumerated row by row, packed i | k << 16
+  unsigned pp[NE];
 #pragma unroll
   for (int t = 0; t < NE; ++t) {
-    int e = lane + 64 * t;
-    int i = 0;
-    if (e < NPAIR) { int rem = e; while (rem >= KG - i) { rem -= KG - i; ++i; } pi[t] = (unsigned short)i; pk[t] = (unsigned short)(i + rem); }
-    else { pi[t] = 0; pk[t] = 0; }
+    const int e = tid + 256 * t;
+    int i = 0, k = 0;
+    if (e < NPAIR) { int rem = e; while (rem >= KG - i) { rem -= KG - i; ++i; } k = i + rem; }
+    pp[t] = (unsigned)i | ((unsigned)k << 16);
+  }
+  acc_t acc[NE], racc[NR];
+#pragma unroll
+  for (int t = 0; t < NE; ++t) acc[t] = 0;
+#pragma unroll
+  for (int t = 0; t < NR; ++t) racc[t] = 0;
+  constexpr bool rig = RIG;
+  for (int base = o_begin; base < o_end; base += RB) {
+    const int nrec = o_end - base < RB ? o_end - base : RB;
+    __syncthreads();                             // the previous stage has been consumed
+    for (int e = tid; e < nrec * KG; e += 256) {
+      const int r = e / KG, k = e - r * KG;
+      const double* rec = jrec + (size_t)order[base + r] * rec_doubles;
+      sJ0[r][k] = rec[kRecHeader + k]; sJ1[r][k] = rec[kRecHeader + KG + k];
+    }
+    if (tid < nrec) sW[tid] = jrec[(size_t)order[base + tid] * rec_doubles + 2];
+    if (rig && tid >= 64 && tid < 64 + nrec * 12) {
+      const int r = (tid - 64) / 12, q = (tid - 64) - r * 12;
+      sRig[r][q] = jrec[(size_t)order[base + r] * rec_doubles + 15 + q];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int r = 0; r < nrec; ++r) {
+      const double w = sW[r];
+#pragma unroll
+      for (int t = 0; t < NE; ++t) {
+        const int i = pp[t] & 0xffff, k = pp[t] >> 16;
+        acc[t] += Acc<DET>::from(w * (sJ0[r][i] * sJ0[r][k] + sJ1[r][i] * sJ1[r][k]), scale);
+      }
+      if (rig) {
+#pragma unroll
+        for (int t = 0; t < NR; ++t) {
+          const int e = tid + 256 * t;
+          if (e < 6 * KG) { const int q = e / KG, k = e - q * KG; racc[t] += Acc<DET>::from(w * (sRig[r][q] * sJ0[r][k] + sRig[r][6 + q] * sJ1[r][k]), scale); }
+        }
+      }
+    }
   }
   const CamDev cd = a.cams[cam];
   const int cy0 = cell / cd.gw, cx0 = cell - cy0 * cd.gw;
-  {
-    acc_t acc[NE];
 #pragma unroll
-    for (int t = 0; t < NE; ++t) acc[t] = 0;
-    for (int idx = o_begin; idx < o_end; ++idx) {
-      const int o = order[idx];
-      const double* rec = jrec + (size_t)o * rec_doubles;
-      const double w = rec[2];
-      __builtin_amdgcn_wave_barrier();
-      for (int k = lane; k < KG; k += 64) { sJ0[wv][k] = rec[kRecHeader + k]; sJ1[wv][k] = rec[kRecHeader + KG + k]; }
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#pragma unroll
-      for (int t = 0; t < NE; ++t) {
-        const int i = pi[t], k = pk[t];
-        acc[t] += Acc<DET>::from(w * (sJ0[wv][i] * sJ0[wv][k] + sJ1[wv][i] * sJ1[wv][k]), scale);
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < NE; ++t) {
-      if (lane + 64 * t >= NPAIR) continue;
-      const int i = pi[t], k = pk[t];
-      const int ci = i / PER, di = i - ci * PER, ck = k / PER, dk = k - ck * PER;
-      int row = grid_column(cd, (cx0 + (ci & 3)) + (cy0 + (ci >> 2)) * cd.gw, di);
-      int col = grid_column(cd, (cx0 + (ck & 3)) + (cy0 + (ck >> 2)) * cd.gw, dk);
-      if (row > col) { const int t2 = row; row = col; col = t2; }   // tiled order is not monotone in the patch order
-      Acc<DET>::add(Hdd + (size_t)row * ld + col, acc[t]);
-    }
+  for (int t = 0; t < NE; ++t) {
+    if (tid + 256 * t >= NPAIR) continue;
+    const int i = pp[t] & 0xffff, k = pp[t] >> 16;
+    const int ci = i / PER, di = i - ci * PER, ck = k / PER, dk = k - ck * PER;
+    int row = grid_column(cd, (cx0 + (ci & 3)) + (cy0 + (ci >> 2)) * cd.gw, di);
+    int col = grid_column(cd, (cx0 + (ck & 3)) + (cy0 + (ck >> 2)) * cd.gw, dk);
+    if (row > col) { const int t2 = row; row = col; col = t2; }   // tiled order is not monotone in the patch order
+    Acc<DET>::add(Hdd + (size_t)row * ld + col, acc[t]);
   }
-  if (rig_row0 < 0) return;
-  // second pass over the bucket for the rig rows: a separate loop, so that its accumulators are not live together
-  // with the K_g (K_g + 1) / 2 pair sums above (the non-central instantiation spilled 1.6 KB per lane otherwise)
-  acc_t racc[NR];
-#pragma unroll
-  for (int t = 0; t < NR; ++t) racc[t] = 0;
-  for (int idx = o_begin; idx < o_end; ++idx) {
-    const int o = order[idx];
-    const double* rec = jrec + (size_t)o * rec_doubles;
-    const double w = rec[2];
-    __builtin_amdgcn_wave_barrier();
-    for (int k = lane; k < KG; k += 64) { sJ0[wv][k] = rec[kRecHeader + k]; sJ1[wv][k] = rec[kRecHeader + KG + k]; }
-    if (lane < 12) sRig[wv][lane] = rec[15 + lane];
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#pragma unroll
-    for (int t = 0; t < NR; ++t) {
-      const int e = lane + 64 * t;
-      if (e < 6 * KG) { const int r = e / KG, k = e - r * KG; racc[t] += Acc<DET>::from(w * (sRig[wv][r] * sJ0[wv][k] + sRig[wv][6 + r] * sJ1[wv][k]), scale); }
-    }
-  }
+  if (!rig) return;
 #pragma unroll
   for (int t = 0; t < NR; ++t) {
-    const int e = lane + 64 * t;
+    const int e = tid + 256 * t;
     if (e >= 6 * KG) continue;
-    const int r = e / KG, k = e - r * KG, ck = k / PER, dk = k - ck * PER;
+    const int q = e / KG, k = e - q * KG, ck = k / PER, dk = k - ck * PER;
     const int col = grid_column(cd, (cx0 + (ck & 3)) + (cy0 + (ck >> 2)) * cd.gw, dk);
-    Acc<DET>::add(Hdd + (size_t)(rig_row0 + r) * ld + col, racc[t]);      // rig rows precede the grid columns
+    Acc<DET>::add(Hdd + (size_t)(rig_row0 + q) * ld + col, racc[t]);      // rig rows precede the grid columns
   }
 }
 int launch_accumulate_cells(const PassArgs& a, const std::vector<cba_camera>& cams, const std::vector<int>& cell_base_host,
@@ -888,13 +1038,15 @@ int launch_accumulate_cells(const PassArgs& a, const std::vector<cba_camera>& ca
   hipLaunchKernelGGL(k_cell_fill, grid, block, 0, s, a, flags, cells, cell_base, start, fill, order);
   for (size_t c = 0; c < cams.size(); ++c) {
     const int n_cells = cams[c].grid_w * cams[c].grid_h;
-    dim3 g2((unsigned)((n_cells + 3) / 4));
+    dim3 g2((unsigned)n_cells);
     const int rr = rig_row_first >= 0 ? rig_row_first + 6 * (int)c : -1;
     const bool central = cams[c].model_type == CBA_CENTRAL_GENERIC;
-#define CBA_CELLS(PER_, DET_) hipLaunchKernelGGL((k_accumulate_cells<PER_, DET_>), g2, block, 0, s, a, (int)c, cell_base_host[c], n_cells, \
-                                                 rec_doubles, ld, jrec, start, order, Hdd, rr, det_scale)
+#define CBA_CELLS2(PER_, DET_, RIG_) hipLaunchKernelGGL((k_accumulate_cells<PER_, DET_, RIG_>), g2, block, 0, s, a, (int)c, cell_base_host[c], \
+                                                        n_cells, rec_doubles, ld, jrec, start, order, Hdd, rr, det_scale)
+#define CBA_CELLS(PER_, DET_) do { if (rr >= 0) CBA_CELLS2(PER_, DET_, true); else CBA_CELLS2(PER_, DET_, false); } while (0)
     if (central) { if (det_scale) CBA_CELLS(2, true); else CBA_CELLS(2, false); }
     else { if (det_scale) CBA_CELLS(5, true); else CBA_CELLS(5, false); }
+#undef CBA_CELLS2
 #undef CBA_CELLS
   }
   CBA_HIP(hipGetLastError());
@@ -1042,32 +1194,37 @@ int launch_accumulate(const PassArgs& a, const Layout& L, int rec_doubles, const
 }
 
 // ---- deterministic mode: scale of the fixed-point accumulation, and the conversion back to doubles ----
-// out_bits: bit pattern of max over the observations with a Jacobian of  2 w (max(|J|, |r|))^2  >= every |contribution|
-// (positive doubles order like their bit patterns, and max is order-independent)
+// out_bits[0]: bit pattern of max over the observations with a Jacobian of  2 w |J|max^2  >= every |contribution| to H,
+// out_bits[1]: the same for  2 w |J|max |r|max  >= every |contribution| to b  (the residuals are orders of magnitude below
+// the Jacobian entries, so b gets its own, finer scale).  Positive doubles order like their bit patterns; max is order-independent.
 __global__ void __launch_bounds__(256) k_det_bound(int64_t n, int rec_doubles, int used_doubles, const uint8_t* __restrict__ flags,
                                                    const double* __restrict__ jrec, unsigned long long* __restrict__ out_bits) {
   const int lane = threadIdx.x & 63;
-  double m = 0.0;
+  double m = 0.0, mb = 0.0;
   for (int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); o < n; o += (int64_t)gridDim.x * 4) {
     if (flags[o] != 3) continue;
     const double* rec = jrec + (size_t)o * rec_doubles;
     double jm = 0.0;
-    for (int k = lane; k < used_doubles; k += 64) if (k != 2) jm = fmax(jm, fabs(rec[k]));
+    for (int k = lane; k < used_doubles; k += 64) if (k > 2) jm = fmax(jm, fabs(rec[k]));
     for (int off = 32; off > 0; off >>= 1) jm = fmax(jm, __shfl_xor(jm, off, 64));
     m = fmax(m, 2.0 * rec[2] * jm * jm);
+    mb = fmax(mb, 2.0 * rec[2] * jm * fmax(fabs(rec[0]), fabs(rec[1])));
   }
   if (lane == 0 && m > 0.0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(m));
+  if (lane == 0 && mb > 0.0) atomicMax(out_bits + 1, (unsigned long long)__double_as_longlong(mb));
 }
 __global__ void k_det_scale(const unsigned long long* __restrict__ bits, int64_t n_obs, double* __restrict__ scale) {
-  const double m = __longlong_as_double((long long)*bits);
-  const double bound = m * (double)(n_obs > 0 ? n_obs : 1);     // no entry receives more than n_obs contributions
-  int e = 0;
-  if (bound > 0.0) frexp(bound, &e);                            // bound < 2^e
-  *scale = ldexp(1.0, 62 - e);                                  // bound * scale < 2^62
+  for (int i = 0; i < 2; ++i) {
+    const double m = __longlong_as_double((long long)bits[i]);
+    const double bound = m * (double)(n_obs > 0 ? n_obs : 1);   // no entry receives more than n_obs contributions
+    int e = 0;
+    if (bound > 0.0) frexp(bound, &e);                          // bound < 2^e
+    scale[i] = ldexp(1.0, 62 - e);                              // bound * scale < 2^62
+  }
 }
 int launch_det_scale(int64_t n, int rec_doubles, int used_doubles, const uint8_t* flags, const double* jrec, unsigned long long* bits,
                      double* scale, hipStream_t s) {
-  CBA_HIP(hipMemsetAsync(bits, 0, sizeof(unsigned long long), s));
+  CBA_HIP(hipMemsetAsync(bits, 0, 2 * sizeof(unsigned long long), s));
   if (n > 0) hipLaunchKernelGGL(k_det_bound, dim3(1024), dim3(256), 0, s, n, rec_doubles, used_doubles, flags, jrec, bits);
   hipLaunchKernelGGL(k_det_scale, dim3(1), dim3(1), 0, s, bits, n, scale);
   CBA_HIP(hipGetLastError());

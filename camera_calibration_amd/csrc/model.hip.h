@@ -310,83 +310,105 @@ __device__ __forceinline__ void tangent_derivs(const double* d, const double* jd
     }
 }
 
+// ---- pieces of the iterative projection, shared by the one-lane loop (project_target) and the 16-lanes-per-observation
+// ---- straggler kernel (kernels_obs.hip: k_base_project_slow), so that both evaluate the same expressions ----
+// cost and 2 x 2 normal equations of one LM iteration from UnprojectWithJacobian's outputs at the current pixel
+template <int MODEL>
+__device__ __forceinline__ void projection_normal_equations(const double* dir, const double* org, const double* jd, const double* jo,
+                                                            const double* target, double& cost, double& H00, double& H01,
+                                                            double& H11, double& b0, double& b1) {
+  if (MODEL == kCentral) {
+    double dx = dir[0] - target[0], dy = dir[1] - target[1], dz = dir[2] - target[2];
+    cost = dx * dx + dy * dy + dz * dz;
+    H00 = jd[0] * jd[0] + jd[2] * jd[2] + jd[4] * jd[4];
+    H01 = jd[0] * jd[1] + jd[2] * jd[3] + jd[4] * jd[5];
+    H11 = jd[1] * jd[1] + jd[3] * jd[3] + jd[5] * jd[5];
+    b0 = dx * jd[0] + dy * jd[2] + dz * jd[4];
+    b1 = dx * jd[1] + dy * jd[3] + dz * jd[5];
+  } else {
+    double t1[3], t2[3];
+    tangents_of(dir, t1, t2);
+    double p[3] = {org[0] - target[0], org[1] - target[1], org[2] - target[2]};
+    double d1 = t1[0] * p[0] + t1[1] * p[1] + t1[2] * p[2];
+    double d2 = t2[0] * p[0] + t2[1] * p[1] + t2[2] * p[2];
+    double dt1[6], dt2[6];
+    tangent_derivs(dir, jd, dt1, dt2);
+    double R[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      R[q] = p[0] * dt1[q] + p[1] * dt1[2 + q] + p[2] * dt1[4 + q] + t1[0] * jo[q] + t1[1] * jo[2 + q] + t1[2] * jo[4 + q];
+      R[2 + q] = p[0] * dt2[q] + p[1] * dt2[2 + q] + p[2] * dt2[4 + q] + t2[0] * jo[q] + t2[1] * jo[2 + q] + t2[2] * jo[4 + q];
+    }
+    cost = d1 * d1 + d2 * d2;
+    H00 = R[0] * R[0] + R[2] * R[2];
+    H01 = R[0] * R[1] + R[2] * R[3];
+    H11 = R[1] * R[1] + R[3] * R[3];
+    b0 = d1 * R[0] + d2 * R[2];
+    b1 = d1 * R[1] + d2 * R[3];
+  }
+}
+// the damped 2 x 2 solve and the clamped candidate pixel (central_generic.cc:470-481)
+__device__ __forceinline__ void projection_candidate(const CamDev& c, double H00, double H01, double H11, double b0, double b1,
+                                                     double lambda, double px, double py, double& tx, double& ty) {
+  const double lo_x = (double)c.min_x, hi_x = c.max_x + 0.999, lo_y = (double)c.min_y, hi_y = c.max_y + 0.999;
+  double H00l = H00 + lambda, H11l = H11 + lambda;
+  double x1 = (b1 - H01 / H00l * b0) / (H11l - H01 * H01 / H00l);
+  double x0 = (b0 - H01 * x1) / H00l;
+  double cx = px - x0, cy = py - x1;
+  double mx = (cx < hi_x) ? cx : hi_x;  // std::min(hi, v)
+  tx = (lo_x < mx) ? mx : lo_x;         // std::max(lo, .)
+  double my = (cy < hi_y) ? cy : hi_y;
+  ty = (lo_y < my) ? my : lo_y;
+}
+// cost of a candidate from Unproject's outputs
+template <int MODEL>
+__device__ __forceinline__ double projection_test_cost(const double* td, const double* to, const double* target) {
+  if (MODEL == kCentral) {
+    double ex = td[0] - target[0], ey = td[1] - target[1], ez = td[2] - target[2];
+    return ex * ex + ey * ey + ez * ez;
+  } else {
+    double t1[3], t2[3];
+    tangents_of(td, t1, t2);
+    double p[3] = {to[0] - target[0], to[1] - target[1], to[2] - target[2]};
+    double e1 = t1[0] * p[0] + t1[1] * p[1] + t1[2] * p[2];
+    double e2 = t2[0] * p[0] + t2[1] * p[1] + t2[2] * p[2];
+    return e1 * e1 + e2 * e2;
+  }
+}
+
 // Iterative projection. target = unit direction (central) or local point (non-central).
 // px,py: in = initial estimate (must lie in the calibrated area), out = result.
 // Returns true iff converged (squared error < 1e-12), as the reference does.
 // STG: the spline is evaluated on the patch staged in LDS; if an iterate needs another patch, *miss is set and the call
 // returns false -- the caller then repeats the whole projection on the gather path (rare: a pixel within the last LM
 // step of a cell boundary).
+// max_outer < 100: give up after that many outer iterations with *capped = true (the caller hands the observation to the
+// straggler kernel, which runs the complete loop); nothing of the reference's 100-iteration semantics is cut short.
 template <int MODEL, bool STG = false>
 __device__ bool project_target(const CamDev& c, const Subst& s, const double* target, double& px, double& py,
-                               const StagedPatch<MODEL>* st = nullptr, bool* miss = nullptr) {
+                               const StagedPatch<MODEL>* st = nullptr, bool* miss = nullptr, int max_outer = 100,
+                               bool* capped = nullptr) {
   constexpr double kEpsilon = 1e-12;
   double lambda = -1.0;
-  const double lo_x = (double)c.min_x, hi_x = c.max_x + 0.999, lo_y = (double)c.min_y, hi_y = c.max_y + 0.999;
-  for (int it = 0; it < 100; ++it) {
+  for (int it = 0; it < max_outer; ++it) {
     double dir[3], org[3], jd[6], jo[6];
     bool inside;
     if (STG) inside = unproject_jac_staged<MODEL>(c, s, *st, px, py, dir, org, jd, jo, *miss);
     else inside = unproject_jac<MODEL>(c, s, px, py, dir, org, jd, jo);
     if (!inside) return false;  // CHECK() in the reference
     double cost, H00, H01, H11, b0, b1;
-    if (MODEL == kCentral) {
-      double dx = dir[0] - target[0], dy = dir[1] - target[1], dz = dir[2] - target[2];
-      cost = dx * dx + dy * dy + dz * dz;
-      H00 = jd[0] * jd[0] + jd[2] * jd[2] + jd[4] * jd[4];
-      H01 = jd[0] * jd[1] + jd[2] * jd[3] + jd[4] * jd[5];
-      H11 = jd[1] * jd[1] + jd[3] * jd[3] + jd[5] * jd[5];
-      b0 = dx * jd[0] + dy * jd[2] + dz * jd[4];
-      b1 = dx * jd[1] + dy * jd[3] + dz * jd[5];
-    } else {
-      double t1[3], t2[3];
-      tangents_of(dir, t1, t2);
-      double p[3] = {org[0] - target[0], org[1] - target[1], org[2] - target[2]};
-      double d1 = t1[0] * p[0] + t1[1] * p[1] + t1[2] * p[2];
-      double d2 = t2[0] * p[0] + t2[1] * p[1] + t2[2] * p[2];
-      double dt1[6], dt2[6];
-      tangent_derivs(dir, jd, dt1, dt2);
-      double R[4];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        R[q] = p[0] * dt1[q] + p[1] * dt1[2 + q] + p[2] * dt1[4 + q] + t1[0] * jo[q] + t1[1] * jo[2 + q] + t1[2] * jo[4 + q];
-        R[2 + q] = p[0] * dt2[q] + p[1] * dt2[2 + q] + p[2] * dt2[4 + q] + t2[0] * jo[q] + t2[1] * jo[2 + q] + t2[2] * jo[4 + q];
-      }
-      cost = d1 * d1 + d2 * d2;
-      H00 = R[0] * R[0] + R[2] * R[2];
-      H01 = R[0] * R[1] + R[2] * R[3];
-      H11 = R[1] * R[1] + R[3] * R[3];
-      b0 = d1 * R[0] + d2 * R[2];
-      b1 = d1 * R[1] + d2 * R[3];
-    }
+    projection_normal_equations<MODEL>(dir, org, jd, jo, target, cost, H00, H01, H11, b0, b1);
     if (lambda < 0) lambda = 0.01 * 0.5 * (H00 + H11);
     bool accepted = false;
     for (int lm = 0; lm < 10; ++lm) {
-      double H00l = H00 + lambda, H11l = H11 + lambda;
-      double x1 = (b1 - H01 / H00l * b0) / (H11l - H01 * H01 / H00l);
-      double x0 = (b0 - H01 * x1) / H00l;
-      double cx = px - x0, cy = py - x1;
-      double mx = (cx < hi_x) ? cx : hi_x;  // std::min(hi, v)
-      double tx = (lo_x < mx) ? mx : lo_x;  // std::max(lo, .)
-      double my = (cy < hi_y) ? cy : hi_y;
-      double ty = (lo_y < my) ? my : lo_y;
+      double tx, ty;
+      projection_candidate(c, H00, H01, H11, b0, b1, lambda, px, py, tx, ty);
       double test_cost = INFINITY;
       double td[3], to[3];
       bool tin;
       if (STG) { tin = unproject_staged<MODEL>(c, s, *st, tx, ty, td, to, *miss); if (*miss) return false; }
       else tin = unproject<MODEL>(c, s, tx, ty, td, to);
-      if (tin) {
-        if (MODEL == kCentral) {
-          double ex = td[0] - target[0], ey = td[1] - target[1], ez = td[2] - target[2];
-          test_cost = ex * ex + ey * ey + ez * ez;
-        } else {
-          double t1[3], t2[3];
-          tangents_of(td, t1, t2);
-          double p[3] = {to[0] - target[0], to[1] - target[1], to[2] - target[2]};
-          double e1 = t1[0] * p[0] + t1[1] * p[1] + t1[2] * p[2];
-          double e2 = t2[0] * p[0] + t2[1] * p[1] + t2[2] * p[2];
-          test_cost = e1 * e1 + e2 * e2;
-        }
-      }
+      if (tin) test_cost = projection_test_cost<MODEL>(td, to, target);
       if (test_cost < cost) {
         lambda *= 0.5;
         px = tx; py = ty;
@@ -399,19 +421,21 @@ __device__ bool project_target(const CamDev& c, const Subst& s, const double* ta
     if (!accepted) return cost < kEpsilon;
     if (cost < kEpsilon) return true;
   }
+  if (max_outer < 100 && capped) *capped = true;
   return false;
 }
 
 // ProjectWithInitialEstimate(local_point): the central model normalises first (central_grid.h:86-88).
 template <int MODEL, bool STG = false>
 __device__ __forceinline__ bool project_point(const CamDev& c, const Subst& s, const double* local, double& px, double& py,
-                                              const StagedPatch<MODEL>* st = nullptr, bool* miss = nullptr) {
+                                              const StagedPatch<MODEL>* st = nullptr, bool* miss = nullptr, int max_outer = 100,
+                                              bool* capped = nullptr) {
   if (MODEL == kCentral) {
     double d[3] = {local[0], local[1], local[2]};
     normalize3(d[0], d[1], d[2]);
-    return project_target<MODEL, STG>(c, s, d, px, py, st, miss);
+    return project_target<MODEL, STG>(c, s, d, px, py, st, miss, max_outer, capped);
   } else {
-    return project_target<MODEL, STG>(c, s, local, px, py, st, miss);
+    return project_target<MODEL, STG>(c, s, local, px, py, st, miss, max_outer, capped);
   }
 }
 

@@ -62,7 +62,7 @@ class CbaReport(C.Structure):
 EXPORTED_SYMBOLS = [
     "cba_last_error", "cba_version", "cba_create", "cba_destroy", "cba_set_observations", "cba_set_state",
     "cba_get_state", "cba_get_last_projection", "cba_step", "cba_cost", "cba_project", "cba_unproject",
-    "cba_schur_solve", "cba_debug_dump", "cba_debug_accumulate", "cba_debug_solve", "cba_debug_apply_update",
+    "cba_schur_solve", "cba_debug_dump", "cba_debug_accumulate", "cba_set_straggler_threshold", "cba_debug_solve", "cba_debug_apply_update",
     "cba_total_dof", "cba_dense_dof", "cba_jacobian_record_doubles", "cba_reduce_buffer_doubles",
     "cba_kernel_stats", "cba_fit_grid_to_directions", "cba_prepare_device",
     "cba_model_create", "cba_model_destroy", "cba_model_set_grid", "cba_model_project", "cba_model_unproject",
@@ -114,6 +114,7 @@ def load() -> C.CDLL:
     L.cba_fit_grid_to_directions.argtypes = [C.POINTER(CbaCamera), dp, C.c_int64, dp, dp, C.c_int32, C.POINTER(CbaFitReport), C.c_int32]
     L.cba_debug_dump.argtypes = [vp, C.c_int32, vp, C.c_size_t]
     L.cba_debug_accumulate.argtypes = [vp, dp]
+    L.cba_set_straggler_threshold.argtypes = [vp, C.c_int32]
     L.cba_debug_solve.argtypes = [vp, C.c_double]
     L.cba_debug_apply_update.argtypes = [vp, dp]
     L.cba_total_dof.argtypes = [vp]
@@ -270,6 +271,10 @@ class Engine:
         return dict(seconds=s.value, flops=f.value, bytes=b.value, launches=n.value)
 
     # -- parity / debug ----------------------------------------------------------------------------
+    def set_straggler_threshold(self, outer_iterations: int) -> None:
+        """cba_set_straggler_threshold: outer projection iterations before an observation goes to the straggler kernel."""
+        _check(self.L.cba_set_straggler_threshold(self._h, int(outer_iterations)), "cba_set_straggler_threshold")
+
     def debug_accumulate(self) -> float:
         cost = C.c_double(0)
         _check(self.L.cba_debug_accumulate(self._h, C.byref(cost)), "cba_debug_accumulate")

@@ -345,11 +345,17 @@ static void tangents_jacobian_wrt_direction(const double* d, double* J) {
  * non-central: NoncentralGenericModel::ProjectWithInitialEstimate (noncentral_generic.cc:156-264).
  * target: unit direction (central) or the local point (non-central). Returns 1 on convergence,
  * 0 on failure, -1 where the reference CHECK()-aborts. */
+/* developer aid (tools/projection_iteration_histogram.py): B-spline evaluations spent by this thread's projections */
+static _Thread_local long g_eval_count = 0;
+static int32_t* g_eval_trace = NULL;            /* per observation: evaluations of its base projection */
+void orc_debug_set_eval_trace(int32_t* per_observation) { g_eval_trace = per_observation; }
+
 static int project_target(const orc_camera* cam, const double* grid, const double* target, double* result) {
   const double kEpsilon = 1e-12;
   double lambda = -1;
   for (int it = 0; it < 100; ++it) {
     double line[6], J[12];
+    ++g_eval_count;
     if (!orc_unproject_with_jacobian(cam, grid, result[0], result[1], line, J)) return -1;
     double cost, H00, H01, H11, b0, b1;
     if (cam->model_type == ORC_CENTRAL_GENERIC) {
@@ -407,6 +413,7 @@ static int project_target(const orc_camera* cam, const double* grid, const doubl
       }
       double test_cost = INFINITY;
       double tl[6];
+      ++g_eval_count;
       if (orc_unproject(cam, grid, tx, ty, tl)) {
         if (cam->model_type == ORC_CENTRAL_GENERIC) {
           double ex = tl[0] - target[0], ey = tl[1] - target[1], ez = tl[2] - target[2];
@@ -777,13 +784,16 @@ static double add_reprojection_residual(pass_ctx* ctx, int64_t o, const double* 
   double pixel[2] = {pb->last_projection[2 * o], pb->last_projection[2 * o + 1]};
   if (!in_calibrated_area(cam, pixel[0], pixel[1]) || pixel[0] != pixel[0] || pixel[1] != pixel[1])
     center_of_calibrated_area(cam, pixel);
+  const long evals0 = g_eval_count;
   if (!orc_project_with_initial_estimate(cam, grid, local, pixel)) {
     center_of_calibrated_area(cam, pixel);
     if (!orc_project_with_initial_estimate(cam, grid, local, pixel)) {
+      if (g_eval_trace) g_eval_trace[o] = (int32_t)(g_eval_count - evals0);
       if (rec) rec->cost = -1;
       return -1;
     }
   }
+  if (g_eval_trace) g_eval_trace[o] = (int32_t)(g_eval_count - evals0);
   pb->last_projection[2 * o] = pixel[0];
   pb->last_projection[2 * o + 1] = pixel[1];
 

@@ -98,6 +98,8 @@ typedef struct {
  * n <= 0 selects all hardware threads.  Default 1 (the reference path is single-threaded).  Results do not depend on
  * the thread count (bit-identical): threads split independent per-observation work and cache tiles only. */
 void orc_set_num_threads(int n);
+/* developer aid: per-observation count of B-spline evaluations of the base projection in the following passes (NULL = off) */
+void orc_debug_set_eval_trace(int32_t* per_observation);
 int orc_get_num_threads(void);
 int orc_hardware_threads(void);
 
