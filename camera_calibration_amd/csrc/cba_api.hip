@@ -132,8 +132,8 @@ struct cba_problem {
   // centre of their observations so that the 16-row K slabs of the Schur product touch few grid tiles.
   std::vector<int> pose_slot_host; int* pose_slot = nullptr;
   // straggler split of the Jacobian pass (see PassArgs)
-  uint8_t* slow_skip = nullptr; int* slow_list = nullptr; int* slow_count = nullptr;
-  int straggler_threshold = 12;   // outer projection iterations before an observation goes to the straggler kernel
+  uint8_t* slow_skip = nullptr; uint8_t* fd_slow = nullptr; int* slow_list = nullptr; int* slow_count = nullptr;
+  int straggler_threshold = 8;    // outer projection iterations before an observation goes to the straggler kernel
   int64_t* img_start = nullptr;          // first observation of every imageset (+ end), for the strip accumulation
   unsigned* band_mask = nullptr;         // per observation: column bands of B it touches
   // the side stream is the factorisation's far stream (idle during the Jacobian pass): the process must stay
@@ -300,7 +300,7 @@ static int allreduce(cba_problem* p, double* dev, int64_t count) {
 static int residual_pass(cba_problem* p, int which, double* cost_vec) {
   CBA_TRY(launch_compose_poses(p->st[which], p->L.n_images, p->L.n_cameras, p->itg, p->stream));
   PassArgs a = pass_args(p, which);
-  CBA_TRY(launch_base_project(a, p->model_mask, cost_vec, p->pixels, p->flags, p->slow_list, p->slow_count, kSlowCap, p->slow_skip, p->straggler_threshold, p->stream));
+  CBA_TRY(launch_base_project(a, p->model_mask, cost_vec, p->pixels, p->flags, p->slow_list, p->slow_count, kSlowCap, p->slow_skip, p->straggler_threshold, nullptr, p->stream));
   PassArgs as = a;
   as.obs_list = p->slow_list; as.obs_count = p->slow_count; as.obs_list_cap = kSlowCap;
   CBA_TRY(launch_base_project_slow(as, p->model_mask, cost_vec, p->pixels, p->flags, p->stream));
@@ -330,7 +330,7 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
     CBA_HIP(hipMemsetAsync(p->B + (size_t)L.block_dof * p->n_pad, 0, sizeof(double) * (size_t)(p->Kpad - L.block_dof) * p->n_pad, aux));
   CBA_HIP(hipMemsetAsync(p->Hdd, 0, sizeof(double) * (size_t)p->n_pad * p->n_pad, aux));
   CBA_HIP(hipMemsetAsync(p->bd, 0, sizeof(double) * (size_t)p->n_pad, aux));
-  CBA_TRY(launch_base_project(a, p->model_mask, p->cost_ref, p->pixels, p->flags, p->slow_list, p->slow_count, kSlowCap, p->slow_skip, p->straggler_threshold, p->stream));
+  CBA_TRY(launch_base_project(a, p->model_mask, p->cost_ref, p->pixels, p->flags, p->slow_list, p->slow_count, kSlowCap, p->slow_skip, p->straggler_threshold, p->fd_slow, p->stream));
   // ... and the stragglers of the base projection (long projection chains, see k_base_project_slow) are finished there,
   // followed by their finite-difference tasks, underneath the main finite-difference launch
   CBA_HIP(hipEventRecord(p->ev_aux2, p->stream));
@@ -346,7 +346,7 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   // (Running the assembly / accumulation of one chunk of imagesets next to the finite-difference launches of the
   // next chunk was measured and gained nothing: the two share the same CUs and the sum stayed the same.)
   CBA_TRY(launch_assemble(a, L, p->st[w], p->tasks_per_obs, p->rec_doubles, p->pixels, p->flags, p->fd_out, p->fd_ok,
-                          p->jrec, p->cells, p->stream));
+                          p->jrec, p->cells, p->fd_slow, p->stream));
   double t0 = now_s();
   CBA_TRY(timer_begin(p, 2));
   AccumTargets T{p->Dblk, p->bblk, p->B, p->Hdd, p->bd};
@@ -604,7 +604,7 @@ void cba_destroy(cba_problem* p) {
   ldlt_workspace_free(p->ldlt);
   for (auto& t : p->timers) for (auto& sp : t.spans) { hipEventDestroy(sp.e0); hipEventDestroy(sp.e1); }
   if (p->kmask_host) hipHostFree(p->kmask_host);
-  F(p->slow_skip); F(p->slow_list); F(p->slow_count); F(p->img_start); F(p->band_mask); F(p->det_bits); F(p->det_scale); F(p->fd_redo[0]); F(p->fd_redo[1]); F(p->fd_redo_count);
+  F(p->slow_skip); F(p->fd_slow); F(p->slow_list); F(p->slow_count); F(p->img_start); F(p->band_mask); F(p->det_bits); F(p->det_scale); F(p->fd_redo[0]); F(p->fd_redo[1]); F(p->fd_redo_count);
   if (p->ev_aux0) hipEventDestroy(p->ev_aux0);
   if (p->ev_aux1) hipEventDestroy(p->ev_aux1);
   if (p->ev_aux2) hipEventDestroy(p->ev_aux2);
@@ -650,6 +650,9 @@ int cba_set_observations(cba_problem* p, int64_t n, const float* xy, const int32
   F(p->slow_skip); p->slow_skip = nullptr;
   CBA_TRY(dev_alloc(&p->slow_skip, (size_t)(n > 0 ? n : 1)));
   CBA_HIP(hipMemset(p->slow_skip, 0, (size_t)(n > 0 ? n : 1)));
+  F(p->fd_slow); p->fd_slow = nullptr;
+  CBA_TRY(dev_alloc(&p->fd_slow, (size_t)(n > 0 ? n : 1)));
+  CBA_HIP(hipMemset(p->fd_slow, 0, (size_t)(n > 0 ? n : 1)));
   CBA_HIP(hipMemset(p->slow_count, 0, sizeof(int)));
   if (n > 0) {
     CBA_HIP(hipMemcpy(p->obs_xy, xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice));

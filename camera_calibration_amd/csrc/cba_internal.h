@@ -73,7 +73,7 @@ int launch_tangents(const double* dir_grid, double* tang, int G, hipStream_t s);
 // base projection of every observation; lanes that exceed the iteration cap are appended to defer_list (and marked in
 // defer_skip) for launch_base_project_slow, which takes the list through PassArgs::obs_list / obs_count / obs_list_cap
 int launch_base_project(const PassArgs& a, int model_mask, double* cost_vec, double* pixels, uint8_t* flags, int* defer_list,
-                        int* defer_count, int defer_cap, uint8_t* defer_skip, int outer_cap, hipStream_t s);
+                        int* defer_count, int defer_cap, uint8_t* defer_skip, int outer_cap, const uint8_t* fd_slow, hipStream_t s);
 int launch_base_project_slow(const PassArgs& a, int model_mask, double* cost_vec, double* pixels, uint8_t* flags, hipStream_t s);
 // redo / redo_count: device work list (65 536 entries / one int) for the tasks that leave their staged patch
 int launch_fd_tasks(const PassArgs& a, int model_mask, int tasks_per_obs, int localize_only, const double* pixels,
@@ -81,7 +81,7 @@ int launch_fd_tasks(const PassArgs& a, int model_mask, int tasks_per_obs, int lo
 constexpr int kFdRedoEntries = 1 << 16;
 int launch_assemble(const PassArgs& a, const Layout& L, const DevState& st, int tasks_per_obs, int rec_doubles,
                     const double* pixels, uint8_t* flags, const double* fd_out, const uint8_t* fd_ok, double* jrec,
-                    int* cells, hipStream_t s);
+                    int* cells, uint8_t* fd_slow, hipStream_t s);
 struct AccumTargets {
   double* Dblk; double* bblk; double* B; double* Hdd; double* bd;
 };

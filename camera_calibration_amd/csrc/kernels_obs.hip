@@ -139,7 +139,7 @@ __device__ __forceinline__ void local_point_of(const PassArgs& a, int64_t o, int
 // iterations with up to 10 damping attempts each, twice (warm start and centre): ~600 B-spline evaluations, 1.5 ms for a
 // single lane, and a pass cannot end before its slowest lane (0.4 % of the observations of the BASELINE configs fail from
 // the perturbed initial state: points whose projection is pinned at the border of the calibrated area, or that settle in a
-// local minimum next to it).  So a lane gives up after `outer_cap` (default 12) outer iterations of either attempt and puts its
+// local minimum next to it).  So a lane gives up after `outer_cap` (default 8) outer iterations of either attempt and puts its
 // observation on the straggler list; k_base_project_slow then runs the COMPLETE procedure for the list with 16 lanes per
 // observation.  Nothing of the 100 x 10 semantics is cut short, the long chains are only evaluated faster.
 
@@ -180,7 +180,8 @@ template <int MODEL>
 __global__ void __launch_bounds__(256) k_base_project(PassArgs a, double* __restrict__ cost_vec,
                                                       double* __restrict__ pixels, uint8_t* __restrict__ flags,
                                                       int* __restrict__ defer_list, int* __restrict__ defer_count, int defer_cap,
-                                                      uint8_t* __restrict__ defer_skip, int outer_cap) {
+                                                      uint8_t* __restrict__ defer_skip, int outer_cap,
+                                                      const uint8_t* __restrict__ fd_slow) {
   const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= a.n_obs) return;
   const int cam = a.obs_camera[o];
@@ -191,10 +192,12 @@ __global__ void __launch_bounds__(256) k_base_project(PassArgs a, double* __rest
   double px, py;
   bool capped;
   bool ok = base_projection<MODEL>(a, c, o, local, outer_cap, capped, px, py);
-  if (capped) {
+  // fd_slow (Jacobian pass only): a finite-difference projection of this observation failed in the previous Jacobian pass;
+  // the whole observation goes to the list so that its tasks run on the side stream
+  if (capped || (fd_slow && fd_slow[o])) {
     const int idx = atomicAdd(defer_count, 1);
     if (idx < defer_cap) { defer_list[idx] = (int)o; defer_skip[o] = 1; return; }
-    ok = base_projection<MODEL>(a, c, o, local, 100, capped, px, py);     // list full: the one-lane path, to the end
+    if (capped) ok = base_projection<MODEL>(a, c, o, local, 100, capped, px, py);     // list full: the one-lane path, to the end
   }
   defer_skip[o] = 0;
   store_base_projection(a, o, ok, px, py, cost_vec, pixels, flags);
@@ -329,12 +332,12 @@ __global__ void __launch_bounds__(256) k_base_project_slow(PassArgs a, double* _
 // Main launch (one lane per observation, stragglers deferred) followed by the straggler launch on `s_slow` (the same stream
 // in a cost pass; the Jacobian pass passes its side stream and orders it with `ev_main_done`).
 int launch_base_project(const PassArgs& a, int model_mask, double* cost_vec, double* pixels, uint8_t* flags, int* defer_list,
-                        int* defer_count, int defer_cap, uint8_t* defer_skip, int outer_cap, hipStream_t s) {
+                        int* defer_count, int defer_cap, uint8_t* defer_skip, int outer_cap, const uint8_t* fd_slow, hipStream_t s) {
   if (a.n_obs == 0) return CBA_OK;
   CBA_HIP(hipMemsetAsync(defer_count, 0, sizeof(int), s));
   dim3 grid((unsigned)((a.n_obs + 255) / 256)), block(256);
-  if (model_mask & 1) hipLaunchKernelGGL(k_base_project<kCentral>, grid, block, 0, s, a, cost_vec, pixels, flags, defer_list, defer_count, defer_cap, defer_skip, outer_cap);
-  if (model_mask & 2) hipLaunchKernelGGL(k_base_project<kNoncentral>, grid, block, 0, s, a, cost_vec, pixels, flags, defer_list, defer_count, defer_cap, defer_skip, outer_cap);
+  if (model_mask & 1) hipLaunchKernelGGL(k_base_project<kCentral>, grid, block, 0, s, a, cost_vec, pixels, flags, defer_list, defer_count, defer_cap, defer_skip, outer_cap, fd_slow);
+  if (model_mask & 2) hipLaunchKernelGGL(k_base_project<kNoncentral>, grid, block, 0, s, a, cost_vec, pixels, flags, defer_list, defer_count, defer_cap, defer_skip, outer_cap, fd_slow);
   CBA_HIP(hipGetLastError());
   return CBA_OK;
 }
@@ -663,12 +666,15 @@ __global__ void __launch_bounds__(256) k_assemble(PassArgs a, int rig_in_state, 
                                                   int tasks_per_obs, int rec_doubles, const double* __restrict__ pixels,
                                                   uint8_t* __restrict__ flags, const double* __restrict__ fd_out,
                                                   const uint8_t* __restrict__ fd_ok, double* __restrict__ jrec,
-                                                  int* __restrict__ cells) {
+                                                  int* __restrict__ cells, uint8_t* __restrict__ fd_slow) {
   const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   // the header of a record is one lane's work; the 2 x K_g grid part is copied by the whole wavefront afterwards
   // (one lane writing its own 0.8 KB record puts 64 uncoalesced streams on the memory system)
   const bool with_jacobian = assemble_header(a, o, rig_in_state, localize_only, rig7, camrig7, tasks_per_obs, rec_doubles, pixels, flags,
                                              fd_out, fd_ok, jrec, cells);
+  // a residual that lost its Jacobian has a finite-difference projection that FAILED, i.e. ran its whole iteration budget
+  // (5-8 ms for one lane at the non-central config): next time its tasks run on the side stream (k_base_project)
+  if (o < a.n_obs) fd_slow[o] = flags[o] == 1;
   unsigned long long todo = __ballot(with_jacobian);
   const int lane = threadIdx.x & 63;
   const int64_t o0 = o - lane;
@@ -684,11 +690,11 @@ __global__ void __launch_bounds__(256) k_assemble(PassArgs a, int rig_in_state, 
 }
 int launch_assemble(const PassArgs& a, const Layout& L, const DevState& st, int tasks_per_obs, int rec_doubles,
                     const double* pixels, uint8_t* flags, const double* fd_out, const uint8_t* fd_ok, double* jrec,
-                    int* cells, hipStream_t s) {
+                    int* cells, uint8_t* fd_slow, hipStream_t s) {
   if (a.n_obs == 0) return CBA_OK;
   hipLaunchKernelGGL(k_assemble, dim3((unsigned)((a.n_obs + 255) / 256)), dim3(256), 0, s, a, L.rig_in_state,
                      L.localize_only, st.rig_tr_global, st.camera_tr_rig, tasks_per_obs, rec_doubles, pixels, flags,
-                     fd_out, fd_ok, jrec, cells);
+                     fd_out, fd_ok, jrec, cells, fd_slow);
   CBA_HIP(hipGetLastError());
   return CBA_OK;
 }

@@ -205,7 +205,7 @@ enum {
 int cba_debug_dump(cba_problem* p, int32_t what, void* out, size_t bytes);
 /* Tuning knob of the base projection (AddReprojectionResidual's ProjectWithInitialEstimate, joint_optimization.cc:325-343).
  * The one-lane-per-observation kernel hands an observation to the straggler kernel (16 lanes per observation, the same
- * 100 x 10-iteration procedure evaluated speculatively) after this many outer iterations; default 12.  0 sends every
+ * 100 x 10-iteration procedure evaluated speculatively) after this many outer iterations; default 8.  0 sends every
  * observation there (the tests use it to compare the two kernels), >= 100 disables the hand-over.  Results do not depend
  * on the value. */
 int cba_set_straggler_threshold(cba_problem* p, int32_t outer_iterations);

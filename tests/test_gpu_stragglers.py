@@ -25,7 +25,7 @@ def test_straggler_kernel_is_bit_identical_to_the_one_lane_kernel(config, n_imag
     pb, st, _ = syn.baseline_config(config, _gpu_project, n_imagesets=n_imagesets, grid_wh=grid_wh)
     assert pb.n_obs <= 16384          # capacity of the straggler list: every observation fits
     out = {}
-    for name, thr in (("one-lane only", 100), ("default", 12), ("stragglers only", 0)):
+    for name, thr in (("one-lane only", 100), ("default", 8), ("stragglers only", 0)):
         e = eng.Engine(pb, deterministic=True)
         e.set_straggler_threshold(thr)
         e.set_state(st)
