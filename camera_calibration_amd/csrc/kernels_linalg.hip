@@ -155,6 +155,10 @@ struct GemmArgs {
   int epi_mode;                 // bench harness only (tools/bench_linalg.hip): 0 normal, 1 no Cin read, 2 no store
 #endif
   int strips;                   // set by launch_gemm: strip-blocked tile order (square upper dense launches)
+  // SE-balanced slot assignment (128 x 128 launches on a CU-masked stream, set by launch_gemm; null = slot = blockIdx.x)
+  unsigned* dyn;                // device counters: [0..7] next slot of each XCD, [8 + 8 xcc + se] workgroups seen by a short SE, [72] finished
+  unsigned se_cus[8];           // per XCD: CUs available to the stream in SE k, 4 bits each
+  int se_max;                   // CUs of a complete SE
   const double* a_rowdiv;       // small-tile variants only: A[k][m] is divided by a_rowdiv[k] while staged (L = X / d on the fly)
   int tlog_tag;                 // developer timeline (tools/bench_linalg.hip, -DCBA_TLOG): tag + 1, 0 = none
 };
@@ -486,6 +490,49 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
   return true;
 }
 
+// Slot of this workgroup on a CU-masked stream.  The dispatcher hands out workgroups IN ORDER and evenly over the shader
+// engines (tools/dispatch_probe.hip: 114-115 of 3655 workgroups for every one of the 32 SEs, whether an SE has 8 CUs or 7),
+// so an SE that lost a CU to the pivot chain's reservation sets the pace of the whole launch: 8 / 7 of the time, the
+// 12-14 % a CU mask costs the bulk update whatever the number of reserved CUs (8, 16 and 32 gave the same rate).  Here a
+// workgroup that lands on a short SE exits at once one time in `se_max` per missing CU (the grid is oversubscribed by the
+// same ratio), so every CU ends up with the same number of tiles; the tile comes from the counter of the XCD the
+// workgroup really runs on (HW_REG_XCC_ID -- user streams rotate the blockIdx -> XCD map by a per-queue constant), which
+// keeps the chunked tile order and its L2 sharing.
+__device__ __forceinline__ long long gemm_dynamic_slot(const GemmArgs& g) {
+  __shared__ long long s_slot;
+  if (threadIdx.x == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7u;          // HW_REG_XCC_ID
+    const unsigned se = (__builtin_amdgcn_s_getreg((32 - 1) << 11 | 4) >> 13) & 7u;   // HW_REG_HW_ID: se_id
+    const unsigned cnt = (g.se_cus[xcc] >> (4 * se)) & 15u;
+    long long b = -1;
+    bool skip = false;
+    if (cnt < (unsigned)g.se_max) {
+      const unsigned c = atomicAdd(&g.dyn[8 + 8 * xcc + se], 1u);
+      skip = (c % (unsigned)g.se_max) >= cnt;
+    }
+    if (!skip) {
+      for (unsigned d = 0; d < 8; ++d) {           // own XCD first, then whoever still has tiles
+        const unsigned x2 = (xcc + d) & 7u;
+        const long long bb = (long long)atomicAdd(&g.dyn[x2], 1u) * 8 + x2;
+        if (gemm_slot_tile(g, bb) < g.total_tiles) { b = bb; break; }
+      }
+    }
+    s_slot = b;
+  }
+  __syncthreads();
+  return s_slot;
+}
+// the last workgroup to finish leaves the counters zeroed for the next launch on this stream
+__device__ __forceinline__ void gemm_dynamic_done(const GemmArgs& g) {
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&g.dyn[72], 1u) == gridDim.x - 1) {
+      for (int i = 0; i < 73; ++i) g.dyn[i] = 0u;
+      __threadfence();
+    }
+  }
+}
+
 // One tile per workgroup.  Two alternatives to the CU mask on the main stream were measured and dropped (the mask costs
 // the bulk update 13-17 %: the same launch takes 1402 us on the masked stream and 1161 us on an unmasked one,
 // tools/bench_linalg.hip -DCBA_TLOG): (a) drawing the slot from per-XCD counters with an oversubscribed grid on the
@@ -497,9 +544,23 @@ template <int TM, int TN, int WM, int WN, bool SUB>
 __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
   if constexpr (TM < 128) __builtin_amdgcn_s_setprio(2);   // panel-sized products are on the critical path
   tlog_begin(g.tlog_tag - 1);
+  if constexpr (TM == 128 && TN == 128) {
+    if (g.dyn) {
+      const long long b = gemm_dynamic_slot(g);
+      if (b >= 0) gemm_tile<TM, TN, WM, WN, SUB>(g, b);
+      gemm_dynamic_done(g);
+      tlog_end(g.tlog_tag - 1);
+      return;
+    }
+  }
   gemm_tile<TM, TN, WM, WN, SUB>(g, blockIdx.x);
   tlog_end(g.tlog_tag - 1);
 }
+
+// CU layout of the engine's masked streams (filled by device_streams(), further down): which shader engines are short of
+// CUs, and a zeroed counter block per stream for gemm_dynamic_slot
+struct SeBalance { unsigned* counters; unsigned se_cus[8]; int se_max, cus_total, cus_full; };
+static bool se_balance_for_stream(hipStream_t s, SeBalance* out);
 
 static long long count_upper_tiles(int m_off, int n_off, int m_tiles, int n_tiles, int TM, int TN) {
   long long total = 0;
@@ -527,6 +588,17 @@ static int launch_gemm(GemmArgs g, hipStream_t s) {
               g.total_tiles >= 512) ? 1 : 0;
   long long chunks = (g.total_tiles + g.chunk - 1) / g.chunk;
   long long blocks = ((chunks + 7) / 8) * 8 * g.chunk;
+  g.dyn = nullptr;
+  if constexpr (TM == 128 && TN == 128) {
+    SeBalance sb;
+    // (launches with K = 256 are too short for the extra atomics to pay: 40.1 vs 42.1 TFLOP/s, profiles/r02_se_balance_ab.txt)
+    if (g.K >= 512 && se_balance_for_stream(s, &sb) && g.total_tiles >= 2 * sb.cus_total) {
+      g.dyn = sb.counters; g.se_max = sb.se_max;
+      for (int i = 0; i < 8; ++i) g.se_cus[i] = sb.se_cus[i];
+      // oversubscribed by (all CUs of the complete SEs) / (CUs available), plus the workgroups that arrive after the last tile
+      blocks = (g.total_tiles * sb.cus_full + sb.cus_total - 1) / sb.cus_total + 64;
+    }
+  }
   hipLaunchKernelGGL((k_gemm_atb<TM, TN, WM, WN, SUB>), dim3((unsigned)blocks), dim3(256), 0, s, g);
   CBA_HIP(hipGetLastError());
   return CBA_OK;
@@ -1308,7 +1380,24 @@ void panel_cu_mask(uint32_t* mask8, bool panel) {
 //           XCD; mask bits are interleaved over the XCDs)
 //   mid   : look-ahead work of the wide panels, on the same reserved CUs
 //   far   : wide launches next to the bulk update (and the Jacobian pass' stragglers); same mask as main
-struct DeviceStreams { hipStream_t main = nullptr, chain = nullptr, mid = nullptr, far = nullptr; };
+struct DeviceStreams {
+  hipStream_t main = nullptr, chain = nullptr, mid = nullptr, far = nullptr;
+  // shader-engine census of the main / far mask (k_cu_census) and the counter blocks of gemm_dynamic_slot
+  bool short_se = false;
+  unsigned se_cus[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int se_max = 0, cus_total = 0, cus_full = 0;
+  unsigned* counters = nullptr;      // [2][80]: main, far
+};
+// every workgroup marks the CU it runs on: out[8 xcc + se] |= 1 << cu_id
+__global__ void k_cu_census(unsigned* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7u;
+    const unsigned hw = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);
+    atomicOr(&out[8 * xcc + ((hw >> 13) & 7u)], 1u << ((hw >> 8) & 15u));
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < 300) {}          // 3 us: long enough for the launch to spread over every CU
+  }
+}
 static std::mutex g_streams_mutex;
 static std::map<int, DeviceStreams> g_streams;
 static int device_streams(DeviceStreams* out) {
@@ -1326,6 +1415,30 @@ static int device_streams(DeviceStreams* out) {
       CBA_HIP(hipExtStreamCreateWithCUMask(&d.chain, 8, panel));
       CBA_HIP(hipExtStreamCreateWithCUMask(&d.mid, 8, panel));
       CBA_HIP(hipExtStreamCreateWithCUMask(&d.far, 8, rest));
+      // census of the CUs the main / far mask leaves, per (XCD, shader engine)
+      CBA_HIP(hipMalloc(&d.counters, sizeof(unsigned) * 160));
+      CBA_HIP(hipMemset(d.counters, 0, sizeof(unsigned) * 160));
+      hipLaunchKernelGGL(k_cu_census, dim3(32768), dim3(64), 0, d.main, d.counters);
+      unsigned seen[64];
+      CBA_HIP(hipStreamSynchronize(d.main));
+      CBA_HIP(hipMemcpy(seen, d.counters, sizeof(seen), hipMemcpyDeviceToHost));
+      CBA_HIP(hipMemset(d.counters, 0, sizeof(unsigned) * 160));
+      int n_se = 0;
+      for (int x = 0; x < 8; ++x)
+        for (int e = 0; e < 8; ++e) {
+          const int c = __builtin_popcount(seen[8 * x + e]);
+          if (c > 15) { d.se_max = 0; break; }
+          d.se_cus[x] |= (unsigned)c << (4 * e);
+          d.cus_total += c;
+          if (c > 0) ++n_se;
+          if (c > d.se_max) d.se_max = c;
+        }
+      d.cus_full = n_se * d.se_max;
+      d.short_se = d.se_max > 0 && d.cus_total < d.cus_full;
+      // SEs that the mask leaves empty get no workgroups at all: they must not count as "short"
+      for (int x = 0; x < 8; ++x)
+        for (int e = 0; e < 8; ++e)
+          if (((d.se_cus[x] >> (4 * e)) & 15u) == 0) d.se_cus[x] |= (unsigned)(d.se_max & 15) << (4 * e);
     } else {
       int lo = 0, hi = 0;
       CBA_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -1340,6 +1453,21 @@ static int device_streams(DeviceStreams* out) {
   return CBA_OK;
 }
 int prepare_device_streams() { DeviceStreams d; return device_streams(&d); }
+static bool se_balance_for_stream(hipStream_t s, SeBalance* out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lock(g_streams_mutex);
+  auto it = g_streams.find(dev);
+  if (it == g_streams.end() || !it->second.short_se || s == nullptr) return false;
+  static const bool off = CBA_GETENV("CBA_NO_SE_BALANCE") != nullptr;      // developer switch (bench harness only)
+  if (off) return false;
+  const DeviceStreams& d = it->second;
+  if (s != d.main && s != d.far) return false;
+  out->counters = d.counters + (s == d.far ? 80 : 0);
+  for (int i = 0; i < 8; ++i) out->se_cus[i] = d.se_cus[i];
+  out->se_max = d.se_max; out->cus_total = d.cus_total; out->cus_full = d.cus_full;
+  return true;
+}
 
 int make_main_stream(hipStream_t* s) {
   DeviceStreams d;
