@@ -540,9 +540,26 @@ __device__ __forceinline__ void gemm_dynamic_done(const GemmArgs& g) {
 // workgroups on an unmasked stream that exit when they find themselves on a CU reserved for the pivot chain ran the
 // bulk update at the unmasked speed, but two resident workgroups per CU left no LDS for the far stream's launches and
 // the look-ahead collapsed (factorisation 18.0 -> 18.6 ms).
+#ifdef CBA_WGLOG
+// developer harness (tools/gemm_wg_timeline.hip): per workgroup {start, end (100 MHz wall clock), XCC_ID, HW_ID}
+__device__ unsigned long long* g_wglog = nullptr;
+#endif
 template <int TM, int TN, int WM, int WN, bool SUB>
 __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
   if constexpr (TM < 128) __builtin_amdgcn_s_setprio(2);   // panel-sized products are on the critical path
+#ifdef CBA_WGLOG
+  struct WgLog {
+    unsigned long long t0;
+    __device__ WgLog() : t0(wall_clock64()) {}
+    __device__ ~WgLog() {
+      if (g_wglog && threadIdx.x == 0) {
+        unsigned long long* e = g_wglog + 4 * (size_t)blockIdx.x;
+        e[0] = t0; e[1] = wall_clock64();
+        e[2] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7u; e[3] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);
+      }
+    }
+  } wglog;
+#endif
   tlog_begin(g.tlog_tag - 1);
   if constexpr (TM == 128 && TN == 128) {
     if (g.dyn) {
