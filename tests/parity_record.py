@@ -39,8 +39,12 @@ def _flush():
                 old = {f"{r['case']}/{r['quantity']}": r for r in json.load(f).get("rows", [])}
         old.update(_rows)
         host = dict(cpu_count=os.cpu_count())
+        policy = ("one tolerance per quantity, shared by all cases of a test: about 10x the largest value seen over the cases AND "
+                  "over the GPU runs of the round (the default accumulation uses floating-point atomics, so the same row moves by "
+                  "up to two orders of magnitude from run to run); rows whose quantity names a bound (fp32 ulp of sinf / cosf, the "
+                  "reference's own criterion) are checked against that bound; exact = true rows must be 0")
         with open(_OUT, "w") as f:
-            json.dump(dict(host=host, rows=sorted(old.values(), key=lambda r: (r["case"], r["quantity"]))), f, indent=1)
+            json.dump(dict(host=host, tolerance_policy=policy, rows=sorted(old.values(), key=lambda r: (r["case"], r["quantity"]))), f, indent=1)
     except OSError:
         pass
 
