@@ -156,7 +156,8 @@ struct GemmArgs {
 #endif
   int strips;                   // set by launch_gemm: strip-blocked tile order (square upper dense launches)
   // SE-balanced slot assignment (128 x 128 launches on a CU-masked stream, set by launch_gemm; null = slot = blockIdx.x)
-  unsigned* dyn;                // device counters: [0..7] next slot of each XCD, [8 + 8 xcc + se] workgroups seen by a short SE, [72] finished
+  unsigned* dyn;                // device counters: [0..7] next slot of each XCD, [8 + 8 xcc + se] workgroups seen by a short SE, [72] finished, [73] skipped
+  unsigned skip_budget;         // workgroups that may exit without a tile (grid - tiles - reserve): the rest MUST take one
   unsigned se_cus[8];           // per XCD: CUs available to the stream in SE k, 4 bits each
   int se_max;                   // CUs of a complete SE
   const double* a_rowdiv;       // small-tile variants only: A[k][m] is divided by a_rowdiv[k] while staged (L = X / d on the fly)
@@ -508,7 +509,8 @@ __device__ __forceinline__ long long gemm_dynamic_slot(const GemmArgs& g) {
     bool skip = false;
     if (cnt < (unsigned)g.se_max) {
       const unsigned c = atomicAdd(&g.dyn[8 + 8 * xcc + se], 1u);
-      skip = (c % (unsigned)g.se_max) >= cnt;
+      // the budget keeps the launch complete whatever the dispatcher does: at most grid - tiles - reserve workgroups skip
+      if ((c % (unsigned)g.se_max) >= cnt) skip = atomicAdd(&g.dyn[73], 1u) < g.skip_budget;
     }
     if (!skip) {
       for (unsigned d = 0; d < 8; ++d) {           // own XCD first, then whoever still has tiles
@@ -527,7 +529,7 @@ __device__ __forceinline__ void gemm_dynamic_done(const GemmArgs& g) {
   if (threadIdx.x == 0) {
     __threadfence();
     if (atomicAdd(&g.dyn[72], 1u) == gridDim.x - 1) {
-      for (int i = 0; i < 73; ++i) g.dyn[i] = 0u;
+      for (int i = 0; i < 74; ++i) g.dyn[i] = 0u;
       __threadfence();
     }
   }
@@ -614,6 +616,7 @@ static int launch_gemm(GemmArgs g, hipStream_t s) {
       for (int i = 0; i < 8; ++i) g.se_cus[i] = sb.se_cus[i];
       // oversubscribed by (all CUs of the complete SEs) / (CUs available), plus the workgroups that arrive after the last tile
       blocks = (g.total_tiles * sb.cus_full + sb.cus_total - 1) / sb.cus_total + 64;
+      g.skip_budget = (unsigned)(blocks - g.total_tiles - 32);
     }
   }
   hipLaunchKernelGGL((k_gemm_atb<TM, TN, WM, WN, SUB>), dim3((unsigned)blocks), dim3(256), 0, s, g);
