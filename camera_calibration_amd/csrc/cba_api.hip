@@ -103,6 +103,8 @@ struct KernelTimer {
   int launches = 0;
 };
 
+constexpr int kSlowCapMin = 16384;   // capacity of the straggler list: max(this, n_obs / 8), set with the observations
+
 struct cba_problem {
   cba_config cfg{};
   std::vector<cba_camera> cams;
@@ -133,6 +135,7 @@ struct cba_problem {
   std::vector<int> pose_slot_host; int* pose_slot = nullptr;
   // straggler split of the Jacobian pass (see PassArgs)
   uint8_t* slow_skip = nullptr; uint8_t* fd_slow = nullptr; int* slow_list = nullptr; int* slow_count = nullptr;
+  int slow_cap = kSlowCapMin;
   int straggler_threshold = 8;    // outer projection iterations before an observation goes to the straggler kernel
   int64_t* img_start = nullptr;          // first observation of every imageset (+ end), for the strip accumulation
   unsigned* band_mask = nullptr;         // per observation: column bands of B it touches
@@ -163,7 +166,6 @@ struct cba_problem {
 
 namespace cba {
 
-constexpr int kSlowCap = 16384;   // most observations the side-stream launch takes over
 
 static int timer_begin(cba_problem* p, int which, hipStream_t s = nullptr) {
   KernelTimer& t = p->timers[which];
@@ -300,9 +302,9 @@ static int allreduce(cba_problem* p, double* dev, int64_t count) {
 static int residual_pass(cba_problem* p, int which, double* cost_vec) {
   CBA_TRY(launch_compose_poses(p->st[which], p->L.n_images, p->L.n_cameras, p->itg, p->stream));
   PassArgs a = pass_args(p, which);
-  CBA_TRY(launch_base_project(a, p->model_mask, cost_vec, p->pixels, p->flags, p->slow_list, p->slow_count, kSlowCap, p->slow_skip, p->straggler_threshold, nullptr, p->stream));
+  CBA_TRY(launch_base_project(a, p->model_mask, cost_vec, p->pixels, p->flags, p->slow_list, p->slow_count, p->slow_cap, p->slow_skip, p->straggler_threshold, nullptr, p->stream));
   PassArgs as = a;
-  as.obs_list = p->slow_list; as.obs_count = p->slow_count; as.obs_list_cap = kSlowCap;
+  as.obs_list = p->slow_list; as.obs_count = p->slow_count; as.obs_list_cap = p->slow_cap;
   CBA_TRY(launch_base_project_slow(as, p->model_mask, cost_vec, p->pixels, p->flags, p->stream));
   return CBA_OK;
 }
@@ -316,7 +318,7 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   PassArgs a = pass_args(p, w);
   // side stream: the accumulation targets are cleared there (1.3 GB for H_dd at cfg 2), underneath the main launches ...
   PassArgs as = a;
-  as.obs_list = p->slow_list; as.obs_count = p->slow_count; as.obs_list_cap = kSlowCap;
+  as.obs_list = p->slow_list; as.obs_count = p->slow_count; as.obs_list_cap = p->slow_cap;
   a.skip = p->slow_skip;
   hipStream_t aux = p->ldlt.far_stream;
   CBA_HIP(hipEventRecord(p->ev_aux0, p->stream));
@@ -330,7 +332,7 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
     CBA_HIP(hipMemsetAsync(p->B + (size_t)L.block_dof * p->n_pad, 0, sizeof(double) * (size_t)(p->Kpad - L.block_dof) * p->n_pad, aux));
   CBA_HIP(hipMemsetAsync(p->Hdd, 0, sizeof(double) * (size_t)p->n_pad * p->n_pad, aux));
   CBA_HIP(hipMemsetAsync(p->bd, 0, sizeof(double) * (size_t)p->n_pad, aux));
-  CBA_TRY(launch_base_project(a, p->model_mask, p->cost_ref, p->pixels, p->flags, p->slow_list, p->slow_count, kSlowCap, p->slow_skip, p->straggler_threshold, p->fd_slow, p->stream));
+  CBA_TRY(launch_base_project(a, p->model_mask, p->cost_ref, p->pixels, p->flags, p->slow_list, p->slow_count, p->slow_cap, p->slow_skip, p->straggler_threshold, p->fd_slow, p->stream));
   // ... and the stragglers of the base projection (long projection chains, see k_base_project_slow) are finished there,
   // followed by their finite-difference tasks, underneath the main finite-difference launch
   CBA_HIP(hipEventRecord(p->ev_aux2, p->stream));
@@ -487,7 +489,6 @@ int cba_create(const cba_config* config, cba_problem** out) {
   CBA_HIP(hipEventCreateWithFlags(&p->ev_aux0, hipEventDisableTiming));
   CBA_HIP(hipEventCreateWithFlags(&p->ev_aux1, hipEventDisableTiming));
   CBA_HIP(hipEventCreateWithFlags(&p->ev_aux2, hipEventDisableTiming));
-  CBA_TRY(dev_alloc(&p->slow_list, (size_t)kSlowCap));
   CBA_TRY(dev_alloc(&p->slow_count, 1));
   CBA_HIP(hipMemset(p->slow_count, 0, sizeof(int)));
   for (int c = 0; c < L.n_cameras; ++c) p->model_mask |= (p->cams[c].model_type == CBA_CENTRAL_GENERIC) ? 1 : 2;
@@ -647,6 +648,9 @@ int cba_set_observations(cba_problem* p, int64_t n, const float* xy, const int32
     CBA_TRY(dev_alloc(&p->img_start, is.size()));
     CBA_HIP(hipMemcpy(p->img_start, is.data(), sizeof(int64_t) * is.size(), hipMemcpyHostToDevice));
   }
+  F(p->slow_list); p->slow_list = nullptr;
+  p->slow_cap = (int)std::min<int64_t>(std::max<int64_t>(kSlowCapMin, n / 8), 1 << 24);
+  CBA_TRY(dev_alloc(&p->slow_list, (size_t)p->slow_cap));
   F(p->slow_skip); p->slow_skip = nullptr;
   CBA_TRY(dev_alloc(&p->slow_skip, (size_t)(n > 0 ? n : 1)));
   CBA_HIP(hipMemset(p->slow_skip, 0, (size_t)(n > 0 ? n : 1)));

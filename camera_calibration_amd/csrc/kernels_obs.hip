@@ -206,10 +206,11 @@ __global__ void __launch_bounds__(256) k_base_project(PassArgs a, double* __rest
 // The straggler kernel: 16 lanes per listed observation evaluate the SAME procedure speculatively.
 //   lanes 0-7: the warm-start attempt, lanes 8-15: the attempt from the centre of the calibrated area -- the second attempt
 //     does not depend on the first (same target, fixed start), the reference merely skips it when the first succeeds;
-//   within an attempt, lane pair k (k = 0..3) takes damping attempt lm = base + k of the current round (lambda * 2^k): its
-//     even lane evaluates Unproject at the candidate (the test cost), its odd lane UnprojectWithJacobian at the same
-//     candidate (what the NEXT outer iteration needs if this candidate is the first accepted one).  The first accepted
-//     candidate in reference order (lowest lm) wins and its odd lane broadcasts pixel and evaluation to the group.
+//   within an attempt, lane k (k = 0..7) takes damping attempt lm = base + k of the current round (lambda * 2^k) and
+//     evaluates BOTH Unproject at the candidate (the test cost) and UnprojectWithJacobian at the same candidate (what the
+//     NEXT outer iteration needs if this candidate is the first accepted one) -- two independent instruction streams in
+//     one lane, which the scheduler interleaves.  The first accepted candidate in reference order (lowest lm) wins and
+//     broadcasts pixel and evaluation to the group.
 // An outer iteration thus costs one evaluation latency instead of 1 + (attempts until acceptance), and both attempts run
 // side by side: ~100 evaluation latencies instead of ~600.  All arithmetic goes through the same device functions as the
 // one-lane loop (project_target), evaluated on identical inputs.
@@ -228,7 +229,7 @@ __global__ void __launch_bounds__(256) k_base_project_slow(PassArgs a, double* _
   const int cam = a.obs_camera[o];
   const CamDev c = a.cams[cam];
   const bool live = g < cnt && c.model_type == MODEL;
-  const int attempt = (lane >> 3) & 1, cand = (lane >> 1) & 3, kind = lane & 1, gbase = lane & ~7;
+  const int attempt = (lane >> 3) & 1, cand = lane & 7, gbase = lane & ~7;
   double target[3];
   local_point_of(a, o, cam, target);
   if (MODEL == kCentral) normalize3(target[0], target[1], target[2]);
@@ -253,31 +254,33 @@ __global__ void __launch_bounds__(256) k_base_project_slow(PassArgs a, double* _
     }
     bool accepted = false;
 #pragma unroll 1
-    for (int base = 0; base < 10; base += 4) {
+    for (int base = 0; base < 10; base += 8) {
       const int lm = base + cand;
       const bool mine = active && !accepted && lm < 10;
       double lam_c = lambda;
-      if (cand >= 1) lam_c *= 2.0;
-      if (cand >= 2) lam_c *= 2.0;
-      if (cand >= 3) lam_c *= 2.0;
+      for (int k = 0; k < cand; ++k) lam_c *= 2.0;             // the rejected attempts before this one
       double tx = px, ty = py, tc = INFINITY;
       double ndir[3] = {0, 0, 0}, norg[3] = {0, 0, 0}, njd[6] = {0, 0, 0, 0, 0, 0}, njo[6] = {0, 0, 0, 0, 0, 0};
       bool nin = false;
       if (mine) {
         projection_candidate(c, H00, H01, H11, b0, b1, lam_c, px, py, tx, ty);
-        if (kind == 0) {
+        // the clamped candidate lies inside the calibrated area, so Unproject / UnprojectWithJacobian reduce to their
+        // evaluation parts (model.hip.h: unproject, unproject_jac) -- straight-line code for both
+        if (in_calibrated_area(c, tx, ty)) {
+          double gx, gy;
+          pixel_to_grid(c, tx, ty, gx, gy);
+          gx += 2; gy += 2;
           double td[3], to[3];
-          if (unproject<MODEL>(c, none, tx, ty, td, to)) tc = projection_test_cost<MODEL>(td, to, target);
-        } else {
-          nin = unproject_jac<MODEL>(c, none, tx, ty, ndir, norg, njd, njo);
+          unproject_eval<MODEL, false>(c, none, (lds_cdouble_ptr)0, (lds_cdouble_ptr)0, (int)gx, (int)gy, gx, gy, td, to);
+          unproject_jac_eval<MODEL, false>(c, none, (lds_cdouble_ptr)0, (lds_cdouble_ptr)0, (int)floor(gx), (int)floor(gy), gx, gy, ndir, norg, njd, njo);
+          tc = projection_test_cost<MODEL>(td, to, target);
+          nin = true;
         }
       }
-      const double tc_partner = __shfl_xor(tc, 1, 64);
-      const double my_tc = kind == 0 ? tc : tc_partner;
-      const bool acc_c = mine && (my_tc < cost);
+      const bool acc_c = mine && (tc < cost);
       const unsigned m = (unsigned)((__ballot(acc_c) >> gbase) & 0xffull);
-      const int w = m ? ((__ffs(m) - 1) >> 1) : -1;
-      const int src = gbase + 2 * (w < 0 ? 0 : w) + 1;       // odd lane of the winning pair
+      const int w = m ? (__ffs(m) - 1) : -1;
+      const int src = gbase + (w < 0 ? 0 : w);
       const double wtx = __shfl(tx, src, 64), wty = __shfl(ty, src, 64);
       const int w_in = __shfl((int)nin, src, 64);
       double wdir[3], worg[3], wjd[6], wjo[6];
@@ -310,7 +313,7 @@ __global__ void __launch_bounds__(256) k_base_project_slow(PassArgs a, double* _
           cur_in = w_in != 0;
           accepted = true;
         } else {
-          const int tried = 10 - base < 4 ? 10 - base : 4;
+          const int tried = 10 - base < 8 ? 10 - base : 8;
           for (int k = 0; k < tried; ++k) lambda *= 2.0;
         }
       }
