@@ -707,6 +707,12 @@ int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const doubl
 //                tile is amortised over twice the flops
 // ------------------------------------------------------------------------------------------------
 constexpr int kInner = 64;
+// two pivots per barrier in the 64 x 64 diagonal factorisation (ldlt_diag_pair); the bench harness can build the one-pivot loop
+#ifdef CBA_DIAG_SINGLE
+constexpr bool kDiagPairs = false;
+#else
+constexpr bool kDiagPairs = true;
+#endif
 constexpr int kPanel = 256;
 constexpr int kPanelWide = 512;
 // panels are kPanelWide wide while more than this many rows remain (env CBA_WIDE_ROWS overrides; 0 = never)
@@ -820,6 +826,92 @@ __device__ __forceinline__ void ldlt_diag_segment(double (&T)[4][4], double (&X)
   ldlt_diag_step<SA, SA + 1>(T, X, colbuf, rowbuf, ti, tj, 15, 0, bad);
 }
 
+// ---- two elimination steps per barrier -------------------------------------------------------------------------
+// Steps s (even) and s + 1 from the columns s, s + 1 of T and the rows s, s + 1 of X as they are BEFORE step s (published
+// to cb[2 pb + 0 / 1], rb[2 pb + 0 / 1]).  Every lane derives what step s makes of column / row s + 1 itself,
+//     T[i][s+1] -= l_i(s) T[s+1][s],      X[s+1][c] -= l_{s+1}(s) X[s][c],
+// with the very expressions the owning lanes would use, so the two rank-1 updates are the same arithmetic as two single
+// steps -- one barrier and one LDS round trip fewer per pair, and two independent update streams per register.
+template <int SA, int SAN>
+__device__ __forceinline__ void ldlt_diag_pair(double (&T)[4][4], double (&X)[4][4], double (*cb)[kInner], double (*rb)[kInner],
+                                               int ti, int tj, int sr /* even */, bool& bad) {
+  const int s = 16 * SA + sr, pb = (s >> 1) & 1;
+  const double* C0 = cb[2 * pb], *C1 = cb[2 * pb + 1];
+  const double* R0 = rb[2 * pb], *R1 = rb[2 * pb + 1];
+  const double d0 = C0[s], e = C0[s + 1], f = C1[s + 1];
+  double li0[4], lj0[4], li1[4], lj1[4], xr0[4], xr1[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) if (a >= SA) { li0[a] = C0[ti + 16 * a]; li1[a] = C1[ti + 16 * a]; }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    if (b >= SA) { lj0[b] = C0[tj + 16 * b]; lj1[b] = C1[tj + 16 * b]; }
+    if (b <= SA) { xr0[b] = R0[tj + 16 * b]; xr1[b] = R1[tj + 16 * b]; }
+  }
+  if (!(fabs(d0) > 0.0)) bad = true;
+  const double inv0 = pivot_rcp(d0);
+  const double l0n = e * inv0;                                 // l_{s+1}(s)
+  const double d1 = f - l0n * e;                               // T[s+1][s+1] after step s
+  if (!(fabs(d1) > 0.0)) bad = true;
+  const double inv1 = pivot_rcp(d1);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    if (a < SA) continue;
+    const int row = ti + 16 * a;
+    const double l0 = (a == SA) ? ((row > s) ? li0[a] * inv0 : 0.0) : li0[a] * inv0;
+    const double c1 = li1[a] - l0 * e;                         // column s + 1 after step s, at this lane's rows
+    li0[a] = l0;
+    li1[a] = (a == SA) ? ((row > s + 1) ? c1 * inv1 : 0.0) : c1 * inv1;
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    if (b < SA) continue;
+    const int col = tj + 16 * b;
+    const double l0 = lj0[b] * inv0;                           // l_col(s), as the lane that owns (col, s + 1) forms it
+    const double c1 = lj1[b] - l0 * e;                         // column s + 1 after step s, at this lane's columns (raw = d l)
+    if (b == SA) { lj0[b] = (col > s) ? lj0[b] : 0.0; lj1[b] = (col > s + 1) ? c1 : 0.0; }
+    else lj1[b] = c1;
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) if (b <= SA) xr1[b] = xr1[b] - l0n * xr0[b];     // row s + 1 of X after step s
+  if constexpr (SAN < 4) {
+    // the register column / row that holds the NEXT pair's columns and rows first, then publish it
+#pragma unroll
+    for (int a = 0; a < 4; ++a) if (a >= SA) { T[a][SAN] -= li0[a] * lj0[SAN]; T[a][SAN] -= li1[a] * lj1[SAN]; }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) if (b <= SA) { X[SAN][b] -= li0[SAN] * xr0[b]; X[SAN][b] -= li1[SAN] * xr1[b]; }
+    const int n0 = (sr + 2) & 15, n1 = (sr + 3) & 15;
+    {
+      double* cdst = (tj == n0) ? &cb[2 * (pb ^ 1)][ti] : (tj == n1) ? &cb[2 * (pb ^ 1) + 1][ti] : &cb[4][ti];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) cdst[16 * a] = T[a][SAN];
+      double* rdst = (ti == n0) ? &rb[2 * (pb ^ 1)][tj] : (ti == n1) ? &rb[2 * (pb ^ 1) + 1][tj] : &rb[4][tj];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) rdst[16 * b] = X[SAN][b];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (a >= SA && b >= SA && b != SAN) { T[a][b] -= li0[a] * lj0[b]; T[a][b] -= li1[a] * lj1[b]; }
+      if (a >= SA && b <= SA && a != SAN) { X[a][b] -= li0[a] * xr0[b]; X[a][b] -= li1[a] * xr1[b]; }
+    }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {                               // columns s and s + 1 of L in place of T[:,s], T[:,s+1]
+    if (a < SA) continue;
+    const int row = ti + 16 * a;
+    T[a][SA] = (tj == sr && row > s) ? li0[a] : (tj == sr + 1 && row > s + 1) ? li1[a] : T[a][SA];
+  }
+  __syncthreads();
+}
+template <int SA>
+__device__ __forceinline__ void ldlt_diag_segment_pairs(double (&T)[4][4], double (&X)[4][4], double (*cb)[kInner],
+                                                        double (*rb)[kInner], int ti, int tj, bool& bad) {
+#pragma nounroll
+  for (int sr = 0; sr < 14; sr += 2) ldlt_diag_pair<SA, SA>(T, X, cb, rb, ti, tj, sr, bad);
+  ldlt_diag_pair<SA, SA + 1>(T, X, cb, rb, ti, tj, 14, bad);
+}
+
 // Factor the 64x64 diagonal block at (j0,j0): T = L D L^T, and invert the unit-lower factor.
 // Writes L (L(p,q), p>q, at M[j0+q][j0+p]), d into the diagonal and dvec, and invLt[q][p] = (L^-1)(p,q).
 // One workgroup; every lane keeps a cyclic 4x4 sub-grid of T and of X = L^-1 in registers
@@ -845,20 +937,36 @@ __device__ __forceinline__ void ldlt_diag_body(double* __restrict__ M, int ld, i
       T[a][b] = tile ? tile[lo * tile_ld + hi] : M[(size_t)(j0 + lo) * ld + j0 + hi];
       X[a][b] = (i == j) ? 1.0 : 0.0;
     }
-  if (tj == 0) {
-#pragma unroll
-    for (int a = 0; a < 4; ++a) colbuf[0][ti + 16 * a] = T[a][0];
-  }
-  if (ti == 0) {
-#pragma unroll
-    for (int b = 0; b < 4; ++b) rowbuf[0][tj + 16 * b] = X[0][b];
-  }
-  __syncthreads();
   bool bad = false;
-  ldlt_diag_segment<0>(T, X, colbuf, rowbuf, ti, tj, NSTEPS, bad);
-  ldlt_diag_segment<1>(T, X, colbuf, rowbuf, ti, tj, NSTEPS, bad);
-  ldlt_diag_segment<2>(T, X, colbuf, rowbuf, ti, tj, NSTEPS, bad);
-  ldlt_diag_segment<3>(T, X, colbuf, rowbuf, ti, tj, NSTEPS, bad);
+  if constexpr (kDiagPairs && NSTEPS == kInner) {
+    if (tj < 2) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) colbuf[tj][ti + 16 * a] = T[a][0];
+    }
+    if (ti < 2) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) rowbuf[ti][tj + 16 * b] = X[0][b];
+    }
+    __syncthreads();
+    ldlt_diag_segment_pairs<0>(T, X, colbuf, rowbuf, ti, tj, bad);
+    ldlt_diag_segment_pairs<1>(T, X, colbuf, rowbuf, ti, tj, bad);
+    ldlt_diag_segment_pairs<2>(T, X, colbuf, rowbuf, ti, tj, bad);
+    ldlt_diag_segment_pairs<3>(T, X, colbuf, rowbuf, ti, tj, bad);
+  } else {
+    if (tj == 0) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) colbuf[0][ti + 16 * a] = T[a][0];
+    }
+    if (ti == 0) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) rowbuf[0][tj + 16 * b] = X[0][b];
+    }
+    __syncthreads();
+    ldlt_diag_segment<0>(T, X, colbuf, rowbuf, ti, tj, NSTEPS, bad);
+    ldlt_diag_segment<1>(T, X, colbuf, rowbuf, ti, tj, NSTEPS, bad);
+    ldlt_diag_segment<2>(T, X, colbuf, rowbuf, ti, tj, NSTEPS, bad);
+    ldlt_diag_segment<3>(T, X, colbuf, rowbuf, ti, tj, NSTEPS, bad);
+  }
   if (bad && tid == 0) atomicExch(status, 2);
   double* invLt = invLt_all + (size_t)(j0 / kInner) * kInner * kInner;
 #pragma unroll
@@ -876,8 +984,8 @@ __device__ __forceinline__ void ldlt_diag_body(double* __restrict__ M, int ld, i
 template <int NSTEPS = kInner>
 __global__ void __launch_bounds__(256) k_ldlt_diag(double* __restrict__ M, int ld, int j0, double* __restrict__ dvec,
                                                    double* __restrict__ invLt_all, int* __restrict__ status) {
-  __shared__ double colbuf[3][kInner];   // [2] = scratch row for the branch-free publish
-  __shared__ double rowbuf[3][kInner];
+  __shared__ double colbuf[5][kInner];   // two columns per parity + a scratch row for the branch-free publish
+  __shared__ double rowbuf[5][kInner];
   __builtin_amdgcn_s_setprio(3);   // latency-critical: runs underneath the bulk trailing-update GEMM
   tlog_begin((j0 / kInner) * kTlKinds + kTlDiag);
   ldlt_diag_body<NSTEPS>(M, ld, j0, dvec, invLt_all, status, nullptr, 0, colbuf, rowbuf);
@@ -1210,7 +1318,7 @@ __global__ void __launch_bounds__(256) k_near_fused(double* __restrict__ S, int 
     __syncthreads();
     tlog_begin((c0 / kInner) * kTlKinds + kTlDiag);
     double (*colbuf)[kInner] = reinterpret_cast<double (*)[kInner]>(sA);
-    double (*rowbuf)[kInner] = reinterpret_cast<double (*)[kInner]>(sA + 3 * kInner);
+    double (*rowbuf)[kInner] = reinterpret_cast<double (*)[kInner]>(sA + 5 * kInner);
     ldlt_diag_body<kInner>(S, ld, c0, dvec, invLt_all, status, sV, TS, colbuf, rowbuf);
     tlog_end((c0 / kInner) * kTlKinds + kTlDiag);
   } else {
@@ -1343,7 +1451,7 @@ __global__ void __launch_bounds__(256) k_aprime_fused(double* __restrict__ S, in
     __syncthreads();
     tlog_begin((r0 / kInner) * kTlKinds + kTlDiag);
     double (*colbuf)[kInner] = reinterpret_cast<double (*)[kInner]>(sA);
-    double (*rowbuf)[kInner] = reinterpret_cast<double (*)[kInner]>(sA + 3 * kInner);
+    double (*rowbuf)[kInner] = reinterpret_cast<double (*)[kInner]>(sA + 5 * kInner);
     ldlt_diag_body<kInner>(S, ld, r0, dvec, invLt_all, status, sV, TS, colbuf, rowbuf);
     tlog_end((r0 / kInner) * kTlKinds + kTlDiag);
   } else {
