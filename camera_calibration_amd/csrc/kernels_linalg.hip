@@ -1840,6 +1840,13 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
         } else if ((rc = timed_gemm128(v, s3, w, st != nullptr, (double)head * (mt - head - h2)))) return rc;
       }
       if (mt > head) {
+        // In this (chain-bound) part of the matrix the bulk update has time to spare, but (a''n) -- 16 small tiles that
+        // the NEXT panel's chain waits for after its first block -- took 50-110 us when it started together with the
+        // bulk launch, queued behind its ~100-us workgroups.  The bulk update therefore starts after (a''n).
+        // (Only while the bulk launch is short next to the panel's chain: with more than ~3000 rows left it is itself on
+        // the critical path and the delay costs more than it saves -- 262 vs 231 us per panel at 5900 rows.)
+        static const int aa_first_rows = CBA_GETENV("CBA_AA_FIRST_ROWS") ? atoi(CBA_GETENV("CBA_AA_FIRST_ROWS")) : 3072;   // developer switch
+        if (n_pad - r0 <= aa_first_rows) CBA_HIP(hipStreamWaitEvent(s, w.ev_aa, 0));
         u.upper = 1; u.m_off = r0 + head * 128; u.m_tiles = mt - head; u.n_off = r0 + head * 128; u.n_tiles = mt - head;
         u.tlog_tag = (k0 / kInner) * kTlKinds + kTlBulk + 1;
         if ((long long)u.m_tiles * (u.m_tiles + 1) / 2 < kFewTiles) {
