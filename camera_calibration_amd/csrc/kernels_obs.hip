@@ -952,8 +952,14 @@ __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, i
   typedef typename Acc<DET>::T acc_t;
   const double scale = DET ? *det_scale : 1.0;
   constexpr int KG = PER * 16;
-  constexpr int NPAIR = KG * (KG + 1) / 2;
-  constexpr int NE = (NPAIR + 255) / 256;
+  // Every lane owns one TZ x TZ tile of the upper triangle of the K_g x K_g block (4 x 4 of 80 x 80: 210 tiles, 2 x 2 of
+  // 32 x 32: 136 tiles): per record 4 TZ LDS reads feed TZ^2 products, instead of four reads per product with the pairs
+  // dealt out one by one (1.34 -> see DESIGN.md at BASELINE configs[3]).  Diagonal tiles compute their lower half too and
+  // do not store it.
+  constexpr int TZ = PER == 5 ? 4 : 2;
+  constexpr int NT = KG / TZ;
+  constexpr int NTILE = NT * (NT + 1) / 2;
+  static_assert(NTILE <= 256 && KG % TZ == 0, "one tile per lane");
   constexpr int NR = (6 * KG + 255) / 256;
   constexpr int RB = 8;                          // records per stage
   __shared__ double sJ0[RB][KG];
@@ -965,18 +971,16 @@ __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, i
   if (cell >= n_cells) return;
   const int o_begin = start[key0 + cell], o_end = start[key0 + cell + 1];
   if (o_begin == o_end) return;                  // workgroup-uniform
-  // this lane's pairs (i <= k), enumerated row by row, packed i | k << 16
-  unsigned pp[NE];
+  // this lane's tile (ti <= tk), enumerated row by row
+  int ti = 0, tk = 0;
+  const bool has_tile = tid < NTILE;
+  if (has_tile) { int rem = tid; while (rem >= NT - ti) { rem -= NT - ti; ++ti; } tk = ti + rem; }
+  const int i0 = ti * TZ, k0 = tk * TZ;
+  acc_t acc[TZ][TZ], racc[NR];
 #pragma unroll
-  for (int t = 0; t < NE; ++t) {
-    const int e = tid + 256 * t;
-    int i = 0, k = 0;
-    if (e < NPAIR) { int rem = e; while (rem >= KG - i) { rem -= KG - i; ++i; } k = i + rem; }
-    pp[t] = (unsigned)i | ((unsigned)k << 16);
-  }
-  acc_t acc[NE], racc[NR];
+  for (int x = 0; x < TZ; ++x)
 #pragma unroll
-  for (int t = 0; t < NE; ++t) acc[t] = 0;
+    for (int y = 0; y < TZ; ++y) acc[x][y] = 0;
 #pragma unroll
   for (int t = 0; t < NR; ++t) racc[t] = 0;
   constexpr bool rig = RIG;
@@ -997,10 +1001,14 @@ __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, i
 #pragma unroll 1
     for (int r = 0; r < nrec; ++r) {
       const double w = sW[r];
+      if (has_tile) {
+        double a0[TZ], a1[TZ], b0[TZ], b1[TZ];
 #pragma unroll
-      for (int t = 0; t < NE; ++t) {
-        const int i = pp[t] & 0xffff, k = pp[t] >> 16;
-        acc[t] += Acc<DET>::from(w * (sJ0[r][i] * sJ0[r][k] + sJ1[r][i] * sJ1[r][k]), scale);
+        for (int x = 0; x < TZ; ++x) { a0[x] = sJ0[r][i0 + x]; a1[x] = sJ1[r][i0 + x]; b0[x] = sJ0[r][k0 + x]; b1[x] = sJ1[r][k0 + x]; }
+#pragma unroll
+        for (int x = 0; x < TZ; ++x)
+#pragma unroll
+          for (int y = 0; y < TZ; ++y) acc[x][y] += Acc<DET>::from(w * (a0[x] * b0[y] + a1[x] * b1[y]), scale);
       }
       if (rig) {
 #pragma unroll
@@ -1013,15 +1021,19 @@ __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, i
   }
   const CamDev cd = a.cams[cam];
   const int cy0 = cell / cd.gw, cx0 = cell - cy0 * cd.gw;
+  if (has_tile) {
 #pragma unroll
-  for (int t = 0; t < NE; ++t) {
-    if (tid + 256 * t >= NPAIR) continue;
-    const int i = pp[t] & 0xffff, k = pp[t] >> 16;
-    const int ci = i / PER, di = i - ci * PER, ck = k / PER, dk = k - ck * PER;
-    int row = grid_column(cd, (cx0 + (ci & 3)) + (cy0 + (ci >> 2)) * cd.gw, di);
-    int col = grid_column(cd, (cx0 + (ck & 3)) + (cy0 + (ck >> 2)) * cd.gw, dk);
-    if (row > col) { const int t2 = row; row = col; col = t2; }   // tiled order is not monotone in the patch order
-    Acc<DET>::add(Hdd + (size_t)row * ld + col, acc[t]);
+    for (int x = 0; x < TZ; ++x)
+#pragma unroll
+      for (int y = 0; y < TZ; ++y) {
+        const int i = i0 + x, k = k0 + y;
+        if (i > k) continue;                       // lower half of a diagonal tile
+        const int ci = i / PER, di = i - ci * PER, ck = k / PER, dk = k - ck * PER;
+        int row = grid_column(cd, (cx0 + (ci & 3)) + (cy0 + (ci >> 2)) * cd.gw, di);
+        int col = grid_column(cd, (cx0 + (ck & 3)) + (cy0 + (ck >> 2)) * cd.gw, dk);
+        if (row > col) { const int t2 = row; row = col; col = t2; }   // tiled order is not monotone in the patch order
+        Acc<DET>::add(Hdd + (size_t)row * ld + col, acc[x][y]);
+      }
   }
   if (!rig) return;
 #pragma unroll
