@@ -363,7 +363,7 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   if (!L.localize_only)
     CBA_TRY(launch_accumulate_cells(a, p->cams, p->cell_base_host, p->rec_doubles, p->n_pad, p->flags, p->jrec, p->cells, p->cell_base,
                                     p->cell_count, p->cell_start, p->cell_fill, p->cell_order, p->Hdd,
-                                    (!L.eliminate_points && L.rig_in_state) ? L.first_camera_tr_rig - L.block_dof : -1, det, p->stream));
+                                    (!L.eliminate_points && L.rig_in_state) ? L.first_camera_tr_rig - L.block_dof : -1, det, p->bd, p->stream));
   if (det) {   // fixed point -> fp64, in place
     CBA_TRY(launch_det_convert(p->Dblk, nb * bs * bs, det, p->stream));
     CBA_TRY(launch_det_convert(p->bblk, nb * bs, det + 1, p->stream));      // J^T r: second scale

@@ -98,7 +98,7 @@ int launch_accumulate_strips(const PassArgs& a, const Layout& L, int n_images, i
 int launch_accumulate_cells(const PassArgs& a, const std::vector<cba_camera>& cams, const std::vector<int>& cell_base_host,
                             int rec_doubles, int ld, const uint8_t* flags, const double* jrec, const int* cells,
                             const int* cell_base, int* count, int* start, int* fill, int* order, double* Hdd,
-                            int rig_row_first, const double* det_scale, hipStream_t s);
+                            int rig_row_first, const double* det_scale, double* bd, hipStream_t s);
 // 8 outputs: [0] sum ref (valid), [1] sum test (valid), [2] masked ref, [3] masked test, [4] count both valid,
 // [5] n valid ref, [6] n valid test, [7] n jac dropped (flags)
 int launch_reduce_costs(const double* ref, const double* test, const uint8_t* flags, int64_t n, double* partials,

@@ -873,7 +873,7 @@ __global__ void __launch_bounds__(256) k_accumulate(PassArgs a, AccumLayout L, i
       else { const int k = h0 + hs_k[t]; hot[t] += Acc<DET>::from(sW0[wv][i] * sJ0[wv][k] + sW1[wv][i] * sJ1[wv][k], scale); }
     }
     // b += Jw^T r (non-hot positions)
-    for (int k = lane; k < K; k += 64) {
+    for (int k = lane; k < K - Kg; k += 64) {      // the grid entries are summed per cell by k_accumulate_cells
       if (k >= h0 && k < h0 + nh) continue;
       acc_add_b<DET>(L, T, sIdx[wv][k], Acc<DET>::from(r0 * sW0[wv][k] + r1 * sW1[wv][k], scale_b));
     }
@@ -948,9 +948,10 @@ template <int PER, bool DET, bool RIG>
 __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, int key0, int n_cells, int rec_doubles, int ld,
                                                           const double* __restrict__ jrec, const int* __restrict__ start,
                                                           const int* __restrict__ order, double* __restrict__ Hdd, int rig_row0,
-                                                          const double* __restrict__ det_scale) {
+                                                          const double* __restrict__ det_scale, double* __restrict__ bd) {
   typedef typename Acc<DET>::T acc_t;
-  const double scale = DET ? *det_scale : 1.0;
+  const double scale = DET ? det_scale[0] : 1.0;
+  const double scale_b = DET ? det_scale[1] : 1.0;
   constexpr int KG = PER * 16;
   // Every lane owns one TZ x TZ tile of the upper triangle of the K_g x K_g block (4 x 4 of 80 x 80: 210 tiles, 2 x 2 of
   // 32 x 32: 136 tiles): per record 4 TZ LDS reads feed TZ^2 products, instead of four reads per product with the pairs
@@ -966,11 +967,15 @@ __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, i
   __shared__ double sJ1[RB][KG];
   __shared__ double sRig[RB][12];
   __shared__ double sW[RB];
+  __shared__ double sRes[RB][2];
   const int tid = threadIdx.x;
   const int cell = blockIdx.x;
   if (cell >= n_cells) return;
   const int o_begin = start[key0 + cell], o_end = start[key0 + cell + 1];
   if (o_begin == o_end) return;                  // workgroup-uniform
+  // The grid part of J^T r of the bucket as well (lanes 0 .. K_g - 1, one atomic per entry and cell: the per-observation
+  // kernel used to issue K_g atomics per observation for it).
+  acc_t bacc = 0;
   // this lane's tile (ti <= tk), enumerated row by row
   int ti = 0, tk = 0;
   const bool has_tile = tid < NTILE;
@@ -993,6 +998,7 @@ __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, i
       sJ0[r][k] = rec[kRecHeader + k]; sJ1[r][k] = rec[kRecHeader + KG + k];
     }
     if (tid < nrec) sW[tid] = jrec[(size_t)order[base + tid] * rec_doubles + 2];
+    if (tid >= 32 && tid < 32 + 2 * nrec) sRes[(tid - 32) >> 1][(tid - 32) & 1] = jrec[(size_t)order[base + ((tid - 32) >> 1)] * rec_doubles + ((tid - 32) & 1)];
     if (rig && tid >= 64 && tid < 64 + nrec * 12) {
       const int r = (tid - 64) / 12, q = (tid - 64) - r * 12;
       sRig[r][q] = jrec[(size_t)order[base + r] * rec_doubles + 15 + q];
@@ -1001,6 +1007,7 @@ __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, i
 #pragma unroll 1
     for (int r = 0; r < nrec; ++r) {
       const double w = sW[r];
+      if (tid < KG) bacc += Acc<DET>::from(sRes[r][0] * (w * sJ0[r][tid]) + sRes[r][1] * (w * sJ1[r][tid]), scale_b);
       if (has_tile) {
         double a0[TZ], a1[TZ], b0[TZ], b1[TZ];
 #pragma unroll
@@ -1021,6 +1028,10 @@ __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, i
   }
   const CamDev cd = a.cams[cam];
   const int cy0 = cell / cd.gw, cx0 = cell - cy0 * cd.gw;
+  if (tid < KG) {
+    const int ck = tid / PER, dk = tid - ck * PER;
+    Acc<DET>::add(bd + grid_column(cd, (cx0 + (ck & 3)) + (cy0 + (ck >> 2)) * cd.gw, dk), bacc);
+  }
   if (has_tile) {
 #pragma unroll
     for (int x = 0; x < TZ; ++x)
@@ -1048,7 +1059,8 @@ __global__ void __launch_bounds__(256) k_accumulate_cells(PassArgs a, int cam, i
 int launch_accumulate_cells(const PassArgs& a, const std::vector<cba_camera>& cams, const std::vector<int>& cell_base_host,
                             int rec_doubles, int ld, const uint8_t* flags, const double* jrec, const int* cells,
                             const int* cell_base, int* count, int* start, int* fill, int* order, double* Hdd,
-                            int rig_row_first /* dense row of camera 0's rig block, or -1 */, const double* det_scale, hipStream_t s) {
+                            int rig_row_first /* dense row of camera 0's rig block, or -1 */, const double* det_scale, double* bd,
+                            hipStream_t s) {
   if (a.n_obs == 0) return CBA_OK;
   const int n_keys = cell_base_host.back();
   CBA_HIP(hipMemsetAsync(count, 0, sizeof(int) * (size_t)n_keys, s));
@@ -1063,7 +1075,7 @@ int launch_accumulate_cells(const PassArgs& a, const std::vector<cba_camera>& ca
     const int rr = rig_row_first >= 0 ? rig_row_first + 6 * (int)c : -1;
     const bool central = cams[c].model_type == CBA_CENTRAL_GENERIC;
 #define CBA_CELLS2(PER_, DET_, RIG_) hipLaunchKernelGGL((k_accumulate_cells<PER_, DET_, RIG_>), g2, block, 0, s, a, (int)c, cell_base_host[c], \
-                                                        n_cells, rec_doubles, ld, jrec, start, order, Hdd, rr, det_scale)
+                                                        n_cells, rec_doubles, ld, jrec, start, order, Hdd, rr, det_scale, bd)
 #define CBA_CELLS(PER_, DET_) do { if (rr >= 0) CBA_CELLS2(PER_, DET_, true); else CBA_CELLS2(PER_, DET_, false); } while (0)
     if (central) { if (det_scale) CBA_CELLS(2, true); else CBA_CELLS(2, false); }
     else { if (det_scale) CBA_CELLS(5, true); else CBA_CELLS(5, false); }
