@@ -281,6 +281,7 @@ static PassArgs pass_args(cba_problem* p, int which) {
   a.fd_delta = p->cfg.numerical_diff_delta;
   a.pose_slot = p->pose_slot;
   a.obs_list = nullptr; a.obs_count = nullptr; a.obs_list_cap = 0; a.skip = nullptr;
+  a.jrec = p->jrec; a.rec_doubles = p->rec_doubles;
   return a;
 }
 

@@ -65,6 +65,10 @@ struct PassArgs {
   const int* obs_count;     // device: entries in obs_list (clamped to obs_list_cap)
   int obs_list_cap;
   const uint8_t* skip;      // main launch: per-observation "handled by the list launch" (or null)
+  // Jacobian records: the finite-difference tasks of the grid parameters write d pixel / d parameter straight into the grid
+  // part of their observation's record (k_assemble fills the header); null outside the Jacobian pass
+  double* jrec;
+  int rec_doubles;
 };
 
 // ---- kernels_obs.hip ----

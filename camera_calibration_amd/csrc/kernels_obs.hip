@@ -426,8 +426,15 @@ __device__ __forceinline__ bool fd_task(const PassArgs& a, const CamDev& c, int 
   bool miss = false;
   const bool ok = project_point<MODEL, STG>(c, sub, local, px, py, st, &miss);
   if (STG && miss) return false;
-  fd_out[2 * t] = (px - bx) / delta;
-  fd_out[2 * t + 1] = (py - by) / delta;
+  if (k >= 3 && a.jrec) {          // grid parameter: straight into the record (rows 0 / 1 of the 2 x K_g block)
+    double* g = a.jrec + (size_t)o * a.rec_doubles + kRecHeader;
+    const int Kg = c.params_per_point * 16;
+    g[k - 3] = (px - bx) / delta;
+    g[Kg + k - 3] = (py - by) / delta;
+  } else {
+    fd_out[2 * t] = (px - bx) / delta;
+    fd_out[2 * t + 1] = (py - by) / delta;
+  }
   fd_ok[t] = ok ? 1 : 0;
   return true;
 }
@@ -671,25 +678,13 @@ __global__ void __launch_bounds__(256) k_assemble(PassArgs a, int rig_in_state, 
                                                   const uint8_t* __restrict__ fd_ok, double* __restrict__ jrec,
                                                   int* __restrict__ cells, uint8_t* __restrict__ fd_slow) {
   const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  // the header of a record is one lane's work; the 2 x K_g grid part is copied by the whole wavefront afterwards
-  // (one lane writing its own 0.8 KB record puts 64 uncoalesced streams on the memory system)
+  // the header of a record is one lane's work
   const bool with_jacobian = assemble_header(a, o, rig_in_state, localize_only, rig7, camrig7, tasks_per_obs, rec_doubles, pixels, flags,
                                              fd_out, fd_ok, jrec, cells);
   // a residual that lost its Jacobian has a finite-difference projection that FAILED, i.e. ran its whole iteration budget
   // (5-8 ms for one lane at the non-central config): next time its tasks run on the side stream (k_base_project)
   if (o < a.n_obs) fd_slow[o] = flags[o] == 1;
-  unsigned long long todo = __ballot(with_jacobian);
-  const int lane = threadIdx.x & 63;
-  const int64_t o0 = o - lane;
-  while (todo) {
-    const int i = __builtin_ctzll(todo);
-    todo &= todo - 1;
-    const int64_t oi = o0 + i;
-    const int Kg = a.cams[a.obs_camera[oi]].params_per_point * 16;
-    const double* fd = fd_out + 2 * (size_t)oi * tasks_per_obs + 6;
-    double* Jg = jrec + (size_t)oi * rec_doubles + kRecHeader;
-    for (int k = lane; k < Kg; k += 64) { Jg[k] = fd[2 * k]; Jg[Kg + k] = fd[2 * k + 1]; }
-  }
+  (void)with_jacobian;     // the 2 x K_g grid part of the record was written by the finite-difference tasks themselves (fd_task)
 }
 int launch_assemble(const PassArgs& a, const Layout& L, const DevState& st, int tasks_per_obs, int rec_doubles,
                     const double* pixels, uint8_t* flags, const double* fd_out, const uint8_t* fd_ok, double* jrec,
