@@ -3,6 +3,8 @@
 //  k_compose_poses   image_tr_global = camera_tr_rig[c] * rig_tr_global[i]   (joint_optimization.cc:277-280)
 //  k_tangents        ComputeTangentsImage                                      (joint_optimization.cc:229-238)
 //  k_base_project    AddReprojectionResidual, residual part                    (joint_optimization.cc:321-347)
+//  k_base_project_slow  the same for the observations whose projection runs long (failing projections: the reference's
+//                    whole 100 x 10-iteration budget, twice), 16 lanes per observation
 //  k_fd_tasks        the 3 + K finite-difference re-projections                (joint_optimization.cc:357-372,
 //                                                                               central_grid.h:187-245,
 //                                                                               noncentral_generic.h:224-283)
@@ -12,11 +14,15 @@
 //  k_reduce_costs    cost sums and CostIsSmallerThan                           (lm_optimizer.h:993-1011)
 //  k_update_*        JointOptimizationState::operator-=                        (joint_optimization.cc:172-214)
 //
+//  k_accumulate_strips / k_accumulate_cells   the pose x dense strips and the grid x grid block of JtJ (+ the grid part of
+//                    Jtr), summed per (imageset, column band) / per control-patch cell before they reach HBM
+//
 // Parallel decomposition (MI355X-first, not the reference's single loop): the packed observation
 // array is streamed coalesced; every finite-difference projection is its own lane (35 or 83 lanes
-// per observation, neighbouring lanes share the observation's 4x4 control patch through L1); the
+// per observation, the workgroup stages the observations' 4x4 control patches in LDS); the
 // outer product of one observation is spread over the 64 lanes of a wavefront and lands in HBM with
-// hardware fp64 atomics (global_atomic_add_f64).
+// hardware fp64 atomics (global_atomic_add_f64), except for the terms that many observations share
+// (strips, cells), which are summed on chip first.
 #include "cba_internal.h"
 
 namespace cba {
