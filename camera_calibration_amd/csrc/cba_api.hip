@@ -138,7 +138,7 @@ struct cba_problem {
   int slow_cap = kSlowCapMin;
   int straggler_threshold = 8;    // outer projection iterations before an observation goes to the straggler kernel
   int64_t* img_start = nullptr;          // first observation of every imageset (+ end), for the strip accumulation
-  unsigned* band_mask = nullptr;         // per observation: column bands of B it touches
+  unsigned long long* band_mask = nullptr;   // per observation: column bands of B it touches
   // the side stream is the factorisation's far stream (idle during the Jacobian pass): the process must stay
   // within four HIP streams -- a fifth shares a hardware queue with another one and serialises the LDL^T streams
   // (measured twice, also with GPU_MAX_HW_QUEUES=8)

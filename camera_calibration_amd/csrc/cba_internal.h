@@ -97,7 +97,7 @@ int launch_det_scale(int64_t n, int rec_doubles, int used_doubles, const uint8_t
                      double* scale, hipStream_t s);
 int launch_det_convert(double* p, size_t n, const double* det_scale, hipStream_t s);
 int launch_accumulate_strips(const PassArgs& a, const Layout& L, int n_images, int rec_doubles, const uint8_t* flags, const double* jrec,
-                             const int* cells, unsigned* band_mask, const int64_t* img_start, double* B, int ld, const double* det_scale,
+                             const int* cells, unsigned long long* band_mask, const int64_t* img_start, double* B, int ld, const double* det_scale,
                              hipStream_t s);
 int launch_accumulate_cells(const PassArgs& a, const std::vector<cba_camera>& cams, const std::vector<int>& cell_base_host,
                             int rec_doubles, int ld, const uint8_t* flags, const double* jrec, const int* cells,

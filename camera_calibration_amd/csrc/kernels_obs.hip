@@ -1097,23 +1097,23 @@ int launch_accumulate_cells(const PassArgs& a, const std::vector<cba_camera>& ca
 // global atomics from these terms (210 of the ~350 per observation).
 // ------------------------------------------------------------------------------------------------
 constexpr int kStripBand = 1024;
-// bit t of band_mask[o]: observation o couples its pose to a dense column of band t (<= 32 bands = 65 536 columns;
-// wider systems fall back to "all bands")
+// bit t of band_mask[o]: observation o couples its pose to a dense column of band t (<= 64 bands = 65 536 columns -- the
+// 4-camera rig of BASELINE configs[4] has 42; wider systems fall back to "all bands")
 __global__ void __launch_bounds__(256) k_strip_band_mask(PassArgs a, AccumLayout L, const uint8_t* __restrict__ flags,
-                                                         const int* __restrict__ cells, unsigned* __restrict__ band_mask, int n_bands) {
+                                                         const int* __restrict__ cells, unsigned long long* __restrict__ band_mask, int n_bands) {
   const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= a.n_obs) return;
-  if (flags[o] != 3) { band_mask[o] = 0u; return; }
-  if (n_bands > 32) { band_mask[o] = 0xffffffffu; return; }
+  if (flags[o] != 3) { band_mask[o] = 0ull; return; }
+  if (n_bands > 64) { band_mask[o] = ~0ull; return; }
   const CamDev cd = a.cams[a.obs_camera[o]];
-  unsigned m = 0u;
+  unsigned long long m = 0ull;
   const int pc = L.first_points - L.block_dof + 3 * a.obs_point[o];
-  m |= 1u << (pc / kStripBand); m |= 1u << ((pc + 2) / kStripBand);
+  m |= 1ull << (pc / kStripBand); m |= 1ull << ((pc + 2) / kStripBand);
   if (!L.localize_only) {
     const int cx0 = cells[2 * o], cy0 = cells[2 * o + 1];
     for (int c = 0; c < 16; ++c) {
       const int col = grid_column(cd, (cx0 + (c & 3)) + (cy0 + (c >> 2)) * cd.gw, 0);
-      m |= 1u << (col / kStripBand); m |= 1u << ((col + cd.params_per_point - 1) / kStripBand);
+      m |= 1ull << (col / kStripBand); m |= 1ull << ((col + cd.params_per_point - 1) / kStripBand);
     }
   }
   band_mask[o] = m;
@@ -1122,7 +1122,7 @@ constexpr int kStripWaves = 8;
 template <bool DET>
 __global__ void __launch_bounds__(64 * kStripWaves) k_accumulate_strips(PassArgs a, AccumLayout L, int rec_doubles, const uint8_t* __restrict__ flags,
                                                             const double* __restrict__ jrec, const int* __restrict__ cells,
-                                                            const unsigned* __restrict__ band_mask,
+                                                            const unsigned long long* __restrict__ band_mask,
                                                             const int64_t* __restrict__ img_start, double* __restrict__ B, int ld,
                                                             const double* __restrict__ det_scale) {
   __shared__ double acc[6][kStripBand];      // DET: the same 8-byte slots hold fixed-point integers (zero bits = 0 in both)
@@ -1133,7 +1133,7 @@ __global__ void __launch_bounds__(64 * kStripWaves) k_accumulate_strips(PassArgs
   for (int i = threadIdx.x; i < 6 * kStripBand; i += 64 * kStripWaves) (&acc[0][0])[i] = 0.0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const unsigned bit = 1u << (band & 31);
+  const unsigned long long bit = 1ull << (band & 63);
   const int64_t o_begin = img_start[img], o_end = img_start[img + 1];
   // kStripWaves wavefronts.  Pass = 64 * kStripWaves consecutive observations: every wavefront loads the band masks of one group of 64
   // (one coalesced load instead of a chain of dependent L2 round trips) and publishes its ballot; then the matching
@@ -1190,7 +1190,7 @@ __global__ void __launch_bounds__(64 * kStripWaves) k_accumulate_strips(PassArgs
   }
 }
 int launch_accumulate_strips(const PassArgs& a, const Layout& L, int n_images, int rec_doubles, const uint8_t* flags, const double* jrec,
-                             const int* cells, unsigned* band_mask, const int64_t* img_start, double* B, int ld, const double* det_scale,
+                             const int* cells, unsigned long long* band_mask, const int64_t* img_start, double* B, int ld, const double* det_scale,
                              hipStream_t s) {
   if (n_images == 0) return CBA_OK;
   AccumLayout al;
