@@ -410,7 +410,11 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
   }
   GemmStats gs;
   CBA_TRY(timer_begin(p, 1));
-  CBA_TRY(ldlt_factor(p->S, p->n_fact, ld, p->ldlt, p->stream, &gs));
+  if (multi && p->cfg.distributed_solve && p->cfg.world_size > 1)
+    CBA_TRY(ldlt_factor_distributed(p->S, p->n_fact, ld, p->ldlt, p->stream, p->cfg.rank, p->cfg.world_size, p->cfg.allreduce,
+                                    p->cfg.allreduce_user, p->P, &gs));
+  else
+    CBA_TRY(ldlt_factor(p->S, p->n_fact, ld, p->ldlt, p->stream, &gs));
   CBA_TRY(timer_end(p, 1, gs.flops, 0, gs.launches));
   CBA_TRY(ldlt_back_solve(p->S, p->n_fact, ld, ld - 1, p->ldlt, p->x + L.block_dof, p->stream));
   // block part: x_b = D^-1 b - W x_d      (lm_optimizer.h:1366-1367)

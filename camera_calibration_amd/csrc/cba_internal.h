@@ -153,5 +153,9 @@ int ldlt_workspace_alloc(LdltWorkspace& w, int n);
 int ldlt_collect_spans(LdltWorkspace& w, GemmStats* st);
 void ldlt_workspace_free(LdltWorkspace& w);
 int ldlt_factor(double* S, int n, int ld, LdltWorkspace& w, hipStream_t s, GemmStats* trailing_stats);
+// Distributed variant (cba_config.distributed_solve): `exchange(buf, count)` sums a device buffer over the ranks (synchronous);
+// `stage` holds at least 512 * ld doubles
+int ldlt_factor_distributed(double* S, int n, int ld, LdltWorkspace& w, hipStream_t s, int rank, int world,
+                            int (*exchange)(void* buf, int64_t count, void* user), void* user, double* stage, GemmStats* trailing_stats);
 
 }  // namespace cba

@@ -1977,6 +1977,81 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
   return CBA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Distributed factorisation, first cut (cba_config.distributed_solve).
+//   ownership : 512-column groups of S, block-cyclic over the ranks (group g -> rank g % world)
+//   per panel : (1) the panel's block row [k0, e0) x [k0, n_pad) is assembled from the owners of its columns -- every
+//                   rank contributes its columns, zeros elsewhere, one `exchange` (sum over ranks);
+//               (2) every rank factors the panel and solves the whole block row (identical arithmetic on identical
+//                   data: chain kernels of the single-GPU path, one stream, no look-ahead);
+//               (3) every rank applies the trailing update to the column groups it owns.
+// After the last panel every rank holds the complete factor (all block rows), d and the forward-substituted right-hand
+// side, so the back substitution runs replicated as in the single-GPU path.
+// ------------------------------------------------------------------------------------------------
+constexpr int kOwnGroup = 512;
+// stage[r][c - c_begin] = owned(c) ? S[k0 + r][c] : 0     (pack)      S[k0 + r][c] = stage[r][c - c_begin]     (unpack)
+__global__ void __launch_bounds__(256) k_block_row_exchange(double* __restrict__ S, int ld, int k0, int c_begin, int width,
+                                                            double* __restrict__ stage, int rank, int world, int unpack) {
+  const int r = blockIdx.y;
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < width; c += gridDim.x * 256) {
+    const int col = c_begin + c;
+    double* sp = S + (size_t)(k0 + r) * ld + col;
+    double* st = stage + (size_t)r * width + c;
+    if (unpack) *sp = *st;
+    else *st = ((col / kOwnGroup) % world == rank) ? *sp : 0.0;
+  }
+}
+int ldlt_factor_distributed(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, int rank, int world,
+                            int (*exchange)(void* buf, int64_t count, void* user), void* user, double* stage, GemmStats* st) {
+  const int n_pad = ld;
+  int kidx = 0;
+  for (int k0 = 0; k0 < n_fact; ++kidx) {
+    const int nb = (n_fact - k0 >= kPanelWide) ? kPanelWide : ((n_fact - k0 >= kPanel) ? kPanel : (n_fact - k0));
+    const int e0 = k0 + nb;
+    double* Xk = w.X + (size_t)(kidx & 1) * kPanelWide * n_pad;
+    int rc;
+    // (1) assemble the block row from the owners of its columns (the first panel is complete everywhere: S comes out of the
+    //     all-reduce of the reduced system)
+    if (k0 > 0 && world > 1) {
+      const int width = n_pad - k0;
+      dim3 grid((unsigned)((width + 255) / 256 < 64 ? (width + 255) / 256 : 64), (unsigned)nb);
+      hipLaunchKernelGGL(k_block_row_exchange, grid, dim3(256), 0, s, S, ld, k0, k0, width, stage, rank, world, 0);
+      CBA_HIP(hipStreamSynchronize(s));
+      if (exchange(stage, (int64_t)nb * width, user) != 0) return CBA_ERR_STATE;
+      hipLaunchKernelGGL(k_block_row_exchange, grid, dim3(256), 0, s, S, ld, k0, k0, width, stage, rank, world, 1);
+    }
+    // (2) the panel, replicated
+    for (int j0 = k0; j0 < e0; j0 += kInner) {
+      const int c0 = j0 + kInner;
+      hipLaunchKernelGGL(k_ldlt_diag<kInner>, dim3(1), dim3(256), 0, s, S, ld, j0, w.dvec, w.invLt, w.status);
+      if (c0 < e0) {
+        if ((rc = trsm_cols(S, ld, j0, k0, c0, e0, Xk, w, s, kTlChainTrsm))) return rc;
+        if ((rc = update_block(S, ld, j0, k0, c0, e0, c0, e0, /*upper*/ 1, Xk, s, kTlChainUpd))) return rc;
+      }
+    }
+    if (n_pad > e0)
+      hipLaunchKernelGGL(k_panel_solve, dim3((n_pad - e0) / kInner), dim3(256), 0, s, S, ld, k0, nb, e0, Xk, n_pad, w.dvec, w.invLt);
+    // (3) trailing update of the column groups this rank owns: rows [e0, c_hi) x columns [c_lo, c_hi), upper part
+    if (e0 < n_fact || e0 < n_pad) {
+      for (int c_lo = (e0 / kOwnGroup) * kOwnGroup; c_lo < n_pad; c_lo += kOwnGroup) {
+        if ((c_lo / kOwnGroup) % world != rank) continue;
+        const int lo = c_lo < e0 ? e0 : c_lo;
+        const int hi = c_lo + kOwnGroup < n_pad ? c_lo + kOwnGroup : n_pad;
+        if (lo >= hi) continue;
+        GemmArgs u{};
+        u.A = S + (size_t)k0 * ld; u.lda = ld; u.B = Xk; u.ldb = n_pad; u.K = nb;
+        u.C = S; u.ldc = ld; u.Cin = S; u.ldcin = ld; u.diag = 0; u.upper = 1;
+        u.m_off = e0; u.m_tiles = (hi - e0) / 128; u.n_off = lo; u.n_tiles = (hi - lo) / 128;
+        if ((rc = launch_gemm<128, 128, 64, 64, true>(u, s))) return rc;
+        if (st) { st->flops += 2.0 * 128 * 128 * nb * (double)count_upper_tiles(u.m_off, u.n_off, u.m_tiles, u.n_tiles, 128, 128); st->launches += 1; }
+      }
+    }
+    k0 = e0;
+  }
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
 // Backward substitution L^T x = z for the factored rows; z sits in column `zcol` of S.
 //   x_j = z_j - sum_{i > j} L(i,j) x_i = z_j - sum_{i > j} S[j][i] x[i]
 // Right-looking by panels of 256 rows: the panel's own triangle is solved by one workgroup (four

@@ -42,7 +42,7 @@ class CbaConfig(C.Structure):
                 ("allreduce", ALLREDUCE_FN), ("allreduce_user", C.c_void_p),
                 ("n_images_global", C.c_int32),
                 ("reduce_buffer", C.c_void_p), ("reduce_buffer_doubles", C.c_int64),
-                ("deterministic", C.c_int32)]
+                ("deterministic", C.c_int32), ("distributed_solve", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32)]
 
 
 class CbaFitReport(C.Structure):
@@ -181,7 +181,7 @@ class Engine:
     def __init__(self, problem: Problem, device: int = 0, allreduce: Optional[Callable[[int, int], int]] = None,
                  n_images_global: int = 0, reduce_buffer_ptr: int = 0, reduce_buffer_doubles: int = 0,
                  last_projection: Optional[np.ndarray] = None, deterministic: bool = False,
-                 allreduce_native: Optional[tuple] = None):
+                 allreduce_native: Optional[tuple] = None, distributed_solve: bool = False, rank: int = 0, world_size: int = 1):
         self.L = load()
         self.problem = problem
         self._cams = (CbaCamera * problem.n_cameras)(*[_cam_struct(c) for c in problem.cameras])
@@ -201,7 +201,7 @@ class Engine:
         cfg = CbaConfig(problem.n_cameras, self._cams, problem.n_images, problem.n_points, problem.fd_delta,
                         int(problem.localize_only), int(problem.eliminate_points), device,
                         cb, user, n_images_global,
-                        reduce_buffer_ptr or None, reduce_buffer_doubles, int(deterministic))
+                        reduce_buffer_ptr or None, reduce_buffer_doubles, int(deterministic), int(distributed_solve), int(rank), int(world_size))
         self._cfg = cfg
         self._h = C.c_void_p()
         _check(self.L.cba_create(C.byref(cfg), C.byref(self._h)), "cba_create")

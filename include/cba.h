@@ -76,6 +76,16 @@ typedef struct {
    * x, costs and states.  The reference is single-threaded and therefore reproducible; this is the mode that matches
    * that property.  Costs about 1 ms per LM iteration at BASELINE configs[1].  0 = fp64 atomics. */
   int32_t deterministic;
+  /* Distributed reduced solve (multi-GPU, optional; needs `allreduce`).  0: the factorisation of the reduced system is
+   * replicated on every rank (right up to D ~ 20 000: 17 ms at BASELINE configs[1]).  1: the 512-column groups of the
+   * trailing matrix are owned block-cyclically by the ranks; every rank factors the current panel (identical arithmetic on
+   * identical data), applies the trailing update only to its own column groups, and the panel's block row is assembled
+   * from its owners with one `allreduce` per panel before it is factored -- the volume of all panels together is the
+   * size of the matrix.  For reduced systems like BASELINE configs[4] (D = 42 789: 0.45 s of replicated factorisation
+   * against 35 ms of sharded work per step).  `rank` / `world_size` describe the communicator behind `allreduce`. */
+  int32_t distributed_solve;
+  int32_t rank;
+  int32_t world_size;
 } cba_config;
 
 /* OptimizationReport (LV/lm_optimizer.h:55-77) + what OptimizeJointly returns through pointers */

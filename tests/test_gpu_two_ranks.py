@@ -35,7 +35,7 @@ def _problem():
     return syn.baseline_config(3, lambda cam, grid, pts: eng.project(cam, grid, pts), n_imagesets=24, grid_wh=(20, 16))
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, distributed_solve=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -46,7 +46,7 @@ def _worker(rank, world, port, out_dir):
     sub, sst = pb.image_slice(b, e), st.image_slice(b, e)
     allreduce = dist_mod.make_allreduce_host_staged()
     en = eng.Engine(sub, device=0, allreduce=allreduce, n_images_global=pb.n_images, deterministic=True,
-                    last_projection=sub.obs_xy.astype(np.float64))
+                    last_projection=sub.obs_xy.astype(np.float64), distributed_solve=distributed_solve, rank=rank, world_size=world)
     en.set_state(sst)
     lam = -1.0
     reps = []
@@ -97,6 +97,41 @@ def test_two_ranks_on_one_gpu_match_the_single_process_engine(tmp_path):
     for key in ("points", "camrig", "grid0", "grid1"):
         check_equal(case, f"replicated state identical on both ranks: {key}", int(np.count_nonzero(rk[0][key] != rk[1][key])))
     check_equal(case, "step reports identical on both ranks", int(np.count_nonzero(rk[0]["reps"] != rk[1]["reps"])))
+
+
+def test_two_ranks_with_the_distributed_factorisation(tmp_path):
+    """cba_config.distributed_solve: the 512-column groups of the reduced system are owned block-cyclically by the two ranks, a
+    panel's block row is assembled from its owners before every rank factors it, and each rank applies the trailing update to
+    its own columns only (kernels_linalg.hip: ldlt_factor_distributed).  Same three LM iterations as above against the
+    single-process engine (replicated look-ahead factorisation): same decisions, results equal to the rounding of two
+    different elimination schedules."""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True), nprocs=world, join=True)
+    pb, st, _ = _problem()
+    en = eng.Engine(pb, deterministic=True, last_projection=pb.obs_xy.astype(np.float64))
+    en.set_state(st)
+    lam = -1.0
+    reps = []
+    for _ in range(STEPS):
+        r = en.step(lam)
+        lam = r.final_lambda
+        reps.append([r.initial_cost, r.final_cost, r.final_lambda, r.lm_attempts, float(r.accepted), r.n_residuals_valid])
+    ref = en.get_state(st)
+    en.close()
+    reps = np.array(reps)
+    case = "2 ranks on 1 GPU, distributed factorisation (cfg-3-shaped, 24 imagesets) vs single process"
+    rk = [np.load(os.path.join(str(tmp_path), f"rank{k}.npz")) for k in range(world)]
+    for k in range(world):
+        check_equal(case, f"rank {k}: LM attempts / accept decisions / valid counts",
+                    int(np.count_nonzero(rk[k]["reps"][:, 3:] != reps[:, 3:])))
+        check(case, f"rank {k}: initial cost of the first step rel", abs(rk[k]["reps"][0, 0] - reps[0, 0]) / reps[0, 0], 1e-13)
+        check(case, f"rank {k}: costs rel", (np.abs(rk[k]["reps"][:, :2] - reps[:, :2]) / reps[:, :2]).max(), 1e-6)
+        b, e = int(rk[k]["b"]), int(rk[k]["e"])
+        check(case, f"rank {k}: own poses abs", np.abs(rk[k]["poses"] - ref.rig_tr_global[b:e]).max(), 2e-7)
+        check(case, f"rank {k}: points abs", np.abs(rk[k]["points"] - ref.points).max(), 2e-7)
+        check(case, f"rank {k}: grids abs", max(np.abs(rk[k]["grid0"] - ref.grids[0]).max(), np.abs(rk[k]["grid1"] - ref.grids[1]).max()), 2e-7)
+    for key in ("points", "camrig", "grid0", "grid1"):
+        check_equal(case, f"replicated state identical on both ranks: {key}", int(np.count_nonzero(rk[0][key] != rk[1][key])))
 
 
 def test_native_rccl_callback_world_of_one(tmp_path):
