@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--no-convergence", action="store_true", help="skip the wall-clock-to-convergence run")
     ap.add_argument("--distributed-solve", type=int, default=-1,
                     help="1 / 0: distribute the factorisation of the reduced system over the ranks (cba_config.distributed_solve); "
-                         "default: on for config 5 (D = 42 789, where the replicated factorisation is 0.45 s of a 0.49 s step), off otherwise")
+                         "default off (first cut: no look-ahead yet, DESIGN.md section 6)")
     return ap.parse_args()
 
 
@@ -198,8 +198,8 @@ def main():
         keep = torch.zeros(reduce_n, dtype=torch.float64, device=f"cuda:{local_rank}")
         reduce_ptr = keep.data_ptr()
         allreduce = make_allreduce(keep, local_rank)
-    dist_solve = (args.distributed_solve == 1) or (args.distributed_solve < 0 and args.config == 5)
-    dist_solve = bool(dist_solve and use_dist and world > 1)
+    dist_solve = args.distributed_solve == 1
+    dist_solve = bool(dist_solve and use_dist and (world > 1 or args.distributed_solve == 1))   # world 1 + explicit flag: times the driver alone
     e = eng.Engine(pb, device=local_rank, allreduce=allreduce, n_images_global=n_img * world,
                    reduce_buffer_ptr=reduce_ptr, reduce_buffer_doubles=reduce_n, distributed_solve=dist_solve, rank=rank, world_size=world)
     e.set_state(st0)

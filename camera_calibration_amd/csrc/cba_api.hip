@@ -410,7 +410,7 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
   }
   GemmStats gs;
   CBA_TRY(timer_begin(p, 1));
-  if (multi && p->cfg.distributed_solve && p->cfg.world_size > 1)
+  if (multi && p->cfg.distributed_solve && p->cfg.world_size >= 1)
     CBA_TRY(ldlt_factor_distributed(p->S, p->n_fact, ld, p->ldlt, p->stream, p->cfg.rank, p->cfg.world_size, p->cfg.allreduce,
                                     p->cfg.allreduce_user, p->P, &gs));
   else
