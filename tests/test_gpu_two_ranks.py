@@ -99,13 +99,13 @@ def test_two_ranks_on_one_gpu_match_the_single_process_engine(tmp_path):
     check_equal(case, "step reports identical on both ranks", int(np.count_nonzero(rk[0]["reps"] != rk[1]["reps"])))
 
 
-def test_two_ranks_with_the_distributed_factorisation(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_ranks_with_the_distributed_factorisation(tmp_path, world):
     """cba_config.distributed_solve: the 512-column groups of the reduced system are owned block-cyclically by the two ranks, a
     panel's block row is assembled from its owners before every rank factors it, and each rank applies the trailing update to
     its own columns only (kernels_linalg.hip: ldlt_factor_distributed).  Same three LM iterations as above against the
     single-process engine (replicated look-ahead factorisation): same decisions, results equal to the rounding of two
-    different elimination schedules."""
-    world = 2
+    different elimination schedules.  (Also with three ranks: uneven image shards, three-way column ownership.)"""
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True), nprocs=world, join=True)
     pb, st, _ = _problem()
     en = eng.Engine(pb, deterministic=True, last_projection=pb.obs_xy.astype(np.float64))
@@ -119,7 +119,7 @@ def test_two_ranks_with_the_distributed_factorisation(tmp_path):
     ref = en.get_state(st)
     en.close()
     reps = np.array(reps)
-    case = "2 ranks on 1 GPU, distributed factorisation (cfg-3-shaped, 24 imagesets) vs single process"
+    case = f"{world} ranks on 1 GPU, distributed factorisation (cfg-3-shaped, 24 imagesets) vs single process"
     rk = [np.load(os.path.join(str(tmp_path), f"rank{k}.npz")) for k in range(world)]
     for k in range(world):
         check_equal(case, f"rank {k}: LM attempts / accept decisions / valid counts",
@@ -131,7 +131,8 @@ def test_two_ranks_with_the_distributed_factorisation(tmp_path):
         check(case, f"rank {k}: points abs", np.abs(rk[k]["points"] - ref.points).max(), 2e-7)
         check(case, f"rank {k}: grids abs", max(np.abs(rk[k]["grid0"] - ref.grids[0]).max(), np.abs(rk[k]["grid1"] - ref.grids[1]).max()), 2e-7)
     for key in ("points", "camrig", "grid0", "grid1"):
-        check_equal(case, f"replicated state identical on both ranks: {key}", int(np.count_nonzero(rk[0][key] != rk[1][key])))
+        for k in range(1, world):
+            check_equal(case, f"replicated state identical on ranks 0 and {k}: {key}", int(np.count_nonzero(rk[0][key] != rk[k][key])))
 
 
 def test_native_rccl_callback_world_of_one(tmp_path):
