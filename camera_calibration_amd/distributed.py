@@ -176,3 +176,42 @@ def solve_reduced(S_upper_sum: np.ndarray, s_sum: np.ndarray, lam: float) -> np.
     dd = S_upper_sum.shape[0]
     S = np.triu(S_upper_sum) + np.triu(S_upper_sum, 1).T + lam * np.eye(dd)
     return np.linalg.solve(S, s_sum)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Host mirror of the distributed factorisation schedule (csrc/kernels_linalg.hip: ldlt_factor_distributed), numpy.
+# Same ownership rule, same three phases per panel; `exchange(buf)` sums a float64 array over the ranks in place.
+# Used by the CPU tests of the multi-rank path (gloo, world size 2) -- the device kernels are covered on the GPU.
+# ---------------------------------------------------------------------------------------------------------------
+def distributed_ldlt_upper(S, rank: int, world: int, exchange, group: int = 512, panel: int = 512):
+    """S: (n, n) symmetric positive definite, upper triangle valid (modified in place).  Every rank passes the SAME matrix
+    (the all-reduced reduced system).  Returns (L, d) with S = L diag(d) L^T, complete on every rank."""
+    n = S.shape[0]
+    S = S.copy()
+    iu = np.triu_indices(n, 1)
+    S[(iu[1], iu[0])] = 0.0                                   # keep the upper triangle only, like the device storage
+    owner = (np.arange(n) // group) % world
+    L = np.eye(n)
+    d = np.zeros(n)
+    for k0 in range(0, n, panel):
+        e0 = min(k0 + panel, n)
+        if k0 > 0 and world > 1:                              # (1) assemble the block row from the owners of its columns
+            buf = np.where(owner[None, k0:] == rank, S[k0:e0, k0:], 0.0)
+            exchange(buf)
+            S[k0:e0, k0:] = buf
+        X = np.zeros((e0 - k0, n - k0))                       # (2) the panel, replicated: unblocked LDL^T of the block row
+        for j in range(k0, e0):
+            d[j] = S[j, j]
+            L[j + 1:, j] = S[j, j + 1:] / d[j]                # row j of the upper storage holds column j of L (times d)
+            X[j - k0, j + 1 - k0:] = S[j, j + 1:]
+            # eliminate within the block row
+            for i in range(j + 1, e0):
+                S[i, i:] -= L[i, j] * S[j, i:]
+        # (3) trailing update of the owned columns: S[m][c] -= sum_p L[m][p] d_p L[c][p], rows e0 <= m <= c
+        own = np.nonzero(owner[e0:] == rank)[0] + e0
+        if own.size:
+            Lp = L[e0:, k0:e0]                                # (n - e0) x nb
+            upd = (Lp * d[k0:e0]) @ Lp.T                      # symmetric; only the owned columns' upper part is used
+            for c in own:
+                S[e0:c + 1, c] -= upd[:c + 1 - e0, c - e0]
+    return L, d

@@ -160,3 +160,39 @@ def test_pack_unpack_roundtrip_and_block_offsets():
     S2 = dist_mod.unpack_upper(P, n_pad)
     for blk in range(n_pad // 128):
         np.testing.assert_array_equal(S2[128 * blk:128 * blk + 128, 128 * blk:], S[128 * blk:128 * blk + 128, 128 * blk:])
+
+
+def _dist_ldlt_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(5)
+    n = 7 * 64 + 32
+    A = rng.standard_normal((n, n + 40))
+    S = A @ A.T + 0.5 * np.eye(n)
+
+    def exchange(buf):
+        t = torch.from_numpy(buf)
+        dist.all_reduce(t)
+
+    L, d = dist_mod.distributed_ldlt_upper(S, rank, world, exchange, group=64, panel=128)
+    np.savez(os.path.join(out_dir, f"ldlt{rank}.npz"), L=L, d=d, S=S)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_factorisation_schedule_on_cpu(tmp_path, world):
+    """Host mirror of ldlt_factor_distributed (cba_config.distributed_solve): block-cyclic ownership of column groups, the
+    panel's block row assembled from its owners with one all-reduce, the panel factored on every rank, the trailing update
+    applied to owned columns only.  Every rank must end up with the same complete factor, and L D L^T must be S."""
+    mp.spawn(_dist_ldlt_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    out = [np.load(os.path.join(str(tmp_path), f"ldlt{k}.npz")) for k in range(world)]
+    S = out[0]["S"]
+    for k in range(world):
+        L, d = out[k]["L"], out[k]["d"]
+        assert np.all(d > 0)
+        assert np.abs((L * d) @ L.T - S).max() <= 1e-10 * np.abs(S).max()
+        assert np.array_equal(L, out[0]["L"]) and np.array_equal(d, out[0]["d"])       # identical arithmetic on identical data
+    # and it is the factorisation a single process computes
+    L1, d1 = dist_mod.distributed_ldlt_upper(S, 0, 1, lambda buf: None, group=64, panel=128)
+    assert np.abs(L1 - out[0]["L"]).max() <= 1e-11 and np.abs(d1 - out[0]["d"]).max() <= 1e-10 * d1.max()
