@@ -162,6 +162,7 @@ struct GemmArgs {
   int se_max;                   // CUs of a complete SE
   const double* a_rowdiv;       // small-tile variants only: A[k][m] is divided by a_rowdiv[k] while staged (L = X / d on the fly)
   int tlog_tag;                 // developer timeline (tools/bench_linalg.hip, -DCBA_TLOG): tag + 1, 0 = none
+  int col_group, col_stride;    // distributed factorisation: owned column groups (tiles per group, group stride); 0 = all columns
 };
 
 // Developer switches are compiled only into the bench harness (tools/bench_linalg.hip defines CBA_DEV_SWITCHES): the
@@ -251,11 +252,26 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
       if (rem < cnt) { tn = (int)(first + rem); break; }
       rem -= cnt;
     }
+  } else if (g.col_group > 0) {
+    // 8 x 8 blocks of tiles, block rows first: the ~64 workgroups in flight on an XCD share 8 A and 8 B panels
+    const int nb8 = (g.n_tiles + 7) / 8;
+    const long long blk = t >> 6;
+    const int in = (int)(t & 63);
+    tm = (int)(blk / nb8) * 8 + (in >> 3);
+    tn = (int)(blk % nb8) * 8 + (in & 7);
+    if (tm >= g.m_tiles || tn >= g.n_tiles) return true;
   } else {
     tm = (int)(t / g.n_tiles);
     tn = (int)(t - (long long)tm * g.n_tiles);
   }
-  const int m0 = g.m_off + tm * TM, n0 = g.n_off + tn * TN;
+  const int m0 = g.m_off + tm * TM;
+  int n0 = g.n_off + tn * TN;
+  if (g.col_group > 0) {
+    // distributed factorisation: the launch covers only the column groups this rank owns (every `col_stride`-th group of
+    // `col_group` tiles); tiles below the diagonal are launched and skipped
+    n0 = g.n_off + ((tn / g.col_group) * g.col_stride * g.col_group + tn % g.col_group) * TN;
+    if (n0 + TN - 1 < m0) return true;
+  }
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm0 = (wv / WAVES_N) * WM, wn0 = (wv % WAVES_N) * WN;
@@ -596,12 +612,13 @@ template <int TM, int TN, int WM, int WN, bool SUB>
 static int launch_gemm(GemmArgs g, hipStream_t s) {
   g.total_tiles = g.upper ? count_upper_tiles(g.m_off, g.n_off, g.m_tiles, g.n_tiles, TM, TN)
                           : (long long)g.m_tiles * g.n_tiles;
+  if (g.col_group > 0) g.total_tiles = (long long)((g.m_tiles + 7) / 8) * ((g.n_tiles + 7) / 8) * 64;
   if (g.total_tiles <= 0) return CBA_OK;
   // chunk = 64 tiles for big launches; small launches use smaller chunks so that all eight XCDs get work
   long long per = (g.total_tiles + 7) / 8;
   // dense launches: one contiguous range per XCD (best L2 reuse); block-sparse launches: chunks of 64
   // interleaved over the XCDs so that dense and sparse regions of the matrix are spread evenly
-  g.chunk = (int)((g.kmask && per > 64) ? 64 : (per < 1 ? 1 : per));
+  g.chunk = (int)(((g.kmask || g.col_group > 0) && per > 64) ? 64 : (per < 1 ? 1 : per));   // col_group: half of the enumerated tiles are skipped, unevenly
   static const int use_strips = CBA_GETENV("CBA_NO_STRIPS") ? 0 : 1;
   g.strips = (use_strips && TM == 128 && TN == 128 && g.upper && !g.kmask && g.m_off == g.n_off && g.m_tiles == g.n_tiles &&
               g.total_tiles >= 512) ? 1 : 0;
@@ -1085,9 +1102,13 @@ __device__ __forceinline__ void tile_mma(v4f64 (&acc)[2][2], const double* __res
 #undef CBA_TSTORE
 }
 
-__global__ void __launch_bounds__(256) k_panel_solve(double* __restrict__ S, int ld, int k0, int nb, int col0,
-                                                     double* __restrict__ Xk, int ldx, const double* __restrict__ dvec,
-                                                     const double* __restrict__ invLt_all) {
+// INV = true: U is the identity (generated, not read) and nothing is written into S -- Xk then receives the inverse of the
+// panel's unit-lower factor, Xk[p][c] = (L_panel^-1)(p, c), c in [0, nb): what the distributed driver multiplies the block row
+// with (ldlt_factor_distributed).
+template <bool INV>
+__global__ void __launch_bounds__(256) k_panel_solve_t(double* __restrict__ S, int ld, int k0, int nb, int col0,
+                                                       double* __restrict__ Xk, int ldx, const double* __restrict__ dvec,
+                                                       const double* __restrict__ invLt_all) {
   __shared__ double sA[2 * KT * TS];
   __shared__ double sB[2 * KT * TS];
   __shared__ double sV[kInner * TS];
@@ -1114,7 +1135,8 @@ __global__ void __launch_bounds__(256) k_panel_solve(double* __restrict__ S, int
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = wm0 + i * 16 + lk + 4 * r, n = wn0 + jj * 16 + li;
-          sV[m * TS + n] = Urow[(size_t)m * ld + n] - acc[i][jj][r];
+          const double u = INV ? ((kInner * j + m == n0 + n) ? 1.0 : 0.0) : Urow[(size_t)m * ld + n];
+          sV[m * TS + n] = u - acc[i][jj][r];
         }
     __syncthreads();
     v4f64 x[2][2];
@@ -1135,7 +1157,7 @@ __global__ void __launch_bounds__(256) k_panel_solve(double* __restrict__ S, int
           const int n = wn0 + jj * 16 + li;
           const double v = x[i][jj][r];
           Xk[(size_t)(kInner * j + m) * ldx + n0 + n] = v;
-          Urow[(size_t)m * ld + n] = v / d;
+          if (!INV) Urow[(size_t)m * ld + n] = v / d;
         }
       }
     __syncthreads();   // the stores are acknowledged by L2 (vmcnt) before any lane re-reads X with agent-scope loads
@@ -1611,6 +1633,7 @@ int ldlt_workspace_alloc(LdltWorkspace& w, int n_pad) {
   CBA_HIP(hipMalloc(&w.invLt, sizeof(double) * (size_t)(n_pad / kInner) * kInner * kInner));
   CBA_HIP(hipMalloc(&w.dvec, sizeof(double) * (size_t)n_pad));
   CBA_HIP(hipMalloc(&w.status, sizeof(int)));
+  CBA_HIP(hipMalloc(&w.inv_panel, sizeof(double) * 2 * (size_t)kPanelWide * kPanelWide));
   {
     DeviceStreams d;
     int rc = device_streams(&d);
@@ -1633,6 +1656,7 @@ void ldlt_workspace_free(LdltWorkspace& w) {
   if (w.invLt) hipFree(w.invLt);
   if (w.dvec) hipFree(w.dvec);
   if (w.status) hipFree(w.status);
+  if (w.inv_panel) hipFree(w.inv_panel);
   if (w.ev_panel) hipEventDestroy(w.ev_panel);
   if (w.ev_strip) hipEventDestroy(w.ev_strip);
   if (w.ev_mid) hipEventDestroy(w.ev_mid);
@@ -1812,7 +1836,7 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
       CBA_HIP(hipStreamWaitEvent(s3, w.ev_chain, 0));
       hipLaunchKernelGGL(k_scale_rows, dim3(kPanel - kInner), dim3(256), 0, s3, S, ld, k0, k0, k0 + kInner, e0, Xk, n_pad, w.dvec);
       if (n_pad > nx)
-        hipLaunchKernelGGL(k_panel_solve, dim3((n_pad - nx) / kInner), dim3(256), 0, s3, S, ld, k0, nb, nx, Xk, n_pad, w.dvec, w.invLt);
+        hipLaunchKernelGGL(k_panel_solve_t<false>, dim3((n_pad - nx) / kInner), dim3(256), 0, s3, S, ld, k0, nb, nx, Xk, n_pad, w.dvec, w.invLt);
       CBA_HIP(hipEventRecord(w.ev_panel, s3));
       CBA_HIP(hipStreamWaitEvent(s, w.ev_panel, 0));
       if (mt > head) {
@@ -1915,7 +1939,7 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
     CBA_HIP(hipStreamWaitEvent(s3, w.ev_chain, 0));          // the panel's last block is factored
     CBA_HIP(hipStreamWaitEvent(s3, w.ev_mid, 0));            // ... and L is in place inside the panel
     if (n_pad > nx)
-      hipLaunchKernelGGL(k_panel_solve, dim3((n_pad - nx) / kInner), dim3(256), 0, s3, S, ld, k0, nb, nx, Xk, n_pad,
+      hipLaunchKernelGGL(k_panel_solve_t<false>, dim3((n_pad - nx) / kInner), dim3(256), 0, s3, S, ld, k0, nb, nx, Xk, n_pad,
                          w.dvec, w.invLt);
     CBA_HIP(hipEventRecord(w.ev_panel, s3));
     CBA_HIP(hipStreamWaitEvent(s, w.ev_panel, 0));
@@ -2001,9 +2025,18 @@ __global__ void __launch_bounds__(256) k_block_row_exchange(double* __restrict__
     else *st = ((col / kOwnGroup) % world == rank) ? *sp : 0.0;
   }
 }
+__global__ void k_transpose_square(const double* __restrict__ A, double* __restrict__ At, int n) {
+  __shared__ double t[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  for (int r = threadIdx.y; r < 32; r += 8) t[r][threadIdx.x] = A[(size_t)(by + r) * kPanelWide + bx + threadIdx.x];
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += 8) At[(size_t)(bx + r) * kPanelWide + by + threadIdx.x] = t[threadIdx.x][r];
+  (void)n;
+}
 int ldlt_factor_distributed(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, int rank, int world,
                             int (*exchange)(void* buf, int64_t count, void* user), void* user, double* stage, GemmStats* st) {
   const int n_pad = ld;
+  double* inv_buf = w.inv_panel;      // 2 x 512 x 512 doubles (ldlt_workspace_alloc)
   int kidx = 0;
   for (int k0 = 0; k0 < n_fact; ++kidx) {
     const int nb = (n_fact - k0 >= kPanelWide) ? kPanelWide : ((n_fact - k0 >= kPanel) ? kPanel : (n_fact - k0));
@@ -2029,21 +2062,46 @@ int ldlt_factor_distributed(double* S, int n_fact, int ld, LdltWorkspace& w, hip
         if ((rc = update_block(S, ld, j0, k0, c0, e0, c0, e0, /*upper*/ 1, Xk, s, kTlChainUpd))) return rc;
       }
     }
-    if (n_pad > e0)
-      hipLaunchKernelGGL(k_panel_solve, dim3((n_pad - e0) / kInner), dim3(256), 0, s, S, ld, k0, nb, e0, Xk, n_pad, w.dvec, w.invLt);
-    // (3) trailing update of the column groups this rank owns: rows [e0, c_hi) x columns [c_lo, c_hi), upper part
-    if (e0 < n_fact || e0 < n_pad) {
-      for (int c_lo = (e0 / kOwnGroup) * kOwnGroup; c_lo < n_pad; c_lo += kOwnGroup) {
-        if ((c_lo / kOwnGroup) % world != rank) continue;
-        const int lo = c_lo < e0 ? e0 : c_lo;
-        const int hi = c_lo + kOwnGroup < n_pad ? c_lo + kOwnGroup : n_pad;
-        if (lo >= hi) continue;
+    if (n_pad > e0) {
+      if (nb == kPanelWide && inv_buf) {
+        // X = L_panel^-1 U as ONE product over the whole block row instead of the per-tile forward substitution (a chain of
+        // 8 dependent 64-blocks per 64-column tile, ~5 TFLOP/s -- hidden under the bulk update in the look-ahead schedule,
+        // exposed and replicated here): L_panel^-1 by substitution on the identity (8 workgroups), its transpose as the
+        // K-major operand, the product, then L = X / d in place.
+        double* Xinv = inv_buf;                                   // [nb][nb]
+        double* XinvT = inv_buf + (size_t)kPanelWide * kPanelWide;
+        hipLaunchKernelGGL(k_panel_solve_t<true>, dim3(nb / kInner), dim3(256), 0, s, S, ld, k0, nb, 0, Xinv, kPanelWide, w.dvec, w.invLt);
+        hipLaunchKernelGGL(k_transpose_square, dim3(nb / 32, nb / 32), dim3(32, 8), 0, s, Xinv, XinvT, nb);
+        GemmArgs g{};
+        g.A = XinvT; g.lda = kPanelWide; g.B = S + (size_t)k0 * ld; g.ldb = ld; g.K = nb;
+        g.C = Xk; g.ldc = n_pad; g.Cin = nullptr; g.ldcin = 0; g.diag = 0; g.upper = 0;
+        g.m_off = 0; g.m_tiles = nb / 128; g.n_off = e0; g.n_tiles = (n_pad - e0) / 128;
+        if ((rc = launch_gemm<128, 128, 64, 64, false>(g, s))) return rc;
+        hipLaunchKernelGGL(k_scale_rows, dim3(nb), dim3(256), 0, s, S, ld, k0, k0, e0, n_pad, Xk, n_pad, w.dvec);
+      } else {
+        hipLaunchKernelGGL(k_panel_solve_t<false>, dim3((n_pad - e0) / kInner), dim3(256), 0, s, S, ld, k0, nb, e0, Xk, n_pad, w.dvec, w.invLt);
+      }
+    }
+    // (3) trailing update of the column groups this rank owns, ONE launch: rows [e0, n_pad) x owned columns, tiles below the
+    //     diagonal skipped inside the kernel
+    {
+      constexpr int G = kOwnGroup / 128;
+      const int g_first = e0 / kOwnGroup;                                 // first group that reaches past the panel
+      int g0 = g_first;
+      while (g0 % world != rank) ++g0;
+      int owned_tiles = 0;
+      for (int gi = g0; gi * kOwnGroup < n_pad; gi += world) {
+        const int hi = (gi + 1) * kOwnGroup < n_pad ? (gi + 1) * kOwnGroup : n_pad;
+        owned_tiles += (hi - gi * kOwnGroup) / 128;
+      }
+      if (owned_tiles > 0 && e0 < n_pad) {
         GemmArgs u{};
         u.A = S + (size_t)k0 * ld; u.lda = ld; u.B = Xk; u.ldb = n_pad; u.K = nb;
-        u.C = S; u.ldc = ld; u.Cin = S; u.ldcin = ld; u.diag = 0; u.upper = 1;
-        u.m_off = e0; u.m_tiles = (hi - e0) / 128; u.n_off = lo; u.n_tiles = (hi - lo) / 128;
+        u.C = S; u.ldc = ld; u.Cin = S; u.ldcin = ld; u.diag = 0; u.upper = 0;
+        u.m_off = e0; u.m_tiles = (n_pad - e0) / 128; u.n_off = g0 * kOwnGroup; u.n_tiles = owned_tiles;
+        u.col_group = G; u.col_stride = world;
         if ((rc = launch_gemm<128, 128, 64, 64, true>(u, s))) return rc;
-        if (st) { st->flops += 2.0 * 128 * 128 * nb * (double)count_upper_tiles(u.m_off, u.n_off, u.m_tiles, u.n_tiles, 128, 128); st->launches += 1; }
+        if (st) { const double rows = (double)(n_pad - e0); st->flops += rows * rows * nb / world; st->launches += 1; }
       }
     }
     k0 = e0;
