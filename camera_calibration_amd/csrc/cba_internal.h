@@ -148,12 +148,24 @@ struct LdltWorkspace {
   struct Span { hipEvent_t e0 = nullptr, e1 = nullptr; double flops = 0; };
   std::vector<Span> spans;
   int spans_used = 0;
+  // persistent tail launch (ldlt_tail): flags hold the number of the call that set them, nothing is cleared between calls
+  unsigned* tail_flags = nullptr;    // tile flags [tail_rows_cap / 64][n / 64], then diag / upre / part flags [n / 64] each
+  unsigned* tail_ctrl = nullptr;     // tickets, abort flag, role tickets, chain CU
+  unsigned tail_epoch = 0;
+  int tail_rows_cap = 0;             // largest tail this workspace has flags for
+  hipEvent_t tail_e0 = nullptr, tail_e1 = nullptr;   // span of the last tail launch (statistics only)
+  bool tail_timed = false;
 };
 int ldlt_workspace_alloc(LdltWorkspace& w, int n);
 // adds the GEMM launches timed since the last call to `st` (waits for them)
 int ldlt_collect_spans(LdltWorkspace& w, GemmStats* st);
 void ldlt_workspace_free(LdltWorkspace& w);
 int ldlt_factor(double* S, int n, int ld, LdltWorkspace& w, hipStream_t s, GemmStats* trailing_stats);
+// Rows (from the end of the matrix) that the persistent tail launch factors; 0 = the blocked multi-stream schedule all the way.
+void ldlt_set_tail_rows(int rows);
+int ldlt_tail_rows();
+// milliseconds of the last tail launch (waits for it); 0 when there was none
+double ldlt_tail_last_ms(LdltWorkspace& w);
 // Distributed variant (cba_config.distributed_solve): `exchange(buf, count)` sums a device buffer over the ranks (synchronous);
 // `stage` holds at least 512 * ld doubles
 int ldlt_factor_distributed(double* S, int n, int ld, LdltWorkspace& w, hipStream_t s, int rank, int world,

@@ -732,6 +732,7 @@ constexpr bool kDiagPairs = true;
 #endif
 constexpr int kPanel = 256;
 constexpr int kPanelWide = 512;
+constexpr int kTailMaxBlockRows = 192;      // the persistent tail launch covers at most this many 64-row blocks (flag storage)
 // panels are kPanelWide wide while more than this many rows remain (env CBA_WIDE_ROWS overrides; 0 = never)
 static int wide_rows_threshold() {
   static int v = -1;
@@ -938,22 +939,12 @@ __device__ __forceinline__ void ldlt_diag_segment_pairs(double (&T)[4][4], doubl
 // -- the second is the product form L^-1 = (I - l_62 e_62^T) ... (I - l_0 e_0^T).  One barrier per step.
 // `tile` == nullptr: T is read from the stored upper triangle of M; otherwise from a 64 x 64 tile in LDS (row stride
 // tile_ld, upper triangle valid) -- the fused chain kernel hands over the block it has just updated.
+// The elimination loop itself: T (symmetric, cyclic 4 x 4 sub-grid per lane) -> L below / d on the diagonal, X (identity on
+// entry) -> L^-1.  colbuf / rowbuf: 5 x 64 doubles of LDS each.  Returns true when a pivot was zero or NaN.
 template <int NSTEPS>
-__device__ __forceinline__ void ldlt_diag_body(double* __restrict__ M, int ld, int j0, double* __restrict__ dvec,
-                                               double* __restrict__ invLt_all, int* __restrict__ status,
-                                               const double* tile, int tile_ld, double (*colbuf)[kInner],
+__device__ __forceinline__ bool ldlt_diag_core(double (&T)[4][4], double (&X)[4][4], double (*colbuf)[kInner],
                                                double (*rowbuf)[kInner]) {
   const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
-  double T[4][4], X[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      int i = ti + 16 * a, j = tj + 16 * b;
-      int lo = i < j ? i : j, hi = i < j ? j : i;           // symmetric fill from the upper triangle
-      T[a][b] = tile ? tile[lo * tile_ld + hi] : M[(size_t)(j0 + lo) * ld + j0 + hi];
-      X[a][b] = (i == j) ? 1.0 : 0.0;
-    }
   bool bad = false;
   if constexpr (kDiagPairs && NSTEPS == kInner) {
     if (tj < 2) {
@@ -984,6 +975,26 @@ __device__ __forceinline__ void ldlt_diag_body(double* __restrict__ M, int ld, i
     ldlt_diag_segment<2>(T, X, colbuf, rowbuf, ti, tj, NSTEPS, bad);
     ldlt_diag_segment<3>(T, X, colbuf, rowbuf, ti, tj, NSTEPS, bad);
   }
+  return bad;
+}
+
+template <int NSTEPS>
+__device__ __forceinline__ void ldlt_diag_body(double* __restrict__ M, int ld, int j0, double* __restrict__ dvec,
+                                               double* __restrict__ invLt_all, int* __restrict__ status,
+                                               const double* tile, int tile_ld, double (*colbuf)[kInner],
+                                               double (*rowbuf)[kInner]) {
+  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  double T[4][4], X[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      int i = ti + 16 * a, j = tj + 16 * b;
+      int lo = i < j ? i : j, hi = i < j ? j : i;           // symmetric fill from the upper triangle
+      T[a][b] = tile ? tile[lo * tile_ld + hi] : M[(size_t)(j0 + lo) * ld + j0 + hi];
+      X[a][b] = (i == j) ? 1.0 : 0.0;
+    }
+  bool bad = ldlt_diag_core<NSTEPS>(T, X, colbuf, rowbuf);
   if (bad && tid == 0) atomicExch(status, 2);
   double* invLt = invLt_all + (size_t)(j0 / kInner) * kInner * kInner;
 #pragma unroll
@@ -1502,6 +1513,467 @@ __global__ void __launch_bounds__(256) k_scale_rows(double* __restrict__ S, int 
   tlog_end((j0 / kInner) * kTlKinds + kTlScale);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tail of the factorisation: ONE persistent dataflow launch for the last rows (ldlt_tail, k_ldlt_tail).
+//
+// Below ~6000 remaining rows the blocked schedule above is bound by its pivot chain: per 64-block 18 us of pivots plus
+// 25-30 us of near step, launch gaps, waits for the last workgroup of the previous launch and cross-stream stalls
+// (profiles/r02_factor_timeline_pairs.txt: 5.1 ms for 12 % of the flops at config 2).  Here the whole trailing block is
+// factored by one launch in which every 64 x 64 tile is a task and tasks synchronise through device-scope flags:
+//
+//   chain workgroup (the first one to arrive): for r = r0, r0 + 1, ...: X = invL_{r-1} U_{r-1,r} (both operands in LDS: the
+//       inverse it has just computed never leaves the CU), L_{r-1,r} = X / d published, T_rr = P_r - L^T X, 64 pivots
+//       (ldlt_diag_core), L_rr / d / invL_rr published.  No launch, no stream event, no other tile on its critical path.
+//   helper workgroups: tasks drawn from one ticket counter in row-major order (a task only ever waits for tasks with smaller
+//       tickets or for the chain, so the launch cannot deadlock however many workgroups are resident):
+//       PRE(r)    U_{r,r+1} = A_{r,r+1} - sum_{k<r} (d_k L_kr)^T L_{k,r+1}       in place (what the chain's next step reads)
+//       PART(r+1) P_{r+1}   = A_{r+1,r+1} - sum_{k<r} (d_k L_{k,r+1})^T L_{k,r+1}  in place
+//       REG(r,c)  U = A_rc - sum_{k<r} (d_k L_kr)^T L_kc, then (after block r is factored) X = invL_r U, L_rc = X / d_r.
+//   LEFT-looking: a tile is read once, accumulated in registers over all earlier block rows (one K loop that follows the
+//   frontier of finished rows: as many ready rows per batch as there are, at most 16) and written once -- no read-modify-write
+//   of the trailing matrix per panel.  Only S is read: the update uses d_k L_k^T L_k (L scaled while staged), no panel buffer.
+//
+// Cross-workgroup visibility: everything another workgroup reads is written with agent-scope stores (sc1, write-through) and
+// read with agent-scope loads (sc1 buffer loads, 16 B per lane); a flag is raised after s_waitcnt vmcnt(0) + barrier.  Flags hold
+// the number of the factorisation call ("epoch"), so nothing has to be cleared between calls.  Every spin is bounded
+// (kTailTimeoutTicks of the 100 MHz clock): on a timeout the launch sets status 3, raises the abort flag and ends.
+// ------------------------------------------------------------------------------------------------
+struct TailArgs {
+  double* S; int ld;
+  int rt0, nr, ntc;                 // first tail block row, number of block rows to factor, number of block columns (64 wide)
+  double* dvec; double* invLt; int* status;
+  unsigned* tile_flag;              // [(r - rt0) * ntc + c]: L_rc published
+  unsigned* diag_flag;              // [r - rt0]: block r factored (L_rr, d, invL_rr published)
+  unsigned* upre_flag;              // [r - rt0]: U_{r,r+1} in place
+  unsigned* part_flag;              // [r - rt0]: P_r in place
+  unsigned* ctrl;                   // [0] task tickets, [1] abort, [2] role tickets, [3] CU of the chain workgroup
+  unsigned epoch;
+  int ntasks;
+  int evict;                        // helper workgroups that share the chain's CU stop taking tasks
+};
+constexpr unsigned long long kTailTimeoutTicks = 300000000ull;   // 3 s
+
+typedef unsigned v4u32_t __attribute__((ext_vector_type(4)));
+typedef unsigned v2u32_t __attribute__((ext_vector_type(2)));
+typedef double v2f64_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tail_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7ffffffe, 0x00020000);
+}
+// agent-scope (sc1) loads: 16 B / 8 B per lane, tracked by the compiler's wait counts
+__device__ __forceinline__ v2f64_t tail_ld2(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+  return __builtin_bit_cast(v2f64_t, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16));
+}
+__device__ __forceinline__ double tail_ld1(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 16));
+}
+__device__ __forceinline__ unsigned tail_ldflag(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void tail_stflag(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void tail_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double tail_ld(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// all stores of this workgroup are acknowledged, then one lane raises the flag
+__device__ __forceinline__ void tail_publish(unsigned* flag, unsigned epoch) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) tail_stflag(flag, epoch);
+}
+__device__ __forceinline__ void tail_abort(const TailArgs& t) {
+  atomicExch(t.status, 3);
+  tail_stflag(&t.ctrl[1], 1u);
+}
+// Waits until *f0 (and *f1, if given) carry the epoch.  false = the launch was aborted.  `slot`: an int in LDS.
+__device__ __forceinline__ bool tail_wait(const TailArgs& t, const unsigned* f0, const unsigned* f1, volatile int* slot) {
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = wall_clock64();
+    int ok = 1;
+    unsigned spins = 0;
+    while (tail_ldflag(f0) != t.epoch || (f1 && tail_ldflag(f1) != t.epoch)) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 63u) == 0) {
+        if (tail_ldflag(&t.ctrl[1]) != 0) { ok = 0; break; }
+        if (wall_clock64() - t0 > kTailTimeoutTicks) { tail_abort(t); ok = 0; break; }
+      }
+    }
+    *slot = ok;
+  }
+  __syncthreads();
+  const int ok = *slot;
+  return ok != 0;
+}
+// Number of consecutive block rows k, k + 1, ... (< kend, at most 16) whose tiles (row, ca) and (row, cb) are published; waits for
+// at least one.  0 = aborted.  One wavefront polls 32 flags per round.
+__device__ __forceinline__ int tail_wait_rows(const TailArgs& t, int k, int kend, int ca, int cb, volatile int* slot) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const int row = k + (lane >> 1);
+    const bool in = lane < 32 && row < kend;
+    const unsigned* f = t.tile_flag + (size_t)((in ? row : k) - t.rt0) * t.ntc + ((lane & 1) ? cb : ca);
+    const unsigned long long t0 = wall_clock64();
+    int n = 0;
+    unsigned spins = 0;
+    for (;;) {
+      const bool ok = in && tail_ldflag(f) == t.epoch;
+      const unsigned long long m = __ballot(ok);
+      const unsigned long long both = m & (m >> 1) & 0x5555555555555555ull;
+      n = 0;
+      while (n < 16 && ((both >> (2 * n)) & 1ull)) ++n;
+      if (n > 0) break;
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 63u) == 0) {
+        if (tail_ldflag(&t.ctrl[1]) != 0) break;
+        if (__builtin_amdgcn_readfirstlane((int)(wall_clock64() - t0 > kTailTimeoutTicks))) { if (lane == 0) tail_abort(t); break; }
+      }
+    }
+    if (lane == 0) *slot = n;
+  }
+  __syncthreads();
+  const int n = *slot;
+  return n;
+}
+
+// acc (64 x 64, 4 waves x 32 x 32) += sum_{k < K} (dk[k] A[k][m]) B[k][n]; A, B: K rows of `ld` doubles, written by other workgroups
+// of this launch (agent-scope loads).  SYM: B == A (loaded once).  Register-staged, three slabs in flight; ends with a barrier.
+template <bool SYM>
+__device__ __forceinline__ void tail_mma(v4f64 (&acc)[2][2], const double* A, const double* B, int ld, const double* dk, int K,
+                                         double* sA, double* sB) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
+  const int r = tid >> 5, c2 = 2 * (tid & 31);
+  const int nk = K / KT;
+  const __amdgpu_buffer_rsrc_t ra = tail_rsrc(A), rb = tail_rsrc(B), rd = tail_rsrc(dk);
+  const int rowb = ld * 8;
+  v2f64_t a0_0, a0_1, a1_0, a1_1, a2_0, a2_1;
+  v2f64_t b0_0 = {0, 0}, b0_1 = {0, 0}, b1_0 = {0, 0}, b1_1 = {0, 0}, b2_0 = {0, 0}, b2_1 = {0, 0};
+  double d0_0, d0_1, d1_0, d1_1, d2_0, d2_1;
+#define CBA_XLOAD(slot_, k0_)                                                                    \
+  {                                                                                              \
+    const int o = ((k0_) + r) * rowb + c2 * 8;                                                   \
+    a##slot_##_0 = tail_ld2(ra, o); a##slot_##_1 = tail_ld2(ra, o + 8 * rowb);                   \
+    if constexpr (!SYM) { b##slot_##_0 = tail_ld2(rb, o); b##slot_##_1 = tail_ld2(rb, o + 8 * rowb); } \
+    d##slot_##_0 = tail_ld1(rd, ((k0_) + r) * 8); d##slot_##_1 = tail_ld1(rd, ((k0_) + r + 8) * 8); \
+  }
+#define CBA_XSTORE(buf_, slot_)                                                                  \
+  {                                                                                              \
+    double* qa = sA + (buf_) * KT * TS + r * TS + c2;                                            \
+    double* qb = sB + (buf_) * KT * TS + r * TS + c2;                                            \
+    qa[0] = a##slot_##_0.x * d##slot_##_0; qa[1] = a##slot_##_0.y * d##slot_##_0;                \
+    qa[8 * TS] = a##slot_##_1.x * d##slot_##_1; qa[8 * TS + 1] = a##slot_##_1.y * d##slot_##_1;  \
+    if constexpr (SYM) { qb[0] = a##slot_##_0.x; qb[1] = a##slot_##_0.y; qb[8 * TS] = a##slot_##_1.x; qb[8 * TS + 1] = a##slot_##_1.y; } \
+    else { qb[0] = b##slot_##_0.x; qb[1] = b##slot_##_0.y; qb[8 * TS] = b##slot_##_1.x; qb[8 * TS + 1] = b##slot_##_1.y; } \
+  }
+  CBA_XLOAD(0, 0);
+  CBA_XLOAD(1, (1 < nk ? 1 : nk - 1) * KT);
+  CBA_XLOAD(2, (2 < nk ? 2 : nk - 1) * KT);
+  CBA_XSTORE(0, 0);
+  __syncthreads();
+#define CBA_XSTEP(slot_, next_slot_)                                                                         \
+  if (kb0 + (slot_) < nk) {                                                                                  \
+    const int kb = kb0 + (slot_);                                                                            \
+    const int buf = kb & 1;                                                                                  \
+    CBA_XLOAD(slot_, (kb + 3 < nk ? kb + 3 : nk - 1) * KT);                                                  \
+    const double* a_s = sA + buf * KT * TS;                                                                  \
+    const double* b_s = sB + buf * KT * TS;                                                                  \
+    _Pragma("unroll") for (int kk = 0; kk < KT; kk += 4) {                                                   \
+      double af[2], bf[2];                                                                                   \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) af[i] = a_s[(kk + lk) * TS + wm0 + i * 16 + li];         \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) bf[j] = b_s[(kk + lk) * TS + wn0 + j * 16 + li];         \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);                \
+    }                                                                                                        \
+    CBA_XSTORE(buf ^ 1, next_slot_);                                                                         \
+    __syncthreads();                                                                                         \
+  }
+#pragma nounroll
+  for (int kb0 = 0; kb0 < nk; kb0 += 3) {
+    CBA_XSTEP(0, 1)
+    CBA_XSTEP(1, 2)
+    CBA_XSTEP(2, 0)
+  }
+#undef CBA_XSTEP
+#undef CBA_XLOAD
+#undef CBA_XSTORE
+}
+
+// ticket -> task.  kind 0 = PRE(r), 1 = PART(r + 1), 2 = REG(r, c)
+__device__ __forceinline__ void tail_task(const TailArgs& t, int ticket, int* kind, int* r_out, int* c_out) {
+  int r = t.rt0;
+  for (; r < t.nr; ++r) {
+    const int cnt = (r + 1 < t.nr) ? t.ntc - r : t.ntc - t.nr;
+    if (ticket < cnt) break;
+    ticket -= cnt;
+  }
+  *r_out = r;
+  if (r + 1 < t.nr) {
+    if (ticket == 0) { *kind = 0; *c_out = r + 1; }
+    else if (ticket == 1) { *kind = 1; *c_out = r + 1; }
+    else { *kind = 2; *c_out = r + ticket; }          // ticket 2 -> column r + 2
+  } else {
+    *kind = 2; *c_out = r + 1 + ticket;
+  }
+}
+
+__device__ __forceinline__ unsigned tail_cu_id() {
+  const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7u;          // HW_REG_XCC_ID
+  const unsigned hw = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);                // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
+  return 0x80000000u | (xcc << 8) | ((hw >> 8) & 0xffu);
+}
+
+// developer timeline of the chain workgroup (tools/bench_tail.hip, -DCBA_TAILLOG): 100 MHz stamps per block and phase
+#ifdef CBA_TAILLOG
+__device__ unsigned long long* g_taillog = nullptr;
+#define TAIL_STAMP(blk_, ph_) do { if (g_taillog && threadIdx.x == 0) g_taillog[(size_t)(blk_) * 16 + (ph_)] = wall_clock64(); } while (0)
+#else
+#define TAIL_STAMP(blk_, ph_) do { } while (0)
+#endif
+
+// ---- the chain workgroup ----
+__device__ __forceinline__ void tail_chain(const TailArgs& t, double* sV, double* sW) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
+  const int ti = tid >> 4, tj = tid & 15;
+  double (*colbuf)[kInner] = reinterpret_cast<double (*)[kInner]>(sV);                  // the pivot loop's buffers live in sV
+  double (*rowbuf)[kInner] = reinterpret_cast<double (*)[kInner]>(sV + 5 * kInner);
+  double* s_d = sW + kInner;                      // d of the block factored last: padding columns of rows 0 .. 3 of sW
+  volatile int* slot = reinterpret_cast<volatile int*>(sW + 4 * TS + kInner);            // padding of row 4
+  const int ld = t.ld;
+  if (tid == 0 && t.evict) tail_stflag(&t.ctrl[3], tail_cu_id());
+  for (int r = t.rt0; r < t.nr; ++r) {
+    const int j0 = kInner * r;
+    TAIL_STAMP(r - t.rt0, 0);
+    if (r > t.rt0) {
+      const int b = r - t.rt0;
+      if (!tail_wait(t, &t.upre_flag[b - 1], &t.part_flag[b], slot)) return;
+      TAIL_STAMP(b, 1);
+      // U_{r-1,r} -> sV; P_r -> registers (accumulator layout)
+      {
+        const __amdgpu_buffer_rsrc_t ru = tail_rsrc(t.S + (size_t)(j0 - kInner) * ld + j0);
+        const int row = tid >> 2, cq = (tid & 3) * 16;
+        v2f64_t u[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u[i] = tail_ld2(ru, (row * ld + cq + 2 * i) * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { sV[row * TS + cq + 2 * i] = u[i].x; sV[row * TS + cq + 2 * i + 1] = u[i].y; }
+      }
+      v4f64 P[2][2];
+      {
+        const __amdgpu_buffer_rsrc_t rp = tail_rsrc(t.S + (size_t)j0 * ld + j0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
+              P[i][jj][r4] = tail_ld1(rp, (m * ld + n) * 8);
+            }
+      }
+      __syncthreads();
+      TAIL_STAMP(b, 2);
+      v4f64 X[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) X[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
+      tile_mma_lds(X, sW, sV);                   // X[p][n] = sum_q invLt[q][p] U[q][n]
+      __syncthreads();                           // every wave is done reading sW (inverse) and sV (U)
+      TAIL_STAMP(b, 3);
+      double* Lrow = t.S + (size_t)(j0 - kInner) * ld + j0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int p = wm0 + i * 16 + lk + 4 * r4;
+          const double d = s_d[(p >> 4) * TS + (p & 15)];
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int n = wn0 + jj * 16 + li;
+            const double x = X[i][jj][r4], l = x / d;
+            sW[p * TS + n] = l;
+            sV[p * TS + n] = x;
+            tail_st(Lrow + (size_t)p * ld + n, l);
+          }
+        }
+      __syncthreads();
+      TAIL_STAMP(b, 4);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) X[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
+      tile_mma_lds(X, sW, sV);                   // sum_p L[p][m] X[p][n]
+      __syncthreads();
+      TAIL_STAMP(b, 5);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
+            sW[m * TS + n] = P[i][jj][r4] - X[i][jj][r4];
+          }
+      tail_publish(&t.tile_flag[(size_t)(b - 1) * t.ntc + r], t.epoch);       // L_{r-1,r}; its barrier also covers the tile in sW
+      TAIL_STAMP(b, 6);
+    } else {
+      // first block of the tail: nothing to subtract
+      for (int e = tid; e < kInner * kInner; e += 256) {
+        const int m = e >> 6, n = e & 63;
+        sW[m * TS + n] = t.S[(size_t)(j0 + m) * ld + j0 + n];
+      }
+      __syncthreads();
+    }
+    double T[4][4], Xi[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const int i = ti + 16 * a, j = tj + 16 * bb;
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        T[a][bb] = sW[lo * TS + hi];
+        Xi[a][bb] = (i == j) ? 1.0 : 0.0;
+      }
+    __syncthreads();                             // sW is read; sV (colbuf / rowbuf) is free since the barrier after the second product
+    TAIL_STAMP(r - t.rt0, 7);
+    const bool bad = ldlt_diag_core<kInner>(T, Xi, colbuf, rowbuf);
+    TAIL_STAMP(r - t.rt0, 8);
+    if (bad && tid == 0) atomicExch(t.status, 2);
+    double* invLt = t.invLt + (size_t)r * kInner * kInner;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const int i = ti + 16 * a, j = tj + 16 * bb;
+        const double xv = (i >= j) ? Xi[a][bb] : 0.0;
+        if (i >= j) tail_st(&t.S[(size_t)(j0 + j) * ld + j0 + i], T[a][bb]);
+        tail_st(&invLt[j * kInner + i], xv);
+        sW[j * TS + i] = xv;                     // invLt[q][p], the K-major operand of the next step's first product
+        if (i == j) { tail_st(&t.dvec[j0 + i], T[a][bb]); s_d[(i >> 4) * TS + (i & 15)] = T[a][bb]; }
+      }
+    tail_publish(&t.diag_flag[r - t.rt0], t.epoch);
+    TAIL_STAMP(r - t.rt0, 9);
+  }
+}
+
+// ---- helper workgroups ----
+__device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, double* sAB) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
+  double* sA = sAB;
+  double* sB = sAB + 2 * KT * TS;
+  volatile int* slot = reinterpret_cast<volatile int*>(sV + kInner);          // padding of row 0 of sV
+  volatile int* slot2 = reinterpret_cast<volatile int*>(sV + TS + kInner);    // padding of row 1
+  const int ld = t.ld;
+  const unsigned my_cu = tail_cu_id();
+  for (;;) {
+    __syncthreads();                             // the previous task is done with sV / sAB / the slots
+    if (tid == 0) {
+      int tk = -1;
+      const bool evicted = t.evict && tail_ldflag(&t.ctrl[3]) == my_cu;
+      if (!evicted && tail_ldflag(&t.ctrl[1]) == 0) tk = (int)atomicAdd(&t.ctrl[0], 1u);
+      *slot2 = tk;
+    }
+    __syncthreads();
+    const int tk = *slot2;
+    if (tk < 0 || tk >= t.ntasks) return;
+    int kind, r, c;
+    tail_task(t, tk, &kind, &r, &c);
+    if (kind == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3);
+    const int ca = (kind == 1) ? c : r;          // column block of the A operand: PART is L_{k,r+1}^T d L_{k,r+1}
+    v4f64 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    for (int k = t.rt0; k < r;) {
+      const int nrows = tail_wait_rows(t, k, r, ca, c, slot);
+      if (nrows <= 0) return;
+      const double* A = t.S + (size_t)k * kInner * ld + (size_t)ca * kInner;
+      const double* B = t.S + (size_t)k * kInner * ld + (size_t)c * kInner;
+      if (kind == 1) tail_mma<true>(acc, A, A, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sA, sB);
+      else tail_mma<false>(acc, A, B, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sA, sB);
+      k += nrows;
+    }
+    // U = A_rc - acc.  The tile itself was written before this launch (plain loads).
+    const int row0 = (kind == 1 ? c : r) * kInner;
+    double* Trc = t.S + (size_t)row0 * ld + (size_t)c * kInner;
+    if (kind != 2) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
+            if (kind == 1 && n < m) continue;                               // diagonal tile: upper triangle only
+            const double u = Trc[(size_t)m * ld + n] - acc[i][jj][r4];
+            tail_st(&Trc[(size_t)m * ld + n], u);
+          }
+      tail_publish(kind == 0 ? &t.upre_flag[r - t.rt0] : &t.part_flag[c - t.rt0], t.epoch);
+      continue;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
+          sV[m * TS + n] = Trc[(size_t)m * ld + n] - acc[i][jj][r4];
+        }
+    if (!tail_wait(t, &t.diag_flag[r - t.rt0], nullptr, slot)) return;       // (its barrier also publishes sV to the other waves)
+    {
+      // invL_r (K-major, [q][p]) -> sAB as a 64 x TS tile
+      const __amdgpu_buffer_rsrc_t ri = tail_rsrc(t.invLt + (size_t)r * kInner * kInner);
+      const int row = tid >> 2, cq = (tid & 3) * 16;
+      v2f64_t u[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) u[i] = tail_ld2(ri, (row * kInner + cq + 2 * i) * 8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { sAB[row * TS + cq + 2 * i] = u[i].x; sAB[row * TS + cq + 2 * i + 1] = u[i].y; }
+    }
+    double dr[2][4];
+    {
+      const __amdgpu_buffer_rsrc_t rd = tail_rsrc(t.dvec + (size_t)r * kInner);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) dr[i][r4] = tail_ld1(rd, (wm0 + i * 16 + lk + 4 * r4) * 8);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    tile_mma_lds(acc, sAB, sV);                  // X[p][n] = sum_q invLt[q][p] U[q][n]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int p = wm0 + i * 16 + lk + 4 * r4;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int n = wn0 + jj * 16 + li;
+          tail_st(&Trc[(size_t)p * ld + n], acc[i][jj][r4] / dr[i][r4]);
+        }
+      }
+    tail_publish(&t.tile_flag[(size_t)(r - t.rt0) * t.ntc + c], t.epoch);
+  }
+}
+
+__global__ void __launch_bounds__(256, 2) k_ldlt_tail(TailArgs t) {
+  __shared__ double smem[2 * kInner * TS];       // two 64 x TS tiles = 80 KB: two workgroups per CU
+  volatile int* s_role = reinterpret_cast<volatile int*>(smem + kInner);   // padding of row 0 (4 more bytes of LDS would cost the second workgroup per CU)
+  if (threadIdx.x == 0) *s_role = (int)atomicAdd(&t.ctrl[2], 1u);
+  __syncthreads();
+  const int role = *s_role;
+  __syncthreads();
+  if (role == 0) {
+    __builtin_amdgcn_s_setprio(3);
+    tail_chain(t, smem, smem + kInner * TS);
+  } else {
+    tail_helper(t, smem, smem + kInner * TS);
+  }
+}
+
 int panel_cu_count() {
   static int n = -1;
   if (n < 0) {
@@ -1648,6 +2120,19 @@ int ldlt_workspace_alloc(LdltWorkspace& w, int n_pad) {
   CBA_HIP(hipEventCreateWithFlags(&w.ev_aa, hipEventDisableTiming | hipEventDisableSystemFence));
   CBA_HIP(hipEventCreateWithFlags(&w.ev_chain, hipEventDisableTiming | hipEventDisableSystemFence));
   CBA_HIP(hipEventCreateWithFlags(&w.ev_bulk, hipEventDisableTiming | hipEventDisableSystemFence));
+  {
+    const int ntc = n_pad / kInner;
+    const int rows = ntc < kTailMaxBlockRows ? ntc : kTailMaxBlockRows;
+    const size_t words = (size_t)rows * ntc + 3 * (size_t)ntc;
+    CBA_HIP(hipMalloc(&w.tail_flags, sizeof(unsigned) * words));
+    CBA_HIP(hipMemset(w.tail_flags, 0, sizeof(unsigned) * words));
+    CBA_HIP(hipMalloc(&w.tail_ctrl, sizeof(unsigned) * 8));
+    CBA_HIP(hipMemset(w.tail_ctrl, 0, sizeof(unsigned) * 8));
+    w.tail_rows_cap = rows * kInner;
+    w.tail_epoch = 0;
+    CBA_HIP(hipEventCreate(&w.tail_e0));
+    CBA_HIP(hipEventCreate(&w.tail_e1));
+  }
   w.n_alloc = n_pad;
   return CBA_OK;
 }
@@ -1666,6 +2151,10 @@ void ldlt_workspace_free(LdltWorkspace& w) {
   if (w.ev_aa) hipEventDestroy(w.ev_aa);
   if (w.ev_chain) hipEventDestroy(w.ev_chain);
   if (w.ev_bulk) hipEventDestroy(w.ev_bulk);
+  if (w.tail_flags) hipFree(w.tail_flags);
+  if (w.tail_ctrl) hipFree(w.tail_ctrl);
+  if (w.tail_e0) hipEventDestroy(w.tail_e0);
+  if (w.tail_e1) hipEventDestroy(w.tail_e1);
   w = LdltWorkspace();
 }
 
@@ -1765,6 +2254,66 @@ static int timed_gemm128(const GemmArgs& g, hipStream_t s, LdltWorkspace& w, boo
   return CBA_OK;
 }
 
+
+// ---- persistent tail: host side ----
+static int g_tail_rows = 6144;
+void ldlt_set_tail_rows(int rows) { g_tail_rows = rows < 0 ? 0 : rows; }
+int ldlt_tail_rows() {
+  static const char* e = CBA_GETENV("CBA_TAIL_ROWS");      // developer switch (bench harness only)
+  const int v = e ? atoi(e) : g_tail_rows;
+  return v < 0 ? 0 : v;
+}
+double ldlt_tail_last_ms(LdltWorkspace& w) {
+  if (!w.tail_timed) return 0.0;
+  float ms = 0;
+  if (hipEventSynchronize(w.tail_e1) != hipSuccess || hipEventElapsedTime(&ms, w.tail_e0, w.tail_e1) != hipSuccess) return 0.0;
+  return ms;
+}
+// first row of the tail: the first panel boundary of the blocked schedule with at most ldlt_tail_rows() rows left (n_fact = none)
+static int tail_start_row(int n_fact, const LdltWorkspace& w) {
+  int rows = ldlt_tail_rows();
+  if (rows > w.tail_rows_cap) rows = w.tail_rows_cap;
+  if (rows <= 0 || !w.tail_flags) return n_fact;
+  int k0 = 0;
+  while (k0 < n_fact && n_fact - k0 > rows) k0 += panel_width_at(k0, n_fact);
+  return k0 < n_fact ? k0 : n_fact;
+}
+// Factors rows [t0, n_fact) of S, whose trailing block [t0, n_pad)^2 carries every update of the rows above, with one launch
+// on stream s.  t0 and n_fact are multiples of 64.
+static int ldlt_tail(double* S, int n_fact, int ld, int t0, LdltWorkspace& w, hipStream_t s, GemmStats* st) {
+  TailArgs t{};
+  t.S = S; t.ld = ld;
+  t.rt0 = t0 / kInner; t.nr = n_fact / kInner; t.ntc = ld / kInner;
+  t.dvec = w.dvec; t.invLt = w.invLt; t.status = w.status;
+  const int rows_cap = w.tail_rows_cap / kInner;
+  t.tile_flag = w.tail_flags;
+  t.diag_flag = w.tail_flags + (size_t)rows_cap * t.ntc;
+  t.upre_flag = t.diag_flag + t.ntc;
+  t.part_flag = t.upre_flag + t.ntc;
+  t.ctrl = w.tail_ctrl;
+  t.epoch = ++w.tail_epoch;
+  long long ntasks = 0;
+  for (int r = t.rt0; r < t.nr; ++r) ntasks += (r + 1 < t.nr) ? t.ntc - r : t.ntc - t.nr;
+  t.ntasks = (int)ntasks;
+  static const bool no_evict = CBA_GETENV("CBA_TAIL_NO_EVICT") != nullptr;     // developer switch
+  t.evict = no_evict ? 0 : 1;
+  CBA_HIP(hipMemsetAsync(w.tail_ctrl, 0, sizeof(unsigned) * 8, s));
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  long long grid = ntasks + 1;
+  if (grid > 2LL * cus) grid = 2LL * cus;        // two workgroups per CU are resident (80 KB of LDS each)
+  if (st) CBA_HIP(hipEventRecord(w.tail_e0, s));
+  hipLaunchKernelGGL(k_ldlt_tail, dim3((unsigned)grid), dim3(256), 0, s, t);
+  CBA_HIP(hipGetLastError());
+  if (st) {
+    CBA_HIP(hipEventRecord(w.tail_e1, s));
+    w.tail_timed = true;
+    const double R = (double)(n_fact - t0), C = (double)(ld - n_fact);
+    st->flops += R * R * R / 3.0 + R * R * C;
+  }
+  return CBA_OK;
+}
+
 int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, GemmStats* st) {
   const int n_pad = ld;
   hipStream_t s2 = w.panel_stream, s3 = w.far_stream, s4 = w.mid_stream;
@@ -1777,7 +2326,10 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
   CBA_HIP(hipEventRecord(w.ev_bulk, s));
   int kidx = 0;
   int prefactored = -1;          // first column of a diagonal block that the previous panel's (a') launch has already factored
-  for (int k0 = 0, pw = 0; k0 < n_fact; k0 += pw, ++kidx) {
+  // rows [t0, n_fact) are left to the persistent tail launch (ldlt_tail); the panel that ends at t0 ("junction") applies its
+  // whole trailing update in one launch, without look-ahead pieces
+  const int t0 = tail_start_row(n_fact, w);
+  for (int k0 = 0, pw = 0; k0 < n_fact && k0 < t0; k0 += pw, ++kidx) {
     pw = panel_width_at(k0, n_fact);
     const int nb = (n_fact - k0 < pw) ? (n_fact - k0) : pw;
     const int e0 = k0 + nb;   // first column right of the panel
@@ -1786,7 +2338,8 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
     const int r0 = e0;
     // look-ahead structure: the next panel's columns [e0, nx) are kept ahead of the rest
     const bool more = e0 < n_fact;                 // the last panel needs no trailing update
-    const bool la = more && (r0 < n_pad) && (r0 % 128 == 0);
+    const bool junction = more && e0 == t0;
+    const bool la = more && !junction && (r0 < n_pad) && (r0 % 128 == 0);
     const int mt = la ? (n_pad - r0) / 128 : 0;
     const int head = mt < pw_next / 128 ? mt : pw_next / 128;   // 128-tile rows of the next panel
     const int nx = la ? r0 + head * 128 : e0;
@@ -1978,8 +2531,15 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
         CBA_HIP(hipEventRecord(w.ev_bulk, s));
       } else {
         u.upper = 1;
-        u.m_off = r0; u.m_tiles = (n_pad - r0) / 64; u.n_off = r0; u.n_tiles = (n_pad - r0) / 64;
-        if ((rc = launch_gemm<64, 64, 32, 32, true>(u, s))) return rc;
+        if (r0 % 128 == 0 && n_pad - r0 >= 1024) {
+          const int tl = (n_pad - r0) / 128;
+          u.m_off = r0; u.m_tiles = tl; u.n_off = r0; u.n_tiles = tl;
+          u.tlog_tag = (k0 / kInner) * kTlKinds + kTlBulk + 1;
+          if ((rc = timed_gemm128(u, s, w, st != nullptr, (double)tl * (tl + 1) / 2))) return rc;
+        } else {
+          u.m_off = r0; u.m_tiles = (n_pad - r0) / 64; u.n_off = r0; u.n_tiles = (n_pad - r0) / 64;
+          if ((rc = launch_gemm<64, 64, 32, 32, true>(u, s))) return rc;
+        }
         CBA_HIP(hipEventRecord(w.ev_strip, s));
         CBA_HIP(hipStreamWaitEvent(s2, w.ev_strip, 0));
         CBA_HIP(hipStreamWaitEvent(s3, w.ev_strip, 0));
@@ -1991,6 +2551,11 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
         st->launches += 1;
       }
     }
+  }
+  if (t0 < n_fact) {
+    // the junction panel's update (main stream) is the last thing the head did; the side streams are idle by then
+    int rc = ldlt_tail(S, n_fact, ld, t0, w, s, st);
+    if (rc) return rc;
   }
   // everything the side streams did is ordered before whatever follows on the main stream
   CBA_HIP(hipEventRecord(w.ev_strip, s2));

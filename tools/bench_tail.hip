@@ -1,0 +1,129 @@
+// Developer harness (not shipped): the persistent tail launch of the factorisation (ldlt_tail) against the blocked
+// multi-stream schedule -- same matrix, factors / solution compared, both timed.
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -mllvm -amdgpu-mfma-vgpr-form tools/bench_tail.hip -o tools/bin/bench_tail
+#define CBA_DEV_SWITCHES 1
+#define CBA_TAILLOG 1
+#include "../camera_calibration_amd/csrc/kernels_linalg.hip"
+#include <cstdio>
+#include <vector>
+#include <cmath>
+#include <algorithm>
+namespace cba { void set_error(const std::string& m) { fprintf(stderr, "error: %s\n", m.c_str()); } }
+using namespace cba;
+namespace cba { int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWorkspace& w, double* x, hipStream_t s); }
+
+static float timeit(hipEvent_t e0, hipEvent_t e1) { float ms; hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); return ms; }
+
+struct Case { int n, n_fact; };
+
+int main(int argc, char** argv) {
+  std::vector<Case> cases;
+  if (argc > 2) cases.push_back({atoi(argv[1]), atoi(argv[2])});
+  else cases = {{1152, 1088}, {2304, 2240}, {12672, 12544}};
+  std::vector<int> tails = {1024, 2048, 3072, 4096, 6144, 8192};
+  if (const char* e = getenv("TAILS")) { tails.clear(); for (const char* c = e; *c;) { tails.push_back(atoi(c)); while (*c && *c != ',') ++c; if (*c) ++c; } }
+  const int reps = getenv("REPS") ? atoi(getenv("REPS")) : 3;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  prepare_device_streams();
+  hipStream_t ms; make_main_stream(&ms);
+  for (const Case& cs : cases) {
+    const int n = cs.n, n_fact = cs.n_fact, K = 1024;
+    printf("=== n_pad %d n_fact %d ===\n", n, n_fact);
+    double *A, *S0, *S, *H, *x;
+    hipMalloc(&A, sizeof(double) * (size_t)K * n); hipMalloc(&S0, sizeof(double) * (size_t)n * n); hipMalloc(&S, sizeof(double) * (size_t)n * n);
+    hipMalloc(&H, sizeof(double) * (size_t)n * n); hipMalloc(&x, sizeof(double) * n);
+    std::vector<double> hA((size_t)K * n);
+    for (size_t i = 0; i < hA.size(); ++i) hA[i] = ((double)((i * 2654435761u) % 2001) / 1000.0 - 1.0) * 0.05;
+    hipMemcpy(A, hA.data(), hA.size() * 8, hipMemcpyHostToDevice);
+    hipMemset(H, 0, sizeof(double) * (size_t)n * n);
+    // S0 = -lambda' I - A^T A (negative definite, fine for LDL^T); rows >= n_fact: identity; last column: right-hand side
+    schur_gemm(A, A, K, n, H, S0, n, n, n_fact, 1, -1.0 * K * 0.001, nullptr, nullptr);
+    hipDeviceSynchronize();
+    {
+      std::vector<double> row(n);
+      for (int r = n_fact; r < n; ++r) {           // padding rows: unit diagonal, zero elsewhere (as the engine keeps them)
+        std::fill(row.begin(), row.end(), 0.0); row[r] = 1.0;
+        hipMemcpy(S0 + (size_t)r * n, row.data(), sizeof(double) * n, hipMemcpyHostToDevice);
+      }
+      std::vector<double> col(n_fact);
+      for (int r = 0; r < n_fact; ++r) col[r] = std::sin(0.37 * r) + 0.25;
+      hipMemcpy2D(S0 + (n - 1), sizeof(double) * n, col.data(), sizeof(double), sizeof(double), n_fact, hipMemcpyHostToDevice);
+      // columns [n_fact, n - 1) of the factored rows: zero
+      if (n - 1 > n_fact) hipMemset2D(S0 + n_fact, sizeof(double) * n, 0, sizeof(double) * (n - 1 - n_fact), n_fact);
+    }
+    LdltWorkspace w; ldlt_workspace_alloc(w, n);
+    auto run = [&](int tail, std::vector<double>* hx, std::vector<double>* hS, std::vector<double>* hd, double* best_ms, double* tail_ms) {
+      ldlt_set_tail_rows(tail);
+      *best_ms = 1e30; *tail_ms = 0;
+      int st = 0;
+      for (int rep = 0; rep < reps; ++rep) {
+        hipMemcpy(S, S0, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice);
+        hipMemset(w.status, 0, 4);
+        hipDeviceSynchronize();
+        GemmStats gs;
+        hipEventRecord(e0, ms);
+        ldlt_factor(S, n_fact, n, w, ms, &gs);
+        hipEventRecord(e1, ms);
+        const double t = timeit(e0, e1);
+        ldlt_collect_spans(w, nullptr);
+        if (t < *best_ms) { *best_ms = t; *tail_ms = ldlt_tail_last_ms(w); }
+        hipMemcpy(&st, w.status, 4, hipMemcpyDeviceToHost);
+        if (st) break;
+      }
+      w.tail_timed = false;
+      ldlt_back_solve(S, n_fact, n, n - 1, w, x, ms);
+      hipStreamSynchronize(ms);
+      hx->resize(n_fact); hipMemcpy(hx->data(), x, sizeof(double) * n_fact, hipMemcpyDeviceToHost);
+      hd->resize(n_fact); hipMemcpy(hd->data(), w.dvec, sizeof(double) * n_fact, hipMemcpyDeviceToHost);
+      if (hS) { hS->resize((size_t)n * n); hipMemcpy(hS->data(), S, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost); }
+      return st;
+    };
+    std::vector<double> xr, Sr, dr;
+    double ms_ref, tms;
+    int st = run(0, &xr, n <= 4096 ? &Sr : nullptr, &dr, &ms_ref, &tms);
+    printf("blocked schedule (tail off): %.3f ms  status %d\n", ms_ref, st);
+    double xmax = 0; for (double v : xr) xmax = std::max(xmax, std::fabs(v));
+    for (int tail : tails) {
+      std::vector<double> xt, St, dt;
+      double ms_t;
+      st = run(tail, &xt, n <= 4096 ? &St : nullptr, &dt, &ms_t, &tms);
+      double dx = 0, dd = 0, dmax = 0, dS = 0, smax = 0;
+      for (int i = 0; i < n_fact; ++i) { dx = std::max(dx, std::fabs(xt[i] - xr[i])); dd = std::max(dd, std::fabs(dt[i] - dr[i])); dmax = std::max(dmax, std::fabs(dr[i])); }
+      bool nan = false; for (double v : xt) if (!(v == v)) nan = true;
+      if (!St.empty())
+        for (int r = 0; r < n_fact; ++r) for (int c = r; c < n; ++c) {
+          const double a = St[(size_t)r * n + c], b = Sr[(size_t)r * n + c];
+          dS = std::max(dS, std::fabs(a - b)); smax = std::max(smax, std::fabs(b));
+        }
+      const int t0 = tail_start_row(n_fact, w);
+      if (getenv("TAILLOG") && n_fact - t0 >= 512) {
+        // one more run with the chain timeline
+        const int nb = (n_fact - t0) / 64;
+        unsigned long long* tl; hipMalloc(&tl, sizeof(unsigned long long) * 16 * nb); hipMemset(tl, 0, sizeof(unsigned long long) * 16 * nb);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_taillog), &tl, sizeof(tl));
+        std::vector<double> x2, d2; double m2, tm2;
+        run(tail, &x2, nullptr, &d2, &m2, &tm2);
+        std::vector<unsigned long long> h(16 * (size_t)nb);
+        hipMemcpy(h.data(), tl, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
+        unsigned long long* nul = nullptr; hipMemcpyToSymbol(HIP_SYMBOL(g_taillog), &nul, sizeof(nul));
+        hipFree(tl);
+        static const char* names[9] = {"wait flags", "load U,P", "X = invL U", "X epilogue", "T product", "T write + publish tile", "T -> regs", "pivots", "epilogue + publish"};
+        auto avg = [&](int b0, int b1) {
+          double acc[9] = {0}; int cnt = 0;
+          for (int b = std::max(b0, 1); b < b1; ++b) { for (int ph = 0; ph < 9; ++ph) acc[ph] += (double)(h[16 * b + ph + 1] - h[16 * b + ph]) / 100.0; ++cnt; }
+          printf("   chain phases, blocks %d-%d (us):", b0, b1);
+          double tot = 0; for (int ph = 0; ph < 9; ++ph) { printf(" %s %.2f |", names[ph], acc[ph] / cnt); tot += acc[ph] / cnt; }
+          printf(" total %.2f\n", tot);
+        };
+        avg(1, std::min(nb, 8)); avg(nb / 2 - 4, nb / 2 + 4); avg(nb - 8, nb);
+        printf("   chain span %.1f us for %d blocks = %.2f us / block\n", (double)(h[16 * (nb - 1) + 9] - h[0]) / 100.0, nb, (double)(h[16 * (nb - 1) + 9] - h[0]) / 100.0 / nb);
+      }
+      printf("tail %5d (starts at row %5d, %4d rows): %.3f ms total, tail launch %.3f ms, status %d | x rel %.2e  d rel %.2e  L rel %.2e%s\n",
+             tail, t0, n_fact - t0, ms_t, tms, st, dx / xmax, dd / dmax, smax > 0 ? dS / smax : 0.0, nan ? "  NaN!" : "");
+    }
+    // residual of the solution with the last setting on small cases (host, O(n^2))
+    ldlt_workspace_free(w);
+    hipFree(A); hipFree(S0); hipFree(S); hipFree(H); hipFree(x);
+  }
+  return 0;
+}
