@@ -1546,10 +1546,12 @@ struct TailArgs {
   unsigned* diag_flag;              // [r - rt0]: block r factored (L_rr, d, invL_rr published)
   unsigned* upre_flag;              // [r - rt0]: U_{r,r+1} in place
   unsigned* part_flag;              // [r - rt0]: P_r in place
-  unsigned* ctrl;                   // [0] task tickets, [1] abort, [2] role tickets, [3] CU of the chain workgroup
+  unsigned* ctrl;                   // [1] abort, [2] role tickets, [3] CU of the chain workgroup, [8 + x] task tickets of list x
   unsigned epoch;
   int ntasks;
   int evict;                        // helper workgroups that share the chain's CU stop taking tasks
+  int xcd_lists;                    // 1: one task list per XCD (column block c -> XCD c % 8), own list first; 0: one list
+  int ntasks_x[8];                  // tasks per list
 };
 constexpr unsigned long long kTailTimeoutTicks = 300000000ull;   // 3 s
 
@@ -1560,11 +1562,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tail_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7ffffffe, 0x00020000);
 }
 // agent-scope (sc1) loads: 16 B / 8 B per lane, tracked by the compiler's wait counts
-__device__ __forceinline__ v2f64_t tail_ld2(__amdgpu_buffer_rsrc_t rs, int byte_off) {
-  return __builtin_bit_cast(v2f64_t, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16));
+__device__ __forceinline__ v2f64_t tail_ld2(__amdgpu_buffer_rsrc_t rs, int byte_off, int soff = 0) {
+  return __builtin_bit_cast(v2f64_t, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, soff, 16));
 }
-__device__ __forceinline__ double tail_ld1(__amdgpu_buffer_rsrc_t rs, int byte_off) {
-  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 16));
+__device__ __forceinline__ double tail_ld1(__amdgpu_buffer_rsrc_t rs, int byte_off, int soff = 0) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, soff, 16));
+}
+__device__ __forceinline__ void tail_st1(__amdgpu_buffer_rsrc_t rs, int byte_off, int soff, double v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32_t, v), rs, byte_off, soff, 16);
+}
+__device__ __forceinline__ void tail_st2(__amdgpu_buffer_rsrc_t rs, int byte_off, int soff, v2f64_t v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32_t, v), rs, byte_off, soff, 16);
 }
 __device__ __forceinline__ unsigned tail_ldflag(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void tail_stflag(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1672,13 +1680,22 @@ __device__ __forceinline__ void tail_mma(v4f64 (&acc)[2][2], const double* A, co
     CBA_XLOAD(slot_, (kb + 3 < nk ? kb + 3 : nk - 1) * KT);                                                  \
     const double* a_s = sA + buf * KT * TS;                                                                  \
     const double* b_s = sB + buf * KT * TS;                                                                  \
+    /* operands of k-step kk + 4 are read before the MFMAs of step kk are issued (the compiler's own order, read -> wait -> */ \
+    /* 4 MFMAs, left the matrix pipe idle for an LDS round trip per step) */                                 \
+    double af[2][2], bf[2][2];                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) af[0][i] = a_s[lk * TS + wm0 + i * 16 + li];               \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) bf[0][j] = b_s[lk * TS + wn0 + j * 16 + li];               \
     _Pragma("unroll") for (int kk = 0; kk < KT; kk += 4) {                                                   \
-      double af[2], bf[2];                                                                                   \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) af[i] = a_s[(kk + lk) * TS + wm0 + i * 16 + li];         \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j) bf[j] = b_s[(kk + lk) * TS + wn0 + j * 16 + li];         \
+      const int cur = (kk >> 2) & 1, nxt = cur ^ 1;                                                          \
+      if (kk + 4 < KT) {                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) af[nxt][i] = a_s[(kk + 4 + lk) * TS + wm0 + i * 16 + li]; \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) bf[nxt][j] = b_s[(kk + 4 + lk) * TS + wn0 + j * 16 + li]; \
+      }                                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
       _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);                \
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);      \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
     }                                                                                                        \
     CBA_XSTORE(buf ^ 1, next_slot_);                                                                         \
     __syncthreads();                                                                                         \
@@ -1694,22 +1711,113 @@ __device__ __forceinline__ void tail_mma(v4f64 (&acc)[2][2], const double* A, co
 #undef CBA_XSTORE
 }
 
-// ticket -> task.  kind 0 = PRE(r), 1 = PART(r + 1), 2 = REG(r, c)
-__device__ __forceinline__ void tail_task(const TailArgs& t, int ticket, int* kind, int* r_out, int* c_out) {
+// The same product for TWO adjacent column blocks: acc (64 x 128, 4 waves x 32 x 64) += sum_k (dk[k] A[k][m]) B[k][n], B 128 columns
+// wide.  One barrier per 2048 MFMA-cycles per wave instead of 1024 (the 64 x 64 loop keeps the MFMA pipe 49 % busy with two
+// workgroups per CU, tools/bench_tail.hip MMA_ONLY), and the A slab is staged once for both tiles.
+// sA: 2 x KT x TS doubles, sB: 2 x KT x TSB doubles.
+constexpr int TSB = 2 * kInner + 16;
+__device__ __forceinline__ void tail_mma2(v4f64 (&acc)[2][4], const double* A, const double* B, int ld, const double* dk, int K,
+                                          double* sA, double* sB) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 64, li = lane & 15, lk = lane >> 4;
+  const int r = tid >> 5, c2 = 2 * (tid & 31);          // A: rows r, r + 8
+  const int rb = tid >> 6, cb = 2 * (tid & 63);         // B: rows rb, rb + 4, rb + 8, rb + 12 (one full 1 KB row per wave-instruction)
+  const int nk = K / KT;
+  const __amdgpu_buffer_rsrc_t ra = tail_rsrc(A), rbs = tail_rsrc(B), rd = tail_rsrc(dk);
+  const int rowb = ld * 8;
+  v2f64_t a0_0, a0_1, a1_0, a1_1, a2_0, a2_1;
+  v2f64_t b0_0, b0_1, b0_2, b0_3, b1_0, b1_1, b1_2, b1_3, b2_0, b2_1, b2_2, b2_3;
+  double d0_0, d0_1, d1_0, d1_1, d2_0, d2_1;
+#define CBA_YLOAD(slot_, k0_)                                                                    \
+  {                                                                                              \
+    const int oa = ((k0_) + r) * rowb + c2 * 8;                                                  \
+    const int ob = ((k0_) + rb) * rowb + cb * 8;                                                 \
+    a##slot_##_0 = tail_ld2(ra, oa); a##slot_##_1 = tail_ld2(ra, oa, 8 * rowb);                  \
+    b##slot_##_0 = tail_ld2(rbs, ob); b##slot_##_1 = tail_ld2(rbs, ob, 4 * rowb);                \
+    b##slot_##_2 = tail_ld2(rbs, ob, 8 * rowb); b##slot_##_3 = tail_ld2(rbs, ob, 12 * rowb);     \
+    d##slot_##_0 = tail_ld1(rd, ((k0_) + r) * 8); d##slot_##_1 = tail_ld1(rd, ((k0_) + r + 8) * 8); \
+  }
+#define CBA_YSTORE(buf_, slot_)                                                                  \
+  {                                                                                              \
+    double* qa = sA + (buf_) * KT * TS + r * TS + c2;                                            \
+    double* qb = sB + (buf_) * KT * TSB + rb * TSB + cb;                                         \
+    qa[0] = a##slot_##_0.x * d##slot_##_0; qa[1] = a##slot_##_0.y * d##slot_##_0;                \
+    qa[8 * TS] = a##slot_##_1.x * d##slot_##_1; qa[8 * TS + 1] = a##slot_##_1.y * d##slot_##_1;  \
+    qb[0] = b##slot_##_0.x; qb[1] = b##slot_##_0.y;                                              \
+    qb[4 * TSB] = b##slot_##_1.x; qb[4 * TSB + 1] = b##slot_##_1.y;                              \
+    qb[8 * TSB] = b##slot_##_2.x; qb[8 * TSB + 1] = b##slot_##_2.y;                              \
+    qb[12 * TSB] = b##slot_##_3.x; qb[12 * TSB + 1] = b##slot_##_3.y;                            \
+  }
+  CBA_YLOAD(0, 0);
+  CBA_YLOAD(1, (1 < nk ? 1 : nk - 1) * KT);
+  CBA_YLOAD(2, (2 < nk ? 2 : nk - 1) * KT);
+  CBA_YSTORE(0, 0);
+  __syncthreads();
+#define CBA_YSTEP(slot_, next_slot_)                                                                         \
+  if (kb0 + (slot_) < nk) {                                                                                  \
+    const int kb = kb0 + (slot_);                                                                            \
+    const int buf = kb & 1;                                                                                  \
+    CBA_YLOAD(slot_, (kb + 3 < nk ? kb + 3 : nk - 1) * KT);                                                  \
+    const double* a_s = sA + buf * KT * TS;                                                                  \
+    const double* b_s = sB + buf * KT * TSB;                                                                 \
+    double af[2][2], bf[2][4];                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) af[0][i] = a_s[lk * TS + wm0 + i * 16 + li];               \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) bf[0][j] = b_s[lk * TSB + wn0 + j * 16 + li];              \
+    _Pragma("unroll") for (int kk = 0; kk < KT; kk += 4) {                                                   \
+      const int cur = (kk >> 2) & 1, nxt = cur ^ 1;                                                          \
+      if (kk + 4 < KT) {                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) af[nxt][i] = a_s[(kk + 4 + lk) * TS + wm0 + i * 16 + li]; \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) bf[nxt][j] = b_s[(kk + 4 + lk) * TSB + wn0 + j * 16 + li]; \
+      }                                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);      \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }                                                                                                        \
+    CBA_YSTORE(buf ^ 1, next_slot_);                                                                         \
+    __syncthreads();                                                                                         \
+  }
+#pragma nounroll
+  for (int kb0 = 0; kb0 < nk; kb0 += 3) {
+    CBA_YSTEP(0, 1)
+    CBA_YSTEP(1, 2)
+    CBA_YSTEP(2, 0)
+  }
+#undef CBA_YSTEP
+#undef CBA_YLOAD
+#undef CBA_YSTORE
+}
+
+// ticket of list x -> task.  kind 0 = PRE(r), 1 = PART(r + 1), 2 = REG(r, c).  List x (of `nl` lists) holds the tasks whose column
+// block c has c % nl == x, rows in increasing order -- a task only waits for tiles of earlier rows, so every list is in
+// dependency order and the launch makes progress as long as each list's pending head is held by a running workgroup or nobody
+// is left to wait for it (workgroups steal from the other lists once their own is empty).
+__device__ __forceinline__ int tail_row_count(const TailArgs& t, int r, int x, int nl) {
+  // columns c in [r + 1, ntc) with c % nl == x; column r + 1 counts twice (PRE + PART) while r + 1 is a row of the tail
+  const int lo = r + 1;
+  const int first = lo + ((x - lo % nl) + nl) % nl;
+  int cnt = first < t.ntc ? (t.ntc - 1 - first) / nl + 1 : 0;
+  if (r + 1 < t.nr && (r + 1) % nl == x) cnt += 1;
+  return cnt;
+}
+__device__ __forceinline__ void tail_task(const TailArgs& t, int ticket, int x, int nl, int* kind, int* r_out, int* c_out) {
   int r = t.rt0;
   for (; r < t.nr; ++r) {
-    const int cnt = (r + 1 < t.nr) ? t.ntc - r : t.ntc - t.nr;
+    const int cnt = tail_row_count(t, r, x, nl);
     if (ticket < cnt) break;
     ticket -= cnt;
   }
   *r_out = r;
-  if (r + 1 < t.nr) {
-    if (ticket == 0) { *kind = 0; *c_out = r + 1; }
-    else if (ticket == 1) { *kind = 1; *c_out = r + 1; }
-    else { *kind = 2; *c_out = r + ticket; }          // ticket 2 -> column r + 2
-  } else {
-    *kind = 2; *c_out = r + 1 + ticket;
+  const int lo = r + 1;
+  const int first = lo + ((x - lo % nl) + nl) % nl;
+  if (r + 1 < t.nr && first == r + 1) {
+    if (ticket == 0) { *kind = 0; *c_out = r + 1; return; }
+    if (ticket == 1) { *kind = 1; *c_out = r + 1; return; }
+    *kind = 2; *c_out = first + (ticket - 1) * nl;          // ticket 2 -> first + nl
+    return;
   }
+  *kind = 2; *c_out = first + ticket * nl;
 }
 
 __device__ __forceinline__ unsigned tail_cu_id() {
@@ -1721,53 +1829,64 @@ __device__ __forceinline__ unsigned tail_cu_id() {
 // developer timeline of the chain workgroup (tools/bench_tail.hip, -DCBA_TAILLOG): 100 MHz stamps per block and phase
 #ifdef CBA_TAILLOG
 __device__ unsigned long long* g_taillog = nullptr;
-#define TAIL_STAMP(blk_, ph_) do { if (g_taillog && threadIdx.x == 0) g_taillog[(size_t)(blk_) * 16 + (ph_)] = wall_clock64(); } while (0)
+#define TAIL_STAMP(blk_, ph_) do { __builtin_amdgcn_sched_barrier(0); if (g_taillog && threadIdx.x == 0) g_taillog[(size_t)(blk_) * 16 + (ph_)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define TAIL_STAMP(blk_, ph_) do { } while (0)
 #endif
 
 // ---- the chain workgroup ----
+// Tile I/O goes through buffer instructions with ONE per-lane offset register (voffset) and a wave-uniform offset (soffset, an
+// SGPR): with 64-bit global addresses the compiler kept 16 loop-invariant address pairs per tile alive across the pivot loop,
+// spilled them, and every load then waited for a scratch reload AND the previous load (6 us for one tile).  Row-wise tile
+// traffic moves full 512-byte rows per half wave (16 bytes per lane at a stride of 128 bytes -- 64 partial lines per
+// instruction -- made the agent-scope stores of one tile take 12 us).
+//
+// Per block (measured, tools/bench_tail.hip -DCBA_TAILLOG, us): flags 0.65, U / P loads 1.4, X = invL U 2.0, its epilogue 1.0,
+// T product 2.0, T to LDS + publication of L_{r-1,r} 0.75, T to registers 0.35, 64 pivots 14.7, epilogue 5.0 = 27.9.  Measured
+// and dropped: polling / loading the next step's operands underneath the pivots from a hook in the pivot loop (per pair: pivots
+// 14.3 -> 16.6 us; between the 16-step segments: 15.5-17 us) or inside the epilogue (32 us per block) -- the extra live state
+// spills, and every spill reload waits for vmcnt(0), i.e. for the write-through acknowledgement of the stores in flight.
 __device__ __forceinline__ void tail_chain(const TailArgs& t, double* sV, double* sW) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
   const int ti = tid >> 4, tj = tid & 15;
   double (*colbuf)[kInner] = reinterpret_cast<double (*)[kInner]>(sV);                  // the pivot loop's buffers live in sV
   double (*rowbuf)[kInner] = reinterpret_cast<double (*)[kInner]>(sV + 5 * kInner);
-  double* s_d = sW + kInner;                      // d of the block factored last: padding columns of rows 0 .. 3 of sW
+  double* s_rd = sW + kInner;                     // 1 / d of the block factored last: padding columns of rows 0 .. 3 of sW
   volatile int* slot = reinterpret_cast<volatile int*>(sW + 4 * TS + kInner);            // padding of row 4
   const int ld = t.ld;
+  const int acc_voff = ((wm0 + lk) * ld + wn0 + li) * 8;       // accumulator layout: element (i, jj, r4) at + ((16 i + 4 r4) ld + 16 jj) * 8
+  // row-wise layout: instruction k of a wave moves rows rw + 2 k (lanes 0-31) and rw + 2 k + 1 (lanes 32-63), 16 bytes per lane
+  const int rw = 16 * wv + (lane >> 5), cw = 2 * (lane & 31);
+  const int u_voff = (rw * ld + cw) * 8;
   if (tid == 0 && t.evict) tail_stflag(&t.ctrl[3], tail_cu_id());
   for (int r = t.rt0; r < t.nr; ++r) {
     const int j0 = kInner * r;
-    TAIL_STAMP(r - t.rt0, 0);
+    const int b = r - t.rt0;
+    TAIL_STAMP(b, 0);
     if (r > t.rt0) {
-      const int b = r - t.rt0;
+      const __amdgpu_buffer_rsrc_t ru = tail_rsrc(t.S + (size_t)(j0 - kInner) * ld + j0);
       if (!tail_wait(t, &t.upre_flag[b - 1], &t.part_flag[b], slot)) return;
       TAIL_STAMP(b, 1);
-      // U_{r-1,r} -> sV; P_r -> registers (accumulator layout)
-      {
-        const __amdgpu_buffer_rsrc_t ru = tail_rsrc(t.S + (size_t)(j0 - kInner) * ld + j0);
-        const int row = tid >> 2, cq = (tid & 3) * 16;
-        v2f64_t u[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) u[i] = tail_ld2(ru, (row * ld + cq + 2 * i) * 8);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { sV[row * TS + cq + 2 * i] = u[i].x; sV[row * TS + cq + 2 * i + 1] = u[i].y; }
-      }
+      // U_{r-1,r} -> sV; P_r -> registers (accumulator layout): all 24 loads of a lane in flight together
+      const __amdgpu_buffer_rsrc_t rp = tail_rsrc(t.S + (size_t)j0 * ld + j0);
+      v2f64_t u[8];
       v4f64 P[2][2];
-      {
-        const __amdgpu_buffer_rsrc_t rp = tail_rsrc(t.S + (size_t)j0 * ld + j0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+      for (int k = 0; k < 8; ++k) u[k] = tail_ld2(ru, u_voff, 2 * k * ld * 8);
 #pragma unroll
-          for (int jj = 0; jj < 2; ++jj)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-              const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
-              P[i][jj][r4] = tail_ld1(rp, (m * ld + n) * 8);
-            }
-      }
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) P[i][jj][r4] = tail_ld1(rp, acc_voff, ((16 * i + 4 * r4) * ld + 16 * jj) * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { sV[(rw + 2 * k) * TS + cw] = u[k].x; sV[(rw + 2 * k) * TS + cw + 1] = u[k].y; }
+      // everything this lane stored in the previous block's epilogue is acknowledged by now: the barrier below completes the
+      // publication of block r - 1 at no cost on the chain
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      if (tid == 0) tail_stflag(&t.diag_flag[b - 1], t.epoch);
       TAIL_STAMP(b, 2);
       v4f64 X[2][2];
 #pragma unroll
@@ -1777,20 +1896,19 @@ __device__ __forceinline__ void tail_chain(const TailArgs& t, double* sV, double
       tile_mma_lds(X, sW, sV);                   // X[p][n] = sum_q invLt[q][p] U[q][n]
       __syncthreads();                           // every wave is done reading sW (inverse) and sV (U)
       TAIL_STAMP(b, 3);
-      double* Lrow = t.S + (size_t)(j0 - kInner) * ld + j0;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
           const int p = wm0 + i * 16 + lk + 4 * r4;
-          const double d = s_d[(p >> 4) * TS + (p & 15)];
+          const double rd = s_rd[(p >> 4) * TS + (p & 15)];
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj) {
             const int n = wn0 + jj * 16 + li;
-            const double x = X[i][jj][r4], l = x / d;
+            const double x = X[i][jj][r4], l = x * rd;
             sW[p * TS + n] = l;
             sV[p * TS + n] = x;
-            tail_st(Lrow + (size_t)p * ld + n, l);
+            tail_st1(ru, acc_voff, ((16 * i + 4 * r4) * ld + 16 * jj) * 8, l);          // L_{r-1,r}
           }
         }
       __syncthreads();
@@ -1832,24 +1950,48 @@ __device__ __forceinline__ void tail_chain(const TailArgs& t, double* sV, double
         Xi[a][bb] = (i == j) ? 1.0 : 0.0;
       }
     __syncthreads();                             // sW is read; sV (colbuf / rowbuf) is free since the barrier after the second product
-    TAIL_STAMP(r - t.rt0, 7);
+    TAIL_STAMP(b, 7);
     const bool bad = ldlt_diag_core<kInner>(T, Xi, colbuf, rowbuf);
-    TAIL_STAMP(r - t.rt0, 8);
+    TAIL_STAMP(b, 8);
     if (bad && tid == 0) atomicExch(t.status, 2);
-    double* invLt = t.invLt + (size_t)r * kInner * kInner;
+    {
+      // L_rr / d (memory row j, column i: transposed) -> sV, invLt -> sW, then both tiles leave row by row.  No global store
+      // is issued before the barrier: a store followed by anything that makes the compiler wait for vmcnt(0) (a register
+      // reload, here) costs a full write-through acknowledgement, ~1 us each.
+      int tid2 = threadIdx.x;
+      asm volatile("" : "+v"(tid2));               // lane indices are re-derived here instead of staying live across the pivots
+      const int ti2 = tid2 >> 4, tj2 = tid2 & 15;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int bb = 0; bb < 4; ++bb) {
-        const int i = ti + 16 * a, j = tj + 16 * bb;
-        const double xv = (i >= j) ? Xi[a][bb] : 0.0;
-        if (i >= j) tail_st(&t.S[(size_t)(j0 + j) * ld + j0 + i], T[a][bb]);
-        tail_st(&invLt[j * kInner + i], xv);
-        sW[j * TS + i] = xv;                     // invLt[q][p], the K-major operand of the next step's first product
-        if (i == j) { tail_st(&t.dvec[j0 + i], T[a][bb]); s_d[(i >> 4) * TS + (i & 15)] = T[a][bb]; }
+        for (int bb = 0; bb < 4; ++bb) {
+          const int i = ti2 + 16 * a, j = tj2 + 16 * bb;
+          sV[j * TS + i] = (i >= j) ? T[a][bb] : 0.0;       // below the diagonal of a diagonal tile nothing is ever read
+          sW[j * TS + i] = (i >= j) ? Xi[a][bb] : 0.0;      // invLt[q][p], the K-major operand of the next step's first product
+          if (a == bb && ti2 == tj2) s_rd[(i >> 4) * TS + (i & 15)] = pivot_rcp(T[a][bb]);
+        }
+      __syncthreads();
+      const int lane2 = tid2 & 63, wv2 = tid2 >> 6;
+      const int rw2 = 16 * wv2 + (lane2 >> 5), cw2 = 2 * (lane2 & 31);
+      const int s_voff = (rw2 * ld + cw2) * 8, i_voff = (rw2 * kInner + cw2) * 8;
+      const __amdgpu_buffer_rsrc_t rs = tail_rsrc(t.S + (size_t)j0 * ld + j0);
+      const __amdgpu_buffer_rsrc_t ri = tail_rsrc(t.invLt + (size_t)r * kInner * kInner);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v2f64_t v, w;
+        v.x = sV[(rw2 + 2 * k) * TS + cw2]; v.y = sV[(rw2 + 2 * k) * TS + cw2 + 1];
+        w.x = sW[(rw2 + 2 * k) * TS + cw2]; w.y = sW[(rw2 + 2 * k) * TS + cw2 + 1];
+        tail_st2(rs, s_voff, 2 * k * ld * 8, v);
+        tail_st2(ri, i_voff, 2 * k * kInner * 8, w);
       }
-    tail_publish(&t.diag_flag[r - t.rt0], t.epoch);
-    TAIL_STAMP(r - t.rt0, 9);
+      if (tid2 < kInner) {
+        const __amdgpu_buffer_rsrc_t rv = tail_rsrc(t.dvec + j0);
+        tail_st1(rv, tid2 * 8, 0, sV[tid2 * TS + tid2]);
+      }
+    }
+    TAIL_STAMP(b, 9);
+    // published by the next step (after its loads) -- or here, for the last block
+    if (r + 1 == t.nr) tail_publish(&t.diag_flag[b], t.epoch);
   }
 }
 
@@ -1861,21 +2003,31 @@ __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, doubl
   double* sB = sAB + 2 * KT * TS;
   volatile int* slot = reinterpret_cast<volatile int*>(sV + kInner);          // padding of row 0 of sV
   volatile int* slot2 = reinterpret_cast<volatile int*>(sV + TS + kInner);    // padding of row 1
+  volatile int* slot3 = reinterpret_cast<volatile int*>(sV + 2 * TS + kInner);
   const int ld = t.ld;
   const unsigned my_cu = tail_cu_id();
+  const int nl = t.xcd_lists ? 8 : 1;
+  const int my_list = t.xcd_lists ? (int)((my_cu >> 8) & 7u) : 0;
   for (;;) {
     __syncthreads();                             // the previous task is done with sV / sAB / the slots
     if (tid == 0) {
-      int tk = -1;
+      int tk = -1, lst = 0;
       const bool evicted = t.evict && tail_ldflag(&t.ctrl[3]) == my_cu;
-      if (!evicted && tail_ldflag(&t.ctrl[1]) == 0) tk = (int)atomicAdd(&t.ctrl[0], 1u);
-      *slot2 = tk;
+      if (!evicted && tail_ldflag(&t.ctrl[1]) == 0) {
+        for (int d = 0; d < nl; ++d) {             // own list first, then the others
+          const int x = (my_list + d) % nl;
+          if (tail_ldflag(&t.ctrl[8 + x]) >= (unsigned)t.ntasks_x[x]) continue;
+          const int k = (int)atomicAdd(&t.ctrl[8 + x], 1u);
+          if (k < t.ntasks_x[x]) { tk = k; lst = x; break; }
+        }
+      }
+      *slot2 = tk; *slot3 = lst;
     }
     __syncthreads();
     const int tk = *slot2;
-    if (tk < 0 || tk >= t.ntasks) return;
+    if (tk < 0) return;
     int kind, r, c;
-    tail_task(t, tk, &kind, &r, &c);
+    tail_task(t, tk, *slot3, nl, &kind, &r, &c);
     if (kind == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3);
     const int ca = (kind == 1) ? c : r;          // column block of the A operand: PART is L_{k,r+1}^T d L_{k,r+1}
     v4f64 acc[2][2];
@@ -1892,9 +2044,17 @@ __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, doubl
       else tail_mma<false>(acc, A, B, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sA, sB);
       k += nrows;
     }
-    // U = A_rc - acc.  The tile itself was written before this launch (plain loads).
+    // U = A_rc - acc.  The tile itself was written before this launch.
     const int row0 = (kind == 1 ? c : r) * kInner;
-    double* Trc = t.S + (size_t)row0 * ld + (size_t)c * kInner;
+    const __amdgpu_buffer_rsrc_t rt = tail_rsrc(t.S + (size_t)row0 * ld + (size_t)c * kInner);
+    const int acc_voff = ((wm0 + lk) * ld + wn0 + li) * 8;
+    double a_rc[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) a_rc[i][jj][r4] = tail_ld1(rt, acc_voff, ((16 * i + 4 * r4) * ld + 16 * jj) * 8);
     if (kind != 2) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -1904,10 +2064,10 @@ __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, doubl
           for (int r4 = 0; r4 < 4; ++r4) {
             const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
             if (kind == 1 && n < m) continue;                               // diagonal tile: upper triangle only
-            const double u = Trc[(size_t)m * ld + n] - acc[i][jj][r4];
-            tail_st(&Trc[(size_t)m * ld + n], u);
+            tail_st1(rt, acc_voff, ((16 * i + 4 * r4) * ld + 16 * jj) * 8, a_rc[i][jj][r4] - acc[i][jj][r4]);
           }
       tail_publish(kind == 0 ? &t.upre_flag[r - t.rt0] : &t.part_flag[c - t.rt0], t.epoch);
+      TAIL_STAMP(c - t.rt0, kind == 0 ? 10 : 11);
       continue;
     }
 #pragma unroll
@@ -1917,26 +2077,28 @@ __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, doubl
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
           const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
-          sV[m * TS + n] = Trc[(size_t)m * ld + n] - acc[i][jj][r4];
+          sV[m * TS + n] = a_rc[i][jj][r4] - acc[i][jj][r4];
         }
     if (!tail_wait(t, &t.diag_flag[r - t.rt0], nullptr, slot)) return;       // (its barrier also publishes sV to the other waves)
+    double rdr[2][4];
     {
-      // invL_r (K-major, [q][p]) -> sAB as a 64 x TS tile
+      // invL_r (K-major, [q][p]) -> sAB as a 64 x TS tile; 1 / d_r of this lane's rows
       const __amdgpu_buffer_rsrc_t ri = tail_rsrc(t.invLt + (size_t)r * kInner * kInner);
-      const int row = tid >> 2, cq = (tid & 3) * 16;
+      const __amdgpu_buffer_rsrc_t rd = tail_rsrc(t.dvec + (size_t)r * kInner);
+      const int rw = 16 * wv + (lane >> 5), cw = 2 * (lane & 31);             // full 512-byte rows per half wave
       v2f64_t u[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) u[i] = tail_ld2(ri, (row * kInner + cq + 2 * i) * 8);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { sAB[row * TS + cq + 2 * i] = u[i].x; sAB[row * TS + cq + 2 * i + 1] = u[i].y; }
-    }
-    double dr[2][4];
-    {
-      const __amdgpu_buffer_rsrc_t rd = tail_rsrc(t.dvec + (size_t)r * kInner);
+      for (int k = 0; k < 8; ++k) u[k] = tail_ld2(ri, (rw * kInner + cw) * 8, 2 * k * kInner * 8);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) dr[i][r4] = tail_ld1(rd, (wm0 + i * 16 + lk + 4 * r4) * 8);
+        for (int r4 = 0; r4 < 4; ++r4) rdr[i][r4] = tail_ld1(rd, (wm0 + lk) * 8, (16 * i + 4 * r4) * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { sAB[(rw + 2 * k) * TS + cw] = u[k].x; sAB[(rw + 2 * k) * TS + cw + 1] = u[k].y; }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) rdr[i][r4] = 1.0 / rdr[i][r4];
     }
     __syncthreads();
 #pragma unroll
@@ -1947,14 +2109,10 @@ __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, doubl
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int p = wm0 + i * 16 + lk + 4 * r4;
+      for (int r4 = 0; r4 < 4; ++r4)
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          const int n = wn0 + jj * 16 + li;
-          tail_st(&Trc[(size_t)p * ld + n], acc[i][jj][r4] / dr[i][r4]);
-        }
-      }
+        for (int jj = 0; jj < 2; ++jj)
+          tail_st1(rt, acc_voff, ((16 * i + 4 * r4) * ld + 16 * jj) * 8, acc[i][jj][r4] * rdr[i][r4]);
     tail_publish(&t.tile_flag[(size_t)(r - t.rt0) * t.ntc + c], t.epoch);
   }
 }
@@ -2126,8 +2284,8 @@ int ldlt_workspace_alloc(LdltWorkspace& w, int n_pad) {
     const size_t words = (size_t)rows * ntc + 3 * (size_t)ntc;
     CBA_HIP(hipMalloc(&w.tail_flags, sizeof(unsigned) * words));
     CBA_HIP(hipMemset(w.tail_flags, 0, sizeof(unsigned) * words));
-    CBA_HIP(hipMalloc(&w.tail_ctrl, sizeof(unsigned) * 8));
-    CBA_HIP(hipMemset(w.tail_ctrl, 0, sizeof(unsigned) * 8));
+    CBA_HIP(hipMalloc(&w.tail_ctrl, sizeof(unsigned) * 16));
+    CBA_HIP(hipMemset(w.tail_ctrl, 0, sizeof(unsigned) * 16));
     w.tail_rows_cap = rows * kInner;
     w.tail_epoch = 0;
     CBA_HIP(hipEventCreate(&w.tail_e0));
@@ -2295,9 +2453,17 @@ static int ldlt_tail(double* S, int n_fact, int ld, int t0, LdltWorkspace& w, hi
   long long ntasks = 0;
   for (int r = t.rt0; r < t.nr; ++r) ntasks += (r + 1 < t.nr) ? t.ntc - r : t.ntc - t.nr;
   t.ntasks = (int)ntasks;
-  static const bool no_evict = CBA_GETENV("CBA_TAIL_NO_EVICT") != nullptr;     // developer switch
+  static const bool no_evict = CBA_GETENV("CBA_TAIL_NO_EVICT") != nullptr;     // developer switches (bench harness only)
+  static const bool one_list = CBA_GETENV("CBA_TAIL_XCD_LISTS") == nullptr;   // per-XCD lists measured: no gain (the helpers are not operand-bandwidth bound)
   t.evict = no_evict ? 0 : 1;
-  CBA_HIP(hipMemsetAsync(w.tail_ctrl, 0, sizeof(unsigned) * 8, s));
+  t.xcd_lists = one_list ? 0 : 1;
+  {
+    const int nl = t.xcd_lists ? 8 : 1;
+    for (int x = 0; x < 8; ++x) t.ntasks_x[x] = 0;
+    for (int r = t.rt0; r < t.nr; ++r)
+      for (int c = r + 1; c < t.ntc; ++c) t.ntasks_x[c % nl] += (c == r + 1 && r + 1 < t.nr) ? 2 : 1;
+  }
+  CBA_HIP(hipMemsetAsync(w.tail_ctrl, 0, sizeof(unsigned) * 16, s));
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   long long grid = ntasks + 1;

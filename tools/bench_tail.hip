@@ -16,6 +16,37 @@ static float timeit(hipEvent_t e0, hipEvent_t e1) { float ms; hipEventSynchroniz
 
 struct Case { int n, n_fact; };
 
+__global__ void __launch_bounds__(256, 2) k_mma2_only(const double* S, int ld, const double* dvec, int K, int ntc, double* out) {
+  __shared__ double smem[2 * kInner * TS];
+  double* sA = smem;
+  double* sB = smem + 2 * KT * TS;
+  const int c = blockIdx.x % ntc, r = (blockIdx.x / ntc) % (2 * ntc);
+  v4f64 acc[2][4];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  for (int k = 0; k < K; k += 1024) {
+    const int kk = K - k < 1024 ? K - k : 1024;
+    tail_mma2(acc, S + (size_t)k * ld + r * kInner, S + (size_t)k * ld + c * 2 * kInner, ld, dvec + k, kk, sA, sB);
+  }
+  double v = 0; for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) for (int q = 0; q < 4; ++q) v += acc[i][j][q];
+  if (v == 1.2345e300) out[blockIdx.x] = v;
+}
+// synthetic ceiling of the helpers' inner loop: every workgroup accumulates one 64 x 64 tile over K rows, no flags
+template <bool SYM>
+__global__ void __launch_bounds__(256, 2) k_mma_only(const double* S, int ld, const double* dvec, int K, int ntc, double* out) {
+  __shared__ double smem[2 * kInner * TS];
+  double* sA = smem + kInner * TS;
+  double* sB = sA + 2 * KT * TS;
+  const int c = blockIdx.x % ntc, r = (blockIdx.x / ntc) % ntc;
+  v4f64 acc[2][2];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  for (int k = 0; k < K; k += 1024) {
+    const int kk = K - k < 1024 ? K - k : 1024;
+    tail_mma<SYM>(acc, S + (size_t)k * ld + r * kInner, S + (size_t)k * ld + c * kInner, ld, dvec + k, kk, sA, sB);
+  }
+  double v = 0; for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int q = 0; q < 4; ++q) v += acc[i][j][q];
+  if (v == 1.2345e300) out[blockIdx.x] = v;
+}
+
 int main(int argc, char** argv) {
   std::vector<Case> cases;
   if (argc > 2) cases.push_back({atoi(argv[1]), atoi(argv[2])});
@@ -26,6 +57,36 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   prepare_device_streams();
   hipStream_t ms; make_main_stream(&ms);
+  if (getenv("MMA2_ONLY")) {
+    const int n = 12672, K = 4096, ntc = 48;
+    double *S, *dv, *out; hipMalloc(&S, sizeof(double) * (size_t)K * n); hipMalloc(&dv, sizeof(double) * K); hipMalloc(&out, 8 * 4096);
+    std::vector<double> h((size_t)K * n); for (size_t i = 0; i < h.size(); ++i) h[i] = ((double)((i * 2654435761u) % 2001) / 1000.0 - 1.0) * 0.05;
+    hipMemcpy(S, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+    std::vector<double> hd(K, 1.5); hipMemcpy(dv, hd.data(), K * 8, hipMemcpyHostToDevice);
+    for (int grid : {256, 512, 1024, 2048}) for (int rep = 0; rep < 2; ++rep) {
+      hipEventRecord(e0, ms);
+      hipLaunchKernelGGL(k_mma2_only, dim3(grid), dim3(256), 0, ms, S, n, dv, K, ntc, out);
+      hipEventRecord(e1, ms);
+      const float t = timeit(e0, e1);
+      printf("mma2_only (64x128) grid %d K %d: %.3f ms  %.2f TFLOP/s\n", grid, K, t, grid * 2.0 * 64 * 128 * K / t / 1e9);
+    }
+    return 0;
+  }
+  if (getenv("MMA_ONLY")) {
+    const int n = 12672, K = 4096, ntc = 96;
+    double *S, *dv, *out; hipMalloc(&S, sizeof(double) * (size_t)K * n); hipMalloc(&dv, sizeof(double) * K); hipMalloc(&out, 8 * 4096);
+    std::vector<double> h((size_t)K * n); for (size_t i = 0; i < h.size(); ++i) h[i] = ((double)((i * 2654435761u) % 2001) / 1000.0 - 1.0) * 0.05;
+    hipMemcpy(S, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+    std::vector<double> hd(K, 1.5); hipMemcpy(dv, hd.data(), K * 8, hipMemcpyHostToDevice);
+    for (int grid : {256, 512, 1024, 2048}) for (int rep = 0; rep < 2; ++rep) {
+      hipEventRecord(e0, ms);
+      hipLaunchKernelGGL(k_mma_only<false>, dim3(grid), dim3(256), 0, ms, S, n, dv, K, ntc, out);
+      hipEventRecord(e1, ms);
+      const float t = timeit(e0, e1);
+      printf("mma_only grid %d K %d: %.3f ms  %.2f TFLOP/s\n", grid, K, t, grid * 2.0 * 64 * 64 * K / t / 1e9);
+    }
+    return 0;
+  }
   for (const Case& cs : cases) {
     const int n = cs.n, n_fact = cs.n_fact, K = 1024;
     printf("=== n_pad %d n_fact %d ===\n", n, n_fact);
