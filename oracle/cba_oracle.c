@@ -756,6 +756,23 @@ static int projection_jacobian_wrt_intrinsics(const orc_camera* cam, double* gri
   return 1;
 }
 
+/* test hook: M5 / N3 on a caller-supplied grid (copied: the routine perturbs it in place); tangents are computed here */
+int orc_debug_projection_jacobian_wrt_intrinsics(const orc_camera* cam, const double* grid, const double* local_point,
+                                                 const double* pixel, double delta, int32_t* indices, double* J) {
+  size_t G = (size_t)cam->grid_w * cam->grid_h;
+  size_t n = (cam->model_type == ORC_CENTRAL_GENERIC ? 3 : 6) * G;
+  double* g = (double*)malloc(n * sizeof(double));
+  double* tang = (double*)malloc(6 * G * sizeof(double));
+  memcpy(g, grid, n * sizeof(double));
+  for (size_t i = 0; i < G; ++i) orc_tangents(g + 3 * i, tang + 6 * i, tang + 6 * i + 3);
+  int idx[MAXK];
+  int ok = projection_jacobian_wrt_intrinsics(cam, g, tang, local_point, pixel, delta, idx, J);
+  int K = cam->model_type == ORC_CENTRAL_GENERIC ? 32 : 80;
+  for (int k = 0; k < K; ++k) indices[k] = idx[k];
+  free(g); free(tang);
+  return ok;
+}
+
 /* what one observation adds to the normal equations (K = 0: nothing) */
 typedef struct {
   int K;

@@ -128,6 +128,10 @@ void orc_compute_rig_jacobian(const double* cq, const double* p, const double* r
 
 /* ---- problem level ---- */
 int32_t orc_intrinsics_param_count(const orc_camera* cam);
+/* test hook: ProjectionJacobianWrtIntrinsics (M5 / N3) on one point; J is 2 x K row-major, K = 32 / 80; returns 1 ok, 0 a
+ * perturbed projection failed, -1 the 4 x 4 patch leaves the grid (a CHECK abort in the reference) */
+int orc_debug_projection_jacobian_wrt_intrinsics(const orc_camera* cam, const double* grid, const double* local_point,
+                                                 const double* pixel, double delta, int32_t* indices, double* J);
 int32_t orc_dense_dof(const orc_problem* pb);
 int32_t orc_total_dof(const orc_problem* pb);
 /* Compute<false>: cost-only pass.  cost_vec has n_obs entries (-1 = invalid). */

@@ -437,6 +437,25 @@ def fit_grid_to_points(gw: int, gh: int, grid, grid_points, directions, max_iter
     return g, dict(initial_cost=rep[0], final_cost=rep[1], iterations=int(rep[2]), final_lambda=rep[3])
 
 
+def projection_jacobian_wrt_intrinsics(cam, grid: np.ndarray, local_point, pixel, delta: float):
+    """ProjectionJacobianWrtIntrinsics (M5 / N3) of one point: (ok, indices[K], J[2, K])."""
+    L = lib()
+    L.orc_debug_projection_jacobian_wrt_intrinsics.argtypes = [C.POINTER(OrcCamera), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                                               C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_int32),
+                                                               C.POINTER(C.c_double)]
+    L.orc_debug_projection_jacobian_wrt_intrinsics.restype = C.c_int
+    K = 32 if int(cam.model_type) == 0 else 80
+    g = np.ascontiguousarray(grid, dtype=np.float64).ravel()
+    lp = np.ascontiguousarray(local_point, dtype=np.float64)
+    px = np.ascontiguousarray(pixel, dtype=np.float64)
+    idx = np.zeros(K, dtype=np.int32)
+    J = np.zeros(2 * K)
+    cs = camera_struct(cam)
+    ok = L.orc_debug_projection_jacobian_wrt_intrinsics(C.byref(cs), _dp(g), _dp(lp), _dp(px), float(delta),
+                                                        idx.ctypes.data_as(C.POINTER(C.c_int32)), _dp(J))
+    return int(ok), idx, J.reshape(2, K)
+
+
 def pixel_to_grid_point(cam, pixels):
     L = _fit_sigs()
     cs = camera_struct(cam)

@@ -80,6 +80,22 @@ def lib() -> C.CDLL:
         for name in ("ref_huber_cost_sq", "ref_huber_weight_sq", "ref_huber_cost", "ref_huber_weight"):
             getattr(L, name).argtypes = [C.c_double, C.c_double]
             getattr(L, name).restype = C.c_double
+        # round 3: LV accumulators + APP/models/central_grid.h (oracle/ref_lm.cc)
+        L.ref_accum_create.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.ref_accum_create.restype = vp
+        L.ref_accum_destroy.argtypes = [vp]
+        L.ref_accum_add.argtypes = [vp, C.c_int, C.c_int, dp, C.c_int, dp, C.c_int, dp, C.c_int, dp, ip, dp]
+        L.ref_accum_add_residual.argtypes = [vp, dp]
+        L.ref_accum_add_invalid.argtypes = [vp]
+        L.ref_accum_get.argtypes = [vp, dp, dp, dp, dp, dp, dp, dp, ip]
+        L.ref_central_grid_projection_jacobian.argtypes = [ip, dp, dp, dp, dp, C.c_double, ip, dp]
+        L.ref_central_grid_projection_jacobian.restype = C.c_int
+        L.ref_central_grid_subtract_delta.argtypes = [ip, dp, dp]
+        L.ref_central_grid_subtract_delta.restype = C.c_int
+        L.ref_noncentral_grid_projection_jacobian.argtypes = [ip, dp, dp, dp, dp, C.c_double, ip, dp]
+        L.ref_noncentral_grid_projection_jacobian.restype = C.c_int
+        L.ref_noncentral_grid_subtract_delta.argtypes = [ip, dp, dp]
+        L.ref_noncentral_grid_subtract_delta.restype = C.c_int
         _lib = L
     return _lib
 
@@ -148,3 +164,116 @@ class RefCamera:
             return bool(ok), out, jac.reshape(n, 2)
         ok = getattr(lib(), self._pfx + "unproject")(self._h, _dp(px), _dp(out))
         return bool(ok), out
+
+
+def _ip(a: np.ndarray):
+    assert a.dtype == np.int32 and a.flags.c_contiguous
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def accumulate_records(pb, recs):
+    """Feeds the per-observation records of an oracle Jacobian pass (oracle.OrcObsRecord: residual, Jacobian blocks, grid
+    indices) through the REFERENCE's UpdateEquationAccumulator with the call sequence of AccumulateModelJacobian
+    (APP/bundle_adjustment/joint_optimization.cc:479-590; oracle/ref_lm.cc).  Returns a dict with the reference's
+    block_diag_H [nb, bs, bs], off_diag_H, dense_H, block_diag_b, dense_b, cost, cost_vector."""
+    L = lib()
+    bs, nb, dd = pb.block_size, pb.n_blocks, pb.dense_dof
+    h = L.ref_accum_create(bs * nb, bs, dd)
+    first_rig = 0
+    first_cam = 6 * pb.n_images
+    first_pts = first_cam + pb.rig_dof
+    intr = [first_pts + 3 * pb.n_points]
+    for c in pb.cameras[:-1]:
+        intr.append(intr[-1] + c.intrinsics_param_count)
+    if pb.eliminate_points:        # JointOptimizationState ordering with points first (joint_optimization.cc:142-170)
+        first_pts = 0
+        first_rig = 3 * pb.n_points
+        first_cam = first_rig + 6 * pb.n_images
+    mode = (1 if pb.rig_in_state else 0) | (2 if pb.eliminate_points else 0) | (4 if pb.localize_only else 0)
+    try:
+        for o in range(pb.n_obs):
+            r = recs[o]
+            res = np.array([r.residual[0], r.residual[1]])
+            if not r.valid:
+                L.ref_accum_add_invalid(h)
+                continue
+            if not r.has_jacobian:
+                L.ref_accum_add_residual(h, _dp(res))
+                continue
+            cam = pb.cameras[int(pb.obs_camera[o])]
+            kg = 0 if pb.localize_only else (32 if int(cam.model_type) == 0 else 80)
+            gi = np.zeros(max(kg, 1), dtype=np.int32)
+            gj = np.zeros(2 * max(kg, 1))
+            if kg:
+                gi[:] = np.array(r.grid_indices[:kg], dtype=np.int32) + intr[int(pb.obs_camera[o])]
+                gj[:] = np.array(r.grid_jac[:2 * kg])
+            L.ref_accum_add(h, mode, kg, _dp(res), first_rig + 6 * int(pb.obs_image[o]), _dp(np.array(r.pose_jac[:])),
+                            first_cam + 6 * int(pb.obs_camera[o]), _dp(np.array(r.rig_jac[:])),
+                            first_pts + 3 * int(pb.obs_point[o]), _dp(np.array(r.point_jac[:])), _ip(gi), _dp(gj))
+        out = dict(block_diag_H=np.zeros((nb, bs, bs)), off_diag_H=np.zeros((nb * bs, dd)), dense_H=np.zeros((dd, dd)),
+                   dense_b=np.zeros(dd), block_diag_b=np.zeros(nb * bs))
+        cost = np.zeros(1)
+        vec = np.zeros(pb.n_obs)
+        n = (C.c_int * 1)()
+        L.ref_accum_get(h, _dp(out["block_diag_H"]), _dp(out["off_diag_H"]), _dp(out["dense_H"]), _dp(out["dense_b"]),
+                        _dp(out["block_diag_b"]), _dp(cost), _dp(vec), n)
+        assert n[0] == pb.n_obs
+        out["cost"] = float(cost[0])
+        out["cost_vector"] = vec
+        return out
+    finally:
+        L.ref_accum_destroy(h)
+
+
+def _cam_params8(cam) -> np.ndarray:
+    return np.array([cam.width, cam.height, cam.calib_min_x, cam.calib_min_y, cam.calib_max_x, cam.calib_max_y, cam.grid_w, cam.grid_h],
+                    dtype=np.int32)
+
+
+def central_grid_projection_jacobian(cam, grid, local_point, pixel, delta: float):
+    """CentralGridModel::ProjectionJacobianWrtIntrinsics (APP/models/central_grid.h:187-245): (ok, indices[32], J[2, 32])."""
+    L = lib()
+    g = np.ascontiguousarray(grid, dtype=np.float64).reshape(-1, 3)
+    tang = np.zeros((g.shape[0], 6))
+    for i in range(g.shape[0]):
+        L.ref_tangents(_dp(g[i].copy()), _dp(tang[i, :3]), _dp(tang[i, 3:]))
+    idx = np.zeros(32, dtype=np.int32)
+    J = np.zeros(64)
+    ok = L.ref_central_grid_projection_jacobian(_ip(_cam_params8(cam)), _dp(g.ravel()), _dp(tang.ravel()),
+                                                _dp(np.ascontiguousarray(local_point, dtype=np.float64)),
+                                                _dp(np.ascontiguousarray(pixel, dtype=np.float64)), float(delta), _ip(idx), _dp(J))
+    return int(ok), idx, J.reshape(2, 32)
+
+
+def central_grid_subtract_delta(cam, grid, delta):
+    """CentralGridModel::SubtractDelta (central_grid.h:168-185) on a copy of the grid."""
+    g = np.ascontiguousarray(grid, dtype=np.float64).ravel().copy()
+    ok = lib().ref_central_grid_subtract_delta(_ip(_cam_params8(cam)), _dp(g), _dp(np.ascontiguousarray(delta, dtype=np.float64)))
+    if not ok:
+        raise ValueError("grid size not compiled into oracle/ref_lm.cc")
+    return g.reshape(-1, 3)
+
+
+def noncentral_grid_projection_jacobian(cam, grids, local_point, pixel, delta: float):
+    """NoncentralGenericModel::ProjectionJacobianWrtIntrinsics (APP/models/noncentral_generic.h:224-283): (ok, indices[80], J[2, 80]).
+    grids: [2, G, 3] = direction grid, point grid."""
+    L = lib()
+    g = np.ascontiguousarray(grids, dtype=np.float64).reshape(2, -1, 3)
+    tang = np.zeros((g.shape[1], 6))
+    for i in range(g.shape[1]):
+        L.ref_tangents(_dp(g[0, i].copy()), _dp(tang[i, :3]), _dp(tang[i, 3:]))
+    idx = np.zeros(80, dtype=np.int32)
+    J = np.zeros(160)
+    ok = L.ref_noncentral_grid_projection_jacobian(_ip(_cam_params8(cam)), _dp(g.ravel()), _dp(tang.ravel()),
+                                                   _dp(np.ascontiguousarray(local_point, dtype=np.float64)),
+                                                   _dp(np.ascontiguousarray(pixel, dtype=np.float64)), float(delta), _ip(idx), _dp(J))
+    return int(ok), idx, J.reshape(2, 80)
+
+
+def noncentral_grid_subtract_delta(cam, grids, delta):
+    """NoncentralGenericModel::SubtractDelta (noncentral_generic.h:195-222) on a copy of the grids [2, G, 3]."""
+    g = np.ascontiguousarray(grids, dtype=np.float64).ravel().copy()
+    ok = lib().ref_noncentral_grid_subtract_delta(_ip(_cam_params8(cam)), _dp(g), _dp(np.ascontiguousarray(delta, dtype=np.float64)))
+    if not ok:
+        raise ValueError("grid size not compiled into oracle/ref_lm.cc")
+    return g.reshape(2, -1, 3)

@@ -19,4 +19,9 @@ typedef int8_t i8; typedef int16_t i16; typedef int32_t i32; typedef int64_t i64
 // e.g. sin(float) in ApplyLocalUpdateToQuaternion resolves to std::sin(float), evaluated in fp32 -- so it is mirrored.
 using namespace std;
 }
+// Eigen's class-level operator new for aligned members: nothing to align in the stand-in
+#ifndef EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+#define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+#endif
+#include "libvis/logging.h"   // the real libvis.h makes the CHECK_* macros available to every includer
 #endif

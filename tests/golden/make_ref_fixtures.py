@@ -67,6 +67,59 @@ def write_reference_dataset_bin(L, path):
         put(I32, fid); put(I32, x); put(I32, y)
 
 
+def write_accumulated(path):
+    """B2 / B3 / A5: the oracle's per-observation records fed through the REFERENCE's accumulator (ref.accumulate_records) for every
+    mode of tests/ref_modes.py, and -- M5 on a whole problem -- the reference's ProjectionJacobianWrtIntrinsics at every observation
+    of the central single-camera fixture."""
+    from oracle import oracle as orc
+    from tests.ref_modes import ACC_FIELDS, ACC_MODES, load_mode
+    out = {}
+    for name in ACC_MODES:
+        pb, st = load_mode(name, HERE)
+        op = orc.OracleProblem(pb)
+        _, _, recs = op.jacobian_pass(st, op.new_system(), want_records=True)
+        r = ref.accumulate_records(pb, recs)
+        for f in ACC_FIELDS:
+            out[f"{name}__{f}"] = r[f]
+        out[f"{name}__cost"] = np.float64(r["cost"])
+        out[f"{name}__cost_vector"] = r["cost_vector"]
+    pb, st = load_mode("central", HERE)
+    op = orc.OracleProblem(pb)
+    _, _, recs = op.jacobian_pass(st, op.new_system(), want_records=True)
+    cam = pb.cameras[0]
+    idx = np.full((pb.n_obs, 32), -1, dtype=np.int32); jac = np.zeros((pb.n_obs, 2, 32)); ok = np.zeros(pb.n_obs, dtype=np.int32)
+    for o in range(pb.n_obs):
+        if not recs[o].valid:
+            continue
+        itg = orc.se3_mul(st.camera_tr_rig[0], st.rig_tr_global[int(pb.obs_image[o])])
+        q = itg[:4]; w, x, y, z = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        local = R @ st.points[int(pb.obs_point[o])] + itg[4:]
+        ok[o], idx[o], jac[o] = ref.central_grid_projection_jacobian(cam, st.grids[0], local, np.array(recs[o].pixel[:]), pb.fd_delta)
+    out.update(central__m5_ok=ok, central__m5_idx=idx, central__m5_jac=jac)
+    # N3: the same for the non-central fixture (80 parameters per observation)
+    pb, st = load_mode("noncentral", HERE)
+    op = orc.OracleProblem(pb)
+    _, _, recs = op.jacobian_pass(st, op.new_system(), want_records=True)
+    cam = pb.cameras[0]
+    idx = np.full((pb.n_obs, 80), -1, dtype=np.int32); jac = np.zeros((pb.n_obs, 2, 80)); ok = np.zeros(pb.n_obs, dtype=np.int32)
+    for o in range(pb.n_obs):
+        if not recs[o].valid:
+            continue
+        itg = orc.se3_mul(st.camera_tr_rig[0], st.rig_tr_global[int(pb.obs_image[o])])
+        w, x, y, z = itg[:4]
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        local = R @ st.points[int(pb.obs_point[o])] + itg[4:]
+        ok[o], idx[o], jac[o] = ref.noncentral_grid_projection_jacobian(cam, st.grids[0], local, np.array(recs[o].pixel[:]), pb.fd_delta)
+    out.update(noncentral__m5_ok=ok, noncentral__m5_idx=idx, noncentral__m5_jac=jac)
+    np.savez_compressed(path, **out)
+    print("wrote", path, len(out), "arrays")
+
+
 def main():
     L = ref.lib()
     dp = ref._dp
@@ -188,7 +241,20 @@ def main():
         L.ref_bspline_surface(dp(net64.ravel()), 4, 4, 2, x, 1.5, 1, dp(slow64[i]))
     assert np.abs(fast - slow).max() <= 1e-5          # the reference's own assertion
     out.update(bsp_net=net64, bsp_x=xs, bsp_fast_f32=fast, bsp_slow_f32=slow, bsp_fast=fast64, bsp_slow=slow64)
+    # --- round 3: CentralGridModel::ProjectionJacobianWrtIntrinsics / SubtractDelta (APP/models/central_grid.h:168-245) on the 17 x 13 camera ---
+    c17 = Camera(CENTRAL_GENERIC, *params)
+    m5n = 80
+    m5_ok = np.zeros(m5n, dtype=np.int32); m5_idx = np.zeros((m5n, 32), dtype=np.int32); m5_jac = np.zeros((m5n, 2, 32))
+    for i in range(m5n):
+        m5_ok[i], m5_idx[i], m5_jac[i] = ref.central_grid_projection_jacobian(c17, grid17, pts[i], reproj[i], 1e-4)
+    m6_delta = rng.normal(size=2 * params[6] * params[7]) * 0.01
+    out.update(m5_pts=pts[:m5n], m5_px=reproj[:m5n], m5_delta=np.float64(1e-4), m5_ok=m5_ok, m5_idx=m5_idx, m5_jac=m5_jac,
+               m6_delta=m6_delta, m6_grid=ref.central_grid_subtract_delta(c17, grid17, m6_delta))
+    # N3 SubtractDelta on the non-central 8 x 8 self-test camera
+    n3_delta = rng.normal(size=5 * gw * gh) * 0.01
+    out.update(n3_delta=n3_delta, n3_grids=ref.noncentral_grid_subtract_delta(ncam, ngrid, n3_delta))
     np.savez_compressed(os.path.join(HERE, "ref_vectors.npz"), **out)
+    write_accumulated(os.path.join(HERE, "ref_accumulated.npz"))
     write_reference_dataset_bin(L, os.path.join(HERE, "ref_dataset.bin"))
     print("wrote", yaml_path, "and ref_vectors.npz:", {k_: v.shape for k_, v in out.items()})
 

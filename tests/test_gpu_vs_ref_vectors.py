@@ -50,3 +50,69 @@ def test_noncentral_8x8_reference_camera_on_gpu():
     check_equal(case, "project ok flags", int(np.count_nonzero(pok != V["n8_reproj_ok"].astype(bool))))
     check(case, "project pixel abs [px]", np.abs(px[pok] - V["n8_reproj"][pok]).max(), 5e-11)
     check(case, "round trip [px] (reference criterion 1e-3)", np.linalg.norm(px[pok] - V["n8_px"][pok], axis=1).max(), 1e-3)
+
+
+# ---- round 3: normal equations against the REFERENCE's accumulator, grid Jacobians against the reference's grid model --------
+ACC = np.load(os.path.join(GOLDEN, "ref_accumulated.npz"))
+from tests.ref_modes import ACC_MODES, load_mode  # noqa: E402
+
+
+@pytest.mark.parametrize("mode", sorted(ACC_MODES))
+def test_normal_equations_against_the_reference_accumulator(mode):
+    """Engine: residuals, Jacobians AND accumulation on the GPU.  Expected: the reference's own UpdateEquationAccumulator
+    (LV/lm_optimizer_update_accumulator.h compiled by oracle/Makefile) fed with the per-observation Jacobians of the fixture
+    (tests/golden/make_ref_fixtures.py).  Every branch of AccumulateModelJacobian (joint_optimization.cc:479-590)."""
+    case = f"GPU vs reference accumulator, {mode}"
+    pb, st = load_mode(mode, GOLDEN)
+    e = eng.Engine(pb)
+    e.set_state(st)
+    cost = e.debug_accumulate()
+    check(case, "cost rel", abs(cost - float(ACC[f"{mode}__cost"])) / float(ACC[f"{mode}__cost"]), 5e-10)
+    vec = e.dump(eng.DUMP_COST_VECTOR)
+    check_equal(case, "valid mask", int(np.count_nonzero((vec >= 0) != (ACC[f"{mode}__cost_vector"] >= 0))))
+    got = {"block_diag_H": np.array([np.triu(b) for b in e.dump(eng.DUMP_BLOCK_DIAG_H)]), "block_diag_b": e.dump(eng.DUMP_BLOCK_DIAG_B),
+           "off_diag_H": e.dump(eng.DUMP_OFF_DIAG_H), "dense_H": np.triu(e.dump(eng.DUMP_DENSE_H)), "dense_b": e.dump(eng.DUMP_DENSE_B)}
+    for name, a in got.items():
+        b = ACC[f"{mode}__{name}"]
+        b = np.array([np.triu(x) for x in b]) if name == "block_diag_H" else (np.triu(b) if name == "dense_H" else b)
+        if np.abs(b).max() == 0:
+            check_equal(case, name + " (all zero)", int(np.count_nonzero(a)))
+        else:
+            check(case, name + " / max", np.abs(a - b).max() / np.abs(b).max(), 5e-9)
+    e.close()
+
+
+def test_grid_jacobians_against_the_reference_grid_model():
+    """k_fd_tasks / k_fd_redo (the 32 finite-difference re-projections per observation) against
+    CentralGridModel::ProjectionJacobianWrtIntrinsics (APP/models/central_grid.h:187-245) compiled from the reference."""
+    case = "GPU vs reference ProjectionJacobianWrtIntrinsics"
+    pb, st = load_mode("central", GOLDEN)
+    e = eng.Engine(pb)
+    e.set_state(st)
+    e.debug_accumulate()
+    flags = e.dump(eng.DUMP_FLAGS)
+    rec = e.dump(eng.DUMP_JACOBIANS)
+    hasj = ((flags >> 1) & 1).astype(bool)
+    check_equal(case, "has-Jacobian flags", int(np.count_nonzero(hasj != (ACC["central__m5_ok"] == 1))))
+    gj = rec[:, 33:33 + 64].reshape(-1, 2, 32)[hasj]
+    ref_j = ACC["central__m5_jac"][hasj]
+    check(case, "grid block of the Jacobian records / max", np.abs(gj - ref_j).max() / np.abs(ref_j).max(), 5e-9)
+    e.close()
+
+
+def test_noncentral_grid_jacobians_against_the_reference_model():
+    """N3 on the GPU: the 80 finite-difference re-projections per observation (k_fd_tasks<1>) against
+    NoncentralGenericModel::ProjectionJacobianWrtIntrinsics (APP/models/noncentral_generic.h:224-283) compiled from the reference."""
+    case = "GPU vs reference non-central ProjectionJacobianWrtIntrinsics"
+    pb, st = load_mode("noncentral", GOLDEN)
+    e = eng.Engine(pb)
+    e.set_state(st)
+    e.debug_accumulate()
+    flags = e.dump(eng.DUMP_FLAGS)
+    rec = e.dump(eng.DUMP_JACOBIANS)
+    hasj = ((flags >> 1) & 1).astype(bool)
+    check_equal(case, "has-Jacobian flags", int(np.count_nonzero(hasj != (ACC["noncentral__m5_ok"] == 1))))
+    gj = rec[:, 33:33 + 160].reshape(-1, 2, 80)[hasj]
+    ref_j = ACC["noncentral__m5_jac"][hasj]
+    check(case, "grid block of the Jacobian records / max", np.abs(gj - ref_j).max() / np.abs(ref_j).max(), 5e-9)
+    e.close()
