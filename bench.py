@@ -43,6 +43,9 @@ def parse_args():
                     help="exercise the multi-GPU all-reduce path even with one rank (1-GPU validation of the N>1 code)")
     ap.add_argument("--cpu-sample-images", type=int, default=250)
     ap.add_argument("--no-convergence", action="store_true", help="skip the wall-clock-to-convergence run")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="exercise only the self-launch path (spawn --gpus ranks, one gloo all-reduce on CPU, rank 0 prints a JSON "
+                         "line); needs no GPU -- tests/test_bench_launcher.py")
     ap.add_argument("--distributed-solve", type=int, default=-1,
                     help="1 / 0: distribute the factorisation of the reduced system over the ranks (cba_config.distributed_solve); "
                          "default off (first cut: no look-ahead yet, DESIGN.md section 6)")
@@ -118,7 +121,7 @@ def cpu_baseline(pb, st0, n_sample_images, n_obs_total, n_images_total):
             "sample": (f"oracle Jacobian+cost passes on the first {n_sample_images} imagesets ({sub.n_obs} obs, "
                        f"{t_jac:.2f}s + {t_cost:.2f}s) scaled to {n_obs_total} obs; Schur solve timed at D={Ds},N={Ns} "
                        f"({t_solve_s:.2f}s) scaled by 6N*D^2 + D^3/3 to D={D},N={N} -> {t_solve:.0f}s"),
-            "t_iter_s_extrapolated": t_iter,
+            "t_iter_s_extrapolated": t_iter, "extrapolated": True,
         }
         # ---- all hardware threads ----
         nthreads = orc.set_num_threads(0)
@@ -130,7 +133,7 @@ def cpu_baseline(pb, st0, n_sample_images, n_obs_total, n_images_total):
         ts_small = time.perf_counter() - t0
         ts_a = ts_small * flops / flops_s
         how = f"timed at D={Ds},N={Ns} ({ts_small:.2f}s) and scaled to D={D},N={N}: {ts_a:.1f}s"
-        if ts_a < 15.0 and D <= 26000:          # cheap enough: measure the solve at the full size instead of extrapolating
+        if ts_a < 60.0 and D <= 26000:          # measure the solve at the full size instead of extrapolating (config 2: ~30 s on 256 threads)
             s = synthetic_system(D, N, seed=2)
             orc.set_num_threads(nthreads)
             t0 = time.perf_counter()
@@ -139,7 +142,7 @@ def cpu_baseline(pb, st0, n_sample_images, n_obs_total, n_images_total):
             how = f"measured at the full size D={D},N={N}: {ts_a:.1f}s"
         ti_a = tj_a * scale_obs + tc_a * scale_obs + ts_a
         out["all_cores"] = {
-            "value": n_obs_total / ti_a / 1e6, "cores": nthreads, "t_iter_s": ti_a,
+            "value": n_obs_total / ti_a / 1e6, "cores": nthreads, "t_iter_s": ti_a, "solve_extrapolated": not how.startswith("measured"),
             "sample": f"same passes with {nthreads} threads ({tj_a:.2f}s + {tc_a:.2f}s on {sub.n_obs} obs); Schur solve {how}",
         }
         return out
@@ -147,8 +150,54 @@ def cpu_baseline(pb, st0, n_sample_images, n_obs_total, n_images_total):
         orc.set_num_threads(1)
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: re-exec under torch.distributed.run, one rank per GPU
+    (exactly the command line the module docstring shows).  Returns the launcher's exit code."""
+    import subprocess
+    if not args.launcher_selftest:
+        import torch
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_dev < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} needs {args.gpus} devices on this node, found {n_dev} "
+                  f"(one rank per GPU; the engine has no CPU fallback)", file=sys.stderr)
+            return 3
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env["CBA_BENCH_SELF_LAUNCHED"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
+def launcher_selftest(args) -> None:
+    """What a rank does under --launcher-selftest: the rendezvous and one collective of the real path, on CPU."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dist.init_process_group(backend="gloo")
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "n_gpus": args.gpus, "world": world, "sum": float(t.item()),
+                          "self_launched": os.environ.get("CBA_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+    if args.launcher_selftest:
+        launcher_selftest(args)
+        return
     # the engine uses four concurrent HIP streams; with RCCL's own streams on top the default of four
     # hardware queues would make two of them share a queue (and serialise the factorisation's look-ahead)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -159,9 +208,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print("bench.py: --gpus N>1 must be launched with torch.distributed.run", file=sys.stderr)
-            sys.exit(2)
+        print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no GPU available (the engine has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
@@ -252,10 +300,34 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
+    # the library's DGEMM on the same device, measured once outside the timed region: the in-situ gap of the hand-written GEMM
+    # (roofline.frac_vs_library) is visible in the line itself
+    lib_tflops = None
+    if rank == 0:
+        try:
+            n_l = ((pb.dense_dof + 1 + 127) // 128) * 128
+            A_l = torch.randn(512, n_l, dtype=torch.float64, device=f"cuda:{local_rank}")
+            B_l = torch.randn(512, n_l, dtype=torch.float64, device=f"cuda:{local_rank}")
+            torch.mm(A_l.t(), B_l)
+            torch.cuda.synchronize()
+            best = None
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); torch.mm(A_l.t(), B_l); e1.record()
+                torch.cuda.synchronize()
+                t_ms = e0.elapsed_time(e1)
+                best = t_ms if best is None or t_ms < best else best
+            lib_tflops = 2.0 * n_l * n_l * 512 / (best * 1e-3) / 1e12
+            del A_l, B_l
+        except Exception:
+            lib_tflops = None
     out = None
     if rank == 0:
         ms_per_step = elapsed / max(1, args.steps) * 1e3
-        value = n_obs_total * args.steps / elapsed / 1e6
+        # n_valid / t_iter.  n_residuals_valid is the whole job's count (the 8-double scalar all-reduce of the
+        # Jacobian pass sums it over the ranks); invalid residuals (projection failed, APP joint_optimization.cc:334-342) do not count
+        n_valid_steps = sum(r.n_residuals_valid for r in reports)
+        value = n_valid_steps / elapsed / 1e6
         # dominant kernel: the fp64 MFMA GEMMs (Schur product + factorisation trailing updates)
         gemm_s = agg[0]["seconds"] + agg[1]["seconds"]
         gemm_f = agg[0]["flops"] + agg[1]["flops"]
@@ -270,9 +342,11 @@ def main():
         # HBM bytes of the dominant kernel come from PMC passes that cannot run inside the timed region; the last
         # committed measurement (tools/rocprof_pmc.py) is quoted when the workload is the one it was taken on.
         pmc_traffic = {}
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
-        if not os.path.exists(pmc_path):
-            pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        pmc_path = ""
+        for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", cand)
+            if os.path.exists(pmc_path):
+                break
         if args.config == 2 and world == 1 and os.path.exists(pmc_path):
             with open(pmc_path) as fh:
                 pmc_traffic = json.load(fh)
@@ -280,6 +354,8 @@ def main():
             "metric": "M observations/sec per LM iteration", "value": value, "unit": "M obs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "n_obs": n_obs_total, "n_valid": n_valid_steps / max(1, len(reports)),
+            "rccl_ranks": (dist.get_world_size() if use_dist else 1), "collective_backend": (dist.get_backend() if use_dist else None),
             "config": {"workload": f"BASELINE configs[{args.config - 1}]: {pb.n_cameras} cam "
                                    f"{'central' if pb.cameras[0].model_type == 0 else 'non-central'}-generic "
                                    f"{pb.cameras[0].grid_w}x{pb.cameras[0].grid_h} grid, {n_img} imagesets/GPU x {world} GPU"
@@ -290,7 +366,12 @@ def main():
                        "trajectory_restart_every": RESTART,
                        "cost": [reports[0].initial_cost, reports[-1].final_cost]},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic.get("traffic_bytes_per_launch"),
+                         "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                         "library_tflops": lib_tflops, "frac_vs_library": (ach / lib_tflops) if lib_tflops else None,
+                         "library_note": "rocBLAS / hipBLASLt DGEMM through torch.mm on the same device in this process, outside the "
+                                         "timed region: C[n x n] = A^T[n x K] B[K x n], n = the padded reduced system, K = 512 (the "
+                                         "shape of a trailing update), best of 5",
+                         "traffic": pmc_traffic.get("traffic_bytes_per_launch"),
                          "traffic_unit": "bytes/launch", "traffic_source": pmc_traffic.get("source"),
                          "kernel": "k_gemm_atb<128,128,64,64> (Schur product B^T D^-1 B + LDL^T trailing updates), kernel time",
                          "launches": dom_n, "avg_launch_ms": dom_s / max(1, dom_n) * 1e3,
@@ -367,8 +448,14 @@ def main():
         tc = time.perf_counter()
         final_cost, iters, reps = eng.run_bundle_adjustment(e, st0, 100, 1e-4)
         torch.cuda.synchronize()
+        n_acc = sum(1 for r in reps if r.accepted)
+        n_att = sum(r.lm_attempts for r in reps)
         conv = {"seconds": time.perf_counter() - tc, "outer_iterations": iters, "final_cost": final_cost,
-                "lm_attempts_total": sum(r.lm_attempts for r in reps), "initial_cost": reps[0].initial_cost}
+                "lm_attempts_total": n_att, "solves_accepted": n_acc, "solves_rejected": n_att - n_acc,
+                "lm_attempts_per_iteration": [r.lm_attempts for r in reps],
+                "seconds_in_solves": sum(r.t_solve for r in reps), "seconds_in_jacobian_passes": sum(r.t_jac for r in reps),
+                "seconds_in_cost_passes": sum(r.t_cost for r in reps),
+                "initial_cost": reps[0].initial_cost}
     e.close()
     if use_dist:
         dist.destroy_process_group()

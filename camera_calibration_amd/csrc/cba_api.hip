@@ -160,7 +160,8 @@ struct cba_problem {
   // deterministic mode (cba_config.deterministic): fixed-point scale of the current pass
   unsigned long long* det_bits = nullptr; double* det_scale = nullptr;
   // finite-difference kernel: work lists of the tasks that leave their staged patch (main launch / side-stream launch)
-  int64_t* fd_redo[2] = {nullptr, nullptr}; int* fd_redo_count = nullptr;
+  int64_t* fd_redo[2] = {nullptr, nullptr}; int* fd_redo_count = nullptr;   // counts: [0] main list, [1] side-stream list, [2] tasks that found a list full
+  int fd_redo_cap = 0;
   double last_lambda = 0;
 };
 
@@ -333,16 +334,19 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
     CBA_HIP(hipMemsetAsync(p->B + (size_t)L.block_dof * p->n_pad, 0, sizeof(double) * (size_t)(p->Kpad - L.block_dof) * p->n_pad, aux));
   CBA_HIP(hipMemsetAsync(p->Hdd, 0, sizeof(double) * (size_t)p->n_pad * p->n_pad, aux));
   CBA_HIP(hipMemsetAsync(p->bd, 0, sizeof(double) * (size_t)p->n_pad, aux));
+  CBA_HIP(hipMemsetAsync(p->fd_redo_count + 2, 0, sizeof(int), p->stream));      // tasks that found a follow-up list full, this pass
   CBA_TRY(launch_base_project(a, p->model_mask, p->cost_ref, p->pixels, p->flags, p->slow_list, p->slow_count, p->slow_cap, p->slow_skip, p->straggler_threshold, p->fd_slow, p->stream));
   // ... and the stragglers of the base projection (long projection chains, see k_base_project_slow) are finished there,
   // followed by their finite-difference tasks, underneath the main finite-difference launch
   CBA_HIP(hipEventRecord(p->ev_aux2, p->stream));
   CBA_HIP(hipStreamWaitEvent(aux, p->ev_aux2, 0));
   CBA_TRY(launch_base_project_slow(as, p->model_mask, p->cost_ref, p->pixels, p->flags, aux));
-  CBA_TRY(launch_fd_tasks(as, p->model_mask, p->tasks_per_obs, L.localize_only, p->pixels, p->flags, p->fd_out, p->fd_ok, p->fd_redo[1], p->fd_redo_count + 1, aux));
+  CBA_TRY(launch_fd_tasks(as, p->model_mask, p->tasks_per_obs, L.localize_only, p->pixels, p->flags, p->fd_out, p->fd_ok, p->fd_redo[1], p->fd_redo_count + 1, p->fd_redo_cap,
+                          p->fd_redo_count + 2, aux));
   CBA_HIP(hipEventRecord(p->ev_aux1, aux));
   CBA_TRY(timer_begin(p, 3));
-  CBA_TRY(launch_fd_tasks(a, p->model_mask, p->tasks_per_obs, L.localize_only, p->pixels, p->flags, p->fd_out, p->fd_ok, p->fd_redo[0], p->fd_redo_count, p->stream));
+  CBA_TRY(launch_fd_tasks(a, p->model_mask, p->tasks_per_obs, L.localize_only, p->pixels, p->flags, p->fd_out, p->fd_ok, p->fd_redo[0], p->fd_redo_count, p->fd_redo_cap,
+                          p->fd_redo_count + 2, p->stream));
   CBA_TRY(timer_end(p, 3, 0, 0, 1));
   CBA_HIP(hipStreamWaitEvent(p->stream, p->ev_aux1, 0));
   a.skip = nullptr;
@@ -475,6 +479,13 @@ int cba_create(const cba_config* config, cba_problem** out) {
   for (int c = 0; c < config->n_cameras; ++c)
     if (!camera_ok(config->cameras[c])) { set_error("cba_create: bad camera"); return CBA_ERR_ARG; }
   if (config->allreduce && config->eliminate_points) { set_error("image sharding requires eliminate_points = 0"); return CBA_ERR_UNSUPPORTED; }
+  if (config->distributed_solve) {
+    // the distributed factorisation walks the column groups by rank: an invalid rank would loop for ever or leave groups unowned
+    if (!config->allreduce) { set_error("cba_create: distributed_solve needs an allreduce callback"); return CBA_ERR_ARG; }
+    if (config->world_size < 1 || config->rank < 0 || config->rank >= config->world_size) {
+      set_error("cba_create: distributed_solve needs 0 <= rank < world_size"); return CBA_ERR_ARG;
+    }
+  }
   setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);   // read by the HIP runtime when it initialises (see cba_problem)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device available (the engine has no CPU fallback)"); return CBA_ERR_HIP; }
@@ -546,7 +557,8 @@ int cba_create(const cba_config* config, cba_problem** out) {
     CBA_TRY(dev_alloc(&p->cell_count, nk + 1)); CBA_TRY(dev_alloc(&p->cell_start, nk + 1)); CBA_TRY(dev_alloc(&p->cell_fill, nk + 1));
   }
   CBA_TRY(dev_alloc(&p->det_bits, 2)); CBA_TRY(dev_alloc(&p->det_scale, 2));
-  CBA_TRY(dev_alloc(&p->fd_redo[0], (size_t)kFdRedoEntries)); CBA_TRY(dev_alloc(&p->fd_redo[1], (size_t)kFdRedoEntries)); CBA_TRY(dev_alloc(&p->fd_redo_count, 2));
+  CBA_TRY(dev_alloc(&p->fd_redo_count, 4));
+  CBA_HIP(hipMemset(p->fd_redo_count, 0, sizeof(int) * 4));
   CBA_TRY(dev_alloc(&p->red_partials, 256 * 8));
   CBA_TRY(dev_alloc(&p->red8, 16));
   // normal equations
@@ -641,6 +653,13 @@ int cba_set_observations(cba_problem* p, int64_t n, const float* xy, const int32
   CBA_TRY(dev_alloc(&p->pixels, 2 * (size_t)n)); CBA_TRY(dev_alloc(&p->flags, (size_t)n));
   CBA_TRY(dev_alloc(&p->fd_out, 2 * (size_t)n * p->tasks_per_obs)); CBA_TRY(dev_alloc(&p->fd_ok, (size_t)n * p->tasks_per_obs));
   CBA_TRY(dev_alloc(&p->jrec, (size_t)n * p->rec_doubles)); CBA_TRY(dev_alloc(&p->cells, 2 * (size_t)n));
+  {
+    // gather-path follow-up lists of the finite-difference kernel: a quarter of all tasks (the share of tasks whose iterate
+    // crosses a cell boundary is a few per cent) + 65 536
+    const size_t cap = (size_t)n * p->tasks_per_obs / 4 + 65536;
+    p->fd_redo_cap = (int)(cap > 0x7fffff00u ? 0x7fffff00u : cap);
+    for (int i = 0; i < 2; ++i) { if (p->fd_redo[i]) hipFree(p->fd_redo[i]); p->fd_redo[i] = nullptr; CBA_TRY(dev_alloc(&p->fd_redo[i], (size_t)p->fd_redo_cap)); }
+  }
   CBA_HIP(hipMemset(p->jrec, 0, sizeof(double) * (size_t)(n > 0 ? n : 1) * p->rec_doubles));   // records of mixed-model problems have unused tails
   CBA_TRY(dev_alloc(&p->cell_order, (size_t)n));
   F(p->img_start); p->img_start = nullptr;
@@ -1016,6 +1035,16 @@ void cba_model_destroy(cba_model* m) {
   F(m->d_grid); F(m->d_cam); F(m->d_a); F(m->d_b); F(m->d_c); F(m->d_j); F(m->d_ok);
   delete m;
 }
+int64_t cba_fd_redo_overflow(cba_problem* p) {
+  if (!p || !p->fd_redo_count) return -1;
+  int v = 0;
+  if (hipSetDevice(p->device) != hipSuccess || hipStreamSynchronize(p->stream) != hipSuccess ||
+      hipMemcpy(&v, p->fd_redo_count + 2, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return v;
+}
+void cba_set_factor_tail_rows(int32_t rows) { ldlt_set_tail_rows(rows); }
+int32_t cba_factor_tail_rows(void) { return ldlt_tail_rows(); }
+
 int cba_model_set_grid(cba_model* m, const double* grid) {
   if (!m || !grid) { set_error("cba_model_set_grid: bad argument"); return CBA_ERR_ARG; }
   CBA_HIP(hipSetDevice(m->device));

@@ -378,7 +378,9 @@ constexpr int kFdMaxObsPerBlock = 10;
 #ifndef CBA_FD_WAVES_NONCENTRAL
 #define CBA_FD_WAVES_NONCENTRAL 2
 #endif
-constexpr int kFdRedoCap = 1 << 16;   // tasks the gather-path follow-up launch can take (a miss needs a pixel within one LM step of a cell boundary)
+// The gather-path follow-up list is sized with the problem (launch_fd_tasks' redo_cap = a quarter of all tasks + 65 536; a miss
+// needs a pixel within one LM step of a cell boundary).  A task that still finds the list full is counted in redo_count[2]
+// (cba_fd_redo_overflow) and loses its Jacobian like a failed projection -- visible, never silent.
 
 // One finite-difference task: (observation o, task k) -> fd_out / fd_ok at index t = o * tasks_per_obs + k.
 // STG: spline evaluated on the staged patch `st`; returns false if an iterate left that patch (nothing is written then).
@@ -454,7 +456,8 @@ __device__ __forceinline__ bool fd_task(const PassArgs& a, const CamDev& c, int 
 template <int MODEL>
 __global__ void __launch_bounds__(256, MODEL == kCentral ? CBA_FD_WAVES_CENTRAL : CBA_FD_WAVES_NONCENTRAL)
 k_fd_tasks(PassArgs a, int tasks_per_obs, int localize_only, const double* __restrict__ pixels, const uint8_t* __restrict__ flags,
-           double* __restrict__ fd_out, uint8_t* __restrict__ fd_ok, int64_t* __restrict__ redo, int* __restrict__ redo_count) {
+           double* __restrict__ fd_out, uint8_t* __restrict__ fd_ok, int64_t* __restrict__ redo, int* __restrict__ redo_count, int redo_cap,
+           int* __restrict__ redo_overflow) {
   constexpr int PER = (MODEL == kCentral) ? 2 : 5;
   constexpr int DIM = (MODEL == kCentral) ? 3 : 6;
   __shared__ double sPatch[kFdMaxObsPerBlock][16 * DIM];
@@ -522,8 +525,8 @@ k_fd_tasks(PassArgs a, int tasks_per_obs, int localize_only, const double* __res
   st.fx = sOrigin[j][0]; st.fy = sOrigin[j][1];
   if (!fd_task<MODEL, true>(a, c, cam, o, k, t, pixels, fd_out, fd_ok, &st, &sSub[threadIdx.x][0])) {
     const int slot = atomicAdd(redo_count, 1);
-    if (slot < kFdRedoCap) redo[slot] = t;
-    else fd_ok[t] = 0;                 // cannot happen in practice (65 536 boundary cases in one pass); dropped Jacobian, as a failed projection
+    if (slot < redo_cap) redo[slot] = t;
+    else { fd_ok[t] = 0; atomicAdd(redo_overflow, 1); }     // list full: dropped Jacobian, as a failed projection, and counted
   }
 }
 // localize_only (3 tasks per observation, no grid tasks): a workgroup would cover 86 observations -- nothing to share, the
@@ -552,9 +555,9 @@ __global__ void __launch_bounds__(256) k_fd_tasks_gather(PassArgs a, int tasks_p
 // follow-up: the tasks whose iterates left the staged patch, on the gather path
 template <int MODEL>
 __global__ void __launch_bounds__(256) k_fd_redo(PassArgs a, int tasks_per_obs, const double* __restrict__ pixels, double* __restrict__ fd_out,
-                                                 uint8_t* __restrict__ fd_ok, const int64_t* __restrict__ redo, const int* __restrict__ redo_count) {
+                                                 uint8_t* __restrict__ fd_ok, const int64_t* __restrict__ redo, const int* __restrict__ redo_count, int redo_cap) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = min(*redo_count, kFdRedoCap);
+  const int n = min(*redo_count, redo_cap);
   if (i >= n) return;
   const int64_t t = redo[i];
   const int64_t o = t / tasks_per_obs;
@@ -565,7 +568,8 @@ __global__ void __launch_bounds__(256) k_fd_redo(PassArgs a, int tasks_per_obs, 
   fd_task<MODEL, false>(a, c, cam, o, k, t, pixels, fd_out, fd_ok, nullptr, nullptr);
 }
 int launch_fd_tasks(const PassArgs& a, int model_mask, int tasks_per_obs, int localize_only, const double* pixels,
-                    const uint8_t* flags, double* fd_out, uint8_t* fd_ok, int64_t* redo, int* redo_count, hipStream_t s) {
+                    const uint8_t* flags, double* fd_out, uint8_t* fd_ok, int64_t* redo, int* redo_count, int redo_cap, int* redo_overflow,
+                    hipStream_t s) {
   if (a.n_obs == 0) return CBA_OK;
   int64_t total = (a.obs_list ? (int64_t)a.obs_list_cap : a.n_obs) * tasks_per_obs;
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
@@ -577,13 +581,15 @@ int launch_fd_tasks(const PassArgs& a, int model_mask, int tasks_per_obs, int lo
   }
   CBA_HIP(hipMemsetAsync(redo_count, 0, sizeof(int), s));
   if (model_mask & 1)
-    hipLaunchKernelGGL(k_fd_tasks<kCentral>, grid, block, 0, s, a, tasks_per_obs, localize_only, pixels, flags, fd_out, fd_ok, redo, redo_count);
+    hipLaunchKernelGGL(k_fd_tasks<kCentral>, grid, block, 0, s, a, tasks_per_obs, localize_only, pixels, flags, fd_out, fd_ok, redo, redo_count, redo_cap, redo_overflow);
   if (model_mask & 2)
-    hipLaunchKernelGGL(k_fd_tasks<kNoncentral>, grid, block, 0, s, a, tasks_per_obs, localize_only, pixels, flags, fd_out, fd_ok, redo, redo_count);
+    hipLaunchKernelGGL(k_fd_tasks<kNoncentral>, grid, block, 0, s, a, tasks_per_obs, localize_only, pixels, flags, fd_out, fd_ok, redo, redo_count, redo_cap,
+                       redo_overflow);
   // gather-path follow-up for the (rare) tasks that left their staged patch: fixed grid over the list capacity, the count
   // stays on the device (workgroups past it exit at once)
-  if (model_mask & 1) hipLaunchKernelGGL(k_fd_redo<kCentral>, dim3(kFdRedoCap / 256), block, 0, s, a, tasks_per_obs, pixels, fd_out, fd_ok, redo, redo_count);
-  if (model_mask & 2) hipLaunchKernelGGL(k_fd_redo<kNoncentral>, dim3(kFdRedoCap / 256), block, 0, s, a, tasks_per_obs, pixels, fd_out, fd_ok, redo, redo_count);
+  const dim3 rgrid((unsigned)((redo_cap + 255) / 256));
+  if (model_mask & 1) hipLaunchKernelGGL(k_fd_redo<kCentral>, rgrid, block, 0, s, a, tasks_per_obs, pixels, fd_out, fd_ok, redo, redo_count, redo_cap);
+  if (model_mask & 2) hipLaunchKernelGGL(k_fd_redo<kNoncentral>, rgrid, block, 0, s, a, tasks_per_obs, pixels, fd_out, fd_ok, redo, redo_count, redo_cap);
   CBA_HIP(hipGetLastError());
   return CBA_OK;
 }
@@ -730,8 +736,10 @@ constexpr int kHotPairs = kHotMax * (kHotMax + 1) / 2;   // 78
 // point with ONE power-of-two scale per pass (k_det_scale: 2^62 / (n_obs * largest possible |contribution|), so no sum
 // can overflow) and added with integer atomics; integer addition is associative, so registers, LDS and HBM sums are
 // bit-identical for every execution order -- no sorting, no second data layout.  The targets hold the integers during
-// the pass (same 8-byte slots) and k_det_convert turns them into doubles afterwards.  Resolution: about 19 decimal
-// digits below the largest possible sum, i.e. far below the finite-difference noise of the Jacobians.
+// the pass (same 8-byte slots) and k_det_convert turns them into doubles afterwards.  Resolution: ABSOLUTE, about 19 decimal
+// digits below the largest possible sum -- an entry 1e-8 of the largest one keeps ~10 digits of its own (relative), still below
+// the finite-difference noise of the Jacobians; the n_obs bound assumes at most one contribution per entry and observation,
+// which holds for every target (an observation touches an entry of H / b once).  DESIGN.md section 4a.
 template <bool DET> struct Acc;
 template <> struct Acc<false> {
   typedef double T;

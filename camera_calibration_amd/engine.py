@@ -66,6 +66,7 @@ EXPORTED_SYMBOLS = [
     "cba_total_dof", "cba_dense_dof", "cba_jacobian_record_doubles", "cba_reduce_buffer_doubles",
     "cba_kernel_stats", "cba_fit_grid_to_directions", "cba_prepare_device",
     "cba_model_create", "cba_model_destroy", "cba_model_set_grid", "cba_model_project", "cba_model_unproject",
+    "cba_fd_redo_overflow", "cba_set_factor_tail_rows", "cba_factor_tail_rows",
 ]
 
 DUMP_COST_VECTOR, DUMP_PIXELS, DUMP_FLAGS, DUMP_JACOBIANS = 1, 2, 3, 4
@@ -132,6 +133,19 @@ def load() -> C.CDLL:
     L.cba_model_unproject.argtypes = [vp, C.c_int64, dp, dp, dp, C.POINTER(C.c_uint8)]
     _lib = L
     return L
+
+
+def set_factor_tail_rows(rows: int) -> None:
+    """cba_set_factor_tail_rows (process-wide): rows factored by the persistent tail launch; 0 = blocked schedule only."""
+    L = load()
+    L.cba_set_factor_tail_rows.argtypes = [C.c_int32]
+    L.cba_set_factor_tail_rows(int(rows))
+
+
+def factor_tail_rows() -> int:
+    L = load()
+    L.cba_factor_tail_rows.restype = C.c_int32
+    return int(L.cba_factor_tail_rows())
 
 
 def prepare(device: int = 0) -> None:
@@ -274,6 +288,12 @@ class Engine:
     def set_straggler_threshold(self, outer_iterations: int) -> None:
         """cba_set_straggler_threshold: outer projection iterations before an observation goes to the straggler kernel."""
         _check(self.L.cba_set_straggler_threshold(self._h, int(outer_iterations)), "cba_set_straggler_threshold")
+
+    def fd_redo_overflow(self) -> int:
+        """cba_fd_redo_overflow: finite-difference tasks of the last Jacobian pass that found the follow-up list full (expected 0)."""
+        self.L.cba_fd_redo_overflow.restype = C.c_int64
+        self.L.cba_fd_redo_overflow.argtypes = [C.c_void_p]
+        return int(self.L.cba_fd_redo_overflow(self._h))
 
     def debug_accumulate(self) -> float:
         cost = C.c_double(0)

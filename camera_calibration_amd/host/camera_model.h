@@ -64,6 +64,9 @@ class CameraModel {
   mutable cba_model* m_dev = nullptr;
   mutable int m_dev_device = -1;
   mutable bool m_dev_stale = true;
+  mutable cba_camera m_dev_camera = {};   // what m_dev was created for; a model whose description changed gets a new handle
+  // NOTE: a reference returned by the non-const grid() accessors must not be kept across Project / Unproject calls -- the
+  // accessor marks the device copy stale when it is CALLED, later writes through the kept reference are not seen.
   int m_width, m_height, m_calibration_min_x, m_calibration_min_y, m_calibration_max_x, m_calibration_max_y;
   Type m_type;
 };

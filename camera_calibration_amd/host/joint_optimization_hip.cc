@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace vis {
 
@@ -22,10 +23,17 @@ void SetHipDevice(int device) { g_device = device; }
 // ---- CameraModel calls -> the device-resident model (cba_model_*) -----------------------------------------
 cba_model* CameraModel::device_model(int device_ordinal) const {
   if (m_dev && m_dev_device != device_ordinal) release_device_model();
+  if (m_dev) {
+    // the handle was created for one camera description: a SetGrid / operator= with another grid resolution or other
+    // calibration bounds needs a new one (cba_model_set_grid would copy the OLD grid's length out of the new vector)
+    const cba_camera now = abi_camera();
+    if (std::memcmp(&now, &m_dev_camera, sizeof(cba_camera)) != 0) release_device_model();
+  }
   if (!m_dev) {
     cba_camera cam = abi_camera();
     std::vector<double> grid = abi_grid();
     if (cba_model_create(&cam, grid.data(), device_ordinal, &m_dev) != CBA_OK) { m_dev = nullptr; return nullptr; }
+    m_dev_camera = cam;
     m_dev_device = device_ordinal;
     m_dev_stale = false;
   } else if (m_dev_stale) {

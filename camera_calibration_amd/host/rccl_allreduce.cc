@@ -4,9 +4,13 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <thread>
 
@@ -50,10 +54,33 @@ int cba_rccl_create(int rank, int world, const char id[CBA_RCCL_ID_BYTES], int d
   return 0;
 }
 
+// Waits for the id file and reads it.  A file older than `max_age_s` is a leftover of a run that died before it could remove
+// its file (see below) and is ignored -- rank 0 of THIS launch replaces it.  0 = read, -1 = timed out.
+int cba_rccl_debug_read_id_file(const char* path, char id[CBA_RCCL_ID_BYTES], int timeout_ms, int max_age_s) {
+  for (int waited = 0; waited <= timeout_ms; waited += 10) {
+    struct stat st;
+    if (stat(path, &st) == 0 && st.st_size == CBA_RCCL_ID_BYTES && std::difftime(std::time(nullptr), st.st_mtime) <= max_age_s) {
+      FILE* f = std::fopen(path, "rb");
+      if (f) {
+        const bool got = std::fread(id, 1, CBA_RCCL_ID_BYTES, f) == CBA_RCCL_ID_BYTES;
+        std::fclose(f);
+        if (got) return 0;
+      }
+    }
+    std::this_thread::sleep_for(std::chrono::milliseconds(10));
+  }
+  return -1;
+}
+
+// The id file lives only while the communicator is being set up: rank 0 removes whatever is at `path` first, writes the new id
+// atomically (rename), every rank joins, a one-element all-reduce proves that ALL ranks have read the file, and rank 0 removes
+// it again.  A later launch with the same path therefore never finds this run's id; the leftover of a run that crashed in
+// between is recognised by its age (ranks start within seconds of each other, a stale file is minutes old or older).
 int cba_rccl_create_via_file(int rank, int world, const char* path, int device, cba_rccl** out) {
   if (!path) return fail("cba_rccl_create_via_file", "null path");
   char id[CBA_RCCL_ID_BYTES];
   if (rank == 0) {
+    ::unlink(path);
     if (cba_rccl_unique_id(id) != 0) return -1;
     const std::string tmp = std::string(path) + ".tmp";
     FILE* f = std::fopen(tmp.c_str(), "wb");
@@ -61,15 +88,20 @@ int cba_rccl_create_via_file(int rank, int world, const char* path, int device, 
     std::fclose(f);
     if (std::rename(tmp.c_str(), path) != 0) return fail("cba_rccl_create_via_file", "rename failed");
   } else {
-    bool got = false;
-    for (int i = 0; i < 6000 && !got; ++i) {           // up to 60 s
-      FILE* f = std::fopen(path, "rb");
-      if (f) { got = std::fread(id, 1, sizeof(id), f) == sizeof(id); std::fclose(f); }
-      if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(10));
-    }
-    if (!got) return fail("cba_rccl_create_via_file", "timed out waiting for the id file");
+    if (cba_rccl_debug_read_id_file(path, id, /*timeout_ms*/ 60000, /*max_age_s*/ 120) != 0)
+      return fail("cba_rccl_create_via_file", "timed out waiting for the id file");
   }
-  return cba_rccl_create(rank, world, id, device, out);
+  int rc = cba_rccl_create(rank, world, id, device, out);
+  if (rc != 0) { if (rank == 0) ::unlink(path); return rc; }
+  // handshake: when it returns on rank 0, every rank has passed ncclCommInitRank, i.e. has read the file
+  double* one = nullptr;
+  if (hipMalloc(&one, sizeof(double)) == hipSuccess) {
+    hipMemset(one, 0, sizeof(double));
+    rc = cba_rccl_allreduce(one, 1, *out);
+    hipFree(one);
+  }
+  if (rank == 0) ::unlink(path);
+  return rc;
 }
 
 void cba_rccl_destroy(cba_rccl* c) {

@@ -74,7 +74,11 @@ typedef struct {
   /* 1 = run-to-run reproducible normal equations: JtJ / Jtr terms are accumulated in 64-bit fixed point (integer
    * atomics are order-independent) instead of fp64 atomics; two runs on the same input then give bit-identical H, b,
    * x, costs and states.  The reference is single-threaded and therefore reproducible; this is the mode that matches
-   * that property.  Costs about 1 ms per LM iteration at BASELINE configs[1].  0 = fp64 atomics. */
+   * that property.  Resolution: one power-of-two quantum per pass for JtJ (2^62 / (n_obs x the largest single contribution))
+   * and a finer one for Jtr -- ABSOLUTE, i.e. ~19 digits below the largest possible sum; an entry that is 1e-8 of the
+   * largest one (pose / point blocks next to the grid-direction blocks) keeps ~10 significant digits of its own, still below
+   * the finite-difference noise of the Jacobians (1e-9 relative).  Costs about 1 ms per LM iteration at BASELINE configs[1]
+   * (DESIGN.md section 4a).  0 = fp64 atomics. */
   int32_t deterministic;
   /* Distributed reduced solve (multi-GPU, optional; needs `allreduce`).  0: the factorisation of the reduced system is
    * replicated on every rank (right up to D ~ 20 000: 17 ms at BASELINE configs[1]).  1: the 512-column groups of the
@@ -147,6 +151,18 @@ int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double
 /* Compute<false> on the current state (VerifyCost, joint_optimization.cc:866-877; also the report
  * statistics F4).  cost_vector (n, host, may be NULL) gets the per-residual Huber cost or -1. */
 int cba_cost(cba_problem* p, double* cost, int64_t* n_valid, double* cost_vector);
+
+/* Finite-difference tasks of the last Jacobian pass whose iterate left the staged control patch AND found the gather-path
+ * follow-up list full (the list holds a quarter of all tasks + 65 536): such a task loses its Jacobian like a failed
+ * projection (the residual is kept, joint_optimization.cc:373-376) -- counted here so that it is never silent.  Expected: 0.
+ * -1 on error.  (No reference counterpart.) */
+int64_t cba_fd_redo_overflow(cba_problem* p);
+
+/* Scheduling knob of the reduced-system factorisation (process-wide; results change only in the last bits): the last `rows`
+ * rows are factored by ONE persistent dataflow launch instead of the blocked multi-stream schedule.
+ * Default 6144; 0 = off.  (No reference counterpart: Eigen's LDLT, LV/lm_optimizer.h:1361.) */
+void cba_set_factor_tail_rows(int32_t rows);
+int32_t cba_factor_tail_rows(void);
 
 /* ---- stateless model-level entry points (CameraModel API) ---- */
 /* CameraModel::Project / ProjectWithInitialEstimate for n local points (APP/models/central_grid.h:79-97,

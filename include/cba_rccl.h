@@ -20,8 +20,12 @@ typedef struct cba_rccl cba_rccl;
 int cba_rccl_unique_id(char id[CBA_RCCL_ID_BYTES]);
 /* collective over all ranks; `device` is this rank's HIP device */
 int cba_rccl_create(int rank, int world, const char id[CBA_RCCL_ID_BYTES], int device, cba_rccl** out);
-/* the same, with the id exchanged through a file: rank 0 writes `path`, the others wait for it (single-node launchers) */
+/* the same, with the id exchanged through a file (single-node launchers): rank 0 replaces whatever is at `path`, the others
+ * wait for a FRESH file (leftovers older than two minutes are ignored), and rank 0 removes the file once every rank has joined,
+ * so a later launch with the same path never reads this run's id */
 int cba_rccl_create_via_file(int rank, int world, const char* path, int device, cba_rccl** out);
+/* the reader half of the above (tests): 0 = id read, -1 = no fresh file within timeout_ms */
+int cba_rccl_debug_read_id_file(const char* path, char id[CBA_RCCL_ID_BYTES], int timeout_ms, int max_age_s);
 void cba_rccl_destroy(cba_rccl* c);
 /* cba_allreduce_fn: in-place fp64 sum of a DEVICE buffer over all ranks; `user` is the cba_rccl*.  Enqueues
  * ncclAllReduce on the communicator's own stream and waits for THAT stream only (no device-wide synchronisation). */
