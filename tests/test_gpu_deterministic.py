@@ -51,7 +51,7 @@ def test_deterministic_mode_is_bit_reproducible(cfg, n):
     c = _run(pb, st, False, 3)
     check(case, "dense_H vs default mode / max", np.abs(a["H"] - c["H"]).max() / np.abs(c["H"]).max(), 1e-11)
     check(case, "off_diag_H vs default mode / max", np.abs(a["B"] - c["B"]).max() / np.abs(c["B"]).max(), 1e-11)
-    check(case, "final cost vs default mode rel (after 3 iterations)", abs(a["reps"][-1][1] - c["reps"][-1][1]) / c["reps"][-1][1], 1e-4)   # the default mode moves with the order of its atomics: 6e-9 ... 8e-6 over the runs of the round
+    check(case, "final cost vs default mode rel (after 3 iterations)", abs(a["reps"][-1][1] - c["reps"][-1][1]) / c["reps"][-1][1], 5e-5)   # the default mode moves with the order of its atomics: 6e-9 ... 8e-6 observed over two rounds
     orc.set_num_threads(0)
     try:
         op = orc.OracleProblem(pb, last_projection=pb.obs_xy.astype(np.float64))

@@ -86,13 +86,13 @@ def test_two_ranks_on_one_gpu_match_the_single_process_engine(tmp_path):
         # after the first solve carries the rounding of the partial Schur products amplified by the condition of the reduced
         # system (observed 1.1e-7 on the cost after three iterations)
         check(case, f"rank {k}: initial cost of the first step rel", abs(rk[k]["reps"][0, 0] - reps[0, 0]) / reps[0, 0], 1e-13)
-        check(case, f"rank {k}: costs rel", (np.abs(rk[k]["reps"][:, :2] - reps[:, :2]) / reps[:, :2]).max(), 1e-6)
+        check(case, f"rank {k}: costs rel", (np.abs(rk[k]["reps"][:, :2] - reps[:, :2]) / reps[:, :2]).max(), 5e-7)     # observed 1.1e-7 (3 iterations)
         check(case, f"rank {k}: lambda rel", (np.abs(rk[k]["reps"][:, 2] - reps[:, 2]) / reps[:, 2]).max(), 5e-13)
         b, e = int(rk[k]["b"]), int(rk[k]["e"])
-        check(case, f"rank {k}: own poses abs", np.abs(rk[k]["poses"] - ref.rig_tr_global[b:e]).max(), 2e-7)
-        check(case, f"rank {k}: points abs", np.abs(rk[k]["points"] - ref.points).max(), 2e-7)
-        check(case, f"rank {k}: camera_tr_rig abs", np.abs(rk[k]["camrig"] - ref.camera_tr_rig).max(), 2e-7)
-        check(case, f"rank {k}: grids abs", max(np.abs(rk[k]["grid0"] - ref.grids[0]).max(), np.abs(rk[k]["grid1"] - ref.grids[1]).max()), 2e-7)
+        check(case, f"rank {k}: own poses abs", np.abs(rk[k]["poses"] - ref.rig_tr_global[b:e]).max(), 5e-8)     # observed 2e-9
+        check(case, f"rank {k}: points abs", np.abs(rk[k]["points"] - ref.points).max(), 5e-8)
+        check(case, f"rank {k}: camera_tr_rig abs", np.abs(rk[k]["camrig"] - ref.camera_tr_rig).max(), 5e-8)
+        check(case, f"rank {k}: grids abs", max(np.abs(rk[k]["grid0"] - ref.grids[0]).max(), np.abs(rk[k]["grid1"] - ref.grids[1]).max()), 1e-7)
     # the replicated part of the state is bit-identical on both ranks (same reduced system, same factorisation)
     for key in ("points", "camrig", "grid0", "grid1"):
         check_equal(case, f"replicated state identical on both ranks: {key}", int(np.count_nonzero(rk[0][key] != rk[1][key])))
@@ -125,11 +125,11 @@ def test_two_ranks_with_the_distributed_factorisation(tmp_path, world):
         check_equal(case, f"rank {k}: LM attempts / accept decisions / valid counts",
                     int(np.count_nonzero(rk[k]["reps"][:, 3:] != reps[:, 3:])))
         check(case, f"rank {k}: initial cost of the first step rel", abs(rk[k]["reps"][0, 0] - reps[0, 0]) / reps[0, 0], 1e-13)
-        check(case, f"rank {k}: costs rel", (np.abs(rk[k]["reps"][:, :2] - reps[:, :2]) / reps[:, :2]).max(), 1e-6)
+        check(case, f"rank {k}: costs rel", (np.abs(rk[k]["reps"][:, :2] - reps[:, :2]) / reps[:, :2]).max(), 5e-7)     # observed 1.1e-7 (3 iterations)
         b, e = int(rk[k]["b"]), int(rk[k]["e"])
-        check(case, f"rank {k}: own poses abs", np.abs(rk[k]["poses"] - ref.rig_tr_global[b:e]).max(), 2e-7)
-        check(case, f"rank {k}: points abs", np.abs(rk[k]["points"] - ref.points).max(), 2e-7)
-        check(case, f"rank {k}: grids abs", max(np.abs(rk[k]["grid0"] - ref.grids[0]).max(), np.abs(rk[k]["grid1"] - ref.grids[1]).max()), 2e-7)
+        check(case, f"rank {k}: own poses abs", np.abs(rk[k]["poses"] - ref.rig_tr_global[b:e]).max(), 5e-8)     # observed 2e-9
+        check(case, f"rank {k}: points abs", np.abs(rk[k]["points"] - ref.points).max(), 5e-8)
+        check(case, f"rank {k}: grids abs", max(np.abs(rk[k]["grid0"] - ref.grids[0]).max(), np.abs(rk[k]["grid1"] - ref.grids[1]).max()), 1e-7)
     for key in ("points", "camrig", "grid0", "grid1"):
         for k in range(1, world):
             check_equal(case, f"replicated state identical on ranks 0 and {k}: {key}", int(np.count_nonzero(rk[0][key] != rk[k][key])))
