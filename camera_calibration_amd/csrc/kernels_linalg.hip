@@ -732,6 +732,7 @@ constexpr bool kDiagPairs = true;
 #endif
 constexpr int kPanel = 256;
 constexpr int kPanelWide = 512;
+constexpr int kSuperMax = 4096;              // widest super-panel (rows factored by one dataflow launch in front of a bulk update)
 constexpr int kTailMaxBlockRows = 192;      // the persistent tail launch covers at most this many 64-row blocks (flag storage)
 // panels are kPanelWide wide while more than this many rows remain (env CBA_WIDE_ROWS overrides; 0 = never)
 static int wide_rows_threshold() {
@@ -1550,6 +1551,8 @@ struct TailArgs {
   unsigned epoch;
   int ntasks;
   int evict;                        // helper workgroups that share the chain's CU stop taking tasks
+  double* X; int ldx; int x_c0;     // super-panel mode: X = d L of the tiles with column block >= x_c0 goes to X[(64 (r - rt0) + p) * ldx + col]
+                                    // (the K-major B operand of the bulk update that follows); null = not needed
   int xcd_lists;                    // 1: one task list per XCD (column block c -> XCD c % 8), own list first; 0: one list
   int ntasks_x[8];                  // tasks per list
 };
@@ -2113,6 +2116,17 @@ __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, doubl
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
           tail_st1(rt, acc_voff, ((16 * i + 4 * r4) * ld + 16 * jj) * 8, acc[i][jj][r4] * rdr[i][r4]);
+    if (t.X && c >= t.x_c0) {
+      // read by the bulk update, i.e. by a later launch: plain stores
+      double* Xt = t.X + (size_t)(r - t.rt0) * kInner * t.ldx + (size_t)c * kInner;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+            Xt[(size_t)(wm0 + i * 16 + lk + 4 * r4) * t.ldx + wn0 + jj * 16 + li] = acc[i][jj][r4];
+    }
     tail_publish(&t.tile_flag[(size_t)(r - t.rt0) * t.ntc + c], t.epoch);
   }
 }
@@ -2135,9 +2149,13 @@ __global__ void __launch_bounds__(256, 2) k_ldlt_tail(TailArgs t) {
 int panel_cu_count() {
   static int n = -1;
   if (n < 0) {
+    // Round 3: no CUs are reserved any more.  The two-level schedule (super-panels factored by the dataflow launch + one
+    // exclusive bulk update each) has no pivot chain running next to a GEMM, and a CU mask costs every launch on the masked
+    // stream 5-15 % (in-order, per-shader-engine dispatch).  CBA_PANEL_CUS=8 restores the round-2 setup
+    // for the blocked multi-stream schedule (CBA_SUPER_W=0) in the bench harness.
     const char* e = CBA_GETENV("CBA_PANEL_CUS");
-    n = e ? atoi(e) : 8;
-    if (n < 0 || n > 128) n = 8;
+    n = e ? atoi(e) : 0;
+    if (n < 0 || n > 128) n = 0;
   }
   return n;
 }
@@ -2259,7 +2277,8 @@ int make_main_stream(hipStream_t* s) {
 
 int ldlt_workspace_alloc(LdltWorkspace& w, int n_pad) {
   ldlt_workspace_free(w);
-  CBA_HIP(hipMalloc(&w.X, sizeof(double) * 2 * (size_t)kPanelWide * n_pad));   // two panel buffers (look-ahead)
+  // two panel buffers of the blocked schedule (look-ahead) = one X buffer of a super-panel (kSuperMax rows)
+  CBA_HIP(hipMalloc(&w.X, sizeof(double) * (size_t)(2 * kPanelWide > kSuperMax ? 2 * kPanelWide : kSuperMax) * n_pad));
   CBA_HIP(hipMalloc(&w.invLt, sizeof(double) * (size_t)(n_pad / kInner) * kInner * kInner));
   CBA_HIP(hipMalloc(&w.dvec, sizeof(double) * (size_t)n_pad));
   CBA_HIP(hipMalloc(&w.status, sizeof(int)));
@@ -2414,6 +2433,14 @@ static int timed_gemm128(const GemmArgs& g, hipStream_t s, LdltWorkspace& w, boo
 
 
 // ---- persistent tail: host side ----
+static int g_super_w = 2048;
+static int super_width() {
+  static const char* e = CBA_GETENV("CBA_SUPER_W");        // developer switch (bench harness only); 0 = blocked multi-stream schedule in the head
+  int v = e ? atoi(e) : g_super_w;
+  if (v < 0) v = 0;
+  if (v > kSuperMax) v = kSuperMax;
+  return v / 128 * 128;
+}
 static int g_tail_rows = 6144;
 void ldlt_set_tail_rows(int rows) { g_tail_rows = rows < 0 ? 0 : rows; }
 int ldlt_tail_rows() {
@@ -2438,9 +2465,10 @@ static int tail_start_row(int n_fact, const LdltWorkspace& w) {
 }
 // Factors rows [t0, n_fact) of S, whose trailing block [t0, n_pad)^2 carries every update of the rows above, with one launch
 // on stream s.  t0 and n_fact are multiples of 64.
-static int ldlt_tail(double* S, int n_fact, int ld, int t0, LdltWorkspace& w, hipStream_t s, GemmStats* st) {
+static int ldlt_tail(double* S, int n_fact, int ld, int t0, LdltWorkspace& w, hipStream_t s, GemmStats* st, double* X = nullptr) {
   TailArgs t{};
   t.S = S; t.ld = ld;
+  t.X = X; t.ldx = ld; t.x_c0 = n_fact / kInner;
   t.rt0 = t0 / kInner; t.nr = n_fact / kInner; t.ntc = ld / kInner;
   t.dvec = w.dvec; t.invLt = w.invLt; t.status = w.status;
   const int rows_cap = w.tail_rows_cap / kInner;
@@ -2494,7 +2522,32 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
   int prefactored = -1;          // first column of a diagonal block that the previous panel's (a') launch has already factored
   // rows [t0, n_fact) are left to the persistent tail launch (ldlt_tail); the panel that ends at t0 ("junction") applies its
   // whole trailing update in one launch, without look-ahead pieces
-  const int t0 = tail_start_row(n_fact, w);
+  int t0 = tail_start_row(n_fact, w);
+  // Two-level schedule (default): super-panels of `super_w` rows are factored -- diagonal part AND the whole row strip right of
+  // it -- by the dataflow launch (ldlt_tail with X output), each followed by ONE trailing update with K = super_w on the
+  // 128 x 128 MFMA GEMM, alone on the chip; the last tail_rows rows by the dataflow launch as before.  No side streams, no
+  // look-ahead: the chain of a super-panel (super_w / 64 x 28 us) is hidden behind its own row-strip tiles, and the bulk
+  // update runs at its stand-alone rate with a quarter of the C-tile traffic of the 512-wide panels.
+  const int sw = super_width();
+  if (sw > 0 && t0 < n_fact) {
+    int k0 = 0;
+    while (n_fact - k0 > ldlt_tail_rows() + sw / 2 && n_pad - (k0 + sw) >= 1024) {
+      int rc = ldlt_tail(S, k0 + sw, ld, k0, w, s, st, w.X);
+      if (rc) return rc;
+      GemmArgs u{};
+      u.A = S + (size_t)k0 * ld; u.lda = ld; u.B = w.X; u.ldb = n_pad; u.K = sw;
+      u.C = S; u.ldc = ld; u.Cin = S; u.ldcin = ld; u.diag = 0; u.upper = 1;
+      const int tl = (n_pad - (k0 + sw)) / 128;
+      u.m_off = k0 + sw; u.m_tiles = tl; u.n_off = k0 + sw; u.n_tiles = tl;
+      if ((rc = timed_gemm128(u, s, w, st != nullptr, (double)tl * (tl + 1) / 2))) return rc;
+      if (st) { const double rows = (double)(n_pad - (k0 + sw)); st->flops += rows * rows * sw; st->launches += 1; }
+      k0 += sw;
+    }
+    int rc = ldlt_tail(S, n_fact, ld, k0, w, s, st);
+    if (rc) return rc;
+    CBA_HIP(hipGetLastError());
+    return CBA_OK;
+  }
   for (int k0 = 0, pw = 0; k0 < n_fact && k0 < t0; k0 += pw, ++kidx) {
     pw = panel_width_at(k0, n_fact);
     const int nb = (n_fact - k0 < pw) ? (n_fact - k0) : pw;
@@ -2682,7 +2735,13 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
           if (mt - head > h2) {
             v.m_tiles = head; v.n_off = r0 + (head + h2) * 128; v.n_tiles = mt - head - h2;
             v.tlog_tag = (k0 / kInner) * kTlKinds + kTlAA_rest + 1;
-            if ((rc = timed_gemm128(v, s3, w, st != nullptr, (double)head * (mt - head - h2)))) return rc;
+            static const bool aa_main = CBA_GETENV("CBA_AA_MAIN") != nullptr;     // developer switch: row strip in front of the bulk update, same stream
+            if (aa_main) {
+              CBA_HIP(hipStreamWaitEvent(s, w.ev_strip, 0));
+              if ((rc = timed_gemm128(v, s, w, st != nullptr, (double)head * (mt - head - h2)))) return rc;
+              CBA_HIP(hipEventRecord(w.ev_diag, s));
+              CBA_HIP(hipStreamWaitEvent(s3, w.ev_diag, 0));
+            } else if ((rc = timed_gemm128(v, s3, w, st != nullptr, (double)head * (mt - head - h2)))) return rc;
           }
         } else {
           CBA_HIP(hipEventRecord(w.ev_aa, s3));

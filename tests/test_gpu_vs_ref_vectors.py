@@ -67,7 +67,7 @@ def test_normal_equations_against_the_reference_accumulator(mode):
     e = eng.Engine(pb)
     e.set_state(st)
     cost = e.debug_accumulate()
-    check(case, "cost rel", abs(cost - float(ACC[f"{mode}__cost"])) / float(ACC[f"{mode}__cost"]), 5e-10)
+    check(case, "cost rel", abs(cost - float(ACC[f"{mode}__cost"])) / float(ACC[f"{mode}__cost"]), 5e-13)
     vec = e.dump(eng.DUMP_COST_VECTOR)
     check_equal(case, "valid mask", int(np.count_nonzero((vec >= 0) != (ACC[f"{mode}__cost_vector"] >= 0))))
     got = {"block_diag_H": np.array([np.triu(b) for b in e.dump(eng.DUMP_BLOCK_DIAG_H)]), "block_diag_b": e.dump(eng.DUMP_BLOCK_DIAG_B),

@@ -15,6 +15,7 @@ namespace cba { int ldlt_back_solve(const double* S, int n_fact, int ld, int zco
 static float timeit(hipEvent_t e0, hipEvent_t e1) { float ms; hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); return ms; }
 
 struct Case { int n, n_fact; };
+static double g_rate = 0; static int g_launches = 0;
 
 __global__ void __launch_bounds__(256, 2) k_mma2_only(const double* S, int ld, const double* dvec, int K, int ntc, double* out) {
   __shared__ double smem[2 * kInner * TS];
@@ -126,8 +127,9 @@ int main(int argc, char** argv) {
         ldlt_factor(S, n_fact, n, w, ms, &gs);
         hipEventRecord(e1, ms);
         const double t = timeit(e0, e1);
-        ldlt_collect_spans(w, nullptr);
-        if (t < *best_ms) { *best_ms = t; *tail_ms = ldlt_tail_last_ms(w); }
+        GemmStats g2;
+        ldlt_collect_spans(w, &g2);
+        if (t < *best_ms) { *best_ms = t; *tail_ms = ldlt_tail_last_ms(w); g_rate = g2.seconds > 0 ? g2.flops / g2.seconds / 1e12 : 0; g_launches = g2.launches; }
         hipMemcpy(&st, w.status, 4, hipMemcpyDeviceToHost);
         if (st) break;
       }
@@ -142,7 +144,7 @@ int main(int argc, char** argv) {
     std::vector<double> xr, Sr, dr;
     double ms_ref, tms;
     int st = run(0, &xr, n <= 4096 ? &Sr : nullptr, &dr, &ms_ref, &tms);
-    printf("blocked schedule (tail off): %.3f ms  status %d\n", ms_ref, st);
+    printf("blocked schedule (tail off): %.3f ms  status %d   [128x128 GEMM launches: %d at %.1f TFLOP/s per launch]\n", ms_ref, st, g_launches, g_rate);
     double xmax = 0; for (double v : xr) xmax = std::max(xmax, std::fabs(v));
     for (int tail : tails) {
       std::vector<double> xt, St, dt;
@@ -179,8 +181,8 @@ int main(int argc, char** argv) {
         avg(1, std::min(nb, 8)); avg(nb / 2 - 4, nb / 2 + 4); avg(nb - 8, nb);
         printf("   chain span %.1f us for %d blocks = %.2f us / block\n", (double)(h[16 * (nb - 1) + 9] - h[0]) / 100.0, nb, (double)(h[16 * (nb - 1) + 9] - h[0]) / 100.0 / nb);
       }
-      printf("tail %5d (starts at row %5d, %4d rows): %.3f ms total, tail launch %.3f ms, status %d | x rel %.2e  d rel %.2e  L rel %.2e%s\n",
-             tail, t0, n_fact - t0, ms_t, tms, st, dx / xmax, dd / dmax, smax > 0 ? dS / smax : 0.0, nan ? "  NaN!" : "");
+      printf("tail %5d (starts at row %5d, %4d rows): %.3f ms total, tail launch %.3f ms, status %d | x rel %.2e  d rel %.2e  L rel %.2e%s  [GEMM launches: %d at %.1f TFLOP/s]\n",
+             tail, t0, n_fact - t0, ms_t, tms, st, dx / xmax, dd / dmax, smax > 0 ? dS / smax : 0.0, nan ? "  NaN!" : "", g_launches, g_rate);
     }
     // residual of the solution with the last setting on small cases (host, O(n^2))
     ldlt_workspace_free(w);
