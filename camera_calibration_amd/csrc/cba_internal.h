@@ -154,6 +154,8 @@ struct LdltWorkspace {
   unsigned* tail_ctrl = nullptr;     // tickets, abort flag, role tickets, chain CU
   unsigned tail_epoch = 0;
   int tail_rows_cap = 0;             // largest tail this workspace has flags for
+  double* back_xe = nullptr;         // back substitution (k_back_dataflow): {value, tag} pairs, 2 * n doubles
+  unsigned long long back_epoch = 0;
   hipEvent_t tail_e0 = nullptr, tail_e1 = nullptr;   // span of the last tail launch (statistics only)
   bool tail_timed = false;
 };
@@ -165,6 +167,7 @@ int ldlt_factor(double* S, int n, int ld, LdltWorkspace& w, hipStream_t s, GemmS
 // Rows (from the end of the matrix) that the persistent tail launch factors; 0 = the blocked multi-stream schedule all the way.
 void ldlt_set_tail_rows(int rows);
 int ldlt_tail_rows();
+void ldlt_set_back_dataflow(int on);   // back substitution as one dataflow launch (default) or by panels of 256 (round 2)
 // milliseconds of the last tail launch (waits for it); 0 when there was none
 double ldlt_tail_last_ms(LdltWorkspace& w);
 // Distributed variant (cba_config.distributed_solve): `exchange(buf, count)` sums a device buffer over the ranks (synchronous);

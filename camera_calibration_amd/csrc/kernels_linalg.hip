@@ -1831,10 +1831,13 @@ __device__ __forceinline__ unsigned tail_cu_id() {
 
 // developer timeline of the chain workgroup (tools/bench_tail.hip, -DCBA_TAILLOG): 100 MHz stamps per block and phase
 #ifdef CBA_TAILLOG
+__device__ unsigned long long* g_helplog = nullptr;   // per helper task (ticket): start, wait-rows ticks, k-loop ticks, diag-wait ticks, end, kind, r, c
+#define HELP_NOW() (g_helplog ? wall_clock64() : 0ull)
 __device__ unsigned long long* g_taillog = nullptr;
 #define TAIL_STAMP(blk_, ph_) do { __builtin_amdgcn_sched_barrier(0); if (g_taillog && threadIdx.x == 0) g_taillog[(size_t)(blk_) * 16 + (ph_)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define TAIL_STAMP(blk_, ph_) do { } while (0)
+#define HELP_NOW() 0ull
 #endif
 
 // ---- the chain workgroup ----
@@ -2038,15 +2041,21 @@ __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, doubl
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const unsigned long long h_start = HELP_NOW();
+    unsigned long long h_wait = 0, h_mma = 0;
     for (int k = t.rt0; k < r;) {
+      const unsigned long long h0 = HELP_NOW();
       const int nrows = tail_wait_rows(t, k, r, ca, c, slot);
       if (nrows <= 0) return;
+      const unsigned long long h1 = HELP_NOW();
       const double* A = t.S + (size_t)k * kInner * ld + (size_t)ca * kInner;
       const double* B = t.S + (size_t)k * kInner * ld + (size_t)c * kInner;
       if (kind == 1) tail_mma<true>(acc, A, A, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sA, sB);
       else tail_mma<false>(acc, A, B, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sA, sB);
       k += nrows;
+      h_wait += h1 - h0; h_mma += HELP_NOW() - h1;
     }
+    const unsigned long long h_kend = HELP_NOW();
     // U = A_rc - acc.  The tile itself was written before this launch.
     const int row0 = (kind == 1 ? c : r) * kInner;
     const __amdgpu_buffer_rsrc_t rt = tail_rsrc(t.S + (size_t)row0 * ld + (size_t)c * kInner);
@@ -2083,6 +2092,7 @@ __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, doubl
           sV[m * TS + n] = a_rc[i][jj][r4] - acc[i][jj][r4];
         }
     if (!tail_wait(t, &t.diag_flag[r - t.rt0], nullptr, slot)) return;       // (its barrier also publishes sV to the other waves)
+    const unsigned long long h_diag = HELP_NOW();
     double rdr[2][4];
     {
       // invL_r (K-major, [q][p]) -> sAB as a 64 x TS tile; 1 / d_r of this lane's rows
@@ -2128,6 +2138,12 @@ __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, doubl
             Xt[(size_t)(wm0 + i * 16 + lk + 4 * r4) * t.ldx + wn0 + jj * 16 + li] = acc[i][jj][r4];
     }
     tail_publish(&t.tile_flag[(size_t)(r - t.rt0) * t.ntc + c], t.epoch);
+#ifdef CBA_TAILLOG
+    if (g_helplog && tid == 0 && tk < (1 << 20)) {
+      unsigned long long* e = g_helplog + (size_t)tk * 8;
+      e[0] = h_start; e[1] = h_wait; e[2] = h_mma; e[3] = h_diag - h_kend; e[4] = wall_clock64(); e[5] = (unsigned long long)kind; e[6] = (unsigned long long)r; e[7] = (unsigned long long)c;
+    }
+#endif
   }
 }
 
@@ -2309,6 +2325,9 @@ int ldlt_workspace_alloc(LdltWorkspace& w, int n_pad) {
     w.tail_epoch = 0;
     CBA_HIP(hipEventCreate(&w.tail_e0));
     CBA_HIP(hipEventCreate(&w.tail_e1));
+    CBA_HIP(hipMalloc(&w.back_xe, sizeof(double) * 2 * (size_t)n_pad));
+    CBA_HIP(hipMemset(w.back_xe, 0, sizeof(double) * 2 * (size_t)n_pad));
+    w.back_epoch = 0;
   }
   w.n_alloc = n_pad;
   return CBA_OK;
@@ -2330,6 +2349,7 @@ void ldlt_workspace_free(LdltWorkspace& w) {
   if (w.ev_bulk) hipEventDestroy(w.ev_bulk);
   if (w.tail_flags) hipFree(w.tail_flags);
   if (w.tail_ctrl) hipFree(w.tail_ctrl);
+  if (w.back_xe) hipFree(w.back_xe);
   if (w.tail_e0) hipEventDestroy(w.tail_e0);
   if (w.tail_e1) hipEventDestroy(w.tail_e1);
   w = LdltWorkspace();
@@ -2979,7 +2999,102 @@ __global__ void __launch_bounds__(256) k_back_panel_update(const double* __restr
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if (lane == 0) x[q] -= acc;
 }
+// ---- the same substitution as ONE dataflow launch (default) -------------------------------------------------------------
+// Workgroup b owns block row r = nblk - 1 - b (64 rows): it walks its row strip from the last column block down to r + 1,
+// subtracting S[r-rows][c-cols] x_c as the x_c become available, then solves its 64 x 64 unit triangle with the stored
+// inverse and publishes x_r.  An entry of x travels as a 16-byte pair {value, tag = number of this call} written by ONE
+// store instruction, so the consumer needs a single agent-scope load per entry to get value AND validity (a separate flag
+// costs a second L2 round trip per block: the chain is 196 blocks long).  Workgroups are dispatched in index order and only
+// wait for lower indices, so the launch cannot deadlock; every spin is bounded like in the tail launch.
+// Chain per block: one load round trip + two 64 x 64 matrix-vector products out of registers ~ 2.5 us (the 98 launches of
+// the panel version: 6 us per 64 rows).
+struct BackArgs {
+  const double* S; int ld; int n_fact; int zcol;
+  const double* invLt;
+  double* x;                  // n_fact doubles out
+  double* xe;                 // 2 * n_pad doubles: {value, tag} pairs
+  double tag;
+  int* status;
+};
+__global__ void __launch_bounds__(256) k_back_dataflow(BackArgs a) {
+  __shared__ double s_x[kInner];
+  __shared__ double s_t[kInner];
+  __shared__ int s_ok;
+  const int nblk = (a.n_fact + kInner - 1) / kInner;
+  const int r = nblk - 1 - (int)blockIdx.x;
+  const int tid = threadIdx.x, p = tid >> 2, q4 = tid & 3;     // row p of the block, quarter q4 of a 64-column block
+  const int j0 = r * kInner;
+  const int rows = a.n_fact - j0 < kInner ? a.n_fact - j0 : kInner;
+  // this lane's slice of the stored inverse: x_r[p] = sum_{p'} invLt[p][p'] t[p'], p' in [16 q4, 16 q4 + 16)
+  double inv[16];
+  {
+    const double* ip = a.invLt + (size_t)r * kInner * kInner + (size_t)p * kInner + 16 * q4;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) inv[j] = ip[j];
+  }
+  const double z = (p < rows) ? a.S[(size_t)(j0 + p) * a.ld + a.zcol] : 0.0;
+  const double* row = a.S + (size_t)(j0 + (p < rows ? p : 0)) * a.ld;
+  double acc = 0.0;
+  const __amdgpu_buffer_rsrc_t rx = tail_rsrc(a.xe);
+  for (int c = nblk - 1; c > r; --c) {
+    // the strip's entries do not depend on x: in flight while the pair is polled
+    double l[16];
+    const int cw = a.n_fact - c * kInner < kInner ? a.n_fact - c * kInner : kInner;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) l[j] = (16 * q4 + j < cw) ? row[c * kInner + 16 * q4 + j] : 0.0;
+    if (tid < kInner) {
+      const unsigned long long t0 = wall_clock64();
+      v2f64_t v;
+      unsigned spins = 0;
+      bool ok = true;
+      for (;;) {
+        v = tail_ld2(rx, (c * kInner + tid) * 16);
+        if (__all(v.y == a.tag)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 255u) == 0 && __builtin_amdgcn_readfirstlane((int)(wall_clock64() - t0 > kTailTimeoutTicks))) { ok = false; break; }
+      }
+      s_x[tid] = v.x;
+      if (tid == 0) { s_ok = ok ? 1 : 0; if (!ok) atomicExch(a.status, 3); }
+    }
+    __syncthreads();
+    if (!s_ok) return;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc += l[j] * s_x[16 * q4 + j];
+    __syncthreads();
+  }
+  acc += __shfl_xor(acc, 1, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  if (q4 == 0) s_t[p] = (p < rows) ? z - acc : 0.0;
+  __syncthreads();
+  double xr = 0.0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) xr += inv[j] * s_t[16 * q4 + j];
+  xr += __shfl_xor(xr, 1, 64);
+  xr += __shfl_xor(xr, 2, 64);
+  if (q4 == 0 && p < rows) {
+    v2f64_t v; v.x = xr; v.y = a.tag;
+    tail_st2(rx, (j0 + p) * 16, 0, v);
+    a.x[j0 + p] = xr;
+  }
+}
+
+static bool g_back_dataflow = true;
+void ldlt_set_back_dataflow(int on) { g_back_dataflow = on != 0; }
+
 int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWorkspace& w, double* x, hipStream_t s) {
+  static const bool no_df = CBA_GETENV("CBA_BACK_PANELS") != nullptr;       // developer switch (bench harness only)
+  if (g_back_dataflow && !no_df && w.back_xe && n_fact % kInner == 0) {
+    BackArgs a{};
+    a.S = S; a.ld = ld; a.n_fact = n_fact; a.zcol = zcol; a.invLt = w.invLt; a.x = x; a.xe = w.back_xe; a.status = w.status;
+    LdltWorkspace& wm = const_cast<LdltWorkspace&>(w);
+    wm.back_epoch += 1;
+    a.tag = (double)wm.back_epoch;
+    const int nblk = (n_fact + kInner - 1) / kInner;
+    hipLaunchKernelGGL(k_back_dataflow, dim3(nblk), dim3(256), 0, s, a);
+    CBA_HIP(hipGetLastError());
+    return CBA_OK;
+  }
+
   hipLaunchKernelGGL(k_gather_col, dim3((n_fact + 255) / 256), dim3(256), 0, s, S, ld, zcol, n_fact, x);
   int last = ((n_fact - 1) / kPanel) * kPanel;
   for (int k0 = last; k0 >= 0; k0 -= kPanel) {

@@ -58,6 +58,45 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   prepare_device_streams();
   hipStream_t ms; make_main_stream(&ms);
+  if (getenv("HELPLOG")) {
+    // helper-task breakdown of ONE dataflow launch: rows [k0, k0 + W) of a super-panel (W = 0: a final tail from k0)
+    const int n = 12672, n_fact = 12544, K = 1024;
+    const int k0 = getenv("HL_K0") ? atoi(getenv("HL_K0")) : 0, W = getenv("HL_W") ? atoi(getenv("HL_W")) : 2048;
+    double *A, *S, *H; hipMalloc(&A, sizeof(double) * (size_t)K * n); hipMalloc(&S, sizeof(double) * (size_t)n * n); hipMalloc(&H, sizeof(double) * (size_t)n * n);
+    std::vector<double> hA((size_t)K * n);
+    for (size_t i = 0; i < hA.size(); ++i) hA[i] = ((double)((i * 2654435761u) % 2001) / 1000.0 - 1.0) * 0.05;
+    hipMemcpy(A, hA.data(), hA.size() * 8, hipMemcpyHostToDevice);
+    hipMemset(H, 0, sizeof(double) * (size_t)n * n);
+    schur_gemm(A, A, K, n, H, S, n, n, n_fact, 1, -1.0 * K * 0.001, nullptr, nullptr);
+    hipDeviceSynchronize();
+    LdltWorkspace w; ldlt_workspace_alloc(w, n);
+    unsigned long long* hl; const size_t nlog = (size_t)1 << 20; hipMalloc(&hl, nlog * 64); hipMemset(hl, 0, nlog * 64);
+    for (int rep = 0; rep < 2; ++rep) {
+      if (rep == 1) hipMemcpyToSymbol(HIP_SYMBOL(g_helplog), &hl, sizeof(hl));
+      GemmStats gs;
+      hipEventRecord(e0, ms);
+      ldlt_tail(S, W > 0 ? k0 + W : n_fact, n, k0, w, ms, &gs, W > 0 ? w.X : nullptr);
+      hipEventRecord(e1, ms);
+      printf("dataflow launch rows [%d, %d): %.3f ms\n", k0, W > 0 ? k0 + W : n_fact, timeit(e0, e1));
+    }
+    std::vector<unsigned long long> h(nlog * 8);
+    hipMemcpy(h.data(), hl, nlog * 64, hipMemcpyDeviceToHost);
+    double tot = 0, wait = 0, mma = 0, dwait = 0, epi = 0; long cnt = 0; unsigned long long tmin = ~0ull, tmax = 0;
+    double by_kind[3][5] = {{0}};
+    for (size_t i = 0; i < nlog; ++i) {
+      const unsigned long long* e = &h[i * 8];
+      if (e[4] == 0) continue;
+      const double T = (double)(e[4] - e[0]) / 100.0;
+      const int kd = (int)e[5];
+      tot += T; wait += e[1] / 100.0; mma += e[2] / 100.0; dwait += e[3] / 100.0; epi += T - (e[1] + e[2] + e[3]) / 100.0; ++cnt;
+      by_kind[kd][0] += 1; by_kind[kd][1] += T; by_kind[kd][2] += e[1] / 100.0; by_kind[kd][3] += e[2] / 100.0; by_kind[kd][4] += e[3] / 100.0;
+      tmin = std::min(tmin, e[0]); tmax = std::max(tmax, e[4]);
+    }
+    printf("REG tasks logged: %ld, span %.1f us; workgroup-time: total %.0f us = wait rows %.1f %% + k-loop %.1f %% + wait diag %.1f %% + epilogue/other %.1f %%\n",
+           cnt, (double)(tmax - tmin) / 100.0, tot, 100 * wait / tot, 100 * mma / tot, 100 * dwait / tot, 100 * epi / tot);
+    printf("per REG task: %.1f us (wait rows %.1f, k-loop %.1f, wait diag %.1f, rest %.1f)\n", tot / cnt, wait / cnt, mma / cnt, dwait / cnt, epi / cnt);
+    return 0;
+  }
   if (getenv("MMA2_ONLY")) {
     const int n = 12672, K = 4096, ntc = 48;
     double *S, *dv, *out; hipMalloc(&S, sizeof(double) * (size_t)K * n); hipMalloc(&dv, sizeof(double) * K); hipMalloc(&out, 8 * 4096);
@@ -134,7 +173,21 @@ int main(int argc, char** argv) {
         if (st) break;
       }
       w.tail_timed = false;
-      ldlt_back_solve(S, n_fact, n, n - 1, w, x, ms);
+      {
+        // back substitution: panels of 256 (round 2) against the dataflow launch, same factor
+        std::vector<double> xa(n_fact), xb(n_fact);
+        float tp = 1e30f, td = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+          ldlt_set_back_dataflow(0);
+          hipEventRecord(e0, ms); ldlt_back_solve(S, n_fact, n, n - 1, w, x, ms); hipEventRecord(e1, ms); tp = std::min(tp, timeit(e0, e1));
+          hipMemcpy(xa.data(), x, sizeof(double) * n_fact, hipMemcpyDeviceToHost);
+          ldlt_set_back_dataflow(1);
+          hipEventRecord(e0, ms); ldlt_back_solve(S, n_fact, n, n - 1, w, x, ms); hipEventRecord(e1, ms); td = std::min(td, timeit(e0, e1));
+        }
+        hipMemcpy(xb.data(), x, sizeof(double) * n_fact, hipMemcpyDeviceToHost);
+        double dmax = 0, xm = 0; for (int i = 0; i < n_fact; ++i) { dmax = std::max(dmax, std::fabs(xa[i] - xb[i])); xm = std::max(xm, std::fabs(xa[i])); }
+        printf("   back substitution: panels %.3f ms, dataflow %.3f ms, |dx| / |x|max %.2e\n", tp, td, dmax / xm);
+      }
       hipStreamSynchronize(ms);
       hx->resize(n_fact); hipMemcpy(hx->data(), x, sizeof(double) * n_fact, hipMemcpyDeviceToHost);
       hd->resize(n_fact); hipMemcpy(hd->data(), w.dvec, sizeof(double) * n_fact, hipMemcpyDeviceToHost);
