@@ -128,6 +128,7 @@ struct cba_problem {
   double* cost_ref = nullptr; double* cost_test = nullptr; double* pixels = nullptr; uint8_t* flags = nullptr;
   double* fd_out = nullptr; uint8_t* fd_ok = nullptr; double* jrec = nullptr; int* cells = nullptr;
   uint32_t* pair_tables = nullptr; int* pair_counts = nullptr;
+  int* pt_start = nullptr; int* pt_obs = nullptr;   // observations bucketed by (camera, pattern point): k_accumulate_points
   std::vector<int> cell_base_host; int* cell_base = nullptr; int* cell_count = nullptr; int* cell_start = nullptr; int* cell_fill = nullptr;
   int* cell_order = nullptr;
   // imageset -> position of its 6x6 block / rows of B.  Imagesets are sorted along a Z-order curve of the
@@ -364,7 +365,10 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   if (!L.eliminate_points)   // B strips first (plain stores), the remaining terms are added on top atomically
     CBA_TRY(launch_accumulate_strips(a, Lp, L.n_images, p->rec_doubles, p->flags, p->jrec, p->cells, p->band_mask, p->img_start, p->B,
                                      p->n_pad, det, p->stream));
-  CBA_TRY(launch_accumulate(a, Lp, p->rec_doubles, p->flags, p->jrec, p->cells, p->pair_tables, p->pair_counts, T, det, p->stream));
+  const int points_separate = (!L.eliminate_points && p->pt_start) ? 1 : 0;
+  CBA_TRY(launch_accumulate(a, Lp, p->rec_doubles, p->flags, p->jrec, p->cells, p->pair_tables, p->pair_counts, T, det, points_separate, p->stream));
+  if (points_separate)
+    CBA_TRY(launch_accumulate_points(a, Lp, p->cams, p->rec_doubles, p->flags, p->jrec, p->cells, p->pt_start, p->pt_obs, T, det, p->stream));
   if (!L.localize_only)
     CBA_TRY(launch_accumulate_cells(a, p->cams, p->cell_base_host, p->rec_doubles, p->n_pad, p->flags, p->jrec, p->cells, p->cell_base,
                                     p->cell_count, p->cell_start, p->cell_fill, p->cell_order, p->Hdd,
@@ -539,7 +543,9 @@ int cba_create(const cba_config* config, cba_problem** out) {
           const bool strip = !L.eliminate_points && i < 6 && k >= nh;
           // rig pose x grid is summed per grid cell by k_accumulate_cells as well (several cameras, poses eliminated)
           const bool rig_grid = !L.eliminate_points && L.rig_in_state && i >= 6 && i < 12 && k >= K - Kg;
-          if (!hot && !grid_grid && !strip && !rig_grid) tab[slot * stride + e++] = ((uint32_t)i << 16) | (uint32_t)k;
+          // every pair with a point column is summed per pattern point by k_accumulate_points (poses eliminated)
+          const bool point = !L.eliminate_points && ((i >= nh && i < nh + 3) || (k >= nh && k < nh + 3));
+          if (!hot && !grid_grid && !strip && !rig_grid && !point) tab[slot * stride + e++] = ((uint32_t)i << 16) | (uint32_t)k;
         }
       counts[slot] = e;
     }
@@ -613,7 +619,7 @@ void cba_destroy(cba_problem* p) {
   F(p->itg);
   for (int c = 0; c < kMaxCameras; ++c) { F(p->tangents[c]); F(p->gperm[c]); }
   F(p->cost_ref); F(p->cost_test); F(p->pixels); F(p->flags); F(p->fd_out); F(p->fd_ok); F(p->jrec); F(p->cells);
-  F(p->pair_tables); F(p->pair_counts); F(p->red_partials); F(p->red8);
+  F(p->pair_tables); F(p->pair_counts); F(p->pt_start); F(p->pt_obs); F(p->red_partials); F(p->red8);
   F(p->cell_base); F(p->cell_count); F(p->cell_start); F(p->cell_fill); F(p->cell_order); F(p->pose_slot);
   F(p->Dblk); F(p->bblk); F(p->B); F(p->Hdd); F(p->bd); F(p->Dinv); F(p->dinvb); F(p->W);
   if (p->S_owned) F(p->S);
@@ -671,6 +677,19 @@ int cba_set_observations(cba_problem* p, int64_t n, const float* xy, const int32
     for (int i = 0; i < L.n_images; ++i) is[i + 1] += is[i];
     CBA_TRY(dev_alloc(&p->img_start, is.size()));
     CBA_HIP(hipMemcpy(p->img_start, is.data(), sizeof(int64_t) * is.size(), hipMemcpyHostToDevice));
+  }
+  // observations of each (camera, pattern point), for the per-point accumulation (static: the point of an observation is data)
+  F(p->pt_start); p->pt_start = nullptr; F(p->pt_obs); p->pt_obs = nullptr;
+  if (!L.eliminate_points && n > 0 && n < 0x7fffffff && (int64_t)L.n_cameras * L.n_points < 0x7fffffff) {
+    const size_t nk = (size_t)L.n_cameras * L.n_points;
+    std::vector<int> ks(nk + 1, 0), ko((size_t)n);
+    for (int64_t i = 0; i < n; ++i) ks[(size_t)camera_index[i] * L.n_points + point_index[i] + 1] += 1;
+    for (size_t k = 0; k < nk; ++k) ks[k + 1] += ks[k];
+    std::vector<int> fill(ks.begin(), ks.end() - 1);
+    for (int64_t i = 0; i < n; ++i) ko[(size_t)fill[(size_t)camera_index[i] * L.n_points + point_index[i]]++] = (int)i;
+    CBA_TRY(dev_alloc(&p->pt_start, ks.size())); CBA_TRY(dev_alloc(&p->pt_obs, ko.size()));
+    CBA_HIP(hipMemcpy(p->pt_start, ks.data(), sizeof(int) * ks.size(), hipMemcpyHostToDevice));
+    CBA_HIP(hipMemcpy(p->pt_obs, ko.data(), sizeof(int) * ko.size(), hipMemcpyHostToDevice));
   }
   F(p->slow_list); p->slow_list = nullptr;
   p->slow_cap = (int)std::min<int64_t>(std::max<int64_t>(kSlowCapMin, n / 8), 1 << 24);

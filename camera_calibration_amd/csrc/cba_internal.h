@@ -92,7 +92,11 @@ struct AccumTargets {
 };
 int launch_accumulate(const PassArgs& a, const Layout& L, int rec_doubles, const uint8_t* flags, const double* jrec,
                       const int* cells, const uint32_t* pair_tables, const int* pair_counts, AccumTargets t,
-                      const double* det_scale, hipStream_t s);
+                      const double* det_scale, int points_separate, hipStream_t s);
+// terms with a pattern-point column, bucketed by (camera, point) (poses eliminated); key lists: cba_set_observations
+int launch_accumulate_points(const PassArgs& a, const Layout& L, const std::vector<cba_camera>& cams, int rec_doubles, const uint8_t* flags,
+                             const double* jrec, const int* cells, const int* key_start, const int* key_obs, AccumTargets t,
+                             const double* det_scale, hipStream_t s);
 // deterministic mode (cba_config.deterministic): fixed-point scale of a pass, conversion of an accumulated array
 int launch_det_scale(int64_t n, int rec_doubles, int used_doubles, const uint8_t* flags, const double* jrec, unsigned long long* bits,
                      double* scale, hipStream_t s);

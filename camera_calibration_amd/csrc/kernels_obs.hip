@@ -24,6 +24,8 @@
 // hardware fp64 atomics (global_atomic_add_f64), except for the terms that many observations share
 // (strips, cells), which are summed on chip first.
 #include "cba_internal.h"
+#include <algorithm>
+#include <mutex>
 
 namespace cba {
 
@@ -745,12 +747,16 @@ template <> struct Acc<false> {
   typedef double T;
   static __device__ __forceinline__ T from(double v, double) { return v; }
   static __device__ __forceinline__ void add(double* p, T v) { unsafeAtomicAdd(p, v); }
+  static __device__ __forceinline__ void add_lds(double* p, T v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   static __device__ __forceinline__ double to_double(T v, double) { return v; }
 };
 template <> struct Acc<true> {
   typedef long long T;
   static __device__ __forceinline__ T from(double v, double scale) { return __double2ll_rn(v * scale); }
   static __device__ __forceinline__ void add(double* p, T v) { atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); }
+  static __device__ __forceinline__ void add_lds(double* p, T v) {
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
   static __device__ __forceinline__ double to_double(T v, double scale) { return (double)v / scale; }
 };
 
@@ -779,7 +785,7 @@ __global__ void __launch_bounds__(256) k_accumulate(PassArgs a, AccumLayout L, i
                                                     const uint8_t* __restrict__ flags, const double* __restrict__ jrec,
                                                     const int* __restrict__ cells, const uint32_t* __restrict__ pair_tables,
                                                     const int* __restrict__ pair_counts, AccumTargets T,
-                                                    const double* __restrict__ det_scale) {
+                                                    const double* __restrict__ det_scale, int points_separate) {
   typedef typename Acc<DET>::T acc_t;
   const double scale = DET ? det_scale[0] : 1.0;
   const double scale_b = DET ? det_scale[1] : 1.0;     // the J^T r sums have their own (finer) fixed-point scale
@@ -841,7 +847,10 @@ __global__ void __launch_bounds__(256) k_accumulate(PassArgs a, AccumLayout L, i
     }
     const int cx0 = cells[2 * o], cy0 = cells[2 * o + 1];
     __builtin_amdgcn_wave_barrier();   // previous iteration's LDS reads are done before overwriting
-    for (int k = lane; k < K; k += 64) {
+    // points_separate (poses eliminated): every term with a point column is summed per pattern point by
+    // k_accumulate_points; only the pose / rig-pose ("hot") columns are left here
+    const int Ks = points_separate ? nh : K;
+    for (int k = lane; k < Ks; k += 64) {
       int idx; double j0, j1;
       int kk = k;
       // ascending index order: [point] pose [rig] [point] grid  (joint_optimization.cc:490-590)
@@ -881,6 +890,7 @@ __global__ void __launch_bounds__(256) k_accumulate(PassArgs a, AccumLayout L, i
       if (hs_k[t] == -2) hot[t] += Acc<DET>::from(r0 * sW0[wv][i] + r1 * sW1[wv][i], scale_b);
       else { const int k = h0 + hs_k[t]; hot[t] += Acc<DET>::from(sW0[wv][i] * sJ0[wv][k] + sW1[wv][i] * sJ1[wv][k], scale); }
     }
+    if (points_separate) continue;                 // wave-uniform
     // b += Jw^T r (non-hot positions)
     for (int k = lane; k < K - Kg; k += 64) {      // the grid entries are summed per cell by k_accumulate_cells
       if (k >= h0 && k < h0 + nh) continue;
@@ -899,6 +909,188 @@ __global__ void __launch_bounds__(256) k_accumulate(PassArgs a, AccumLayout L, i
   }
   flush();
 }
+// ------------------------------------------------------------------------------------------------
+// Terms with a pattern-point column, grouped by point (poses eliminated; lm_optimizer_jtj_accumulator_base.h:359-400 adds
+// them observation by observation): point x point, J^T r of the point, rig pose x point and point x grid.  Every one of
+// the ~n_obs / n_points observations of a point adds to the SAME 9 (+18) entries and to the same three rows of H_dd, so
+// the observations are bucketed by (camera, point) ONCE (the point of an observation never changes: cba_set_observations)
+// and one workgroup per bucket and column chunk
+//   * sums the 6 + 3 (+ 18) dense entries in registers -> one atomic per entry (several cameras share a point),
+//   * sums the three point rows over the camera's grid columns in LDS (3 x chunk_cols doubles, LDS atomics) and writes
+//     them out with plain coalesced stores: (point rows) x (grid columns of this camera) belong to this bucket alone.
+// That replaces 9 + 3 K_g global atomics per observation (105 / 249 of them, 456-way contended on the point entries at
+// BASELINE configs[1]) by K_g LDS atomics and 3 x (grid columns) stores per point.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPointChunkColsMax = 5120;        // 3 rows x 5120 doubles = 120 KB of LDS
+constexpr int kPointThreads = 1024;             // one workgroup per CU (LDS): 16 wavefronts keep the record reads in flight
+constexpr int kPointUnroll = 4;                 // items per lane and step, loads of all four issued before the first use
+template <bool DET>
+__global__ void __launch_bounds__(kPointThreads) k_accumulate_points(PassArgs a, AccumLayout L, int rec_doubles, const uint8_t* __restrict__ flags,
+                                                                     const double* __restrict__ jrec, const int* __restrict__ cells,
+                                                                     const int* __restrict__ key_start, const int* __restrict__ key_obs,
+                                                                     int n_points, int nchunks, int chunk_cols, AccumTargets T,
+                                                                     const double* __restrict__ det_scale) {
+  typedef typename Acc<DET>::T acc_t;
+  constexpr int NT = kPointThreads, NW = kPointThreads / 64, U = kPointUnroll;
+  extern __shared__ double s_rows[];            // [3][chunk_cols]; fixed point in deterministic mode
+  __shared__ acc_t s_red[NW][27];
+  const double scale = DET ? det_scale[0] : 1.0;
+  const double scale_b = DET ? det_scale[1] : 1.0;
+  const int key = blockIdx.x / nchunks, chunk = blockIdx.x - key * nchunks;
+  const int cam = key / n_points, pt = key - cam * n_points;
+  const CamDev& cd = a.cams[cam];
+  const int per = cd.params_per_point, gw = cd.gw;
+  const int* __restrict__ gperm = cd.gperm;
+  const int Kg = L.localize_only ? 0 : per * 16;
+  const int ncols = Kg ? per * gw * cd.gh : 0;
+  const int c0 = chunk * chunk_cols;
+  const int o_begin = key_start[key], n = key_start[key + 1] - o_begin;
+  if (n == 0 || (chunk > 0 && c0 >= ncols)) return;      // H_dd is zero-filled before the accumulation
+  const int c1 = c0 + chunk_cols < ncols ? c0 + chunk_cols : ncols;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nrig = L.rig_in_state ? 6 : 0;
+  const int point_idx = L.first_points + 3 * pt;
+  if (c0 < c1) {
+    for (int i = tid; i < 3 * chunk_cols; i += NT) s_rows[i] = 0.0;
+    __syncthreads();
+    // one (observation, grid column) item per lane and slot; three dependent load levels (list -> record / cell -> order
+    // of the control point), each issued for all U slots before anything is used
+    const int items = n * Kg;
+    for (int it0 = tid; it0 < items; it0 += NT * U) {
+      int64_t o[U]; int kk[U]; bool live[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int it = it0 + u * NT;
+        live[u] = it < items;
+        const int oi = live[u] ? it / Kg : 0;
+        kk[u] = live[u] ? it - oi * Kg : 0;
+        o[u] = key_obs[o_begin + oi];
+      }
+      int cx[U], cy[U]; uint8_t fl[U]; double w[U], g0[U], g1[U], q0[U][3], q1[U][3];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double* rec = jrec + (size_t)o[u] * rec_doubles;
+        fl[u] = flags[o[u]]; cx[u] = cells[2 * o[u]]; cy[u] = cells[2 * o[u] + 1];
+        w[u] = rec[2]; g0[u] = rec[kRecHeader + kk[u]]; g1[u] = rec[kRecHeader + Kg + kk[u]];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { q0[u][r] = rec[27 + r]; q1[u][r] = rec[30 + r]; }
+      }
+      int col[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int cell = kk[u] / per, d = kk[u] - cell * per;
+        int seq = (cx[u] + (cell & 3)) + (cy[u] + (cell >> 2)) * gw;
+        live[u] = live[u] && fl[u] == 3;
+        if (!live[u]) seq = 0;                                       // cells of an invalid observation are not defined
+        col[u] = per * (gperm ? gperm[seq] : seq) + d;               // camera-local column (grid_column - intr_offset)
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!live[u] || col[u] < c0 || col[u] >= c1) continue;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+          Acc<DET>::add_lds(&s_rows[r * chunk_cols + (col[u] - c0)], Acc<DET>::from((w[u] * q0[u][r]) * g0[u] + (w[u] * q1[u][r]) * g1[u], scale));
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      double* out = T.Hdd + (size_t)(point_idx - L.block_dof + r) * L.dense_dof + cd.intr_offset + c0;
+      for (int c = tid; c < c1 - c0; c += NT) out[c] = s_rows[r * chunk_cols + c];
+    }
+  }
+  if (chunk != 0) return;
+  // dense entries of the bucket: [0..5] point x point (upper), [6..8] J^T r, [9..26] rig pose x point
+  acc_t acc[27];
+#pragma unroll
+  for (int e = 0; e < 27; ++e) acc[e] = 0;
+  for (int i = tid; i < n; i += NT) {
+    const int64_t o = key_obs[o_begin + i];
+    if (flags[o] != 3) continue;
+    const double* rec = jrec + (size_t)o * rec_doubles;
+    const double r0 = rec[0], r1 = rec[1], w = rec[2];
+    double p0[3], p1[3], w0[3], w1[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { p0[r] = rec[27 + r]; p1[r] = rec[30 + r]; w0[r] = w * p0[r]; w1[r] = w * p1[r]; }
+    int e = 0;
+#pragma unroll
+    for (int i2 = 0; i2 < 3; ++i2)
+#pragma unroll
+      for (int k2 = i2; k2 < 3; ++k2) acc[e++] += Acc<DET>::from(w0[i2] * p0[k2] + w1[i2] * p1[k2], scale);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) acc[6 + r] += Acc<DET>::from(r0 * w0[r] + r1 * w1[r], scale_b);
+    if (nrig) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const double wq0 = w * rec[15 + q], wq1 = w * rec[21 + q];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) acc[9 + 3 * q + r] += Acc<DET>::from(wq0 * p0[r] + wq1 * p1[r], scale);
+      }
+    }
+  }
+  const int ne = nrig ? 27 : 9;
+#pragma unroll
+  for (int e = 0; e < 27; ++e) {
+    if (e >= ne) break;
+    acc_t v = acc[e];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) s_red[wv][e] = v;
+  }
+  __syncthreads();
+  if (tid < ne) {
+    acc_t v = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) v += s_red[i][tid];
+    if (tid < 6) {
+      int i2 = 0, rem = tid;
+      while (rem >= 3 - i2) { rem -= 3 - i2; ++i2; }
+      acc_add_H<DET>(L, T, point_idx + i2, point_idx + i2 + rem, v);
+    } else if (tid < 9) {
+      acc_add_b<DET>(L, T, point_idx + tid - 6, v);
+    } else {
+      const int q = (tid - 9) / 3, r = (tid - 9) - 3 * q;
+      acc_add_H<DET>(L, T, L.first_camera_tr_rig + 6 * cam + q, point_idx + r, v);
+    }
+  }
+}
+int point_chunks(const std::vector<cba_camera>& cams, int localize_only, int* chunk_cols) {
+  int maxcols = 0;
+  if (!localize_only)
+    for (const cba_camera& c : cams) maxcols = std::max(maxcols, (c.model_type == CBA_CENTRAL_GENERIC ? 2 : 5) * c.grid_w * c.grid_h);
+  const int nchunks = std::max(1, (maxcols + kPointChunkColsMax - 1) / kPointChunkColsMax);
+  *chunk_cols = std::max(8, ((maxcols + nchunks - 1) / nchunks + 7) / 8 * 8);
+  return nchunks;
+}
+int launch_accumulate_points(const PassArgs& a, const Layout& L, const std::vector<cba_camera>& cams, int rec_doubles, const uint8_t* flags,
+                             const double* jrec, const int* cells, const int* key_start, const int* key_obs, AccumTargets t,
+                             const double* det_scale, hipStream_t s) {
+  if (a.n_obs == 0 || L.n_points == 0) return CBA_OK;
+  AccumLayout al;
+  al.rig_in_state = L.rig_in_state; al.eliminate_points = L.eliminate_points; al.localize_only = L.localize_only;
+  al.first_rig_tr_global = L.first_rig_tr_global; al.first_camera_tr_rig = L.first_camera_tr_rig;
+  al.first_points = L.first_points; al.block_dof = L.block_dof; al.block_size = L.block_size; al.dense_dof = L.dense_dof;
+  int chunk_cols = 0;
+  const int nchunks = point_chunks(cams, L.localize_only, &chunk_cols);
+  const size_t lds = sizeof(double) * 3 * (size_t)chunk_cols;
+  const dim3 grid((unsigned)((size_t)L.n_cameras * L.n_points * nchunks));
+  static std::once_flag once;
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(once, [] {
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_accumulate_points<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * kPointChunkColsMax * 8);
+    if (attr_rc == hipSuccess)
+      attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_accumulate_points<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * kPointChunkColsMax * 8);
+  });
+  CBA_HIP(attr_rc);
+  if (det_scale)
+    hipLaunchKernelGGL(k_accumulate_points<true>, grid, dim3(kPointThreads), lds, s, a, al, rec_doubles, flags, jrec, cells, key_start, key_obs, L.n_points, nchunks,
+                       chunk_cols, t, det_scale);
+  else
+    hipLaunchKernelGGL(k_accumulate_points<false>, grid, dim3(kPointThreads), lds, s, a, al, rec_doubles, flags, jrec, cells, key_start, key_obs, L.n_points, nchunks,
+                       chunk_cols, t, det_scale);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // grid x grid block of JtJ, grouped by grid cell.  All observations whose 4x4 control patch starts at
 // the same cell add their K_g x K_g products to the same entries of H_dd, so they are first bucketed by
@@ -1220,7 +1412,7 @@ int launch_accumulate_strips(const PassArgs& a, const Layout& L, int n_images, i
 
 int launch_accumulate(const PassArgs& a, const Layout& L, int rec_doubles, const uint8_t* flags, const double* jrec,
                       const int* cells, const uint32_t* pair_tables, const int* pair_counts, AccumTargets t,
-                      const double* det_scale, hipStream_t s) {
+                      const double* det_scale, int points_separate, hipStream_t s) {
   if (a.n_obs == 0) return CBA_OK;
   AccumLayout al;
   al.rig_in_state = L.rig_in_state; al.eliminate_points = L.eliminate_points; al.localize_only = L.localize_only;
@@ -1228,9 +1420,9 @@ int launch_accumulate(const PassArgs& a, const Layout& L, int rec_doubles, const
   al.first_points = L.first_points; al.block_dof = L.block_dof; al.block_size = L.block_size; al.dense_dof = L.dense_dof;
   const dim3 grid((unsigned)((a.n_obs + 4 * kAccChunk - 1) / (4 * kAccChunk)));
   if (det_scale)
-    hipLaunchKernelGGL(k_accumulate<true>, grid, dim3(256), 0, s, a, al, rec_doubles, flags, jrec, cells, pair_tables, pair_counts, t, det_scale);
+    hipLaunchKernelGGL(k_accumulate<true>, grid, dim3(256), 0, s, a, al, rec_doubles, flags, jrec, cells, pair_tables, pair_counts, t, det_scale, points_separate);
   else
-    hipLaunchKernelGGL(k_accumulate<false>, grid, dim3(256), 0, s, a, al, rec_doubles, flags, jrec, cells, pair_tables, pair_counts, t, det_scale);
+    hipLaunchKernelGGL(k_accumulate<false>, grid, dim3(256), 0, s, a, al, rec_doubles, flags, jrec, cells, pair_tables, pair_counts, t, det_scale, points_separate);
   CBA_HIP(hipGetLastError());
   return CBA_OK;
 }

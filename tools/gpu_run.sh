@@ -2,6 +2,7 @@
 # One parameterised GPU-box script (replaces the per-call scripts of rounds 1-2):  tools/gpu_run.sh <what> [tag]
 #   suite   whole GPU test suite + smoke + default bench line                      -> gpurun_out/<tag>_*
 #   record  suite + bench lines of configs 2 / 3 / 4 + kernel stats + PMC traffic  -> gpurun_out/<tag>_*
+#   profile record without the test suite / smoke
 #   tail    tools/bin/bench_tail (factorisation tail vs blocked schedule, chain timeline)
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
@@ -21,12 +22,14 @@ PY
 case $WHAT in
   tail)
     TAILLOG=1 TAILS=${TAILS:-1024,6144,8192} timeout 300 tools/bin/bench_tail 12672 12544 2>&1 | tee $O/${TAG}_tail.txt ;;
-  suite|record)
+  suite|record|profile)
+    if [ "$WHAT" != profile ]; then
     rm -f $O/parity_deviations.json
     timeout 2400 python -m pytest tests -q -m gpu --timeout 900 > $O/${TAG}_gputests.log 2>&1; echo "pytest rc=$?"; tail -4 $O/${TAG}_gputests.log
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+    fi
     timeout 900 python bench.py --steps 20 --warmup 2 > $O/${TAG}_bench_cfg2.log 2>&1; tail -1 $O/${TAG}_bench_cfg2.log > $O/${TAG}_bench_cfg2.json; summary $O/${TAG}_bench_cfg2.json
-    if [ "$WHAT" = record ]; then
+    if [ "$WHAT" != suite ]; then
       timeout 400 python bench.py --config 3 --steps 4 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench_cfg3.log 2>&1; tail -1 $O/${TAG}_bench_cfg3.log > $O/${TAG}_bench_cfg3.json; summary $O/${TAG}_bench_cfg3.json
       timeout 300 python bench.py --config 4 --steps 8 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_cfg4.log 2>&1; tail -1 $O/${TAG}_bench_cfg4.log > $O/${TAG}_bench_cfg4.json; summary $O/${TAG}_bench_cfg4.json
       cd /tmp
