@@ -47,8 +47,8 @@ def parse_args():
                     help="exercise only the self-launch path (spawn --gpus ranks, one gloo all-reduce on CPU, rank 0 prints a JSON "
                          "line); needs no GPU -- tests/test_bench_launcher.py")
     ap.add_argument("--distributed-solve", type=int, default=-1,
-                    help="1 / 0: distribute the factorisation of the reduced system over the ranks (cba_config.distributed_solve); "
-                         "default off (first cut: no look-ahead yet, DESIGN.md section 6)")
+                    help="1 / 0: distribute the factorisation of the reduced system over the ranks (cba_config.distributed_solve, "
+                         "DESIGN.md section 6); default: on with more than one rank")
     return ap.parse_args()
 
 
@@ -227,7 +227,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from camera_calibration_amd import synthetic as syn
-    from camera_calibration_amd.distributed import make_allreduce
+    from camera_calibration_amd.distributed import make_allreduce, make_collective
 
     n_default = syn.BASELINE_CONFIGS[args.config][8]
     # BASELINE.json names the GPU count of every config: 4 = 800 imagesets over 2 GPUs, 5 = 4000 imagesets over 8 GPUs.  A
@@ -241,15 +241,16 @@ def main():
 
     allreduce = None
     reduce_ptr, reduce_n, keep = 0, 0, None
+    # distributed reduced solve: on by default with more than one rank; with one rank only on request (times the driver alone)
+    dist_solve = bool(use_dist and (args.distributed_solve == 1 or (args.distributed_solve < 0 and world > 1)))
     if use_dist:
-        reduce_n = eng.Engine.reduce_buffer_doubles(pb)
+        reduce_n = eng.Engine.reduce_buffer_doubles(pb, dist_solve, world)
         keep = torch.zeros(reduce_n, dtype=torch.float64, device=f"cuda:{local_rank}")
         reduce_ptr = keep.data_ptr()
         allreduce = make_allreduce(keep, local_rank)
-    dist_solve = args.distributed_solve == 1
-    dist_solve = bool(dist_solve and use_dist and (world > 1 or args.distributed_solve == 1))   # world 1 + explicit flag: times the driver alone
     e = eng.Engine(pb, device=local_rank, allreduce=allreduce, n_images_global=n_img * world,
-                   reduce_buffer_ptr=reduce_ptr, reduce_buffer_doubles=reduce_n, distributed_solve=dist_solve, rank=rank, world_size=world)
+                   reduce_buffer_ptr=reduce_ptr, reduce_buffer_doubles=reduce_n, distributed_solve=dist_solve, rank=rank, world_size=world,
+                   collective=make_collective(local_rank) if dist_solve else None)
     e.set_state(st0)
 
     n_obs_local = pb.n_obs

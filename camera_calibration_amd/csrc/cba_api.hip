@@ -151,7 +151,7 @@ struct cba_problem {
   // system
   int n_pad = 0, n_fact = 0, Kpad = 0;
   double* Dblk = nullptr; double* bblk = nullptr; double* B = nullptr; double* Hdd = nullptr; double* bd = nullptr;
-  double* Dinv = nullptr; double* dinvb = nullptr; double* W = nullptr; double* S = nullptr; bool S_owned = true; double* P = nullptr; bool P_owned = true;
+  double* Dinv = nullptr; double* dinvb = nullptr; double* W = nullptr; double* S = nullptr; bool S_owned = true; double* P = nullptr; bool P_owned = true; double* P2 = nullptr; size_t dist_buf_doubles = 0;
   double* x = nullptr; double* scal = nullptr; double* gemv_ws = nullptr;
   unsigned long long* kmask = nullptr;   // block-sparsity of B per (column tile, K slab), rebuilt after every accumulation
   unsigned long long* kmask_host = nullptr; size_t kmask_host_words = 0;   // pinned copy (flop count of the Schur product)
@@ -397,7 +397,10 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
   CBA_TRY(launch_block_inverse(p->Dblk, p->bblk, lambda, bs, nb, p->Dinv, p->dinvb, p->status, p->stream));
   CBA_TRY(launch_dinv_times_B_ld(p->Dinv, p->B, bs, nb, dd, ld, p->W, p->stream));
   CBA_TRY(timer_begin(p, 0));
-  CBA_TRY(schur_gemm(p->B, p->W, p->Kpad, ld, p->Hdd, p->S, p->n_pad, ld, dd, multi ? 0 : 1, lambda, p->kmask, p->stream));
+  // lambda on the diagonal / ones on the padding diagonal: single GPU: in the product; replicated multi-GPU solve: after the
+  // all-reduce; distributed solve: rank 0 adds them to its partial system, the reduction carries them to the owners
+  const bool dist = multi && p->cfg.distributed_solve && p->cfg.world_size >= 1;
+  CBA_TRY(schur_gemm(p->B, p->W, p->Kpad, ld, p->Hdd, p->S, p->n_pad, ld, dd, (!multi || (dist && p->cfg.rank == 0)) ? 1 : 0, lambda, p->kmask, p->stream));
   CBA_TRY(timer_end(p, 0, 0, 0, 1));
   // algorithmic flops of this launch = K slabs actually multiplied (block-sparse loop): the touch masks go to pinned
   // host memory now and are counted after the solve (no host wait in the middle of the step)
@@ -410,7 +413,7 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
   CBA_HIP(hipMemcpyAsync(p->kmask_host, p->kmask, (size_t)mask_tiles * mask_words * sizeof(unsigned long long), hipMemcpyDeviceToHost, p->stream));
   // right-hand side: S[j][n_pad-1] = bd[j] - sum_k B[k][j] dinvb[k]
   CBA_TRY(launch_gemv_t_strided(p->B, L.block_dof, dd, ld, p->dinvb, p->bd, p->S + (ld - 1), ld, p->gemv_ws, p->stream));
-  if (multi) {
+  if (multi && !dist) {
     CBA_TRY(launch_pack_upper(p->S, p->n_pad, p->P, 0, p->stream));
     CBA_TRY(allreduce(p, p->P, packed_upper_doubles(p->n_pad)));
     CBA_TRY(launch_pack_upper(p->S, p->n_pad, p->P, 1, p->stream));
@@ -418,11 +421,18 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
   }
   GemmStats gs;
   CBA_TRY(timer_begin(p, 1));
-  if (multi && p->cfg.distributed_solve && p->cfg.world_size >= 1)
-    CBA_TRY(ldlt_factor_distributed(p->S, p->n_fact, ld, p->ldlt, p->stream, p->cfg.rank, p->cfg.world_size, p->cfg.allreduce,
-                                    p->cfg.allreduce_user, p->P, &gs));
-  else
+  if (dist) {
+    DistComm c;
+    c.rank = p->cfg.rank; c.world = p->cfg.world_size;
+    c.collective = p->cfg.collective; c.collective_user = p->cfg.collective_user;
+    c.allreduce = p->cfg.allreduce; c.allreduce_user = p->cfg.allreduce_user;
+    c.send = p->P; c.recv = p->P2; c.buf_doubles = p->dist_buf_doubles;
+    int rc = ldlt_factor_distributed(p->S, p->n_fact, ld, p->ldlt, p->stream, c, &gs);
+    if (rc == CBA_ERR_STATE) set_error("distributed solve: a collective callback failed");
+    CBA_TRY(rc);
+  } else {
     CBA_TRY(ldlt_factor(p->S, p->n_fact, ld, p->ldlt, p->stream, &gs));
+  }
   CBA_TRY(timer_end(p, 1, gs.flops, 0, gs.launches));
   CBA_TRY(ldlt_back_solve(p->S, p->n_fact, ld, ld - 1, p->ldlt, p->x + L.block_dof, p->stream));
   // block part: x_b = D^-1 b - W x_d      (lm_optimizer.h:1366-1367)
@@ -463,6 +473,7 @@ int64_t cba_reduce_buffer_doubles(const cba_config* config) {
   if (!config || !config->cameras) return 0;
   Layout L; make_layout(*config, L);
   int n_pad, n_fact; padded_dims(L.dense_dof, &n_pad, &n_fact);
+  if (config->distributed_solve) return (int64_t)ldlt_dist_buffer_doubles(n_pad, config->world_size);
   return packed_upper_doubles(n_pad);
 }
 
@@ -582,7 +593,12 @@ int cba_create(const cba_config* config, cba_problem** out) {
   CBA_TRY(dev_alloc(&p->S, (size_t)p->n_pad * p->n_pad));
   if (config->allreduce) {
     // the reduced system crosses ranks as its upper 128-row blocks only (half the all-reduce volume)
-    const int64_t need = packed_upper_doubles(p->n_pad);
+    int64_t need = packed_upper_doubles(p->n_pad);
+    if (config->distributed_solve) {       // staging of the reduce-scatter / all-gathers (send: P, receive: P2)
+      need = (int64_t)ldlt_dist_buffer_doubles(p->n_pad, config->world_size);
+      p->dist_buf_doubles = (size_t)need;
+      CBA_TRY(dev_alloc(&p->P2, (size_t)need));
+    }
     if (config->reduce_buffer) {
       if (config->reduce_buffer_doubles < need) { set_error("reduce_buffer too small"); return CBA_ERR_ARG; }
       p->P = static_cast<double*>(config->reduce_buffer); p->P_owned = false;
@@ -624,6 +640,7 @@ void cba_destroy(cba_problem* p) {
   F(p->Dblk); F(p->bblk); F(p->B); F(p->Hdd); F(p->bd); F(p->Dinv); F(p->dinvb); F(p->W);
   if (p->S_owned) F(p->S);
   if (p->P_owned) F(p->P);
+  F(p->P2);
   F(p->x); F(p->scal); F(p->status); F(p->gemv_ws); F(p->kmask);
   ldlt_workspace_free(p->ldlt);
   for (auto& t : p->timers) for (auto& sp : t.spans) { hipEventDestroy(sp.e0); hipEventDestroy(sp.e1); }

@@ -174,9 +174,15 @@ int ldlt_tail_rows();
 void ldlt_set_back_dataflow(int on);   // back substitution as one dataflow launch (default) or by panels of 256 (round 2)
 // milliseconds of the last tail launch (waits for it); 0 when there was none
 double ldlt_tail_last_ms(LdltWorkspace& w);
-// Distributed variant (cba_config.distributed_solve): `exchange(buf, count)` sums a device buffer over the ranks (synchronous);
-// `stage` holds at least 512 * ld doubles
-int ldlt_factor_distributed(double* S, int n, int ld, LdltWorkspace& w, hipStream_t s, int rank, int world,
-                            int (*exchange)(void* buf, int64_t count, void* user), void* user, double* stage, GemmStats* trailing_stats);
+// Distributed variant (cba_config.distributed_solve): S holds this rank's PARTIAL reduced system on entry; the collectives are
+// blocking host calls.  `send` / `recv`: device staging buffers of at least ldlt_dist_buffer_doubles(n_pad, world) doubles each.
+struct DistComm {
+  int rank = 0, world = 1;
+  cba_collective_fn collective = nullptr; void* collective_user = nullptr;   // may be null: emulated with `allreduce`
+  cba_allreduce_fn allreduce = nullptr; void* allreduce_user = nullptr;
+  double* send = nullptr; double* recv = nullptr; size_t buf_doubles = 0;
+};
+size_t ldlt_dist_buffer_doubles(int n_pad, int world);
+int ldlt_factor_distributed(double* S, int n, int ld, LdltWorkspace& w, hipStream_t s, const DistComm& c, GemmStats* trailing_stats);
 
 }  // namespace cba

@@ -200,6 +200,18 @@ __device__ __forceinline__ long long gemm_slot_tile(const GemmArgs& g, long long
   return (cq * 8 + (b & 7)) * g.chunk + (q - cq * g.chunk);
 }
 
+// col_group launches (distributed factorisation): first column of owned tile column tn, and the number of tile rows of the
+// launch that reach the diagonal of that column
+__host__ __device__ inline int colgroup_col0(const GemmArgs& g, int tn, int TN) {
+  return g.n_off + ((tn / g.col_group) * g.col_stride * g.col_group + tn % g.col_group) * TN;
+}
+template <int TM, int TN>
+__host__ __device__ inline int colgroup_strip_rows(const GemmArgs& g, int tn_last) {
+  const int last = colgroup_col0(g, tn_last, TN) + TN - 1;       // last column of the strip
+  if (last < g.m_off) return 0;
+  const int rows = (last - g.m_off) / TM + 1;
+  return rows < g.m_tiles ? rows : g.m_tiles;
+}
 // One output tile.  `b` is the linear slot of the tile (= blockIdx.x: workgroup b runs on XCD b % 8, observed dispatch
 // order; only speed depends on it).  Returns false when the slot is past the last tile.
 template <int TM, int TN, int WM, int WN, bool SUB>
@@ -253,13 +265,19 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
       rem -= cnt;
     }
   } else if (g.col_group > 0) {
-    // 8 x 8 blocks of tiles, block rows first: the ~64 workgroups in flight on an XCD share 8 A and 8 B panels
-    const int nb8 = (g.n_tiles + 7) / 8;
-    const long long blk = t >> 6;
-    const int in = (int)(t & 63);
-    tm = (int)(blk / nb8) * 8 + (in >> 3);
-    tn = (int)(blk % nb8) * 8 + (in & 7);
-    if (tm >= g.m_tiles || tn >= g.n_tiles) return true;
+    // distributed factorisation: strips of 8 OWNED tile columns, row by row inside a strip down to the diagonal of the strip's
+    // last column (colgroup_strip_rows): the ~64 workgroups in flight on an XCD share 8 A and 8 B panels, and only the few
+    // tiles between the diagonals of a strip's column groups are enumerated in vain (skipped below)
+    long long rem = t;
+    int c0 = 0, w = 0;
+    for (;; c0 += 8) {
+      w = g.n_tiles - c0 < 8 ? g.n_tiles - c0 : 8;
+      const long long cnt = (long long)colgroup_strip_rows<TM, TN>(g, c0 + w - 1) * w;
+      if (rem < cnt) break;
+      rem -= cnt;
+    }
+    tm = (int)(rem / w);
+    tn = c0 + (int)(rem - (long long)tm * w);
   } else {
     tm = (int)(t / g.n_tiles);
     tn = (int)(t - (long long)tm * g.n_tiles);
@@ -269,7 +287,7 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
   if (g.col_group > 0) {
     // distributed factorisation: the launch covers only the column groups this rank owns (every `col_stride`-th group of
     // `col_group` tiles); tiles below the diagonal are launched and skipped
-    n0 = g.n_off + ((tn / g.col_group) * g.col_stride * g.col_group + tn % g.col_group) * TN;
+    n0 = colgroup_col0(g, tn, TN);
     if (n0 + TN - 1 < m0) return true;
   }
 
@@ -612,13 +630,19 @@ template <int TM, int TN, int WM, int WN, bool SUB>
 static int launch_gemm(GemmArgs g, hipStream_t s) {
   g.total_tiles = g.upper ? count_upper_tiles(g.m_off, g.n_off, g.m_tiles, g.n_tiles, TM, TN)
                           : (long long)g.m_tiles * g.n_tiles;
-  if (g.col_group > 0) g.total_tiles = (long long)((g.m_tiles + 7) / 8) * ((g.n_tiles + 7) / 8) * 64;
+  if (g.col_group > 0) {
+    g.total_tiles = 0;
+    for (int c0 = 0; c0 < g.n_tiles; c0 += 8) {
+      const int w = g.n_tiles - c0 < 8 ? g.n_tiles - c0 : 8;
+      g.total_tiles += (long long)colgroup_strip_rows<TM, TN>(g, c0 + w - 1) * w;
+    }
+  }
   if (g.total_tiles <= 0) return CBA_OK;
   // chunk = 64 tiles for big launches; small launches use smaller chunks so that all eight XCDs get work
   long long per = (g.total_tiles + 7) / 8;
   // dense launches: one contiguous range per XCD (best L2 reuse); block-sparse launches: chunks of 64
   // interleaved over the XCDs so that dense and sparse regions of the matrix are spread evenly
-  g.chunk = (int)(((g.kmask || g.col_group > 0) && per > 64) ? 64 : (per < 1 ? 1 : per));   // col_group: half of the enumerated tiles are skipped, unevenly
+  g.chunk = (int)((g.kmask && per > 64) ? 64 : (per < 1 ? 1 : per));   // col_group launches are dense: the few skipped tiles sit at the end of every strip
   static const int use_strips = CBA_GETENV("CBA_NO_STRIPS") ? 0 : 1;
   g.strips = (use_strips && TM == 128 && TN == 128 && g.upper && !g.kmask && g.m_off == g.n_off && g.m_tiles == g.n_tiles &&
               g.total_tiles >= 512) ? 1 : 0;
@@ -2485,7 +2509,8 @@ static int tail_start_row(int n_fact, const LdltWorkspace& w) {
 }
 // Factors rows [t0, n_fact) of S, whose trailing block [t0, n_pad)^2 carries every update of the rows above, with one launch
 // on stream s.  t0 and n_fact are multiples of 64.
-static int ldlt_tail(double* S, int n_fact, int ld, int t0, LdltWorkspace& w, hipStream_t s, GemmStats* st, double* X = nullptr) {
+static int ldlt_tail(double* S, int n_fact, int ld, int t0, LdltWorkspace& w, hipStream_t s, GemmStats* st, double* X = nullptr,
+                     int reserve_wgs = 0) {
   TailArgs t{};
   t.S = S; t.ld = ld;
   t.X = X; t.ldx = ld; t.x_c0 = n_fact / kInner;
@@ -2515,7 +2540,8 @@ static int ldlt_tail(double* S, int n_fact, int ld, int t0, LdltWorkspace& w, hi
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   long long grid = ntasks + 1;
-  if (grid > 2LL * cus) grid = 2LL * cus;        // two workgroups per CU are resident (80 KB of LDS each)
+  if (grid > 2LL * cus - reserve_wgs) grid = 2LL * cus - reserve_wgs;        // two workgroups per CU are resident (80 KB of LDS each)
+  if (grid < 2) grid = 2;
   if (st) CBA_HIP(hipEventRecord(w.tail_e0, s));
   hipLaunchKernelGGL(k_ldlt_tail, dim3((unsigned)grid), dim3(256), 0, s, t);
   CBA_HIP(hipGetLastError());
@@ -2812,110 +2838,202 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Distributed factorisation, first cut (cba_config.distributed_solve).
+// Distributed factorisation (cba_config.distributed_solve) -- the two-level schedule of ldlt_factor with
+// the throughput-bound part (the K = W super-panel updates) split over the ranks and the latency-bound part (the dataflow
+// launches) replicated:
 //   ownership : 512-column groups of S, block-cyclic over the ranks (group g -> rank g % world)
-//   per panel : (1) the panel's block row [k0, e0) x [k0, n_pad) is assembled from the owners of its columns -- every
-//                   rank contributes its columns, zeros elsewhere, one `exchange` (sum over ranks);
-//               (2) every rank factors the panel and solves the whole block row (identical arithmetic on identical
-//                   data: chain kernels of the single-GPU path, one stream, no look-ahead);
-//               (3) every rank applies the trailing update to the column groups it owns.
-// After the last panel every rank holds the complete factor (all block rows), d and the forward-substituted right-hand
-// side, so the back substitution runs replicated as in the single-GPU path.
+//   on entry  : S holds THIS RANK'S PARTIAL reduced system (nothing has been summed over the ranks yet)
+//   (1) rows [0, W) -- one contiguous block of S -- are summed in place (all-reduce: every rank factors them); the first
+//       dataflow launch starts; underneath it the rows below are REDUCE-SCATTERED straight into their owners (rows [W, end of
+//       the group) of each 512-column group travel to the group's owner only: the upper triangle once, no zeros);
+//   (2) per super-panel [k0, k0 + W): every rank runs the dataflow launch on the complete row band (identical arithmetic on
+//       identical data -> identical L, d, X on every rank), then updates ONLY ITS OWN column groups, the rows of the next
+//       band first; as soon as those are done the next band is ALL-GATHERED from its owners (pack -> collective -> unpack on
+//       a second stream) while the update of the rows below is still running on the main stream;
+//   (3) the band in front of the final dataflow launch covers all remaining rows, so that the last launch is replicated too.
+// After the last launch every rank holds the complete factor, d and the forward-substituted right-hand side: the back
+// substitution runs replicated as in the single-GPU path.  Link volume per solve and rank: (world - 1) / world x the upper
+// triangle for the reduce-scatter + the same for all the gathers together = what ONE all-reduce of the packed system moves.
+// The collectives are blocking host calls (cba_collective_fn); they overlap with device work that was queued before them.
 // ------------------------------------------------------------------------------------------------
 constexpr int kOwnGroup = 512;
-// stage[r][c - c_begin] = owned(c) ? S[k0 + r][c] : 0     (pack)      S[k0 + r][c] = stage[r][c - c_begin]     (unpack)
-__global__ void __launch_bounds__(256) k_block_row_exchange(double* __restrict__ S, int ld, int k0, int c_begin, int width,
-                                                            double* __restrict__ stage, int rank, int world, int unpack) {
-  const int r = blockIdx.y;
-  for (int c = blockIdx.x * 256 + threadIdx.x; c < width; c += gridDim.x * 256) {
-    const int col = c_begin + c;
-    double* sp = S + (size_t)(k0 + r) * ld + col;
-    double* st = stage + (size_t)r * width + c;
-    if (unpack) *sp = *st;
-    else *st = ((col / kOwnGroup) % world == rank) ? *sp : 0.0;
+int launch_pack_upper(const double* S, int n_pad, double* P, int unpack, hipStream_t s);
+struct RectArgs {
+  double* S; int ld; int n_pad;
+  int g_begin;          // first column group of the transfer
+  int world;
+  int R0;               // first row
+  int nrows;            // > 0: every group sends rows [R0, R0 + nrows) (a band); 0: rows [R0, end of the group) (the triangle)
+};
+// i-th column group of rank q in this transfer: first column, width, number of rows, offset in q's block of the buffer
+__host__ __device__ inline bool dist_rect(const RectArgs& a, int q, int i, int* col0, int* width, int* height, long long* off) {
+  const int gq0 = a.g_begin + ((q - a.g_begin % a.world) % a.world + a.world) % a.world;
+  const int g = gq0 + i * a.world;
+  *col0 = g * kOwnGroup;
+  if (*col0 >= a.n_pad) return false;
+  *width = a.n_pad - *col0 < kOwnGroup ? a.n_pad - *col0 : kOwnGroup;
+  if (a.nrows > 0) {
+    *height = a.nrows;
+    *off = (long long)i * a.nrows * kOwnGroup;
+  } else {
+    const long long h0 = (long long)(gq0 + 1) * kOwnGroup - a.R0;       // only the last group of the matrix can be narrower / shorter
+    const int end = *col0 + kOwnGroup < a.n_pad ? *col0 + kOwnGroup : a.n_pad;
+    *height = end - a.R0;
+    *off = (long long)kOwnGroup * ((long long)i * h0 + (long long)a.world * kOwnGroup * ((long long)i * (i - 1) / 2));
+  }
+  return true;
+}
+static long long dist_count(const RectArgs& a, int q) {
+  long long total = 0;
+  for (int i = 0;; ++i) {
+    int c0, wd, h; long long off;
+    if (!dist_rect(a, q, i, &c0, &wd, &h, &off)) break;
+    total = off + (long long)h * wd;
+  }
+  return total;
+}
+// buf <-> S for the groups of ranks q_first .. q_first + gridDim.z - 1 (blockIdx.y = group index, grid-stride over its entries)
+__global__ void __launch_bounds__(256) k_dist_copy(RectArgs a, double* __restrict__ buf, long long rank_stride, int q_first, int unpack) {
+  const int q = q_first + blockIdx.z;
+  int col0, width, height; long long off;
+  if (!dist_rect(a, q, blockIdx.y, &col0, &width, &height, &off)) return;
+  double* b = buf + (long long)blockIdx.z * rank_stride + off;
+  // a row of a group is <= 4 KB contiguous on both sides: rows over the x blocks, two doubles per lane (width is a multiple of 128)
+  for (int r = blockIdx.x; r < height; r += gridDim.x) {
+    double2* sp = reinterpret_cast<double2*>(a.S + (size_t)(a.R0 + r) * a.ld + col0);
+    double2* bp = reinterpret_cast<double2*>(b + (long long)r * width);
+    for (int c = threadIdx.x; c < width / 2; c += 256) {
+      if (unpack) sp[c] = bp[c]; else bp[c] = sp[c];
+    }
   }
 }
-__global__ void k_transpose_square(const double* __restrict__ A, double* __restrict__ At, int n) {
-  __shared__ double t[32][33];
-  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
-  for (int r = threadIdx.y; r < 32; r += 8) t[r][threadIdx.x] = A[(size_t)(by + r) * kPanelWide + bx + threadIdx.x];
-  __syncthreads();
-  for (int r = threadIdx.y; r < 32; r += 8) At[(size_t)(bx + r) * kPanelWide + by + threadIdx.x] = t[threadIdx.x][r];
-  (void)n;
+static int dist_copy(const RectArgs& a, double* buf, long long rank_stride, int q_first, int q_count, int unpack, hipStream_t s) {
+  const int groups = (a.n_pad / kOwnGroup - a.g_begin + a.world) / a.world + 1;
+  if (groups <= 0 || q_count <= 0) return CBA_OK;
+  hipLaunchKernelGGL(k_dist_copy, dim3(128, (unsigned)groups, (unsigned)q_count), dim3(256), 0, s, a, buf, rank_stride, q_first, unpack);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
 }
-int ldlt_factor_distributed(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, int rank, int world,
-                            int (*exchange)(void* buf, int64_t count, void* user), void* user, double* stage, GemmStats* st) {
+size_t ldlt_dist_buffer_doubles(int n_pad, int world) {
+  if (world < 1) world = 1;
+  const size_t groups = (size_t)(n_pad + kOwnGroup - 1) / kOwnGroup;
+  const size_t per_rank = ((groups + world - 1) / world) * kOwnGroup * (size_t)n_pad;     // every transfer fits: <= n_pad rows of <= that many columns
+  const size_t packed = (size_t)n_pad * n_pad / 2 + 64 * (size_t)n_pad;
+  return std::max(per_rank * world, packed);
+}
+// The collectives through the caller's callback, or -- when only an all-reduce is available -- emulated with it (same
+// results, more bytes: the tests with several ranks on one GPU and hosts that have not been moved to cba_collective_fn yet)
+static int dist_collective(const DistComm& c, int op, double* send, double* recv, long long count, hipStream_t s2) {
+  if (c.collective) return c.collective(op, send, recv, (int64_t)count, c.collective_user) == 0 ? CBA_OK : CBA_ERR_STATE;
+  if (!c.allreduce) return CBA_ERR_STATE;
+  if (op == CBA_COLL_ALLREDUCE_SUM) return c.allreduce(recv, (int64_t)count, c.allreduce_user) == 0 ? CBA_OK : CBA_ERR_STATE;
+  if (op == CBA_COLL_REDUCE_SCATTER_SUM) {
+    if (c.allreduce(send, (int64_t)count * c.world, c.allreduce_user) != 0) return CBA_ERR_STATE;
+    CBA_HIP(hipMemcpyAsync(recv, send + (size_t)c.rank * count, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, s2));
+    CBA_HIP(hipStreamSynchronize(s2));
+    return CBA_OK;
+  }
+  CBA_HIP(hipMemsetAsync(recv, 0, sizeof(double) * (size_t)count * c.world, s2));
+  CBA_HIP(hipMemcpyAsync(recv + (size_t)c.rank * count, send, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, s2));
+  CBA_HIP(hipStreamSynchronize(s2));
+  return c.allreduce(recv, (int64_t)count * c.world, c.allreduce_user) == 0 ? CBA_OK : CBA_ERR_STATE;
+}
+// trailing update of the column groups this rank owns, rows [r_begin, r_end): C -= L^T X with K = W (one launch)
+static int dist_update(double* S, int ld, int k0, int W, int r_begin, int r_end, const DistComm& c, LdltWorkspace& w, hipStream_t s, GemmStats* st) {
   const int n_pad = ld;
-  double* inv_buf = w.inv_panel;      // 2 x 512 x 512 doubles (ldlt_workspace_alloc)
-  int kidx = 0;
-  for (int k0 = 0; k0 < n_fact; ++kidx) {
-    const int nb = (n_fact - k0 >= kPanelWide) ? kPanelWide : ((n_fact - k0 >= kPanel) ? kPanel : (n_fact - k0));
-    const int e0 = k0 + nb;
-    double* Xk = w.X + (size_t)(kidx & 1) * kPanelWide * n_pad;
-    int rc;
-    // (1) assemble the block row from the owners of its columns (the first panel is complete everywhere: S comes out of the
-    //     all-reduce of the reduced system)
-    if (k0 > 0 && world > 1) {
-      const int width = n_pad - k0;
-      dim3 grid((unsigned)((width + 255) / 256 < 64 ? (width + 255) / 256 : 64), (unsigned)nb);
-      hipLaunchKernelGGL(k_block_row_exchange, grid, dim3(256), 0, s, S, ld, k0, k0, width, stage, rank, world, 0);
-      CBA_HIP(hipStreamSynchronize(s));
-      if (exchange(stage, (int64_t)nb * width, user) != 0) return CBA_ERR_STATE;
-      hipLaunchKernelGGL(k_block_row_exchange, grid, dim3(256), 0, s, S, ld, k0, k0, width, stage, rank, world, 1);
+  if (r_end <= r_begin) return CBA_OK;
+  constexpr int G = kOwnGroup / 128;
+  int g0 = r_begin / kOwnGroup;                           // first group that reaches past row r_begin
+  while (g0 % c.world != c.rank) ++g0;
+  int owned_tiles = 0;
+  double tiles = 0;
+  for (int gi = g0; gi * kOwnGroup < n_pad; gi += c.world) {
+    const int hi = (gi + 1) * kOwnGroup < n_pad ? (gi + 1) * kOwnGroup : n_pad;
+    owned_tiles += (hi - gi * kOwnGroup) / 128;
+    for (int n0 = gi * kOwnGroup; n0 < hi; n0 += 128) {       // tiles at or above the diagonal (the others are skipped in the kernel)
+      const int last_row = n0 + 127 < r_end - 1 ? n0 + 127 : r_end - 1;
+      if (last_row >= r_begin) tiles += (last_row - r_begin) / 128 + 1;
     }
-    // (2) the panel, replicated
-    for (int j0 = k0; j0 < e0; j0 += kInner) {
-      const int c0 = j0 + kInner;
-      hipLaunchKernelGGL(k_ldlt_diag<kInner>, dim3(1), dim3(256), 0, s, S, ld, j0, w.dvec, w.invLt, w.status);
-      if (c0 < e0) {
-        if ((rc = trsm_cols(S, ld, j0, k0, c0, e0, Xk, w, s, kTlChainTrsm))) return rc;
-        if ((rc = update_block(S, ld, j0, k0, c0, e0, c0, e0, /*upper*/ 1, Xk, s, kTlChainUpd))) return rc;
-      }
-    }
-    if (n_pad > e0) {
-      if (nb == kPanelWide && inv_buf) {
-        // X = L_panel^-1 U as ONE product over the whole block row instead of the per-tile forward substitution (a chain of
-        // 8 dependent 64-blocks per 64-column tile, ~5 TFLOP/s -- hidden under the bulk update in the look-ahead schedule,
-        // exposed and replicated here): L_panel^-1 by substitution on the identity (8 workgroups), its transpose as the
-        // K-major operand, the product, then L = X / d in place.
-        double* Xinv = inv_buf;                                   // [nb][nb]
-        double* XinvT = inv_buf + (size_t)kPanelWide * kPanelWide;
-        hipLaunchKernelGGL(k_panel_solve_t<true>, dim3(nb / kInner), dim3(256), 0, s, S, ld, k0, nb, 0, Xinv, kPanelWide, w.dvec, w.invLt);
-        hipLaunchKernelGGL(k_transpose_square, dim3(nb / 32, nb / 32), dim3(32, 8), 0, s, Xinv, XinvT, nb);
-        GemmArgs g{};
-        g.A = XinvT; g.lda = kPanelWide; g.B = S + (size_t)k0 * ld; g.ldb = ld; g.K = nb;
-        g.C = Xk; g.ldc = n_pad; g.Cin = nullptr; g.ldcin = 0; g.diag = 0; g.upper = 0;
-        g.m_off = 0; g.m_tiles = nb / 128; g.n_off = e0; g.n_tiles = (n_pad - e0) / 128;
-        if ((rc = launch_gemm<128, 128, 64, 64, false>(g, s))) return rc;
-        hipLaunchKernelGGL(k_scale_rows, dim3(nb), dim3(256), 0, s, S, ld, k0, k0, e0, n_pad, Xk, n_pad, w.dvec);
-      } else {
-        hipLaunchKernelGGL(k_panel_solve_t<false>, dim3((n_pad - e0) / kInner), dim3(256), 0, s, S, ld, k0, nb, e0, Xk, n_pad, w.dvec, w.invLt);
-      }
-    }
-    // (3) trailing update of the column groups this rank owns, ONE launch: rows [e0, n_pad) x owned columns, tiles below the
-    //     diagonal skipped inside the kernel
-    {
-      constexpr int G = kOwnGroup / 128;
-      const int g_first = e0 / kOwnGroup;                                 // first group that reaches past the panel
-      int g0 = g_first;
-      while (g0 % world != rank) ++g0;
-      int owned_tiles = 0;
-      for (int gi = g0; gi * kOwnGroup < n_pad; gi += world) {
-        const int hi = (gi + 1) * kOwnGroup < n_pad ? (gi + 1) * kOwnGroup : n_pad;
-        owned_tiles += (hi - gi * kOwnGroup) / 128;
-      }
-      if (owned_tiles > 0 && e0 < n_pad) {
-        GemmArgs u{};
-        u.A = S + (size_t)k0 * ld; u.lda = ld; u.B = Xk; u.ldb = n_pad; u.K = nb;
-        u.C = S; u.ldc = ld; u.Cin = S; u.ldcin = ld; u.diag = 0; u.upper = 0;
-        u.m_off = e0; u.m_tiles = (n_pad - e0) / 128; u.n_off = g0 * kOwnGroup; u.n_tiles = owned_tiles;
-        u.col_group = G; u.col_stride = world;
-        if ((rc = launch_gemm<128, 128, 64, 64, true>(u, s))) return rc;
-        if (st) { const double rows = (double)(n_pad - e0); st->flops += rows * rows * nb / world; st->launches += 1; }
-      }
-    }
-    k0 = e0;
   }
+  if (owned_tiles == 0) return CBA_OK;
+  GemmArgs u{};
+  u.A = S + (size_t)k0 * ld; u.lda = ld; u.B = w.X; u.ldb = n_pad; u.K = W;
+  u.C = S; u.ldc = ld; u.Cin = S; u.ldcin = ld; u.diag = 0; u.upper = 0;
+  u.m_off = r_begin; u.m_tiles = (r_end - r_begin) / 128; u.n_off = g0 * kOwnGroup; u.n_tiles = owned_tiles;
+  u.col_group = G; u.col_stride = c.world;
+  int rc = timed_gemm128(u, s, w, st != nullptr, tiles);
+  if (rc) return rc;
+  if (st) { st->flops += tiles * 2.0 * 128 * 128 * W; st->launches += 1; }
+  return CBA_OK;
+}
+int ldlt_factor_distributed(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, const DistComm& c, GemmStats* st) {
+  const int n_pad = ld;
+  int W = super_width();
+  if (W <= 0 || W % kOwnGroup) W = 2048;
+  if (c.world < 1 || c.rank < 0 || c.rank >= c.world || !c.send || !c.recv) return CBA_ERR_ARG;
+  hipStream_t s2 = w.far_stream;
+  int nsp = 0;
+  for (int k0 = 0; n_fact - k0 > ldlt_tail_rows() + W / 2 && n_pad - (k0 + W) >= 1024; k0 += W) ++nsp;
+  int rc;
+  if (nsp == 0) {
+    // small systems: one dataflow launch on everything -- sum the packed upper triangle, factor replicated
+    if ((rc = launch_pack_upper(S, n_pad, c.send, 0, s))) return rc;
+    CBA_HIP(hipStreamSynchronize(s));
+    const long long packed = (long long)n_pad * (n_pad / 128 + 1) * 64;       // sum_i 128 (n_pad - 128 i)
+    if ((rc = dist_collective(c, CBA_COLL_ALLREDUCE_SUM, nullptr, c.send, packed, s2))) return rc;
+    if ((rc = launch_pack_upper(S, n_pad, c.send, 1, s))) return rc;
+    return ldlt_factor(S, n_fact, ld, w, s, st);
+  }
+  // (1) first band: contiguous rows of S, summed in place; its dataflow launch starts; the rest goes to its owners underneath.
+  //     The blocks of the reduce-scatter are packed first (second stream, next to the all-reduce of the band): queued behind
+  //     the dataflow launch the copy kernel would get the few workgroup slots that launch leaves.
+  CBA_HIP(hipStreamSynchronize(s));
+  RectArgs a0{S, ld, n_pad, W / kOwnGroup, c.world, W, 0};
+  long long count0 = 0;
+  for (int q = 0; q < c.world; ++q) count0 = std::max(count0, dist_count(a0, q));
+  if ((size_t)count0 * c.world > c.buf_doubles) return CBA_ERR_ARG;
+  if (count0 > 0 && (rc = dist_copy(a0, c.send, count0, 0, c.world, 0, s2))) return rc;          // every destination's block
+  if ((rc = dist_collective(c, CBA_COLL_ALLREDUCE_SUM, nullptr, S, (long long)W * ld, s2))) return rc;
+  // the first dataflow launch leaves workgroup slots free for the kernels of the reduce-scatter that runs next to it: with all
+  // 2 x CUs slots (and all LDS) taken by helpers, the collective's kernels start only when the helpers run out of tickets,
+  // i.e. after the launch (measured with one rank: the 430 MB copy took 1.57 ms next to a full launch, 0.18 ms alone)
+  static const int reserve = CBA_GETENV("CBA_DIST_RESERVE_WGS") ? atoi(CBA_GETENV("CBA_DIST_RESERVE_WGS")) : 64;
+  if ((rc = ldlt_tail(S, W, ld, 0, w, s, st, w.X, (c.world > 1 || c.collective) ? reserve : 0))) return rc;
+  {
+    if (count0 > 0) {
+      CBA_HIP(hipStreamSynchronize(s2));
+      if ((rc = dist_collective(c, CBA_COLL_REDUCE_SCATTER_SUM, c.send, c.recv, count0, s2))) return rc;
+      if ((rc = dist_copy(a0, c.recv, 0, c.rank, 1, 1, s2))) return rc;               // own groups back into S
+    }
+    CBA_HIP(hipEventRecord(w.ev_mid, s2));
+    CBA_HIP(hipStreamWaitEvent(s, w.ev_mid, 0));
+  }
+  // (2) super-panels
+  for (int k = 0; k < nsp; ++k) {
+    const int k0 = k * W, e0 = k0 + W;
+    const bool last = k == nsp - 1;
+    const int e1 = last ? n_pad : e0 + W;                  // rows every rank needs next: the next band, or all that is left
+    if (k > 0 && (rc = ldlt_tail(S, e0, ld, k0, w, s, st, w.X))) return rc;
+    if ((rc = dist_update(S, ld, k0, W, e0, e1, c, w, s, st))) return rc;
+    CBA_HIP(hipEventRecord(w.ev_strip, s));
+    if (!last && (rc = dist_update(S, ld, k0, W, e1, n_pad, c, w, s, st))) return rc;
+    // gather rows [e0, e1) from the owners of their columns, next to the update of the rows below
+    CBA_HIP(hipStreamWaitEvent(s2, w.ev_strip, 0));
+    RectArgs a{S, ld, n_pad, e0 / kOwnGroup, c.world, e0, e1 - e0};
+    long long count = 0;
+    for (int q = 0; q < c.world; ++q) count = std::max(count, dist_count(a, q));
+    if ((size_t)count * c.world > c.buf_doubles) return CBA_ERR_ARG;
+    if (c.world > 1 || c.collective) {
+      if ((rc = dist_copy(a, c.send, 0, c.rank, 1, 0, s2))) return rc;
+      CBA_HIP(hipStreamSynchronize(s2));
+      if ((rc = dist_collective(c, CBA_COLL_ALLGATHER, c.send, c.recv, count, s2))) return rc;
+      if ((rc = dist_copy(a, c.recv, count, 0, c.world, 1, s2))) return rc;
+    }
+    CBA_HIP(hipEventRecord(w.ev_mid, s2));
+    CBA_HIP(hipStreamWaitEvent(s, w.ev_mid, 0));
+  }
+  // (3) the rest, replicated
+  if ((rc = ldlt_tail(S, n_fact, ld, nsp * W, w, s, st))) return rc;
   CBA_HIP(hipGetLastError());
   return CBA_OK;
 }

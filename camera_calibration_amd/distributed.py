@@ -113,6 +113,7 @@ class NativeRccl:
         if self.lib.cba_rccl_create_via_file(rank, world, id_file.encode(), device, ctypes.byref(self.user)) != 0:
             raise RuntimeError("cba_rccl_create_via_file: " + self.lib.cba_rccl_last_error().decode())
         self.fn = ctypes.cast(self.lib.cba_rccl_allreduce, ctypes.c_void_p)
+        self.collective_fn = ctypes.cast(self.lib.cba_rccl_collective, ctypes.c_void_p)      # cba_config.collective
 
     def close(self):
         if self.user:
@@ -179,39 +180,198 @@ def solve_reduced(S_upper_sum: np.ndarray, s_sum: np.ndarray, lam: float) -> np.
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# Host mirror of the distributed factorisation schedule (csrc/kernels_linalg.hip: ldlt_factor_distributed), numpy.
-# Same ownership rule, same three phases per panel; `exchange(buf)` sums a float64 array over the ranks in place.
-# Used by the CPU tests of the multi-rank path (gloo, world size 2) -- the device kernels are covered on the GPU.
+# cba_collective_fn for the distributed reduced solve: reduce-scatter / all-gather on raw device pointers.
 # ---------------------------------------------------------------------------------------------------------------
-def distributed_ldlt_upper(S, rank: int, world: int, exchange, group: int = 512, panel: int = 512):
-    """S: (n, n) symmetric positive definite, upper triangle valid (modified in place).  Every rank passes the SAME matrix
-    (the all-reduced reduced system).  Returns (L, d) with S = L diag(d) L^T, complete on every rank."""
-    n = S.shape[0]
-    S = S.copy()
-    iu = np.triu_indices(n, 1)
-    S[(iu[1], iu[0])] = 0.0                                   # keep the upper triangle only, like the device storage
-    owner = (np.arange(n) // group) % world
+COLL_ALLREDUCE_SUM, COLL_REDUCE_SCATTER_SUM, COLL_ALLGATHER = 0, 1, 2
+
+
+class _DeviceView:
+    """A raw device pointer as a 1-D fp64 array for torch (zero copy, __cuda_array_interface__ v2)."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def make_collective(local_rank: int):
+    """collective(op, send_ptr, recv_ptr, count) -> 0 with torch.distributed (backend nccl = RCCL over xGMI): ncclAllReduce /
+    ncclReduceScatter / ncclAllGather straight on the engine's staging buffers; waits on torch's current stream only."""
+    import torch
+    import torch.distributed as dist
+
+    dev = torch.device("cuda", local_rank)
+
+    def view(ptr, count):
+        return torch.as_tensor(_DeviceView(ptr, count), device=dev)
+
+    def collective(op: int, send: int, recv: int, count: int) -> int:
+        world = dist.get_world_size()
+        if op == COLL_ALLREDUCE_SUM:
+            dist.all_reduce(view(recv, count))
+        elif op == COLL_REDUCE_SCATTER_SUM:
+            dist.reduce_scatter_tensor(view(recv, count), view(send, count * world))
+        elif op == COLL_ALLGATHER:
+            dist.all_gather_into_tensor(view(recv, count * world), view(send, count))
+        else:
+            return 1
+        torch.cuda.current_stream().synchronize()
+        return 0
+
+    return collective
+
+
+def make_collective_host_staged():
+    """The same three collectives through HOST memory with whatever process group is initialised (gloo): several ranks on ONE
+    GPU in the tests (RCCL refuses two ranks on one device)."""
+    import torch
+    import torch.distributed as dist
+
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipMemcpy.restype = ctypes.c_int
+    D2H, H2D = 2, 1
+
+    def pull(ptr, count):
+        host = np.empty(count, dtype=np.float64)
+        if hip.hipMemcpy(host.ctypes.data, ptr, count * 8, D2H) != 0:
+            raise RuntimeError("hipMemcpy D2H")
+        return host
+
+    def push(ptr, host):
+        if hip.hipMemcpy(ptr, host.ctypes.data, host.size * 8, H2D) != 0:
+            raise RuntimeError("hipMemcpy H2D")
+
+    def collective(op: int, send: int, recv: int, count: int) -> int:
+        world, rank = dist.get_world_size(), dist.get_rank()
+        if op == COLL_ALLREDUCE_SUM:
+            h = pull(recv, count)
+            dist.all_reduce(torch.from_numpy(h))
+            push(recv, h)
+        elif op == COLL_REDUCE_SCATTER_SUM:          # gloo has no reduce-scatter: sum everything, keep the own block
+            h = pull(send, count * world)
+            dist.all_reduce(torch.from_numpy(h))
+            push(recv, np.ascontiguousarray(h[rank * count:(rank + 1) * count]))
+        elif op == COLL_ALLGATHER:
+            h = pull(send, count)
+            out = [torch.empty(count, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(out, torch.from_numpy(h))
+            push(recv, np.concatenate([t.numpy() for t in out]))
+        else:
+            return 1
+        return 0
+
+    return collective
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Host mirror of the distributed factorisation schedule (csrc/kernels_linalg.hip: ldlt_factor_distributed), numpy: same
+# ownership rule, same transfers (dist_rect: which rows of which column groups travel, and where they sit in the
+# buffers), same order of collectives.  `collective(op, send, recv)` works on float64 arrays (recv in place), with
+# the semantics of cba_collective_fn.  Used by the CPU tests of the multi-rank path (gloo, world size 2 and 3) with the
+# schedule scaled down (group / W / tail_rows are parameters) -- the device kernels are covered on the GPU.
+# ---------------------------------------------------------------------------------------------------------------
+def dist_rect(n_pad: int, group: int, g_begin: int, world: int, R0: int, nrows: int, q: int, i: int):
+    """i-th column group of rank q in a transfer: (col0, width, height, offset in q's block) or None (kernels_linalg.hip: dist_rect)."""
+    gq0 = g_begin + (q - g_begin % world) % world
+    g = gq0 + i * world
+    col0 = g * group
+    if col0 >= n_pad:
+        return None
+    width = min(group, n_pad - col0)
+    if nrows > 0:
+        return col0, width, nrows, i * nrows * group
+    h0 = (gq0 + 1) * group - R0
+    height = min(col0 + group, n_pad) - R0
+    return col0, width, height, group * (i * h0 + world * group * (i * (i - 1) // 2))
+
+
+def _dist_rects(n_pad, group, g_begin, world, R0, nrows, q):
+    out, i = [], 0
+    while True:
+        r = dist_rect(n_pad, group, g_begin, world, R0, nrows, q, i)
+        if r is None:
+            return out
+        out.append(r)
+        i += 1
+
+
+def _dist_count(n_pad, group, g_begin, world, R0, nrows):
+    count = 0
+    for q in range(world):
+        for col0, width, height, off in _dist_rects(n_pad, group, g_begin, world, R0, nrows, q):
+            count = max(count, off + height * width)
+    return count
+
+
+def _dist_copy(S, buf, n_pad, group, g_begin, world, R0, nrows, q, unpack):
+    for col0, width, height, off in _dist_rects(n_pad, group, g_begin, world, R0, nrows, q):
+        blk = buf[off:off + height * width].reshape(height, width)
+        if unpack:
+            S[R0:R0 + height, col0:col0 + width] = blk
+        else:
+            blk[:, :] = S[R0:R0 + height, col0:col0 + width]
+
+
+def distributed_ldlt_upper(S_partial, rank: int, world: int, collective, group: int = 512, W: int = 2048, tail_rows: int = 6144):
+    """S_partial: (n, n), this rank's PARTIAL sum of the symmetric positive definite reduced system (upper triangle valid;
+    n a multiple of `group`'s tile, W a multiple of `group`).  Returns (L, d) of the SUM over ranks, S = L diag(d) L^T,
+    complete and identical on every rank."""
+    n = S_partial.shape[0]
+    S = np.triu(S_partial).copy()                       # keep the upper triangle only, like the device storage
     L = np.eye(n)
     d = np.zeros(n)
-    for k0 in range(0, n, panel):
-        e0 = min(k0 + panel, n)
-        if k0 > 0 and world > 1:                              # (1) assemble the block row from the owners of its columns
-            buf = np.where(owner[None, k0:] == rank, S[k0:e0, k0:], 0.0)
-            exchange(buf)
-            S[k0:e0, k0:] = buf
-        X = np.zeros((e0 - k0, n - k0))                       # (2) the panel, replicated: unblocked LDL^T of the block row
+    owner = (np.arange(n) // group) % world
+
+    def factor_rows(k0, e0):                            # the dataflow launch: rows [k0, e0) with their whole row strip
         for j in range(k0, e0):
             d[j] = S[j, j]
-            L[j + 1:, j] = S[j, j + 1:] / d[j]                # row j of the upper storage holds column j of L (times d)
-            X[j - k0, j + 1 - k0:] = S[j, j + 1:]
-            # eliminate within the block row
+            L[j + 1:, j] = S[j, j + 1:] / d[j]
             for i in range(j + 1, e0):
                 S[i, i:] -= L[i, j] * S[j, i:]
-        # (3) trailing update of the owned columns: S[m][c] -= sum_p L[m][p] d_p L[c][p], rows e0 <= m <= c
-        own = np.nonzero(owner[e0:] == rank)[0] + e0
-        if own.size:
-            Lp = L[e0:, k0:e0]                                # (n - e0) x nb
-            upd = (Lp * d[k0:e0]) @ Lp.T                      # symmetric; only the owned columns' upper part is used
-            for c in own:
-                S[e0:c + 1, c] -= upd[:c + 1 - e0, c - e0]
+
+    def update_owned(k0, e0, r_begin, r_end):           # rows [r_begin, r_end) of the owned columns -= L^T D L with K = [k0, e0)
+        if r_end <= r_begin:
+            return
+        Lr = L[r_begin:r_end, k0:e0] * d[k0:e0]
+        for c in np.nonzero(owner == rank)[0]:
+            if c < r_begin:
+                continue
+            hi = min(c + 1, r_end)
+            S[r_begin:hi, c] -= Lr[:hi - r_begin] @ L[c, k0:e0]
+
+    nsp, k0 = 0, 0
+    while n - k0 > tail_rows + W // 2 and n - (k0 + W) >= W // 2:
+        nsp += 1
+        k0 += W
+    if nsp == 0:
+        collective(COLL_ALLREDUCE_SUM, None, S.reshape(-1))
+        factor_rows(0, n)
+        return L, d
+    # (1) first band summed everywhere, the rest reduce-scattered into the owners
+    band = S[:W].reshape(-1)
+    collective(COLL_ALLREDUCE_SUM, None, band)
+    count = _dist_count(n, group, W // group, world, W, 0)
+    send = np.zeros(world * count)
+    recv = np.zeros(count)
+    for q in range(world):
+        _dist_copy(S, send[q * count:(q + 1) * count], n, group, W // group, world, W, 0, q, unpack=False)
+    collective(COLL_REDUCE_SCATTER_SUM, send, recv)
+    _dist_copy(S, recv, n, group, W // group, world, W, 0, rank, unpack=True)
+    # (2) super-panels
+    for k in range(nsp):
+        k0, e0 = k * W, k * W + W
+        last = k == nsp - 1
+        e1 = n if last else e0 + W
+        factor_rows(k0, e0)
+        update_owned(k0, e0, e0, e1)
+        if not last:
+            update_owned(k0, e0, e1, n)
+        count = _dist_count(n, group, e0 // group, world, e0, e1 - e0)
+        send = np.zeros(count)
+        recv = np.zeros(world * count)
+        _dist_copy(S, send, n, group, e0 // group, world, e0, e1 - e0, rank, unpack=False)
+        collective(COLL_ALLGATHER, send, recv)
+        for q in range(world):
+            _dist_copy(S, recv[q * count:(q + 1) * count], n, group, e0 // group, world, e0, e1 - e0, q, unpack=True)
+    # (3) the rest, replicated
+    factor_rows(nsp * W, n)
     return L, d

@@ -32,6 +32,8 @@ class CbaCamera(C.Structure):
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p)
+COLLECTIVE_FN = C.CFUNCTYPE(C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)   # cba_collective_fn
+COLL_ALLREDUCE_SUM, COLL_REDUCE_SCATTER_SUM, COLL_ALLGATHER = 0, 1, 2
 
 
 class CbaConfig(C.Structure):
@@ -42,7 +44,8 @@ class CbaConfig(C.Structure):
                 ("allreduce", ALLREDUCE_FN), ("allreduce_user", C.c_void_p),
                 ("n_images_global", C.c_int32),
                 ("reduce_buffer", C.c_void_p), ("reduce_buffer_doubles", C.c_int64),
-                ("deterministic", C.c_int32), ("distributed_solve", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32)]
+                ("deterministic", C.c_int32), ("distributed_solve", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
+                ("collective", COLLECTIVE_FN), ("collective_user", C.c_void_p)]
 
 
 class CbaFitReport(C.Structure):
@@ -195,7 +198,8 @@ class Engine:
     def __init__(self, problem: Problem, device: int = 0, allreduce: Optional[Callable[[int, int], int]] = None,
                  n_images_global: int = 0, reduce_buffer_ptr: int = 0, reduce_buffer_doubles: int = 0,
                  last_projection: Optional[np.ndarray] = None, deterministic: bool = False,
-                 allreduce_native: Optional[tuple] = None, distributed_solve: bool = False, rank: int = 0, world_size: int = 1):
+                 allreduce_native: Optional[tuple] = None, distributed_solve: bool = False, rank: int = 0, world_size: int = 1,
+                 collective: Optional[Callable[[int, int, int, int], int]] = None, collective_native: Optional[tuple] = None):
         self.L = load()
         self.problem = problem
         self._cams = (CbaCamera * problem.n_cameras)(*[_cam_struct(c) for c in problem.cameras])
@@ -212,10 +216,25 @@ class Engine:
         cb, user = (self._cb if self._cb is not None else ALLREDUCE_FN(0)), None
         if allreduce_native is not None:     # (C function pointer, user pointer), e.g. distributed.NativeRccl.fn / .user
             cb, user = C.cast(allreduce_native[0], ALLREDUCE_FN), allreduce_native[1]
+        # collective(op, send_ptr, recv_ptr, count) -> 0: reduce-scatter / all-gather of the distributed solve (cba_collective_fn)
+        self._ccb = None
+        if collective is not None:
+            def _ccb(op, send, recv, count, user, _f=collective):
+                try:
+                    return int(_f(int(op), int(send or 0), int(recv or 0), int(count)) or 0)
+                except Exception:
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._ccb = COLLECTIVE_FN(_ccb)
+        ccb, cuser = (self._ccb if self._ccb is not None else COLLECTIVE_FN(0)), None
+        if collective_native is not None:
+            ccb, cuser = C.cast(collective_native[0], COLLECTIVE_FN), collective_native[1]
         cfg = CbaConfig(problem.n_cameras, self._cams, problem.n_images, problem.n_points, problem.fd_delta,
                         int(problem.localize_only), int(problem.eliminate_points), device,
                         cb, user, n_images_global,
-                        reduce_buffer_ptr or None, reduce_buffer_doubles, int(deterministic), int(distributed_solve), int(rank), int(world_size))
+                        reduce_buffer_ptr or None, reduce_buffer_doubles, int(deterministic), int(distributed_solve), int(rank), int(world_size),
+                        ccb, cuser)
         self._cfg = cfg
         self._h = C.c_void_p()
         _check(self.L.cba_create(C.byref(cfg), C.byref(self._h)), "cba_create")
@@ -228,10 +247,11 @@ class Engine:
             "cba_set_observations")
 
     @staticmethod
-    def reduce_buffer_doubles(problem: Problem) -> int:
+    def reduce_buffer_doubles(problem: Problem, distributed_solve: bool = False, world_size: int = 1) -> int:
         cams = (CbaCamera * problem.n_cameras)(*[_cam_struct(c) for c in problem.cameras])
         cfg = CbaConfig(problem.n_cameras, cams, problem.n_images, problem.n_points, problem.fd_delta,
-                        int(problem.localize_only), int(problem.eliminate_points), 0, ALLREDUCE_FN(0), None, 0, None, 0, 0)
+                        int(problem.localize_only), int(problem.eliminate_points), 0, ALLREDUCE_FN(0), None, 0, None, 0, 0,
+                        int(distributed_solve), 0, int(world_size), COLLECTIVE_FN(0), None)
         return int(load().cba_reduce_buffer_doubles(C.byref(cfg)))
 
     def close(self) -> None:

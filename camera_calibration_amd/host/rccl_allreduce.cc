@@ -123,4 +123,28 @@ int cba_rccl_allreduce(void* device_ptr, int64_t count, void* user) {
   return 0;
 }
 
+// cba_collective_fn (include/cba.h): the collectives of the distributed reduced solve, same stream discipline
+int cba_rccl_collective(int32_t op, void* sendbuf, void* recvbuf, int64_t count, void* user) {
+  cba_rccl* c = static_cast<cba_rccl*>(user);
+  if (!c || !recvbuf || count < 0) return fail("cba_rccl_collective", "bad argument");
+  if (count == 0) return 0;
+  switch (op) {
+    case 0:   // CBA_COLL_ALLREDUCE_SUM
+      RCCL_TRY(ncclAllReduce(recvbuf, recvbuf, (size_t)count, ncclDouble, ncclSum, c->comm, c->stream));
+      break;
+    case 1:   // CBA_COLL_REDUCE_SCATTER_SUM
+      if (!sendbuf) return fail("cba_rccl_collective", "reduce-scatter without a send buffer");
+      RCCL_TRY(ncclReduceScatter(sendbuf, recvbuf, (size_t)count, ncclDouble, ncclSum, c->comm, c->stream));
+      break;
+    case 2:   // CBA_COLL_ALLGATHER
+      if (!sendbuf) return fail("cba_rccl_collective", "all-gather without a send buffer");
+      RCCL_TRY(ncclAllGather(sendbuf, recvbuf, (size_t)count, ncclDouble, c->comm, c->stream));
+      break;
+    default:
+      return fail("cba_rccl_collective", "unknown operation");
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 }  // extern "C"

@@ -55,6 +55,17 @@ typedef struct {
  * engine's stream idle; must return after the reduced values are visible on the device. */
 typedef int (*cba_allreduce_fn)(void* device_ptr, int64_t count, void* user);
 
+/* Collectives of the distributed reduced solve (optional, cba_config.collective).  Blocking host call on DEVICE fp64
+ * buffers; the buffers' producers have completed when it is called, other engine work may be running on the device (the
+ * call is what that work overlaps with), and the results must be visible on the device when it returns.  `count` is the
+ * per-rank block size in doubles:
+ *   CBA_COLL_ALLREDUCE_SUM       recvbuf[count] summed over the ranks in place (sendbuf unused)
+ *   CBA_COLL_REDUCE_SCATTER_SUM  sendbuf[world * count], block r summed over the ranks into rank r's recvbuf[count]   (ncclReduceScatter)
+ *   CBA_COLL_ALLGATHER           sendbuf[count] of rank r into block r of every rank's recvbuf[world * count]        (ncclAllGather)
+ * Returns 0 on success. */
+enum { CBA_COLL_ALLREDUCE_SUM = 0, CBA_COLL_REDUCE_SCATTER_SUM = 1, CBA_COLL_ALLGATHER = 2 };
+typedef int (*cba_collective_fn)(int32_t op, void* sendbuf, void* recvbuf, int64_t count, void* user);
+
 typedef struct {
   int32_t n_cameras;
   const cba_camera* cameras;
@@ -80,16 +91,22 @@ typedef struct {
    * the finite-difference noise of the Jacobians (1e-9 relative).  Costs about 1 ms per LM iteration at BASELINE configs[1]
    * (DESIGN.md section 4a).  0 = fp64 atomics. */
   int32_t deterministic;
-  /* Distributed reduced solve (multi-GPU, optional; needs `allreduce`).  0: the factorisation of the reduced system is
-   * replicated on every rank (right up to D ~ 20 000: 17 ms at BASELINE configs[1]).  1: the 512-column groups of the
-   * trailing matrix are owned block-cyclically by the ranks; every rank factors the current panel (identical arithmetic on
-   * identical data), applies the trailing update only to its own column groups, and the panel's block row is assembled
-   * from its owners with one `allreduce` per panel before it is factored -- the volume of all panels together is the
-   * size of the matrix.  For reduced systems like BASELINE configs[4] (D = 42 789: 0.45 s of replicated factorisation
-   * against 35 ms of sharded work per step).  `rank` / `world_size` describe the communicator behind `allreduce`. */
+  /* Distributed reduced solve (multi-GPU, optional; needs `allreduce`).  0: the reduced system is all-reduced and its
+   * factorisation replicated on every rank (14 ms at BASELINE configs[1]).  1: the two-level factorisation is split -- the
+   * 512-column groups of the reduced system are owned block-cyclically by the ranks; the partial systems are reduce-scattered
+   * straight into the owners (only the first 2048 rows are all-reduced); per super-panel of 2048 rows every rank runs the
+   * latency-bound dataflow launch on the complete row band (identical arithmetic on identical data) and applies the K = 2048
+   * trailing update only to its own column groups, next band first, which is then all-gathered from its owners while the
+   * rest of the update is still running.  Link volume per solve = that of the one all-reduce it replaces.  For reduced
+   * systems like BASELINE configs[4] (D = 42 789: 0.45 s of replicated factorisation against 35 ms of sharded work per step).
+   * `rank` / `world_size` describe the communicator behind `allreduce` / `collective`. */
   int32_t distributed_solve;
   int32_t rank;
   int32_t world_size;
+  /* reduce-scatter / all-gather of the distributed solve (optional: without it they are emulated with `allreduce`, same
+   * results, 2-world x the bytes) */
+  cba_collective_fn collective;
+  void* collective_user;
 } cba_config;
 
 /* OptimizationReport (LV/lm_optimizer.h:55-77) + what OptimizeJointly returns through pointers */

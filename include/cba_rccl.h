@@ -30,6 +30,9 @@ void cba_rccl_destroy(cba_rccl* c);
 /* cba_allreduce_fn: in-place fp64 sum of a DEVICE buffer over all ranks; `user` is the cba_rccl*.  Enqueues
  * ncclAllReduce on the communicator's own stream and waits for THAT stream only (no device-wide synchronisation). */
 int cba_rccl_allreduce(void* device_ptr, int64_t count, void* user);
+/* cba_collective_fn: ncclAllReduce / ncclReduceScatter / ncclAllGather (fp64) for cba_config.collective -- the reduce-scatter
+ * and all-gathers of the distributed reduced solve; same stream discipline as above. */
+int cba_rccl_collective(int32_t op, void* sendbuf, void* recvbuf, int64_t count, void* user);
 const char* cba_rccl_last_error(void);
 
 #ifdef __cplusplus

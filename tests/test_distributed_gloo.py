@@ -162,30 +162,45 @@ def test_pack_unpack_roundtrip_and_block_offsets():
         np.testing.assert_array_equal(S2[128 * blk:128 * blk + 128, 128 * blk:], S[128 * blk:128 * blk + 128, 128 * blk:])
 
 
-def _dist_ldlt_worker(rank, world, port, out_dir):
+def _gloo_collective(rank, world):
+    """cba_collective_fn semantics on numpy arrays through gloo (no reduce-scatter there: all-reduce + own block)."""
+    def collective(op, send, recv):
+        if op == dist_mod.COLL_ALLREDUCE_SUM:
+            dist.all_reduce(torch.from_numpy(recv))
+        elif op == dist_mod.COLL_REDUCE_SCATTER_SUM:
+            t = torch.from_numpy(send.copy())
+            dist.all_reduce(t)
+            count = recv.size
+            recv[:] = t.numpy()[rank * count:(rank + 1) * count]
+        else:
+            out = [torch.empty(send.size, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(out, torch.from_numpy(send))
+            recv[:] = np.concatenate([t.numpy() for t in out])
+    return collective
+
+
+def _dist_ldlt_worker(rank, world, port, out_dir, n, group, W, tail_rows):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    rng = np.random.default_rng(5)
-    n = 7 * 64 + 32
-    A = rng.standard_normal((n, n + 40))
-    S = A @ A.T + 0.5 * np.eye(n)
-
-    def exchange(buf):
-        t = torch.from_numpy(buf)
-        dist.all_reduce(t)
-
-    L, d = dist_mod.distributed_ldlt_upper(S, rank, world, exchange, group=64, panel=128)
-    np.savez(os.path.join(out_dir, f"ldlt{rank}.npz"), L=L, d=d, S=S)
+    # every rank holds a different partial sum; the sum is symmetric positive definite
+    parts = []
+    for q in range(world):
+        rng = np.random.default_rng(5 + q)
+        A = rng.standard_normal((n, n // world + 40))
+        parts.append(A @ A.T + 0.5 / world * np.eye(n))
+    L, d = dist_mod.distributed_ldlt_upper(parts[rank], rank, world, _gloo_collective(rank, world), group=group, W=W, tail_rows=tail_rows)
+    np.savez(os.path.join(out_dir, f"ldlt{rank}.npz"), L=L, d=d, S=sum(parts))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_distributed_factorisation_schedule_on_cpu(tmp_path, world):
-    """Host mirror of ldlt_factor_distributed (cba_config.distributed_solve): block-cyclic ownership of column groups, the
-    panel's block row assembled from its owners with one all-reduce, the panel factored on every rank, the trailing update
-    applied to owned columns only.  Every rank must end up with the same complete factor, and L D L^T must be S."""
-    mp.spawn(_dist_ldlt_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("world,n,group,W,tail_rows", [(2, 480, 32, 64, 160), (3, 480, 32, 64, 160), (2, 416, 32, 128, 96), (3, 200, 32, 64, 300)])
+def test_distributed_factorisation_schedule_on_cpu(tmp_path, world, n, group, W, tail_rows):
+    """Host mirror of ldlt_factor_distributed (cba_config.distributed_solve), scaled down: first band all-reduced, the rest
+    reduce-scattered into the block-cyclic owners of the column groups, every band factored on every rank, trailing updates on
+    owned columns only, next band all-gathered from its owners, last rows replicated (the last case has no super-panel at all:
+    the packed all-reduce path).  Every rank must end up with the same complete factor of the SUM of the partial systems."""
+    mp.spawn(_dist_ldlt_worker, args=(world, _free_port(), str(tmp_path), n, group, W, tail_rows), nprocs=world, join=True)
     out = [np.load(os.path.join(str(tmp_path), f"ldlt{k}.npz")) for k in range(world)]
     S = out[0]["S"]
     for k in range(world):
@@ -193,6 +208,24 @@ def test_distributed_factorisation_schedule_on_cpu(tmp_path, world):
         assert np.all(d > 0)
         assert np.abs((L * d) @ L.T - S).max() <= 1e-10 * np.abs(S).max()
         assert np.array_equal(L, out[0]["L"]) and np.array_equal(d, out[0]["d"])       # identical arithmetic on identical data
-    # and it is the factorisation a single process computes
-    L1, d1 = dist_mod.distributed_ldlt_upper(S, 0, 1, lambda buf: None, group=64, panel=128)
-    assert np.abs(L1 - out[0]["L"]).max() <= 1e-11 and np.abs(d1 - out[0]["d"]).max() <= 1e-10 * d1.max()
+    # and it is the factorisation a single process computes from the sum
+    L1, d1 = dist_mod.distributed_ldlt_upper(S, 0, 1, lambda op, send, recv: recv.__setitem__(slice(None), send) if op != 0 else None,
+                                             group=group, W=W, tail_rows=tail_rows)
+    assert np.abs(L1 - out[0]["L"]).max() <= 1e-10 and np.abs(d1 - out[0]["d"]).max() <= 1e-10 * d1.max()
+
+
+def test_transfer_layout_matches_the_device_kernels():
+    """dist_rect (distributed.py) against the closed forms of kernels_linalg.hip: the blocks of one rank are contiguous, in
+    group order, and disjoint; every column group at or right of the first row is covered exactly once over the ranks."""
+    for n_pad, group, world, R0, nrows in [(12672, 512, 8, 2048, 0), (12672, 512, 3, 4096, 2048), (42880, 512, 8, 2048, 0), (1152, 512, 2, 512, 640)]:
+        g_begin = R0 // group
+        seen = set()
+        for q in range(world):
+            end = 0
+            for col0, width, height, off in dist_mod._dist_rects(n_pad, group, g_begin, world, R0, nrows, q):
+                assert off == end and (col0 // group) % world == q and col0 >= g_begin * group
+                assert height == (nrows if nrows else min(col0 + group, n_pad) - R0) and 0 < width <= group
+                end = off + height * width
+                seen.add(col0)
+            assert end <= dist_mod._dist_count(n_pad, group, g_begin, world, R0, nrows)
+        assert seen == set(range(g_begin * group, n_pad, group))

@@ -31,22 +31,29 @@ def _free_port():
     return p
 
 
-def _problem():
-    return syn.baseline_config(3, lambda cam, grid, pts: eng.project(cam, grid, pts), n_imagesets=24, grid_wh=(20, 16))
+def _problem(grid_wh=(20, 16)):
+    return syn.baseline_config(3, lambda cam, grid, pts: eng.project(cam, grid, pts), n_imagesets=24, grid_wh=grid_wh)
 
 
-def _worker(rank, world, port, out_dir, distributed_solve=False):
+DIST_GRID = (30, 24)       # D = 5337: with 512 rows left to the final launch the distributed schedule has two super-panels
+DIST_TAIL_ROWS = 512
+
+
+def _worker(rank, world, port, out_dir, distributed_solve=False, use_collective=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     eng.prepare(0)
-    pb, st, _ = _problem()
+    if distributed_solve:
+        eng.set_factor_tail_rows(DIST_TAIL_ROWS)
+    pb, st, _ = _problem(DIST_GRID if distributed_solve else (20, 16))
     shards = dist_mod.shard_images(np.bincount(pb.obs_image, minlength=pb.n_images), world)
     b, e = shards[rank]
     sub, sst = pb.image_slice(b, e), st.image_slice(b, e)
     allreduce = dist_mod.make_allreduce_host_staged()
     en = eng.Engine(sub, device=0, allreduce=allreduce, n_images_global=pb.n_images, deterministic=True,
-                    last_projection=sub.obs_xy.astype(np.float64), distributed_solve=distributed_solve, rank=rank, world_size=world)
+                    last_projection=sub.obs_xy.astype(np.float64), distributed_solve=distributed_solve, rank=rank, world_size=world,
+                    collective=dist_mod.make_collective_host_staged() if use_collective else None)
     en.set_state(sst)
     lam = -1.0
     reps = []
@@ -99,27 +106,34 @@ def test_two_ranks_on_one_gpu_match_the_single_process_engine(tmp_path):
     check_equal(case, "step reports identical on both ranks", int(np.count_nonzero(rk[0]["reps"] != rk[1]["reps"])))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_two_ranks_with_the_distributed_factorisation(tmp_path, world):
-    """cba_config.distributed_solve: the 512-column groups of the reduced system are owned block-cyclically by the two ranks, a
-    panel's block row is assembled from its owners before every rank factors it, and each rank applies the trailing update to
-    its own columns only (kernels_linalg.hip: ldlt_factor_distributed).  Same three LM iterations as above against the
-    single-process engine (replicated look-ahead factorisation): same decisions, results equal to the rounding of two
-    different elimination schedules.  (Also with three ranks: uneven image shards, three-way column ownership.)"""
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True), nprocs=world, join=True)
-    pb, st, _ = _problem()
+@pytest.mark.parametrize("world,use_collective", [(2, False), (3, True)])
+def test_two_ranks_with_the_distributed_factorisation(tmp_path, world, use_collective):
+    """cba_config.distributed_solve (kernels_linalg.hip: ldlt_factor_distributed): the partial reduced systems are
+    reduce-scattered into the block-cyclic owners of the 512-column groups (first band all-reduced), every rank runs the dataflow
+    launch of each super-panel on the complete row band, applies the K = 2048 update to its own column groups only (next band
+    first) and the next band is all-gathered from its owners; two super-panels at this size (D = 5337, 512 rows left to the
+    final launch).  With two ranks the collectives are emulated through the all-reduce callback, with three (uneven image
+    shards, three-way ownership) they go through a cba_collective_fn (host-staged gloo).  Same three LM iterations against
+    the single-process engine: same decisions, results equal to the rounding of two different summation orders."""
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True, use_collective), nprocs=world, join=True)
+    pb, st, _ = _problem(DIST_GRID)
     en = eng.Engine(pb, deterministic=True, last_projection=pb.obs_xy.astype(np.float64))
-    en.set_state(st)
-    lam = -1.0
-    reps = []
-    for _ in range(STEPS):
-        r = en.step(lam)
-        lam = r.final_lambda
-        reps.append([r.initial_cost, r.final_cost, r.final_lambda, r.lm_attempts, float(r.accepted), r.n_residuals_valid])
-    ref = en.get_state(st)
-    en.close()
+    default_rows = eng.factor_tail_rows()
+    eng.set_factor_tail_rows(DIST_TAIL_ROWS)
+    try:
+        en.set_state(st)
+        lam = -1.0
+        reps = []
+        for _ in range(STEPS):
+            r = en.step(lam)
+            lam = r.final_lambda
+            reps.append([r.initial_cost, r.final_cost, r.final_lambda, r.lm_attempts, float(r.accepted), r.n_residuals_valid])
+        ref = en.get_state(st)
+    finally:
+        eng.set_factor_tail_rows(default_rows)
+        en.close()
     reps = np.array(reps)
-    case = f"{world} ranks on 1 GPU, distributed factorisation (cfg-3-shaped, 24 imagesets) vs single process"
+    case = f"{world} ranks on 1 GPU, distributed factorisation (cfg-3-shaped, 24 imagesets, 30x24 grids) vs single process"
     rk = [np.load(os.path.join(str(tmp_path), f"rank{k}.npz")) for k in range(world)]
     for k in range(world):
         check_equal(case, f"rank {k}: LM attempts / accept decisions / valid counts",
@@ -152,3 +166,31 @@ def test_native_rccl_callback_world_of_one(tmp_path):
     s1, s2 = e1.get_state(st), e2.get_state(st)
     check("native RCCL callback, world 1", "points abs", np.abs(s1.points - s2.points).max(), 2e-7)
     e1.close(); e2.close(); rc.close()
+
+
+def test_native_rccl_collective_world_of_one_distributed_solve(tmp_path):
+    """cba_rccl_collective (ncclAllReduce / ncclReduceScatter / ncclAllGather) behind cba_config.collective with a communicator
+    of one rank: the whole distributed schedule (two super-panels, every pack / collective / unpack) must reproduce the
+    single-GPU factorisation of the same system -- all columns owned, every transfer a copy through RCCL."""
+    pb, st, _ = _problem(DIST_GRID)
+    rc = dist_mod.NativeRccl(0, 1, str(tmp_path / "rccl_id"), 0)
+    default_rows = eng.factor_tail_rows()
+    eng.set_factor_tail_rows(DIST_TAIL_ROWS)
+    try:
+        e1 = eng.Engine(pb, deterministic=True)
+        e2 = eng.Engine(pb, deterministic=True, allreduce_native=(rc.fn, rc.user), n_images_global=pb.n_images, distributed_solve=True,
+                        rank=0, world_size=1, collective_native=(rc.collective_fn, rc.user))
+        e1.set_state(st); e2.set_state(st)
+        l1 = l2 = -1.0
+        for _ in range(3):
+            r1 = e1.step(l1); r2 = e2.step(l2)
+            l1, l2 = r1.final_lambda, r2.final_lambda
+            assert r1.accepted == r2.accepted and r1.lm_attempts == r2.lm_attempts
+            check("native RCCL collectives, world 1, distributed solve", "final cost rel", abs(r1.final_cost - r2.final_cost) / r1.final_cost, 5e-8)
+        s1, s2 = e1.get_state(st), e2.get_state(st)
+        check("native RCCL collectives, world 1, distributed solve", "points abs", np.abs(s1.points - s2.points).max(), 2e-7)
+        e1.close(); e2.close()
+    finally:
+        eng.set_factor_tail_rows(default_rows)
+        rc.close()
+
