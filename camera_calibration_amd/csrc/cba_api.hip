@@ -1078,6 +1078,15 @@ int64_t cba_fd_redo_overflow(cba_problem* p) {
       hipMemcpy(&v, p->fd_redo_count + 2, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return v;
 }
+int cba_debug_fd_redo_counts(cba_problem* p, int64_t out[3]) {
+  if (!p || !out || !p->fd_redo_count) { set_error("cba_debug_fd_redo_counts: bad argument"); return CBA_ERR_ARG; }
+  int v[3] = {0, 0, 0};
+  CBA_HIP(hipSetDevice(p->device));
+  CBA_HIP(hipStreamSynchronize(p->stream));
+  CBA_HIP(hipMemcpy(v, p->fd_redo_count, sizeof(v), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 3; ++i) out[i] = v[i];
+  return CBA_OK;
+}
 void cba_set_factor_tail_rows(int32_t rows) { ldlt_set_tail_rows(rows); }
 int32_t cba_factor_tail_rows(void) { return ldlt_tail_rows(); }
 

@@ -69,7 +69,7 @@ EXPORTED_SYMBOLS = [
     "cba_total_dof", "cba_dense_dof", "cba_jacobian_record_doubles", "cba_reduce_buffer_doubles",
     "cba_kernel_stats", "cba_fit_grid_to_directions", "cba_prepare_device",
     "cba_model_create", "cba_model_destroy", "cba_model_set_grid", "cba_model_project", "cba_model_unproject",
-    "cba_fd_redo_overflow", "cba_set_factor_tail_rows", "cba_factor_tail_rows",
+    "cba_fd_redo_overflow", "cba_set_factor_tail_rows", "cba_factor_tail_rows", "cba_debug_fd_redo_counts",
 ]
 
 DUMP_COST_VECTOR, DUMP_PIXELS, DUMP_FLAGS, DUMP_JACOBIANS = 1, 2, 3, 4
@@ -314,6 +314,13 @@ class Engine:
         self.L.cba_fd_redo_overflow.restype = C.c_int64
         self.L.cba_fd_redo_overflow.argtypes = [C.c_void_p]
         return int(self.L.cba_fd_redo_overflow(self._h))
+
+    def fd_redo_counts(self):
+        """cba_debug_fd_redo_counts: (main list, side-stream list, overflow) of the last Jacobian pass."""
+        out = (C.c_int64 * 3)()
+        self.L.cba_debug_fd_redo_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        _check(self.L.cba_debug_fd_redo_counts(self._h, out), "cba_debug_fd_redo_counts")
+        return int(out[0]), int(out[1]), int(out[2])
 
     def debug_accumulate(self) -> float:
         cost = C.c_double(0)

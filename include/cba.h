@@ -174,6 +174,9 @@ int cba_cost(cba_problem* p, double* cost, int64_t* n_valid, double* cost_vector
  * projection (the residual is kept, joint_optimization.cc:373-376) -- counted here so that it is never silent.  Expected: 0.
  * -1 on error.  (No reference counterpart.) */
 int64_t cba_fd_redo_overflow(cba_problem* p);
+/* Diagnostics: out[0] / out[1] = tasks of the last Jacobian pass that went to the gather-path follow-up list of the main /
+ * side-stream finite-difference launch, out[2] = the overflow count above. */
+int cba_debug_fd_redo_counts(cba_problem* p, int64_t out[3]);
 
 /* Scheduling knob of the reduced-system factorisation (process-wide; results change only in the last bits): the last `rows`
  * rows are factored by ONE persistent dataflow launch instead of the blocked multi-stream schedule.
