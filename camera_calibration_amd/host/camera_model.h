@@ -131,6 +131,27 @@ class NoncentralGenericModel : public CameraModel {
   const Image<Vec3d>& direction_grid() const { return m_direction_grid; }
   Image<Vec3d>& point_grid() { grid_changed(); return m_point_grid; }
   Image<Vec3d>& direction_grid() { grid_changed(); return m_direction_grid; }
+  // noncentral_generic.cc:136-146: the central model's direction grid, a zero point grid, its rectangle and size
+  void InitializeFromCentralGenericModel(const CentralGenericModel& other) {
+    m_direction_grid = other.grid();
+    m_point_grid.SetSize(m_direction_grid.width(), m_direction_grid.height());
+    for (size_t i = 0; i < (size_t)m_point_grid.width() * m_point_grid.height(); ++i) m_point_grid.data()[i] = Vec3d(0, 0, 0);
+    m_calibration_min_x = other.calibration_min_x(); m_calibration_min_y = other.calibration_min_y();
+    m_calibration_max_x = other.calibration_max_x(); m_calibration_max_y = other.calibration_max_y();
+    m_width = other.width(); m_height = other.height();
+    grid_changed();
+  }
+  // noncentral_generic.cc:148-154
+  void Scale(double factor) {
+    for (size_t i = 0; i < (size_t)m_point_grid.width() * m_point_grid.height(); ++i)
+      for (int k = 0; k < 3; ++k) m_point_grid.data()[i].v[k] *= factor;
+    grid_changed();
+  }
+  // same conversion as the central model (noncentral_generic.h, central_grid.h:150-154)
+  Vec2d PixelCornerConvToGridPoint(double x, double y) const {
+    return Vec2d(1.f + (m_point_grid.width() - 3.f) * (x - m_calibration_min_x) / (m_calibration_max_x + 1 - m_calibration_min_x),
+                 1.f + (m_point_grid.height() - 3.f) * (y - m_calibration_min_y) / (m_calibration_max_y + 1 - m_calibration_min_y));
+  }
   cba_camera abi_camera() const override {
     return cba_camera{CBA_NONCENTRAL_GENERIC, m_width, m_height, m_calibration_min_x, m_calibration_min_y, m_calibration_max_x,
                       m_calibration_max_y, (int)m_point_grid.width(), (int)m_point_grid.height()};

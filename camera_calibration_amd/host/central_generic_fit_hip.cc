@@ -102,8 +102,40 @@ bool CentralGenericModel::FitToDenseModel(const Image<Vec3d>& dense_model, int s
 
 bool ResampleModel(std::shared_ptr<CameraModel>& model_to_optimize, SE3d* /*camera_tr_rig*/, int calibration_min_x, int calibration_min_y,
                    int calibration_max_x, int calibration_max_y, CameraModel::Type model_type, int target_resolution_x, int target_resolution_y) {
+  // Special case non-central -> non-central (calibration.cc:386-425): both grids re-gridded bilinearly (host only; the result
+  // is an initial state for the next bundle adjustment, not a fit)
+  if (model_to_optimize->type() == CameraModel::Type::NoncentralGeneric && model_type == CameraModel::Type::NoncentralGeneric) {
+    NoncentralGenericModel* old = static_cast<NoncentralGenericModel*>(model_to_optimize.get());
+    Image<Vec3d> new_point_grid(target_resolution_x, target_resolution_y), new_direction_grid(target_resolution_x, target_resolution_y);
+    const int ow = old->point_grid().width(), oh = old->point_grid().height();
+    // libvis Image::InterpolateBilinear for Vec3d pixels (LV/image.h:152-176): the fractions are floats
+    auto bilinear = [](const Image<Vec3d>& img, double x, double y) {
+      const int ix = (int)x, iy = (int)y;
+      const float fx = (float)(x - ix), fy = (float)(y - iy), fxi = 1.f - fx, fyi = 1.f - fy;
+      const Vec3d &a = img(ix, iy), &b = img(ix + 1, iy), &c = img(ix, iy + 1), &d = img(ix + 1, iy + 1);
+      Vec3d r;
+      for (int k = 0; k < 3; ++k) r.v[k] = (double)(fxi * fyi) * a.v[k] + (double)(fx * fyi) * b.v[k] + (double)(fxi * fy) * c.v[k] + (double)(fx * fy) * d.v[k];
+      return r;
+    };
+    for (int y = 0; y < target_resolution_y; ++y)
+      for (int x = 0; x < target_resolution_x; ++x) {
+        // static GridPointToPixelCornerConv of the NEW grid (central_grid.h:132-140, evaluated in float)
+        const double px = calibration_min_x + ((x - 1.f) / (target_resolution_x - 3.f)) * (calibration_max_x + 1 - calibration_min_x);
+        const double py = calibration_min_y + ((y - 1.f) / (target_resolution_y - 3.f)) * (calibration_max_y + 1 - calibration_min_y);
+        Vec2d og = old->PixelCornerConvToGridPoint(px, py);
+        const double ogx = std::min(std::max(og.x(), 0.0), ow - 1.001), ogy = std::min(std::max(og.y(), 0.0), oh - 1.001);
+        new_point_grid(x, y) = bilinear(old->point_grid(), ogx, ogy);
+        new_direction_grid(x, y) = bilinear(old->direction_grid(), ogx, ogy);
+      }
+    auto* fresh = new NoncentralGenericModel(target_resolution_x, target_resolution_y, calibration_min_x, calibration_min_y,
+                                             calibration_max_x, calibration_max_y, model_to_optimize->width(), model_to_optimize->height());
+    fresh->SetPointGrid(new_point_grid);
+    fresh->SetDirectionGrid(new_direction_grid);
+    model_to_optimize.reset(fresh);
+    return true;
+  }
   if (model_to_optimize->type() != CameraModel::Type::CentralGeneric || model_type != CameraModel::Type::CentralGeneric) {
-    std::fprintf(stderr, "ResampleModel: only central-generic -> central-generic is built\n");
+    std::fprintf(stderr, "ResampleModel: built for central-generic -> central-generic and non-central -> non-central (the reference has no other non-central source case either, calibration.cc:427-430)\n");
     return false;
   }
   const int w = model_to_optimize->width(), h = model_to_optimize->height();

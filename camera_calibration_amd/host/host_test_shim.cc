@@ -250,6 +250,32 @@ extern "C" int cba_host_fit_and_resample(const cba_camera* cam, int dense_w, int
 }
 
 
+// F3, non-central helpers: InitializeFromCentralGenericModel (+ Scale of the point grid) and ResampleModel non-central ->
+// non-central.  grids_in / out: direction grid then point grid, 3 doubles per control point (the C-ABI layout).
+extern "C" int cba_host_noncentral_init_and_resample(const cba_camera* central_cam, const double* central_grid /*3G*/, const double* point_grid /*3G or null*/,
+                                                     double scale, double* init_out /*6G*/, int target_w, int target_h, double* resampled_out /*6 tw th*/) {
+  CentralGenericModel central(central_cam->grid_w, central_cam->grid_h, central_cam->calib_min_x, central_cam->calib_min_y, central_cam->calib_max_x,
+                              central_cam->calib_max_y, central_cam->width, central_cam->height);
+  central.set_abi_grid(central_grid);
+  NoncentralGenericModel* nc = new NoncentralGenericModel(4, 4, 0, 0, 1, 1, 2, 2);       // everything is overwritten by the initialisation
+  std::shared_ptr<CameraModel> m(nc);
+  nc->InitializeFromCentralGenericModel(central);
+  const size_t G = (size_t)central_cam->grid_w * central_cam->grid_h;
+  if (nc->width() != central_cam->width || nc->calibration_max_x() != central_cam->calib_max_x || nc->point_grid().width() != (u32)central_cam->grid_w) return -1;
+  if (point_grid) {
+    for (size_t i = 0; i < G; ++i) nc->point_grid().data()[i] = Vec3d(point_grid[3 * i], point_grid[3 * i + 1], point_grid[3 * i + 2]);
+    nc->Scale(scale);
+  }
+  std::vector<double> g = nc->abi_grid();
+  for (size_t i = 0; i < g.size(); ++i) init_out[i] = g[i];
+  SE3d dummy;
+  if (!ResampleModel(m, &dummy, central_cam->calib_min_x, central_cam->calib_min_y, central_cam->calib_max_x, central_cam->calib_max_y,
+                     CameraModel::Type::NoncentralGeneric, target_w, target_h)) return -2;
+  std::vector<double> g2 = m->abi_grid();
+  for (size_t i = 0; i < g2.size(); ++i) resampled_out[i] = g2[i];
+  return 0;
+}
+
 // F1 through the C++ mirror: ChooseNiceCameraOrientation on a central-generic grid (rotation 9 doubles row-major,
 // grid rotated in place) and ScaleToMetric on a one-geometry lattice (returns the scaled points).
 extern "C" int cba_host_nice_orientation(const cba_camera* cam, double* grid /*3G in/out*/, double* rotation9) {

@@ -197,3 +197,30 @@ def test_noncentral_resampling_and_initialisation():
         ref = (float((f(1) - fx) * (f(1) - fy)) * G[iy, ix] + float(fx * (f(1) - fy)) * G[iy, ix + 1] +
                float((f(1) - fx) * fy) * G[iy + 1, ix] + float(fx * fy) * G[iy + 1, ix + 1])
         np.testing.assert_allclose(g2[1].reshape(9, 12, 3)[y, x], ref, rtol=1e-15, atol=1e-18)
+
+
+def test_cpp_mirror_noncentral_helpers_match_python_mirror():
+    """NoncentralGenericModel::InitializeFromCentralGenericModel / Scale (noncentral_generic.cc:136-154) and the non-central
+    branch of ResampleModel (calibration.cc:386-425) of the C++ host mirror against the Python mirror -- host code only."""
+    import ctypes as C
+    from camera_calibration_amd import build, engine as eng
+    L = C.CDLL(build.build_host_test())
+    cam = Camera(0, W, H, 0, 0, W - 1, H - 1, 8, 6)
+    grid = grid_fit.initialize_grid_from_dense_model(cam, dense_pinhole(240, 240, 320, 240))
+    nc, grids = grid_fit.initialize_noncentral_from_central(cam, grid)
+    rng = np.random.default_rng(2)
+    pts = rng.normal(0, 1e-3, grids[1].shape)
+    grids[1] = 2.5 * pts
+    new_cam, g2 = grid_fit.resample_noncentral_model(nc, grids, 12, 9)
+    cs = eng._cam_struct(cam)
+    dp = C.POINTER(C.c_double)
+    init_out = np.zeros(6 * 48); res_out = np.zeros(6 * 108)
+    gflat = np.ascontiguousarray(grid, dtype=np.float64).ravel(); pflat = np.ascontiguousarray(pts).ravel()
+    L.cba_host_noncentral_init_and_resample.argtypes = [C.c_void_p, dp, dp, C.c_double, dp, C.c_int, C.c_int, dp]
+    rc = L.cba_host_noncentral_init_and_resample(C.byref(cs), gflat.ctypes.data_as(dp), pflat.ctypes.data_as(dp), 2.5,
+                                                 init_out.ctypes.data_as(dp), 12, 9, res_out.ctypes.data_as(dp))
+    assert rc == 0
+    np.testing.assert_array_equal(init_out.reshape(2, 48, 3)[0], grids[0])
+    np.testing.assert_allclose(init_out.reshape(2, 48, 3)[1], grids[1], rtol=1e-16, atol=0)
+    np.testing.assert_allclose(res_out.reshape(2, 108, 3), g2, rtol=1e-15, atol=1e-18)
+
