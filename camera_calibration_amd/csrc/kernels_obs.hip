@@ -730,6 +730,10 @@ struct AccumLayout {
 // over the chunk and flushed with one atomic per entry when the (image, camera) key changes; all other
 // entries go straight to HBM with hardware fp64 atomics.
 constexpr int kAccChunk = 8;
+// with the point terms gone (k_accumulate_points) an observation costs ~90 products here, and what limits the kernel is the flush:
+// every wavefront adds its rig-pose sums to the SAME 27 entries per camera (2.4 ms at cfg 3 with chunks of 8: 93 k atomics per
+// address); 64 observations per wavefront = 8x fewer flushes
+constexpr int kAccChunkHot = 64;
 constexpr int kHotMax = 12;                       // pose 6 + rig 6
 constexpr int kHotPairs = kHotMax * (kHotMax + 1) / 2;   // 78
 
@@ -795,7 +799,8 @@ __global__ void __launch_bounds__(256) k_accumulate(PassArgs a, AccumLayout L, i
   __shared__ double sW1[4][kMaxCols];
   __shared__ int sIdx[4][kMaxCols];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t o_begin = ((int64_t)blockIdx.x * 4 + wv) * kAccChunk;
+  const int chunk = points_separate ? kAccChunkHot : kAccChunk;
+  const int64_t o_begin = ((int64_t)blockIdx.x * 4 + wv) * chunk;
   const int nrig = L.rig_in_state ? 6 : 0;
   const int nh = 6 + nrig;                       // hot columns
   const int h0 = L.eliminate_points ? 3 : 0;     // their first position in the ascending column list
@@ -827,7 +832,7 @@ __global__ void __launch_bounds__(256) k_accumulate(PassArgs a, AccumLayout L, i
       hot[t] = 0;
     }
   };
-  for (int c = 0; c < kAccChunk; ++c) {
+  for (int c = 0; c < chunk; ++c) {
     const int64_t o = o_begin + c;
     if (o >= a.n_obs) break;
     if (flags[o] != 3) continue;  // wave-uniform
@@ -1418,7 +1423,8 @@ int launch_accumulate(const PassArgs& a, const Layout& L, int rec_doubles, const
   al.rig_in_state = L.rig_in_state; al.eliminate_points = L.eliminate_points; al.localize_only = L.localize_only;
   al.first_rig_tr_global = L.first_rig_tr_global; al.first_camera_tr_rig = L.first_camera_tr_rig;
   al.first_points = L.first_points; al.block_dof = L.block_dof; al.block_size = L.block_size; al.dense_dof = L.dense_dof;
-  const dim3 grid((unsigned)((a.n_obs + 4 * kAccChunk - 1) / (4 * kAccChunk)));
+  const int chunk = points_separate ? kAccChunkHot : kAccChunk;
+  const dim3 grid((unsigned)((a.n_obs + 4 * chunk - 1) / (4 * chunk)));
   if (det_scale)
     hipLaunchKernelGGL(k_accumulate<true>, grid, dim3(256), 0, s, a, al, rec_doubles, flags, jrec, cells, pair_tables, pair_counts, t, det_scale, points_separate);
   else

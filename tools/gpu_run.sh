@@ -32,9 +32,19 @@ case $WHAT in
     if [ "$WHAT" != suite ]; then
       timeout 400 python bench.py --config 3 --steps 4 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench_cfg3.log 2>&1; tail -1 $O/${TAG}_bench_cfg3.log > $O/${TAG}_bench_cfg3.json; summary $O/${TAG}_bench_cfg3.json
       timeout 300 python bench.py --config 4 --steps 8 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_cfg4.log 2>&1; tail -1 $O/${TAG}_bench_cfg4.log > $O/${TAG}_bench_cfg4.json; summary $O/${TAG}_bench_cfg4.json
+      # one rank's driver of the distributed solve against the replicated one (cfg 2, and one rank's share of cfg 5)
+      timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-convergence --force-allreduce --distributed-solve 0 > $O/${TAG}_bench_cfg2_forced_replicated.log 2>&1; tail -1 $O/${TAG}_bench_cfg2_forced_replicated.log > $O/${TAG}_bench_cfg2_forced_replicated.json; summary $O/${TAG}_bench_cfg2_forced_replicated.json
+      timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-convergence --force-allreduce --distributed-solve 1 > $O/${TAG}_bench_cfg2_forced_distributed.log 2>&1; tail -1 $O/${TAG}_bench_cfg2_forced_distributed.log > $O/${TAG}_bench_cfg2_forced_distributed.json; summary $O/${TAG}_bench_cfg2_forced_distributed.json
+      timeout 600 python bench.py --config 5 --imagesets 500 --steps 3 --warmup 1 --no-cpu-baseline --no-convergence > $O/${TAG}_bench_cfg5_share.log 2>&1; tail -1 $O/${TAG}_bench_cfg5_share.log > $O/${TAG}_bench_cfg5_share.json; summary $O/${TAG}_bench_cfg5_share.json
+      timeout 600 python bench.py --config 5 --imagesets 500 --steps 3 --warmup 1 --no-cpu-baseline --no-convergence --force-allreduce --distributed-solve 1 > $O/${TAG}_bench_cfg5_share_distributed.log 2>&1; tail -1 $O/${TAG}_bench_cfg5_share_distributed.log > $O/${TAG}_bench_cfg5_share_distributed.json; summary $O/${TAG}_bench_cfg5_share_distributed.json
       cd /tmp
       rm -rf /tmp/prof_c2; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_c2 -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-convergence > $R/$O/${TAG}_prof_cfg2.log 2>&1
       db=$(find /tmp/prof_c2 -name "*.db" | head -1); [ -n "$db" ] && python $R/tools/rocprof_summary.py $db > $R/$O/${TAG}_bench_cfg2_kernel_stats.txt 2>&1
+      [ -n "$db" ] && python $R/tools/step_timeline.py $db 15 > $R/$O/${TAG}_step_timeline_cfg2.txt 2>&1
+      for c in 3 4; do
+        rm -rf /tmp/prof_c$c; timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_c$c -o bench -- python $R/bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --no-convergence > $R/$O/${TAG}_prof_cfg$c.log 2>&1
+        db=$(find /tmp/prof_c$c -name "*.db" | head -1); [ -n "$db" ] && python $R/tools/rocprof_summary.py $db > $R/$O/${TAG}_bench_cfg${c}_kernel_stats.txt 2>&1
+      done
       for c in FETCH_SIZE WRITE_SIZE; do
         rm -rf /tmp/pmc_$c
         timeout 400 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o pmc -- python $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-convergence > $R/$O/${TAG}_pmc_$c.log 2>&1
