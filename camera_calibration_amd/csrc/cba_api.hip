@@ -164,6 +164,7 @@ struct cba_problem {
   int64_t* fd_redo[2] = {nullptr, nullptr}; int* fd_redo_count = nullptr;   // counts: [0] main list, [1] side-stream list, [2] tasks that found a list full
   int fd_redo_cap = 0;
   double last_lambda = 0;
+  double last_x0 = 0;     // x[0] of the last solve (read back with the status words: the NaN test of lm_optimizer.h:905 needs no second wait)
 };
 
 namespace cba {
@@ -456,6 +457,7 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
   int st[2] = {0, 0};
   CBA_HIP(hipMemcpyAsync(&st[0], p->status, sizeof(int), hipMemcpyDeviceToHost, p->stream));
   CBA_HIP(hipMemcpyAsync(&st[1], p->ldlt.status, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+  CBA_HIP(hipMemcpyAsync(&p->last_x0, p->x, sizeof(double), hipMemcpyDeviceToHost, p->stream));
   CBA_HIP(hipStreamSynchronize(p->stream));
   {
     double slabs = 0;
@@ -821,7 +823,7 @@ int cba_get_last_projection(cba_problem* p, double* out) {
 int cba_cost(cba_problem* p, double* cost, int64_t* n_valid, double* cost_vector) {
   if (!p || !p->have_obs || !p->have_state) { set_error("cba_cost: observations/state missing"); return CBA_ERR_STATE; }
   CBA_HIP(hipSetDevice(p->device));
-  CBA_TRY(upload_camdevs(p, p->cur));
+  // (the device-side camera descriptions hold pointers and constants only: uploaded once, by cba_create)
   CBA_TRY(residual_pass(p, p->cur, p->cost_test));
   CBA_TRY(launch_reduce_costs(nullptr, p->cost_test, nullptr, p->n_obs, p->red_partials, p->red8, p->stream));
   CBA_TRY(allreduce(p, p->red8, 8));
@@ -842,7 +844,7 @@ int cba_set_straggler_threshold(cba_problem* p, int32_t outer_iterations) {
 int cba_debug_accumulate(cba_problem* p, double* cost) {
   if (!p || !p->have_obs || !p->have_state) { set_error("cba_debug_accumulate: observations/state missing"); return CBA_ERR_STATE; }
   CBA_HIP(hipSetDevice(p->device));
-  CBA_TRY(upload_camdevs(p, p->cur));
+  // (the device-side camera descriptions hold pointers and constants only: uploaded once, by cba_create)
   CBA_TRY(jacobian_pass_and_accumulate(p, nullptr));
   CBA_TRY(launch_reduce_costs(p->cost_ref, nullptr, p->flags, p->n_obs, p->red_partials, p->red8, p->stream));
   double h[8];
@@ -887,7 +889,7 @@ int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double
   double h[8];
   // ---- residual + Jacobian pass, accumulation (lm_optimizer.h:706-720) ----
   double t0 = now_s();
-  CBA_TRY(upload_camdevs(p, p->cur));
+  // (the device-side camera descriptions hold pointers and constants only: uploaded once, by cba_create)
   CBA_TRY(jacobian_pass_and_accumulate(p, &report->t_accumulate));
   CBA_TRY(launch_reduce_costs(p->cost_ref, nullptr, p->flags, p->n_obs, p->red_partials, p->red8, p->stream));
   CBA_TRY(allreduce(p, p->red8, 8));
@@ -918,8 +920,7 @@ int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double
     int rc = solve_system(p, lambda, report);
     report->t_solve += now_s() - t0;
     if (rc != CBA_OK && rc != CBA_ERR_NUMERIC) return rc;
-    double x0 = NAN;
-    if (rc == CBA_OK) CBA_TRY(read_scalars(p, p->x, &x0, 1));
+    const double x0 = rc == CBA_OK ? p->last_x0 : NAN;
     bool failed = rc == CBA_ERR_NUMERIC || std::isnan(x0);
     if (multi) {
       // Image sharding: the pose-block inverses and x[0] are rank-local, the factorisation is replicated.  Every rank must
@@ -939,7 +940,6 @@ int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double
     t0 = now_s();
     const int cand = p->cur ^ 1;
     CBA_TRY(launch_apply_update(L, p->cams, p->st[p->cur], p->x, p->st[cand], p->pose_slot, p->gperm, p->stream));
-    CBA_TRY(upload_camdevs(p, cand));
     CBA_TRY(residual_pass(p, cand, p->cost_test));
     CBA_TRY(launch_reduce_costs(p->cost_ref, p->cost_test, nullptr, p->n_obs, p->red_partials, p->red8, p->stream));
     CBA_TRY(allreduce(p, p->red8, 8));
