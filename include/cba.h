@@ -86,9 +86,11 @@ typedef struct {
    * atomics are order-independent) instead of fp64 atomics; two runs on the same input then give bit-identical H, b,
    * x, costs and states.  The reference is single-threaded and therefore reproducible; this is the mode that matches
    * that property.  Resolution: one power-of-two quantum per pass for JtJ (2^62 / (n_obs x the largest single contribution))
-   * and a finer one for Jtr -- ABSOLUTE, i.e. ~19 digits below the largest possible sum; an entry that is 1e-8 of the
-   * largest one (pose / point blocks next to the grid-direction blocks) keeps ~10 significant digits of its own, still below
-   * the finite-difference noise of the Jacobians (1e-9 relative).  Costs about 1 ms per LM iteration at BASELINE configs[1]
+   * and a finer one for Jtr -- ABSOLUTE, ~19 digits below the largest POSSIBLE sum (n_obs contributions of the largest size;
+   * the largest actual entry is orders of magnitude below that because an entry collects ~1e2..1e3 contributions, not n_obs).
+   * Measured against the fp64-atomic mode at BASELINE configs[1]: diagonal entries within 1e-8 of the largest one agree to
+   * 2e-6 relative, smaller ones (control points that a handful of observations touch) to 3e-14 of the largest entry in absolute
+   * terms; H, B, b to 1e-11 of their maxima -- below the truncation error of the forward-difference Jacobians (delta = 1e-4).  Costs about 1 ms per LM iteration at BASELINE configs[1]
    * (DESIGN.md section 4a).  0 = fp64 atomics. */
   int32_t deterministic;
   /* Distributed reduced solve (multi-GPU, optional; needs `allreduce`).  0: the reduced system is all-reduced and its
