@@ -1,11 +1,8 @@
 cd "$GRAFT_REPO_ROOT"
-rm -f gpurun_out/parity_deviations.json
-timeout 900 python -m pytest tests/test_gpu_deterministic.py -x -q -m gpu > gpurun_out/exp_tests.log 2>&1; grep -E "passed|failed|error|assert" gpurun_out/exp_tests.log | tail -5
-python - <<'PY'
-import json
-rows = json.load(open('gpurun_out/parity_deviations.json'))
-rows = rows if isinstance(rows, list) else rows.get('rows', [])
-for r in rows:
-    s = json.dumps(r)
-    if "per entry" in s: print(s[:300])
-PY
+for i in 1 2; do
+  timeout 1500 python -m pytest tests -q -m gpu --timeout 900 -p no:cacheprovider > gpurun_out/exp_suite_$i.log 2>&1; echo "run $i rc=$?"; grep -E "passed|failed|error" gpurun_out/exp_suite_$i.log | tail -2
+done
+for i in 1 2 3; do
+  timeout 300 python bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-convergence 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('cfg2 ms/step %.2f value %.2f' % (d['ms_per_step'], d['value']), {k: round(v,2) for k,v in d['stage_ms_per_step'].items()})"
+done
