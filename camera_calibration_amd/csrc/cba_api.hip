@@ -364,32 +364,26 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   const double* det = p->cfg.deterministic ? p->det_scale : nullptr;
   if (det) CBA_TRY(launch_det_scale(p->n_obs, p->rec_doubles, p->rec_doubles, p->flags, p->jrec, p->det_bits, p->det_scale, p->stream));
   const int points_separate = (!L.eliminate_points && p->pt_start) ? 1 : 0;
-  // The four accumulation kernels write disjoint parts of the system (or add atomically): the per-point and per-cell kernels
-  // (LDS-bound, one or two workgroups per CU) run on the side stream next to the strips and the pose-entry kernel.
-  const bool side = points_separate && !L.localize_only;
+  // The four accumulation kernels write disjoint parts of the system (or add atomically).  The per-cell kernel runs on the side
+  // stream next to the others; the per-point kernel (120 KB of LDS per workgroup, one per CU) goes FIRST on the main stream, alone:
+  // next to the strips kernel its workgroups rarely find a CU with that much LDS free and the launch takes 3.9 ms instead of
+  // ~0.6 at cfg 3 (measured, profiles/r03_v4_bench_cfg3_kernel_stats.txt).
+  const bool side = !L.localize_only;
   if (side) {
     CBA_HIP(hipEventRecord(p->ev_aux0, p->stream));
     CBA_HIP(hipStreamWaitEvent(aux, p->ev_aux0, 0));
-    CBA_TRY(launch_accumulate_points(a, Lp, p->cams, p->rec_doubles, p->flags, p->jrec, p->cells, p->pt_start, p->pt_obs, T, det, aux));
     CBA_TRY(launch_accumulate_cells(a, p->cams, p->cell_base_host, p->rec_doubles, p->n_pad, p->flags, p->jrec, p->cells, p->cell_base,
                                     p->cell_count, p->cell_start, p->cell_fill, p->cell_order, p->Hdd,
                                     (!L.eliminate_points && L.rig_in_state) ? L.first_camera_tr_rig - L.block_dof : -1, det, p->bd, aux));
     CBA_HIP(hipEventRecord(p->ev_aux1, aux));
   }
-  if (!L.eliminate_points)   // B strips first (plain stores), the remaining terms are added on top atomically
+  if (points_separate)
+    CBA_TRY(launch_accumulate_points(a, Lp, p->cams, p->rec_doubles, p->flags, p->jrec, p->cells, p->pt_start, p->pt_obs, T, det, p->stream));
+  if (!L.eliminate_points)   // B strips (plain stores), the remaining terms are added on top atomically
     CBA_TRY(launch_accumulate_strips(a, Lp, L.n_images, p->rec_doubles, p->flags, p->jrec, p->cells, p->band_mask, p->img_start, p->B,
                                      p->n_pad, det, p->stream));
   CBA_TRY(launch_accumulate(a, Lp, p->rec_doubles, p->flags, p->jrec, p->cells, p->pair_tables, p->pair_counts, T, det, points_separate, p->stream));
-  if (side) {
-    CBA_HIP(hipStreamWaitEvent(p->stream, p->ev_aux1, 0));
-  } else {
-    if (points_separate)
-      CBA_TRY(launch_accumulate_points(a, Lp, p->cams, p->rec_doubles, p->flags, p->jrec, p->cells, p->pt_start, p->pt_obs, T, det, p->stream));
-    if (!L.localize_only)
-      CBA_TRY(launch_accumulate_cells(a, p->cams, p->cell_base_host, p->rec_doubles, p->n_pad, p->flags, p->jrec, p->cells, p->cell_base,
-                                      p->cell_count, p->cell_start, p->cell_fill, p->cell_order, p->Hdd,
-                                      (!L.eliminate_points && L.rig_in_state) ? L.first_camera_tr_rig - L.block_dof : -1, det, p->bd, p->stream));
-  }
+  if (side) CBA_HIP(hipStreamWaitEvent(p->stream, p->ev_aux1, 0));
   if (det) {   // fixed point -> fp64, in place
     CBA_TRY(launch_det_convert(p->Dblk, nb * bs * bs, det, p->stream));
     CBA_TRY(launch_det_convert(p->bblk, nb * bs, det + 1, p->stream));      // J^T r: second scale

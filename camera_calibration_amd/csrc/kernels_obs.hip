@@ -972,15 +972,9 @@ __global__ void __launch_bounds__(kPointThreads) k_accumulate_points(PassArgs a,
         kk[u] = live[u] ? it - oi * Kg : 0;
         o[u] = key_obs[o_begin + oi];
       }
-      int cx[U], cy[U]; uint8_t fl[U]; double w[U], g0[U], g1[U], q0[U][3], q1[U][3];
+      int cx[U], cy[U]; uint8_t fl[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const double* rec = jrec + (size_t)o[u] * rec_doubles;
-        fl[u] = flags[o[u]]; cx[u] = cells[2 * o[u]]; cy[u] = cells[2 * o[u] + 1];
-        w[u] = rec[2]; g0[u] = rec[kRecHeader + kk[u]]; g1[u] = rec[kRecHeader + Kg + kk[u]];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) { q0[u][r] = rec[27 + r]; q1[u][r] = rec[30 + r]; }
-      }
+      for (int u = 0; u < U; ++u) { fl[u] = flags[o[u]]; cx[u] = cells[2 * o[u]]; cy[u] = cells[2 * o[u] + 1]; }
       int col[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -989,10 +983,22 @@ __global__ void __launch_bounds__(kPointThreads) k_accumulate_points(PassArgs a,
         live[u] = live[u] && fl[u] == 3;
         if (!live[u]) seq = 0;                                       // cells of an invalid observation are not defined
         col[u] = per * (gperm ? gperm[seq] : seq) + d;               // camera-local column (grid_column - intr_offset)
+        live[u] = live[u] && col[u] >= c0 && col[u] < c1;
+      }
+      // the record is read only by the chunk its columns fall into (a 4 x 4 patch nearly always lies in one chunk: half the
+      // record traffic of a two-chunk launch)
+      double w[U], g0[U], g1[U], q0[U][3], q1[U][3];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!live[u]) continue;
+        const double* rec = jrec + (size_t)o[u] * rec_doubles;
+        w[u] = rec[2]; g0[u] = rec[kRecHeader + kk[u]]; g1[u] = rec[kRecHeader + Kg + kk[u]];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { q0[u][r] = rec[27 + r]; q1[u][r] = rec[30 + r]; }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (!live[u] || col[u] < c0 || col[u] >= c1) continue;
+        if (!live[u]) continue;
 #pragma unroll
         for (int r = 0; r < 3; ++r)
           Acc<DET>::add_lds(&s_rows[r * chunk_cols + (col[u] - c0)], Acc<DET>::from((w[u] * q0[u][r]) * g0[u] + (w[u] * q1[u][r]) * g1[u], scale));
