@@ -1,6 +1,3 @@
-cd "$GRAFT_REPO_ROOT"; R=$GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_vs_ref_vectors.py tests/test_gpu_deterministic.py -x -q -m gpu > gpurun_out/exp_tests.log 2>&1; grep -E "passed|failed|error" gpurun_out/exp_tests.log | tail -3
-for c in 2 3 4; do
-  timeout 300 python bench.py --config $c --steps 6 --warmup 2 --no-cpu-baseline --no-convergence 2>/dev/null | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('cfg$c ms/step %.2f' % d['ms_per_step'], {k: round(v,2) for k,v in d['stage_ms_per_step'].items()})"
-done
+cd "$GRAFT_REPO_ROOT"
+for r in 0 1; do echo "== REG2=$r"; REG2=$r TAILS=1024,6144 REPS=3 timeout 300 tools/bin/bench_tail 2>&1 | grep -E "^tail|^===|status"; done
+echo "== chain timeline REG2=1"; REG2=1 TAILLOG=1 TAILS=6144 REPS=1 timeout 200 tools/bin/bench_tail 12672 12544 2>&1 | grep -E "per block|chain" | head -6
