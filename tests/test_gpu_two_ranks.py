@@ -39,14 +39,20 @@ DIST_GRID = (30, 24)       # D = 5337: with 512 rows left to the final launch th
 DIST_TAIL_ROWS = 512
 
 
-def _worker(rank, world, port, out_dir, distributed_solve=False, use_collective=False):
+def _problem_full_grid():
+    """BASELINE configs[1] with its full 84 x 60 grid (D = 12 525: three super-panels of 2048 rows and the 6144-row final launch
+    at the DEFAULT schedule parameters) and 60 imagesets."""
+    return syn.baseline_config(2, lambda cam, grid, pts: eng.project(cam, grid, pts), n_imagesets=60)
+
+
+def _worker(rank, world, port, out_dir, distributed_solve=False, use_collective=False, full_grid=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     eng.prepare(0)
-    if distributed_solve:
+    if distributed_solve and not full_grid:
         eng.set_factor_tail_rows(DIST_TAIL_ROWS)
-    pb, st, _ = _problem(DIST_GRID if distributed_solve else (20, 16))
+    pb, st, _ = _problem_full_grid() if full_grid else _problem(DIST_GRID if distributed_solve else (20, 16))
     shards = dist_mod.shard_images(np.bincount(pb.obs_image, minlength=pb.n_images), world)
     b, e = shards[rank]
     sub, sst = pb.image_slice(b, e), st.image_slice(b, e)
@@ -63,7 +69,7 @@ def _worker(rank, world, port, out_dir, distributed_solve=False, use_collective=
         reps.append([r.initial_cost, r.final_cost, r.final_lambda, r.lm_attempts, float(r.accepted), r.n_residuals_valid])
     out = en.get_state(sst)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), b=b, e=e, reps=np.array(reps), poses=out.rig_tr_global, points=out.points,
-             camrig=out.camera_tr_rig, grid0=out.grids[0], grid1=out.grids[1])
+             camrig=out.camera_tr_rig, grid0=out.grids[0], grid1=out.grids[-1])
     en.close()
     dist.destroy_process_group()
 
@@ -193,4 +199,36 @@ def test_native_rccl_collective_world_of_one_distributed_solve(tmp_path):
     finally:
         eng.set_factor_tail_rows(default_rows)
         rc.close()
+
+
+def test_distributed_factorisation_at_the_benchmarked_size(tmp_path):
+    """The distributed schedule with its DEFAULT parameters at the size of BASELINE configs[1] (D = 12 525, n_pad = 12 672: first band
+    of 2048 rows all-reduced, 10 624 rows reduce-scattered into 25 column groups, three super-panels, 6400 rows gathered for the
+    final launch), two processes on one GPU with the collectives through a cba_collective_fn (host-staged gloo), three LM
+    iterations against the single-process engine."""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True, True, True), nprocs=world, join=True)
+    pb, st, _ = _problem_full_grid()
+    en = eng.Engine(pb, deterministic=True, last_projection=pb.obs_xy.astype(np.float64))
+    en.set_state(st)
+    lam = -1.0
+    reps = []
+    for _ in range(STEPS):
+        r = en.step(lam)
+        lam = r.final_lambda
+        reps.append([r.initial_cost, r.final_cost, r.final_lambda, r.lm_attempts, float(r.accepted), r.n_residuals_valid])
+    ref = en.get_state(st)
+    en.close()
+    reps = np.array(reps)
+    case = "2 ranks on 1 GPU, distributed factorisation at cfg-2 size (60 imagesets, 84x60 grid) vs single process"
+    rk = [np.load(os.path.join(str(tmp_path), f"rank{k}.npz")) for k in range(world)]
+    for k in range(world):
+        check_equal(case, f"rank {k}: LM attempts / accept decisions / valid counts", int(np.count_nonzero(rk[k]["reps"][:, 3:] != reps[:, 3:])))
+        check(case, f"rank {k}: costs rel", (np.abs(rk[k]["reps"][:, :2] - reps[:, :2]) / reps[:, :2]).max(), 5e-7)
+        b, e = int(rk[k]["b"]), int(rk[k]["e"])
+        check(case, f"rank {k}: own poses abs", np.abs(rk[k]["poses"] - ref.rig_tr_global[b:e]).max(), 5e-8)
+        check(case, f"rank {k}: points abs", np.abs(rk[k]["points"] - ref.points).max(), 5e-8)
+        check(case, f"rank {k}: grid abs", np.abs(rk[k]["grid0"] - ref.grids[0]).max(), 1e-7)
+    for key in ("points", "grid0"):
+        check_equal(case, f"replicated state identical on both ranks: {key}", int(np.count_nonzero(rk[0][key] != rk[1][key])))
 

@@ -1,5 +1,2 @@
 cd "$GRAFT_REPO_ROOT"
-timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-convergence 2>/dev/null | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('cfg2 ms/step %.2f' % d['ms_per_step'], 'frac', round(r['frac'],3), 'lib', round(r['library_tflops'],1), 'vs lib', round(r['frac_vs_library'],3), d['config'].get('ranks_consistent'))"
-timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-convergence --force-allreduce --distributed-solve 1 2>/dev/null | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('forced dist ms/step %.2f' % d['ms_per_step'], d['config'].get('ranks_consistent'), d['config']['parallelism'])"
+timeout 900 python -m pytest tests/test_gpu_two_ranks.py -x -q -m gpu --durations=8 > gpurun_out/exp_tests.log 2>&1; grep -E "passed|failed|error|Error|s call|assert" gpurun_out/exp_tests.log | tail -14
