@@ -141,7 +141,6 @@ struct LdltWorkspace {
   double* invLt = nullptr;   // [kInner][kInner]
   double* dvec = nullptr;    // n
   int* status = nullptr;
-  double* inv_panel = nullptr;  // distributed factorisation: inverse of a wide panel's unit-lower factor and its transpose
   hipStream_t panel_stream = nullptr;   // pivot chain (look-ahead panel factorisation)
   hipStream_t mid_stream = nullptr;     // panel solves / updates on the next panel's columns
   hipStream_t far_stream = nullptr;     // panel solves / updates right of the next panel

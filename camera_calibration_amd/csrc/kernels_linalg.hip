@@ -2322,7 +2322,6 @@ int ldlt_workspace_alloc(LdltWorkspace& w, int n_pad) {
   CBA_HIP(hipMalloc(&w.invLt, sizeof(double) * (size_t)(n_pad / kInner) * kInner * kInner));
   CBA_HIP(hipMalloc(&w.dvec, sizeof(double) * (size_t)n_pad));
   CBA_HIP(hipMalloc(&w.status, sizeof(int)));
-  CBA_HIP(hipMalloc(&w.inv_panel, sizeof(double) * 2 * (size_t)kPanelWide * kPanelWide));
   {
     DeviceStreams d;
     int rc = device_streams(&d);
@@ -2361,7 +2360,6 @@ void ldlt_workspace_free(LdltWorkspace& w) {
   if (w.invLt) hipFree(w.invLt);
   if (w.dvec) hipFree(w.dvec);
   if (w.status) hipFree(w.status);
-  if (w.inv_panel) hipFree(w.inv_panel);
   if (w.ev_panel) hipEventDestroy(w.ev_panel);
   if (w.ev_strip) hipEventDestroy(w.ev_strip);
   if (w.ev_mid) hipEventDestroy(w.ev_mid);
