@@ -13,6 +13,7 @@
 // which feeds v_mfma_f64_16x16x4_f64 directly from LDS rows.
 // Leading dimensions are padded to multiples of 128 and K to multiples of 16 so the hot loops carry
 // no bounds checks; padded diagonal entries are set to 1.
+#include <cmath>
 #include <cstdlib>
 
 #include "cba_internal.h"
@@ -2483,6 +2484,28 @@ static int super_width() {
   if (v > kSuperMax) v = kSuperMax;
   return v / 128 * 128;
 }
+// Width of the super-panel that starts at row k0: near `sw`, chosen so that the bulk update behind it fills whole rounds of the
+// chip.  The update has m (m + 1) / 2 equal tiles (m = trailing rows / 128) and 2 x CUs of them run at a time, all in step: at
+// W = 2048 the three updates of cfg 2 have 6.81 / 4.45 / 2.59 rounds, i.e. 3 / 11 / 14 % of their last round is idle.
+static int super_width_at(int n_pad, int k0, int sw) {
+  static const bool fixed = CBA_GETENV("CBA_SUPER_FIXED") != nullptr;      // developer switch (bench harness only)
+  if (fixed || sw < 1024) return sw;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const double slots = 2.0 * cus;
+  int best = sw;
+  double best_score = -1.0;
+  for (int w = sw - 512; w <= sw + 512; w += 128) {
+    if (w < 1024 || w > kSuperMax) continue;
+    const long long m = (n_pad - (k0 + w)) / 128;
+    if (m < 8) continue;
+    const double tiles = (double)m * (m + 1) / 2, rounds = std::ceil(tiles / slots);
+    // fill of the last round, minus a small penalty for leaving the nominal width (the strip's cost grows with w^2)
+    const double score = tiles / (rounds * slots) - 0.01 * std::abs(w - sw) / 128.0;
+    if (score > best_score) { best_score = score; best = w; }
+  }
+  return best;
+}
 static int g_tail_rows = 6144;
 void ldlt_set_tail_rows(int rows) { g_tail_rows = rows < 0 ? 0 : rows; }
 int ldlt_tail_rows() {
@@ -2576,16 +2599,17 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
   if (sw > 0 && t0 < n_fact) {
     int k0 = 0;
     while (n_fact - k0 > ldlt_tail_rows() + sw / 2 && n_pad - (k0 + sw) >= 1024) {
-      int rc = ldlt_tail(S, k0 + sw, ld, k0, w, s, st, w.X);
+      const int wk = super_width_at(n_pad, k0, sw);
+      int rc = ldlt_tail(S, k0 + wk, ld, k0, w, s, st, w.X);
       if (rc) return rc;
       GemmArgs u{};
-      u.A = S + (size_t)k0 * ld; u.lda = ld; u.B = w.X; u.ldb = n_pad; u.K = sw;
+      u.A = S + (size_t)k0 * ld; u.lda = ld; u.B = w.X; u.ldb = n_pad; u.K = wk;
       u.C = S; u.ldc = ld; u.Cin = S; u.ldcin = ld; u.diag = 0; u.upper = 1;
-      const int tl = (n_pad - (k0 + sw)) / 128;
-      u.m_off = k0 + sw; u.m_tiles = tl; u.n_off = k0 + sw; u.n_tiles = tl;
+      const int tl = (n_pad - (k0 + wk)) / 128;
+      u.m_off = k0 + wk; u.m_tiles = tl; u.n_off = k0 + wk; u.n_tiles = tl;
       if ((rc = timed_gemm128(u, s, w, st != nullptr, (double)tl * (tl + 1) / 2))) return rc;
-      if (st) { const double rows = (double)(n_pad - (k0 + sw)); st->flops += rows * rows * sw; st->launches += 1; }
-      k0 += sw;
+      if (st) { const double rows = (double)(n_pad - (k0 + wk)); st->flops += rows * rows * wk; st->launches += 1; }
+      k0 += wk;
     }
     int rc = ldlt_tail(S, n_fact, ld, k0, w, s, st);
     if (rc) return rc;
