@@ -1,6 +1,6 @@
-cd "$GRAFT_REPO_ROOT"
-timeout 900 python -m pytest tests/test_gpu_factor_tail.py tests/test_gpu_parity.py tests/test_gpu_two_ranks.py tests/test_gpu_parity_fullsize.py -x -q -m gpu > gpurun_out/exp_tests.log 2>&1; grep -E "passed|failed|error" gpurun_out/exp_tests.log | tail -3
-for c in 3 4; do
-  timeout 300 python bench.py --config $c --steps 4 --warmup 1 --no-cpu-baseline --no-convergence 2>/dev/null | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('cfg$c ms/step %.2f' % d['ms_per_step'], 'frac %.3f' % d['roofline_gemm']['frac'], {k: round(v,2) for k,v in d['stage_ms_per_step'].items()})"
-done
+cd "$GRAFT_REPO_ROOT"; R=$GRAFT_REPO_ROOT
+export TMPDIR=/tmp; cd /tmp
+rm -rf /tmp/pmc_m; timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmc_m -o pmc -- python $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-convergence > $R/gpurun_out/exp_pmc_mfma.log 2>&1
+db=$(find /tmp/pmc_m -name "*.db" | head -1); [ -n "$db" ] && python $R/tools/rocprof_pmc_generic.py $db gemm_atbILi128,ldlt_tail,back_dataflow,fd_tasks,Cijk | tee $R/gpurun_out/exp_pmc_mfma.txt
+rm -rf /tmp/pmc_m2; timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_ANY -d /tmp/pmc_m2 -o pmc -- python $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-convergence > $R/gpurun_out/exp_pmc_mfma2.log 2>&1
+db=$(find /tmp/pmc_m2 -name "*.db" | head -1); [ -n "$db" ] && python $R/tools/rocprof_pmc_generic.py $db gemm_atbILi128,ldlt_tail,Cijk | tee -a $R/gpurun_out/exp_pmc_mfma.txt
