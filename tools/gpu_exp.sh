@@ -1,2 +1,2 @@
 cd "$GRAFT_REPO_ROOT"
-timeout 120 tools/bin/bench_gemm2; timeout 120 tools/bin/bench_gemm3
+echo base; timeout 120 tools/bin/bench_gemm_base | tail -4; echo pipelined; timeout 120 tools/bin/bench_gemm_pipe | tail -4
