@@ -1098,6 +1098,7 @@ int cba_debug_fd_redo_counts(cba_problem* p, int64_t out[3]) {
   return CBA_OK;
 }
 void cba_set_factor_tail_rows(int32_t rows) { ldlt_set_tail_rows(rows); }
+void cba_debug_set_back_substitution(int32_t dataflow) { ldlt_set_back_dataflow(dataflow); }
 int32_t cba_factor_tail_rows(void) { return ldlt_tail_rows(); }
 
 int cba_model_set_grid(cba_model* m, const double* grid) {

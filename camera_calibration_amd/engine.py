@@ -69,7 +69,7 @@ EXPORTED_SYMBOLS = [
     "cba_total_dof", "cba_dense_dof", "cba_jacobian_record_doubles", "cba_reduce_buffer_doubles",
     "cba_kernel_stats", "cba_fit_grid_to_directions", "cba_prepare_device",
     "cba_model_create", "cba_model_destroy", "cba_model_set_grid", "cba_model_project", "cba_model_unproject",
-    "cba_fd_redo_overflow", "cba_set_factor_tail_rows", "cba_factor_tail_rows", "cba_debug_fd_redo_counts",
+    "cba_fd_redo_overflow", "cba_set_factor_tail_rows", "cba_factor_tail_rows", "cba_debug_fd_redo_counts", "cba_debug_set_back_substitution",
 ]
 
 DUMP_COST_VECTOR, DUMP_PIXELS, DUMP_FLAGS, DUMP_JACOBIANS = 1, 2, 3, 4
@@ -143,6 +143,13 @@ def set_factor_tail_rows(rows: int) -> None:
     L = load()
     L.cba_set_factor_tail_rows.argtypes = [C.c_int32]
     L.cba_set_factor_tail_rows(int(rows))
+
+
+def set_back_substitution(dataflow: bool) -> None:
+    """cba_debug_set_back_substitution (process-wide): one dataflow launch (default) or panels of 256 rows."""
+    L = load()
+    L.cba_debug_set_back_substitution.argtypes = [C.c_int32]
+    L.cba_debug_set_back_substitution(int(bool(dataflow)))
 
 
 def factor_tail_rows() -> int:

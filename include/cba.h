@@ -179,6 +179,9 @@ int64_t cba_fd_redo_overflow(cba_problem* p);
 /* Diagnostics: out[0] / out[1] = tasks of the last Jacobian pass that went to the gather-path follow-up list of the main /
  * side-stream finite-difference launch, out[2] = the overflow count above. */
 int cba_debug_fd_redo_counts(cba_problem* p, int64_t out[3]);
+/* Diagnostics (process-wide): 1 = back substitution of the reduced solve as ONE dataflow launch (default), 0 = by panels of 256
+ * rows (98 launches at BASELINE configs[1]); same result to rounding.  Lets the tests keep the fallback path alive. */
+void cba_debug_set_back_substitution(int32_t dataflow);
 
 /* Scheduling knob of the reduced-system factorisation (process-wide; results change only in the last bits): the last `rows`
  * rows are factored by ONE persistent dataflow launch instead of the blocked multi-stream schedule.

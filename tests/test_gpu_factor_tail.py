@@ -46,6 +46,22 @@ def test_tail_launch_matches_blocked_schedule_and_lapack(dense_dof):
     check(case, "tail (default) vs blocked schedule / |x|max", np.abs(xs[default_rows] - xs[0]).max() / scale, 5e-12)
 
 
+@pytest.mark.parametrize("dense_dof", [65, 1089, 3500, 7000])
+def test_back_substitution_dataflow_launch_matches_the_panel_version(dense_dof):
+    """k_back_dataflow (one launch, {value, tag} pairs, agent-scope polling) against the panel kernels on the same factor."""
+    case = f"back substitution, D = {dense_dof}"
+    s = _system(12, dense_dof, seed=1000 + dense_dof)
+    try:
+        eng.set_back_substitution(False)
+        x_panels = eng.schur_solve(s.block_diag_H, s.off_diag_H, s.dense_H, s.block_diag_b, s.dense_b)
+        eng.set_back_substitution(True)
+        x_flow = eng.schur_solve(s.block_diag_H, s.off_diag_H, s.dense_H, s.block_diag_b, s.dense_b)
+    finally:
+        eng.set_back_substitution(True)
+    check_equal(case, "finite", int(np.count_nonzero(~np.isfinite(x_flow)) + np.count_nonzero(~np.isfinite(x_panels))))
+    check(case, "dataflow vs panels / |x|max", np.abs(x_flow - x_panels).max() / np.abs(x_panels).max(), 5e-13)
+
+
 def test_follow_up_list_of_the_finite_difference_kernel_does_not_overflow():
     from camera_calibration_amd import synthetic as syn
     pb, st, _ = syn.baseline_config(4, lambda cam, grid, pts: eng.project(cam, grid, pts), n_imagesets=30)
