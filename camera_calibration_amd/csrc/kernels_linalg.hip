@@ -1865,6 +1865,274 @@ __device__ unsigned long long* g_taillog = nullptr;
 #define HELP_NOW() 0ull
 #endif
 
+// The chain's diagonal blocks: blocked panels (round 4, default) or the barrier-per-pivot-pair loop of round 3 (bench harness: -DCBA_CHAIN_OLD)
+#ifdef CBA_CHAIN_OLD
+constexpr bool kChainBlocked = false;
+#else
+constexpr bool kChainBlocked = true;
+#endif
+// tile_mma_lds with an A operand that is a transposed unit-lower-triangular inverse carrying junk in the 16 x 16 tiles below
+// its block diagonal (chain_factor_blocked): row block I of the result takes the k blocks <= I only
+__device__ __forceinline__ void tile_mma_lds_lowerA(v4f64 (&acc)[2][2], const double* Al, const double* Bl) {
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
+  const int mb0 = wm0 >> 4;
+#pragma unroll
+  for (int kk = 0; kk < kInner; kk += 4) {
+    const int kb = kk >> 4;
+    if (kb <= mb0 + 1) {
+      double bf[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = Bl[(kk + lk) * TS + wn0 + j * 16 + li];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        if (kb <= mb0 + i) {
+          const double af = Al[(kk + lk) * TS + wm0 + i * 16 + li];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+}
+
+// ---- blocked 64 x 64 LDL^T of the chain (round 4) ----
+// The 64 pivots of a diagonal block used to be 32 barrier rounds of the whole workgroup (ldlt_diag_core: two pivots per
+// LDS round trip + barrier, 447 ns per round = 14.3 us per block, the largest item on the critical path of the whole
+// factorisation).  Here the block is factored in four panels of 16 columns:
+//   * ONE wavefront (wave 0) factors a panel with no barrier and no LDS traffic inside: lane i holds row i of the panel
+//     (16 registers), pivot row entries are broadcast with v_readlane into SGPRs, the 16 steps are fully unrolled;
+//   * the other three wavefronts apply the panel to the rest of the block with v_mfma_f64_16x16x4 (rank-16 updates of
+//     16 x 16 tiles, accumulators kept in registers across panels) and build L^-1 in product form
+//     (X <- E_p X per panel: 16 x 16 unit-triangular inverses by forward substitution with LDS-broadcast operands,
+//     everything else MFMA), off the pivot path: after the last pivot only M_33 and one more product level remain.
+// Two barriers per panel instead of sixteen.  LDS (two 64 x TS tiles, as before):
+//   sW  upper triangle (row <= col, 16 x 16 tiles (J, I), J <= I): the working matrix in upper storage W(i, j) at [j][i];
+//       the rows of a factored panel hold d l (the K-major A operand of the updates); tiles are replaced by the transposed
+//       inverse M^T ([q][p] = M(p, q), the layout the next chain step and the helpers multiply with) once they are dead.
+//       strictly lower tiles (I, J), I > J: the inverse being built, natural layout [p][q] (B operand of its own updates);
+//       junk afterwards -- consumers skip them / the global store writes zeros.
+//   sV  L^T with d on the diagonal ([j][i] = L(i, j), i > j; zeros below): the tile that goes to S, and the B operand of the
+//       updates.  Padding columns 64 .. 79 of rows 16 p .. 16 p + 15: the natural copy of M_pp (B operand).
+//   s_rd (padding of sW rows 0 .. 3): 1 / d.
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+// Panel P (columns 16 P .. 16 P + 15) by one wavefront.  Returns true when a pivot was zero or NaN.
+// No per-column lane masks in here (the compiler hoists every `lane > base + c` comparison out of the chain's block loop as an
+// SGPR pair and then spills them: 546 SGPR spills, two v_readlane reloads per use): lanes above the diagonal of the panel's
+// own 16 x 16 block carry junk through the loop -- their results land below the diagonal of sV, which nothing reads and the
+// global store masks -- and the pivots are collected per lane with v_writelane.
+template <int P>
+__device__ __forceinline__ bool chain_panel(double* sW, double* sV, double* s_rd, int lane_in) {
+  constexpr int base = 16 * P;
+  int lane = lane_in;
+  asm volatile("" : "+v"(lane));
+  double a[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) a[c] = sW[(base + c) * TS + lane];        // W(lane, base + c); meaningful for lane >= base + c
+  bool bad = false;
+  int dlo = 0, dhi = 0;                                                  // lane base + c: d_c
+  const bool below = lane >= base + 16;
+  // the pivot of step c + 1 and its reciprocal are started as soon as column c + 1 has its update of step c, underneath the
+  // rest of that step's updates (the reciprocal is a chain of five dependent fp64 operations)
+  int slo = __builtin_amdgcn_readlane(__double2loint(a[0]), base);
+  int shi = __builtin_amdgcn_readlane(__double2hiint(a[0]), base);
+  double inv = pivot_rcp(__hiloint2double(shi, slo));
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(dlo) : "s"(slo), "n"(base + c));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(dhi) : "s"(shi), "n"(base + c));
+    if (!(fabs(__hiloint2double(shi, slo)) > 0.0)) bad = true;
+    const double l = a[c] * inv;
+    if (c + 1 < 16) {
+      const double v = readlane_f64(a[c], base + c + 1);
+      a[c + 1] = __builtin_fma(-l, v, a[c + 1]);
+      slo = __builtin_amdgcn_readlane(__double2loint(a[c + 1]), base + c + 1);
+      shi = __builtin_amdgcn_readlane(__double2hiint(a[c + 1]), base + c + 1);
+      inv = pivot_rcp(__hiloint2double(shi, slo));
+    }
+#pragma unroll
+    for (int c2 = c + 2; c2 < 16; ++c2) {
+      const double v = readlane_f64(a[c], base + c2);                    // d l_{c2}: the column entry before scaling
+      a[c2] = __builtin_fma(-l, v, a[c2]);
+      // (left alone, the scheduler hoists every v_readlane of the panel to the top and spills the SGPRs it cannot hold)
+      if (((c2 - c) & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    // d l of the rows below the panel back in place (the updates' A operand), L^T into sV.  Lanes left of the panel
+    // hold the inverse being built in sW (lower tiles): they must not write there.
+    // (branch-free: a branch here splits the panel into basic blocks and the updates get sunk towards their uses, with every
+    // broadcast SGPR pair alive until then; the other lanes store to the sV slot that the next store overwrites)
+    if (P < 3) { double* dst = below ? &sW[(base + c) * TS + lane] : &sV[(base + c) * TS + lane]; *dst = a[c]; }
+    sV[(base + c) * TS + lane] = l;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if ((unsigned)(lane - base) < 16u) {
+    const double dv = __hiloint2double(dhi, dlo);
+    sV[lane * TS + lane] = dv;                                           // d on the diagonal
+    s_rd[P * TS + lane - base] = pivot_rcp(dv);
+  }
+  return bad;
+}
+// 16 x 16 tile helpers; li = lane & 15, lk = lane >> 4.  MFMA result layout: element (lk + 4 r, li) in component r.
+__device__ __forceinline__ void mma16(v4f64& acc, const double* Ak, const double* Bk, int li, int lk) {
+  // acc[m][n] += sum_{k < 16} Ak[k][m] Bk[k][n]   (both K-major, row stride TS)
+#pragma unroll
+  for (int kk = 0; kk < 16; kk += 4)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ak[(kk + lk) * TS + li], Bk[(kk + lk) * TS + li], acc, 0, 0, 0);
+}
+__device__ __forceinline__ v4f64 ld16(const double* t, int li, int lk) {
+  v4f64 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = t[(lk + 4 * r) * TS + li];
+  return v;
+}
+__device__ __forceinline__ void st16(double* t, v4f64 v, int li, int lk) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) t[(lk + 4 * r) * TS + li] = v[r];
+}
+__device__ __forceinline__ void st16_t(double* t, v4f64 v, int li, int lk) {       // transposed
+#pragma unroll
+  for (int r = 0; r < 4; ++r) t[li * TS + lk + 4 * r] = v[r];
+}
+// M_pp = L_pp^-1 (16 x 16, unit lower): lane j (of every group of 16) carries column j through the forward substitution;
+// the entries of L are wave-uniform LDS reads (broadcast).  Natural copy -> padding of sV, transposed copy (complete tile:
+// zeros below its diagonal) -> diagonal tile of sW.
+__device__ __forceinline__ void chain_inv16(double* sW, double* sV, int p, int lane_in) {
+  int lane = lane_in;
+  asm volatile("" : "+v"(lane));                             // (keeps the 16 comparisons below inside the chain's block loop)
+  const int j = lane & 15, base = 16 * p;
+  double x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+  for (int i = 1; i < 16; ++i) {
+    double s = x[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s = __builtin_fma(-sV[(base + k) * TS + base + i], x[k], s);
+    x[i] = s;
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      sV[(base + i) * TS + kInner + j] = x[i];               // natural: M(i, j)
+      sW[(base + j) * TS + base + i] = x[i];                 // transposed: [q = j][p = i]
+    }
+  }
+}
+// out = -(A B) (FIRST) or Cin - A B, A = L_Ip (from sV), B natural; result natural -> sW lower tile (I, J)
+__device__ __forceinline__ v4f64 chain_xupd(const double* sV, const double* Bk, int I, int p, const double* cin, int li, int lk) {
+  v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+  mma16(acc, sV + 16 * p * TS + 16 * I, Bk, li, lk);
+  if (cin) { const v4f64 c = ld16(cin, li, lk); return c - acc; }
+  return -acc;
+}
+// The whole block.  On entry sW holds T (upper triangle valid); on exit sV / sW / s_rd as described above.  All 256 lanes.
+#ifdef CBA_DIAGLOG
+__device__ unsigned long long* g_diaglog = nullptr;   // tools/bench_diag.hip: accumulated 100 MHz ticks per phase boundary
+#define CHAIN_PH(n_) do { __builtin_amdgcn_sched_barrier(0); if (g_diaglog && threadIdx.x == 0) g_diaglog[n_] += wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CHAIN_PH(n_) do { } while (0)
+#endif
+__device__ __forceinline__ bool chain_factor_blocked(double* sW, double* sV, double* s_rd) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+  bool bad = false;
+#define SW_T(J_, I_) (sW + 16 * (J_) * TS + 16 * (I_))
+#define SV_PAD(p_) (sV + 16 * (p_) * TS + kInner)
+  // update of tile (J, I) by panel P: acc += (d l)(rows J) L(rows I)^T
+#define T_UPD(acc_, P_, J_, I_) mma16(acc_, sW + 16 * (P_) * TS + 16 * (J_), sV + 16 * (P_) * TS + 16 * (I_), li, lk)
+  const v4f64 zero = {0.0, 0.0, 0.0, 0.0};
+  v4f64 keep = zero;                                   // the tile this wave carries across panels: w1 (2,2), w2 (2,3), w3 (3,3)
+  CHAIN_PH(0);
+  // A0
+  if (wv == 0) { bad |= chain_panel<0>(sW, sV, s_rd, lane); CHAIN_PH(10); }
+  __syncthreads();
+  CHAIN_PH(1);
+  // C0: row 1 of the block
+  if (wv >= 1) {
+    v4f64 acc = zero;
+    T_UPD(acc, 0, 1, wv);
+    double* t = SW_T(1, wv);
+    st16(t, ld16(t, li, lk) - acc, li, lk);
+  }
+  __syncthreads();
+  CHAIN_PH(2);
+  // A1
+  if (wv == 0) { bad |= chain_panel<1>(sW, sV, s_rd, lane); CHAIN_PH(11); }
+  else {
+    if (wv == 1) { T_UPD(keep, 0, 2, 2); chain_inv16(sW, sV, 0, lane); }
+    else if (wv == 2) T_UPD(keep, 0, 2, 3);
+    else T_UPD(keep, 0, 3, 3);
+  }
+  __syncthreads();
+  CHAIN_PH(3);
+  // C1: row 2 of the block (w3 keeps (3,3))
+  if (wv == 1) { T_UPD(keep, 1, 2, 2); double* t = SW_T(2, 2); st16(t, ld16(t, li, lk) - keep, li, lk); }
+  else if (wv == 2) { T_UPD(keep, 1, 2, 3); double* t = SW_T(2, 3); st16(t, ld16(t, li, lk) - keep, li, lk); }
+  else if (wv == 3) T_UPD(keep, 1, 3, 3);
+  __syncthreads();
+  CHAIN_PH(4);
+  // A2: inverse, panel 0 applied: X_I0 = -L_I0 M_00
+  if (wv == 0) { bad |= chain_panel<2>(sW, sV, s_rd, lane); CHAIN_PH(12); }
+  else if (wv == 1) chain_inv16(sW, sV, 1, lane);
+  else if (wv == 2) {
+    st16(SW_T(1, 0), chain_xupd(sV, SV_PAD(0), 1, 0, nullptr, li, lk), li, lk);
+    st16(SW_T(2, 0), chain_xupd(sV, SV_PAD(0), 2, 0, nullptr, li, lk), li, lk);
+  } else st16(SW_T(3, 0), chain_xupd(sV, SV_PAD(0), 3, 0, nullptr, li, lk), li, lk);
+  __syncthreads();
+  CHAIN_PH(5);
+  // C2: tile (3,3); M_10 = M_11 X_10; X_21 = -L_21 M_11, X_31 = -L_31 M_11
+  if (wv == 3) { T_UPD(keep, 2, 3, 3); double* t = SW_T(3, 3); st16(t, ld16(t, li, lk) - keep, li, lk); }
+  else if (wv == 1) {
+    v4f64 m = zero;
+    mma16(m, SW_T(1, 1), SW_T(1, 0), li, lk);
+    st16(SW_T(1, 0), m, li, lk);
+    st16_t(SW_T(0, 1), m, li, lk);
+  } else if (wv == 2) {
+    st16(SW_T(2, 1), chain_xupd(sV, SV_PAD(1), 2, 1, nullptr, li, lk), li, lk);
+    st16(SW_T(3, 1), chain_xupd(sV, SV_PAD(1), 3, 1, nullptr, li, lk), li, lk);
+  }
+  __syncthreads();
+  CHAIN_PH(6);
+  // A3: last panel and its inverse on wave 0; M_22; panel 1 applied to column 0 of the inverse
+  if (wv == 0) { bad |= chain_panel<3>(sW, sV, s_rd, lane); CHAIN_PH(13); chain_inv16(sW, sV, 3, lane); CHAIN_PH(14); }
+  else if (wv == 1) chain_inv16(sW, sV, 2, lane);
+  else if (wv == 2) st16(SW_T(2, 0), chain_xupd(sV, SW_T(1, 0), 2, 1, SW_T(2, 0), li, lk), li, lk);
+  else st16(SW_T(3, 0), chain_xupd(sV, SW_T(1, 0), 3, 1, SW_T(3, 0), li, lk), li, lk);
+  __syncthreads();
+  CHAIN_PH(7);
+  // E1: M_20 = M_22 X_20, M_21 = M_22 X_21, X_32 = -L_32 M_22
+  if (wv == 1) {
+    v4f64 m = zero;
+    mma16(m, SW_T(2, 2), SW_T(2, 0), li, lk);
+    st16(SW_T(2, 0), m, li, lk);
+    st16_t(SW_T(0, 2), m, li, lk);
+  } else if (wv == 2) {
+    v4f64 m = zero;
+    mma16(m, SW_T(2, 2), SW_T(2, 1), li, lk);
+    st16(SW_T(2, 1), m, li, lk);
+    st16_t(SW_T(1, 2), m, li, lk);
+  } else if (wv == 3) st16(SW_T(3, 2), chain_xupd(sV, SV_PAD(2), 3, 2, nullptr, li, lk), li, lk);
+  __syncthreads();
+  CHAIN_PH(8);
+  // E2: X_3J -= L_32 M_2J, then M_3J = M_33 X_3J (the wave's own tile goes through LDS to become a B operand)
+  if (wv >= 1) {
+    const int J = wv - 1;
+    double* x = SW_T(3, J);
+    if (J < 2) st16(x, chain_xupd(sV, SW_T(2, J), 3, 2, x, li, lk), li, lk);
+    v4f64 m = zero;
+    mma16(m, SW_T(3, 3), x, li, lk);
+    st16_t(SW_T(J, 3), m, li, lk);
+  }
+  __syncthreads();
+  CHAIN_PH(9);
+#undef T_UPD
+#undef SV_PAD
+#undef SW_T
+  return bad;
+}
+
 // ---- the chain workgroup ----
 // Tile I/O goes through buffer instructions with ONE per-lane offset register (voffset) and a wave-uniform offset (soffset, an
 // SGPR): with 64-bit global addresses the compiler kept 16 loop-invariant address pairs per tile alive across the pivot loop,
@@ -1924,7 +2192,8 @@ __device__ __forceinline__ void tail_chain(const TailArgs& t, double* sV, double
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) X[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
-      tile_mma_lds(X, sW, sV);                   // X[p][n] = sum_q invLt[q][p] U[q][n]
+      if constexpr (kChainBlocked) tile_mma_lds_lowerA(X, sW, sV);   // (sW carries junk below its block diagonal)
+      else tile_mma_lds(X, sW, sV);              // X[p][n] = sum_q invLt[q][p] U[q][n]
       __syncthreads();                           // every wave is done reading sW (inverse) and sV (U)
       TAIL_STAMP(b, 3);
 #pragma unroll
@@ -1970,54 +2239,85 @@ __device__ __forceinline__ void tail_chain(const TailArgs& t, double* sV, double
       }
       __syncthreads();
     }
-    double T[4][4], Xi[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb) {
-        const int i = ti + 16 * a, j = tj + 16 * bb;
-        const int lo = i < j ? i : j, hi = i < j ? j : i;
-        T[a][bb] = sW[lo * TS + hi];
-        Xi[a][bb] = (i == j) ? 1.0 : 0.0;
-      }
-    __syncthreads();                             // sW is read; sV (colbuf / rowbuf) is free since the barrier after the second product
-    TAIL_STAMP(b, 7);
-    const bool bad = ldlt_diag_core<kInner>(T, Xi, colbuf, rowbuf);
-    TAIL_STAMP(b, 8);
-    if (bad && tid == 0) atomicExch(t.status, 2);
-    {
-      // L_rr / d (memory row j, column i: transposed) -> sV, invLt -> sW, then both tiles leave row by row.  No global store
-      // is issued before the barrier: a store followed by anything that makes the compiler wait for vmcnt(0) (a register
-      // reload, here) costs a full write-through acknowledgement, ~1 us each.
-      int tid2 = threadIdx.x;
-      asm volatile("" : "+v"(tid2));               // lane indices are re-derived here instead of staying live across the pivots
-      const int ti2 = tid2 >> 4, tj2 = tid2 & 15;
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-          const int i = ti2 + 16 * a, j = tj2 + 16 * bb;
-          sV[j * TS + i] = (i >= j) ? T[a][bb] : 0.0;       // below the diagonal of a diagonal tile nothing is ever read
-          sW[j * TS + i] = (i >= j) ? Xi[a][bb] : 0.0;      // invLt[q][p], the K-major operand of the next step's first product
-          if (a == bb && ti2 == tj2) s_rd[(i >> 4) * TS + (i & 15)] = pivot_rcp(T[a][bb]);
-        }
-      __syncthreads();
-      const int lane2 = tid2 & 63, wv2 = tid2 >> 6;
-      const int rw2 = 16 * wv2 + (lane2 >> 5), cw2 = 2 * (lane2 & 31);
+    if constexpr (kChainBlocked) {
+      // four panels of 16 columns: wave 0 pivots in registers, waves 1-3 update with MFMA and build the inverse
+      TAIL_STAMP(b, 7);
+      const bool bad = chain_factor_blocked(sW, sV, s_rd);
+      TAIL_STAMP(b, 8);
+      if (bad && tid == 0) atomicExch(t.status, 2);
+      // sV = L^T / d and sW = transposed inverse are complete tiles in LDS (behind the factorisation's last barrier): both leave
+      // row by row, full 512-byte rows per half wave.  The tiles below the block diagonal of sW hold working copies of the
+      // inverse; zeros go to memory in their place.
+      const int rw2 = 16 * wv + (lane >> 5), cw2 = 2 * (lane & 31);
       const int s_voff = (rw2 * ld + cw2) * 8, i_voff = (rw2 * kInner + cw2) * 8;
       const __amdgpu_buffer_rsrc_t rs = tail_rsrc(t.S + (size_t)j0 * ld + j0);
       const __amdgpu_buffer_rsrc_t ri = tail_rsrc(t.invLt + (size_t)r * kInner * kInner);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
+        const int row = rw2 + 2 * k;
         v2f64_t v, w;
-        v.x = sV[(rw2 + 2 * k) * TS + cw2]; v.y = sV[(rw2 + 2 * k) * TS + cw2 + 1];
-        w.x = sW[(rw2 + 2 * k) * TS + cw2]; w.y = sW[(rw2 + 2 * k) * TS + cw2 + 1];
+        v.x = sV[row * TS + cw2]; v.y = sV[row * TS + cw2 + 1];
+        w.x = sW[row * TS + cw2]; w.y = sW[row * TS + cw2 + 1];
+        if ((cw2 >> 4) < (row >> 4)) { w.x = 0.0; w.y = 0.0; }
+        if (cw2 < row) v.x = 0.0;                             // below the diagonal of sV: junk of the panel loops
+        if (cw2 + 1 < row) v.y = 0.0;
         tail_st2(rs, s_voff, 2 * k * ld * 8, v);
         tail_st2(ri, i_voff, 2 * k * kInner * 8, w);
       }
-      if (tid2 < kInner) {
+      if (tid < kInner) {
         const __amdgpu_buffer_rsrc_t rv = tail_rsrc(t.dvec + j0);
-        tail_st1(rv, tid2 * 8, 0, sV[tid2 * TS + tid2]);
+        tail_st1(rv, tid * 8, 0, sV[tid * TS + tid]);
+      }
+    } else {
+      double T[4][4], Xi[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+          const int i = ti + 16 * a, j = tj + 16 * bb;
+          const int lo = i < j ? i : j, hi = i < j ? j : i;
+          T[a][bb] = sW[lo * TS + hi];
+          Xi[a][bb] = (i == j) ? 1.0 : 0.0;
+        }
+      __syncthreads();                             // sW is read; sV (colbuf / rowbuf) is free since the barrier after the second product
+      TAIL_STAMP(b, 7);
+      const bool bad = ldlt_diag_core<kInner>(T, Xi, colbuf, rowbuf);
+      TAIL_STAMP(b, 8);
+      if (bad && tid == 0) atomicExch(t.status, 2);
+      {
+        // L_rr / d (memory row j, column i: transposed) -> sV, invLt -> sW, then both tiles leave row by row.  No global store
+        // is issued before the barrier: a store followed by anything that makes the compiler wait for vmcnt(0) (a register
+        // reload, here) costs a full write-through acknowledgement, ~1 us each.
+        int tid2 = threadIdx.x;
+        asm volatile("" : "+v"(tid2));               // lane indices are re-derived here instead of staying live across the pivots
+        const int ti2 = tid2 >> 4, tj2 = tid2 & 15;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) {
+            const int i = ti2 + 16 * a, j = tj2 + 16 * bb;
+            sV[j * TS + i] = (i >= j) ? T[a][bb] : 0.0;       // below the diagonal of a diagonal tile nothing is ever read
+            sW[j * TS + i] = (i >= j) ? Xi[a][bb] : 0.0;      // invLt[q][p], the K-major operand of the next step's first product
+            if (a == bb && ti2 == tj2) s_rd[(i >> 4) * TS + (i & 15)] = pivot_rcp(T[a][bb]);
+          }
+        __syncthreads();
+        const int lane2 = tid2 & 63, wv2 = tid2 >> 6;
+        const int rw2 = 16 * wv2 + (lane2 >> 5), cw2 = 2 * (lane2 & 31);
+        const int s_voff = (rw2 * ld + cw2) * 8, i_voff = (rw2 * kInner + cw2) * 8;
+        const __amdgpu_buffer_rsrc_t rs = tail_rsrc(t.S + (size_t)j0 * ld + j0);
+        const __amdgpu_buffer_rsrc_t ri = tail_rsrc(t.invLt + (size_t)r * kInner * kInner);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          v2f64_t v, w;
+          v.x = sV[(rw2 + 2 * k) * TS + cw2]; v.y = sV[(rw2 + 2 * k) * TS + cw2 + 1];
+          w.x = sW[(rw2 + 2 * k) * TS + cw2]; w.y = sW[(rw2 + 2 * k) * TS + cw2 + 1];
+          tail_st2(rs, s_voff, 2 * k * ld * 8, v);
+          tail_st2(ri, i_voff, 2 * k * kInner * 8, w);
+        }
+        if (tid2 < kInner) {
+          const __amdgpu_buffer_rsrc_t rv = tail_rsrc(t.dvec + j0);
+          tail_st1(rv, tid2 * 8, 0, sV[tid2 * TS + tid2]);
+        }
       }
     }
     TAIL_STAMP(b, 9);

@@ -20,6 +20,12 @@ except Exception as e:
 PY
 }
 case $WHAT in
+  chain)
+    # round 4: the chain's blocked diagonal factorisation alone, then the dataflow launches with it (and with the round-3 loop)
+    timeout 120 tools/bin/bench_diag 200 2>&1 | tee $O/${TAG}_diag.txt
+    TAILLOG=1 TAILS=${TAILS:-6144} timeout 300 tools/bin/bench_tail 2304 2240 2>&1 | tee $O/${TAG}_tail_small.txt
+    TAILLOG=1 TAILS=${TAILS:-6144} timeout 300 tools/bin/bench_tail 12672 12544 2>&1 | tee $O/${TAG}_tail.txt
+    [ -x tools/bin/bench_tail_old ] && TAILLOG=1 TAILS=${TAILS:-6144} timeout 300 tools/bin/bench_tail_old 12672 12544 2>&1 | tee $O/${TAG}_tail_old.txt ;;
   tail)
     TAILLOG=1 TAILS=${TAILS:-1024,6144,8192} timeout 300 tools/bin/bench_tail 12672 12544 2>&1 | tee $O/${TAG}_tail.txt ;;
   suite|record|profile)
