@@ -2006,13 +2006,12 @@ __device__ __forceinline__ void chain_inv16(double* sW, double* sV, int p, int l
   double x[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) x[i] = (i == j) ? 1.0 : 0.0;
-  // right-looking order: the 15 - k updates of step k are independent of each other (row by row, every x[i] is a chain of i
-  // dependent fp64 FMAs: 1.1 us for the 120 of them)
+  // right-looking order: the 15 - k updates of step k are independent of each other.  (Pinning that order with a scheduling
+  // barrier per step cost 93 spilled registers in the launch and gained 0.1 us.)
 #pragma unroll
   for (int k = 0; k < 15; ++k) {
 #pragma unroll
     for (int i = k + 1; i < 16; ++i) x[i] = __builtin_fma(-sV[(base + k) * TS + base + i], x[k], x[i]);
-    __builtin_amdgcn_sched_barrier(0);       // (the scheduler would regroup the updates row by row)
   }
   if (lane < 16) {
 #pragma unroll
