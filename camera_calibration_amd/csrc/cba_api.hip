@@ -224,6 +224,12 @@ struct DevPool {
   }
 };
 struct LdltGuard { LdltWorkspace* w; ~LdltGuard() { if (w) ldlt_workspace_free(*w); } };
+// cba_solver_options -> the workspace of a problem / call (zero fields keep the defaults)
+static void apply_solver_options(LdltWorkspace& w, const cba_solver_options* o) {
+  if (!o) return;
+  if (o->factor_tail_rows > 0) w.tail_rows = o->factor_tail_rows;
+  w.back_dataflow = o->back_substitution == 0;
+}
 
 static int alloc_state(cba_problem* p, DevState& s) {
   CBA_TRY(dev_alloc(&s.rig_tr_global, 7 * (size_t)p->L.n_images));
@@ -463,6 +469,7 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
     p->timers[0].flops += slabs * 2.0 * 128 * 128 * 16;
     p->timers[0].bytes += tiles * 2.0 * 128 * 128 * 8 + slabs * 2.0 * 16 * 128 * 8;
   }
+  if (st[1] == 3) { set_error("reduced solve: a dataflow launch timed out waiting for another workgroup"); return CBA_ERR_TIMEOUT; }
   if (st[0] || st[1]) return CBA_ERR_NUMERIC;
   return CBA_OK;
 }
@@ -628,6 +635,7 @@ int cba_create(const cba_config* config, cba_problem** out) {
   CBA_TRY(dev_alloc(&p->gemv_ws, (size_t)gemv_t_workspace_doubles(p->n_pad)));
   CBA_TRY(dev_alloc(&p->status, 1));
   CBA_TRY(ldlt_workspace_alloc(p->ldlt, p->n_pad));
+  apply_solver_options(p->ldlt, &config->solver);
   guard.q = nullptr;
   *out = p;
   return CBA_OK;
@@ -1097,9 +1105,6 @@ int cba_debug_fd_redo_counts(cba_problem* p, int64_t out[3]) {
   for (int i = 0; i < 3; ++i) out[i] = v[i];
   return CBA_OK;
 }
-void cba_set_factor_tail_rows(int32_t rows) { ldlt_set_tail_rows(rows); }
-void cba_debug_set_back_substitution(int32_t dataflow) { ldlt_set_back_dataflow(dataflow); }
-int32_t cba_factor_tail_rows(void) { return ldlt_tail_rows(); }
 
 int cba_model_set_grid(cba_model* m, const double* grid) {
   if (!m || !grid) { set_error("cba_model_set_grid: bad argument"); return CBA_ERR_ARG; }
@@ -1176,6 +1181,11 @@ int cba_unproject(const cba_camera* camera, const double* grid, int64_t n, const
 int cba_schur_solve(int32_t block_size, int32_t n_blocks, int32_t dense_dof, const double* block_diag_H,
                     const double* off_diag_H, const double* dense_H, const double* block_diag_b,
                     const double* dense_b, double* x, int32_t device) {
+  return cba_schur_solve_opt(block_size, n_blocks, dense_dof, block_diag_H, off_diag_H, dense_H, block_diag_b, dense_b, x, nullptr, device);
+}
+int cba_schur_solve_opt(int32_t block_size, int32_t n_blocks, int32_t dense_dof, const double* block_diag_H,
+                        const double* off_diag_H, const double* dense_H, const double* block_diag_b,
+                        const double* dense_b, double* x, const cba_solver_options* options, int32_t device) {
   if (block_size < 1 || block_size > 6 || n_blocks < 1 || dense_dof < 1 || !block_diag_H || !off_diag_H || !dense_H ||
       !block_diag_b || !dense_b || !x) { set_error("cba_schur_solve: bad argument"); return CBA_ERR_ARG; }
   int ndev = 0;
@@ -1211,6 +1221,7 @@ int cba_schur_solve(int32_t block_size, int32_t n_blocks, int32_t dense_dof, con
   LdltWorkspace w;
   LdltGuard wguard{&w};
   CBA_TRY(ldlt_workspace_alloc(w, n_pad));
+  apply_solver_options(w, options);
   CBA_HIP(hipMemset(w.status, 0, sizeof(int)));
   hipStream_t s = nullptr;
   CBA_TRY(launch_block_inverse(Dblk, bblk, 0.0, bs, nb, Dinv, dinvb, status, s));
@@ -1225,6 +1236,7 @@ int cba_schur_solve(int32_t block_size, int32_t n_blocks, int32_t dense_dof, con
   CBA_HIP(hipMemcpy(&st[0], status, sizeof(int), hipMemcpyDeviceToHost));
   CBA_HIP(hipMemcpy(&st[1], w.status, sizeof(int), hipMemcpyDeviceToHost));
   CBA_HIP(hipMemcpy(x, xd, sizeof(double) * (bdof + dd), hipMemcpyDeviceToHost));
+  if (st[1] == 3) { set_error("cba_schur_solve: a dataflow launch of the factorisation timed out"); return CBA_ERR_TIMEOUT; }
   if (st[0] || st[1]) { set_error("cba_schur_solve: zero pivot"); return CBA_ERR_NUMERIC; }
   return CBA_OK;
 }

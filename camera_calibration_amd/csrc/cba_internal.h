@@ -137,15 +137,17 @@ int launch_gemv_n(const double* M, int K, int n, int ld, const double* v, const 
 struct GemmStats { double seconds = 0, flops = 0, bytes = 0; int launches = 0; };
 // In-place blocked LDL^T of a symmetric matrix stored "upper in row-major" (= lower in column-major).
 struct LdltWorkspace {
-  double* X = nullptr;       // two panel copies [2][kPanel][ld]
-  double* invLt = nullptr;   // [kInner][kInner]
+  double* X = nullptr;       // X = D L of a super-panel's row strip [kSuperMax][ld]
+  double* invLt = nullptr;   // per 64-block: transposed inverse of the unit factor [kInner][kInner]
+  // scheduling options (cba_solver_options): rows left to the final dataflow launch; back substitution as one dataflow launch
+  int tail_rows = 6144;
+  bool back_dataflow = true;
   double* dvec = nullptr;    // n
   int* status = nullptr;
-  hipStream_t panel_stream = nullptr;   // pivot chain (look-ahead panel factorisation)
-  hipStream_t mid_stream = nullptr;     // panel solves / updates on the next panel's columns
-  hipStream_t far_stream = nullptr;     // panel solves / updates right of the next panel
-  hipEvent_t ev_panel = nullptr, ev_strip = nullptr, ev_mid = nullptr, ev_aa = nullptr, ev_chain = nullptr, ev_bulk = nullptr,
-             ev_diag = nullptr, ev_xn = nullptr;
+  // the device's side streams (shared, not owned): high-priority / two plain ones.  The factorisation itself runs on the caller's
+  // stream; users: the exchanges of the distributed variant, the Jacobian pass' side work (cba_api.hip)
+  hipStream_t panel_stream = nullptr, mid_stream = nullptr, far_stream = nullptr;
+  hipEvent_t ev_strip = nullptr, ev_mid = nullptr;
   size_t n_alloc = 0;
   // kernel-only timing of the 128 x 128 GEMM launches of the factorisation (bulk and row-strip updates): event pairs
   // on the stream of each launch, read back by the caller after the step (ldlt_collect_spans)
@@ -167,10 +169,8 @@ int ldlt_workspace_alloc(LdltWorkspace& w, int n);
 int ldlt_collect_spans(LdltWorkspace& w, GemmStats* st);
 void ldlt_workspace_free(LdltWorkspace& w);
 int ldlt_factor(double* S, int n, int ld, LdltWorkspace& w, hipStream_t s, GemmStats* trailing_stats);
-// Rows (from the end of the matrix) that the persistent tail launch factors; 0 = the blocked multi-stream schedule all the way.
-void ldlt_set_tail_rows(int rows);
-int ldlt_tail_rows();
-void ldlt_set_back_dataflow(int on);   // back substitution as one dataflow launch (default) or by panels of 256 (round 2)
+// Rows that the final dataflow launch factors (w.tail_rows clamped to the workspace's flag storage)
+int ldlt_tail_rows(const LdltWorkspace& w);
 // milliseconds of the last tail launch (waits for it); 0 when there was none
 double ldlt_tail_last_ms(LdltWorkspace& w);
 // Distributed variant (cba_config.distributed_solve): S holds this rank's PARTIAL reduced system on entry; the collectives are

@@ -145,54 +145,21 @@ struct GemmArgs {
   int diag;                     // add to diagonal entries
   const double* diag_add_ptr;   // device scalar (lambda) or null
   double diag_add;              // host scalar used when diag_add_ptr == null
-  double* C2;                   // optional second output  C2[m][n] = value * rowscale[m]  (L = X / d)
-  int ldc2;
-  const double* rowscale_inv;   // d values: C2 = value / d[m]
   long long total_tiles;
   int chunk;                    // tiles per XCD chunk (set by launch_gemm)
   const unsigned long long* kmask;  // optional block-sparsity mask [column tile][kmask_words], bit = K slab of 16 rows
   int kmask_words;
-#ifdef CBA_DEV_SWITCHES
-  int epi_mode;                 // bench harness only (tools/bench_linalg.hip): 0 normal, 1 no Cin read, 2 no store
-#endif
   int strips;                   // set by launch_gemm: strip-blocked tile order (square upper dense launches)
-  // SE-balanced slot assignment (128 x 128 launches on a CU-masked stream, set by launch_gemm; null = slot = blockIdx.x)
-  unsigned* dyn;                // device counters: [0..7] next slot of each XCD, [8 + 8 xcc + se] workgroups seen by a short SE, [72] finished, [73] skipped
-  unsigned skip_budget;         // workgroups that may exit without a tile (grid - tiles - reserve): the rest MUST take one
-  unsigned se_cus[8];           // per XCD: CUs available to the stream in SE k, 4 bits each
-  int se_max;                   // CUs of a complete SE
-  const double* a_rowdiv;       // small-tile variants only: A[k][m] is divided by a_rowdiv[k] while staged (L = X / d on the fly)
-  int tlog_tag;                 // developer timeline (tools/bench_linalg.hip, -DCBA_TLOG): tag + 1, 0 = none
   int col_group, col_stride;    // distributed factorisation: owned column groups (tiles per group, group stride); 0 = all columns
 };
 
-// Developer switches are compiled only into the bench harness (tools/bench_linalg.hip defines CBA_DEV_SWITCHES): the
+// Developer switches are compiled only into the bench harness (tools/bench_tail.hip, tools/bench_diag.hip define CBA_DEV_SWITCHES): the
 // product library has no epilogue modes and reads no CBA_* environment variables.
 #ifdef CBA_DEV_SWITCHES
-#define CBA_EPI_MODE(g_) ((g_).epi_mode)
 #define CBA_GETENV(name_) getenv(name_)
 #else
-#define CBA_EPI_MODE(g_) 0
 #define CBA_GETENV(name_) ((const char*)nullptr)
 #endif
-
-// Developer timeline of the factorisation schedule: with -DCBA_TLOG (tools/bench_linalg.hip only) every kernel of
-// ldlt_factor stamps the 100 MHz wall clock at its first workgroup's start and its last workgroup's end into
-// g_tlog[tag], without a profiler attached (rocprofv3's queue interception stretches the cross-stream hops).
-#ifdef CBA_TLOG
-__device__ unsigned long long* g_tlog = nullptr;
-__device__ __forceinline__ void tlog_begin(int tag) {
-  if (g_tlog && tag >= 0 && threadIdx.x == 0) atomicMin(&g_tlog[2 * tag], (unsigned long long)wall_clock64());
-}
-__device__ __forceinline__ void tlog_end(int tag) {
-  if (g_tlog && tag >= 0 && threadIdx.x == 0) atomicMax(&g_tlog[2 * tag + 1], (unsigned long long)wall_clock64());
-}
-#else
-__device__ __forceinline__ void tlog_begin(int) {}
-__device__ __forceinline__ void tlog_end(int) {}
-#endif
-enum { kTlDiag = 0, kTlNear, kTlScale, kTlMidTrsm, kTlMidUpd, kTlChainTrsm, kTlChainUpd, kTlAPrime, kTlPanelSolve,
-       kTlAA_n, kTlAA_rest, kTlBulk, kTlXn, kTlKinds = 16 };
 
 // slot -> position in the launch's tile enumeration (>= total_tiles: no tile)
 __device__ __forceinline__ long long gemm_slot_tile(const GemmArgs& g, long long b) {
@@ -218,8 +185,6 @@ __host__ __device__ inline int colgroup_strip_rows(const GemmArgs& g, int tn_las
 template <int TM, int TN, int WM, int WN, bool SUB>
 __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
   constexpr int LDA_S = TM + 16, LDB_S = TN + 16;
-  __shared__ double sA[2][KT * LDA_S];
-  __shared__ double sB[2][KT * LDB_S];
   constexpr int WAVES_N = TN / WN;
   constexpr int MI = WM / 16, NJ = WN / 16;
 
@@ -303,7 +268,7 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
   // SUB: the accumulators start as -(Cin + diag) (see below); in the LDS-DMA variant the tile is loaded AFTER the
   // first operand slab has been put in flight so that the two HBM round trips overlap.
   auto preload_c = [&]() {
-    if (SUB && CBA_EPI_MODE(g) != 1) {
+    if (SUB) {
       double dadd0 = 0.0;
       if (g.diag) dadd0 = g.diag_add_ptr ? *g.diag_add_ptr : g.diag_add;
 #pragma unroll
@@ -325,22 +290,12 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
         for (int j = 0; j < NJ; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
     }
   };
-  // The panel-sized variants keep the C tile in its own registers instead (loaded behind the first operand slabs, never
-  // waited for before the epilogue): C = Cin - sum.
-  constexpr bool kSmall = !(TM == 128 && TN == 128);
-  v4f64 cin[MI][NJ];
-  if constexpr (kSmall) {
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) { acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0}; cin[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0}; }
-  }
-
 
   const double* Ag = g.A + m0;
   const double* Bg = g.B + n0;
   const int nk = g.K / KT;
-  if constexpr (TM == 128 && TN == 128) {
+  static_assert(TM == 128 && TN == 128, "only the 128 x 128 LDS-DMA tile is built (the register-staged panel variants went with the blocked schedule)");
+  {
     // Stage pipeline with LDS-DMA (global_load_lds_dwordx4): each wavefront-instruction moves one
     // 1 KiB row segment (64 lanes x 16 B) of the K-major operand straight into its (padded) LDS row,
     // no staging registers.  The slab for stage kb+1 is in flight while the MFMAs consume stage kb;
@@ -413,92 +368,6 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
     }
 #undef CBA_MMA_STAGE
 #undef CBA_DMA_STAGE
-  } else {
-    // small-tile variant (panel operations): register-staged, with kDepth slabs in flight.  These launches are a
-    // handful of workgroups on the critical path of the factorisation; with one slab in flight every K step paid a
-    // full L2 / HBM round trip (~1.5 us per 16-row slab against 0.4 us of MFMA work).
-    constexpr int kDepth = 3;
-    constexpr int A_PER = KT * TM / 2 / 256, B_PER = KT * TN / 2 / 256;
-    constexpr int A_ROWSTEP = 256 / (TM / 2), B_ROWSTEP = 256 / (TN / 2);
-    const int a_row = tid / (TM / 2), a_c2 = tid % (TM / 2);
-    const int b_row = tid / (TN / 2), b_c2 = tid % (TN / 2);
-    static_assert(A_PER == 2 && (B_PER == 2 || B_PER == 4), "staging registers below are written out for these shapes");
-    // staging registers, written out as scalars: one set per slot (arrays here end up in scratch memory)
-    double2 ra0_0, ra0_1, ra1_0, ra1_1, ra2_0, ra2_1;
-    double rd0_0 = 1.0, rd0_1 = 1.0, rd1_0 = 1.0, rd1_1 = 1.0, rd2_0 = 1.0, rd2_1 = 1.0;    // a_rowdiv values of the slot's two rows
-    double2 rb0_0, rb0_1, rb0_2, rb0_3, rb1_0, rb1_1, rb1_2, rb1_3, rb2_0, rb2_1, rb2_2, rb2_3;
-#define CBA_LDA(j_, k0_) (*reinterpret_cast<const double2*>(Ag + (size_t)((k0_) + a_row + (j_) * A_ROWSTEP) * g.lda + 2 * a_c2))
-#define CBA_LDB(j_, k0_) (*reinterpret_cast<const double2*>(Bg + (size_t)((k0_) + b_row + (j_) * B_ROWSTEP) * g.ldb + 2 * b_c2))
-#define CBA_STA(buf_, j_) (*reinterpret_cast<double2*>(&sA[(buf_)][(a_row + (j_) * A_ROWSTEP) * LDA_S + 2 * a_c2]))
-#define CBA_STB(buf_, j_) (*reinterpret_cast<double2*>(&sB[(buf_)][(b_row + (j_) * B_ROWSTEP) * LDB_S + 2 * b_c2]))
-#define CBA_GLOAD(slot_, k0_)                                                                                   \
-  {                                                                                                             \
-    const int kq = (k0_);                                                                                       \
-    ra##slot_##_0 = CBA_LDA(0, kq); ra##slot_##_1 = CBA_LDA(1, kq);                                             \
-    if (g.a_rowdiv) { rd##slot_##_0 = g.a_rowdiv[kq + a_row]; rd##slot_##_1 = g.a_rowdiv[kq + a_row + A_ROWSTEP]; } \
-    rb##slot_##_0 = CBA_LDB(0, kq); rb##slot_##_1 = CBA_LDB(1, kq);                                             \
-    if constexpr (B_PER == 4) { rb##slot_##_2 = CBA_LDB(2, kq); rb##slot_##_3 = CBA_LDB(3, kq); }               \
-  }
-#define CBA_SSTORE(buf_, slot_)                                                                                 \
-  {                                                                                                             \
-    const int bq = (buf_);                                                                                      \
-    if (g.a_rowdiv) {                                                                                           \
-      ra##slot_##_0.x /= rd##slot_##_0; ra##slot_##_0.y /= rd##slot_##_0;                                       \
-      ra##slot_##_1.x /= rd##slot_##_1; ra##slot_##_1.y /= rd##slot_##_1;                                       \
-    }                                                                                                           \
-    CBA_STA(bq, 0) = ra##slot_##_0; CBA_STA(bq, 1) = ra##slot_##_1;                                             \
-    CBA_STB(bq, 0) = rb##slot_##_0; CBA_STB(bq, 1) = rb##slot_##_1;                                             \
-    if constexpr (B_PER == 4) { CBA_STB(bq, 2) = rb##slot_##_2; CBA_STB(bq, 3) = rb##slot_##_3; }               \
-  }
-    // slabs past the last one are re-reads of the last slab (in bounds, never stored to LDS)
-    CBA_GLOAD(0, 0);
-    CBA_GLOAD(1, (1 < nk ? 1 : nk - 1) * KT);
-    CBA_GLOAD(2, (2 < nk ? 2 : nk - 1) * KT);
-    if (SUB && CBA_EPI_MODE(g) != 1) {       // raw tile only: touching the values here would wait for the loads
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            cin[i][j][r] = g.Cin[(size_t)(m0 + wm0 + i * 16 + lk + 4 * r) * g.ldcin + n0 + wn0 + j * 16 + li];
-    }
-    CBA_SSTORE(0, 0);
-    __syncthreads();
-    // one K slab: the register slot that held slab kb (in LDS by now) is refilled with slab kb + kDepth.  The slot
-    // numbers are literals (a run-time slot index would put the staging registers into scratch memory).
-#define CBA_KSTEP(slot_, next_slot_)                                                                            \
-  if (kb0 + (slot_) < nk) {                                                                                     \
-    const int kb = kb0 + (slot_);                                                                               \
-    const int buf = kb & 1;                                                                                     \
-    CBA_GLOAD(slot_, (kb + kDepth < nk ? kb + kDepth : nk - 1) * KT);                                           \
-    const double* a_s = &sA[buf][0];                                                                            \
-    const double* b_s = &sB[buf][0];                                                                            \
-    _Pragma("unroll") for (int kk = 0; kk < KT; kk += 4) {                                                      \
-      double af[MI], bf[NJ];                                                                                    \
-      _Pragma("unroll") for (int i = 0; i < MI; ++i) af[i] = a_s[(kk + lk) * LDA_S + wm0 + i * 16 + li];        \
-      _Pragma("unroll") for (int j = 0; j < NJ; ++j) bf[j] = b_s[(kk + lk) * LDB_S + wn0 + j * 16 + li];        \
-      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                            \
-        _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                          \
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);                   \
-    }                                                                                                           \
-    CBA_SSTORE(buf ^ 1, next_slot_);                                                                            \
-    __syncthreads();                                                                                            \
-  }
-    static_assert(kDepth == 3, "CBA_KSTEP sequence below is written for three slots");
-#pragma nounroll
-    for (int kb0 = 0; kb0 < nk; kb0 += kDepth) {
-      CBA_KSTEP(0, 1)
-      CBA_KSTEP(1, 2)
-      CBA_KSTEP(2, 0)
-    }
-#undef CBA_KSTEP
-#undef CBA_GLOAD
-#undef CBA_SSTORE
-#undef CBA_LDA
-#undef CBA_LDB
-#undef CBA_STA
-#undef CBA_STB
   }
 
   // ---- epilogue ----
@@ -511,110 +380,17 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
         const int m = m0 + wm0 + i * 16 + lk + 4 * r;
         const int n = n0 + wn0 + j * 16 + li;
         double v = acc[i][j][r];
-        if (CBA_EPI_MODE(g) == 2) { if (v == 1.2345e300) g.C[(size_t)m * g.ldc + n] = v; continue; }
-        if constexpr (kSmall) {
-          if (SUB) {
-            double c = cin[i][j][r];
-            if (g.diag && m == n && CBA_EPI_MODE(g) != 1) c += (m < g.n_real) ? (g.diag_add_ptr ? *g.diag_add_ptr : g.diag_add) : 1.0;
-            v = c - v;
-          }
-        }
-        else if (SUB) v = -v;
+        if (SUB) v = -v;
         g.C[(size_t)m * g.ldc + n] = v;
-        if (g.C2) g.C2[(size_t)m * g.ldc2 + n] = v / g.rowscale_inv[m];
       }
   return true;
 }
 
-// Slot of this workgroup on a CU-masked stream.  The dispatcher hands out workgroups IN ORDER and evenly over the shader
-// engines (tools/dispatch_probe.hip: 114-115 of 3655 workgroups for every one of the 32 SEs, whether an SE has 8 CUs or 7),
-// so an SE that lost a CU to the pivot chain's reservation sets the pace of the whole launch: 8 / 7 of the time, the
-// 12-14 % a CU mask costs the bulk update whatever the number of reserved CUs (8, 16 and 32 gave the same rate).  Here a
-// workgroup that lands on a short SE exits at once one time in `se_max` per missing CU (the grid is oversubscribed by the
-// same ratio), so every CU ends up with the same number of tiles; the tile comes from the counter of the XCD the
-// workgroup really runs on (HW_REG_XCC_ID -- user streams rotate the blockIdx -> XCD map by a per-queue constant), which
-// keeps the chunked tile order and its L2 sharing.
-__device__ __forceinline__ long long gemm_dynamic_slot(const GemmArgs& g) {
-  __shared__ long long s_slot;
-  if (threadIdx.x == 0) {
-    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7u;          // HW_REG_XCC_ID
-    const unsigned se = (__builtin_amdgcn_s_getreg((32 - 1) << 11 | 4) >> 13) & 7u;   // HW_REG_HW_ID: se_id
-    const unsigned cnt = (g.se_cus[xcc] >> (4 * se)) & 15u;
-    long long b = -1;
-    bool skip = false;
-    if (cnt < (unsigned)g.se_max) {
-      const unsigned c = atomicAdd(&g.dyn[8 + 8 * xcc + se], 1u);
-      // the budget keeps the launch complete whatever the dispatcher does: at most grid - tiles - reserve workgroups skip
-      if ((c % (unsigned)g.se_max) >= cnt) skip = atomicAdd(&g.dyn[73], 1u) < g.skip_budget;
-    }
-    if (!skip) {
-      for (unsigned d = 0; d < 8; ++d) {           // own XCD first, then whoever still has tiles
-        const unsigned x2 = (xcc + d) & 7u;
-        const long long bb = (long long)atomicAdd(&g.dyn[x2], 1u) * 8 + x2;
-        if (gemm_slot_tile(g, bb) < g.total_tiles) { b = bb; break; }
-      }
-    }
-    s_slot = b;
-  }
-  __syncthreads();
-  return s_slot;
-}
-// the last workgroup to finish leaves the counters zeroed for the next launch on this stream
-__device__ __forceinline__ void gemm_dynamic_done(const GemmArgs& g) {
-  if (threadIdx.x == 0) {
-    __threadfence();
-    if (atomicAdd(&g.dyn[72], 1u) == gridDim.x - 1) {
-      for (int i = 0; i < 74; ++i) g.dyn[i] = 0u;
-      __threadfence();
-    }
-  }
-}
-
-// One tile per workgroup.  Two alternatives to the CU mask on the main stream were measured and dropped (the mask costs
-// the bulk update 13-17 %: the same launch takes 1402 us on the masked stream and 1161 us on an unmasked one,
-// tools/bench_linalg.hip -DCBA_TLOG): (a) drawing the slot from per-XCD counters with an oversubscribed grid on the
-// masked stream changed nothing, so the loss is not an end-of-launch imbalance between shader engines; (b) persistent
-// workgroups on an unmasked stream that exit when they find themselves on a CU reserved for the pivot chain ran the
-// bulk update at the unmasked speed, but two resident workgroups per CU left no LDS for the far stream's launches and
-// the look-ahead collapsed (factorisation 18.0 -> 18.6 ms).
-#ifdef CBA_WGLOG
-// developer harness (tools/gemm_wg_timeline.hip): per workgroup {start, end (100 MHz wall clock), XCC_ID, HW_ID}
-__device__ unsigned long long* g_wglog = nullptr;
-#endif
+// One tile per workgroup.
 template <int TM, int TN, int WM, int WN, bool SUB>
 __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
-  if constexpr (TM < 128) __builtin_amdgcn_s_setprio(2);   // panel-sized products are on the critical path
-#ifdef CBA_WGLOG
-  struct WgLog {
-    unsigned long long t0;
-    __device__ WgLog() : t0(wall_clock64()) {}
-    __device__ ~WgLog() {
-      if (g_wglog && threadIdx.x == 0) {
-        unsigned long long* e = g_wglog + 4 * (size_t)blockIdx.x;
-        e[0] = t0; e[1] = wall_clock64();
-        e[2] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7u; e[3] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);
-      }
-    }
-  } wglog;
-#endif
-  tlog_begin(g.tlog_tag - 1);
-  if constexpr (TM == 128 && TN == 128) {
-    if (g.dyn) {
-      const long long b = gemm_dynamic_slot(g);
-      if (b >= 0) gemm_tile<TM, TN, WM, WN, SUB>(g, b);
-      gemm_dynamic_done(g);
-      tlog_end(g.tlog_tag - 1);
-      return;
-    }
-  }
   gemm_tile<TM, TN, WM, WN, SUB>(g, blockIdx.x);
-  tlog_end(g.tlog_tag - 1);
 }
-
-// CU layout of the engine's masked streams (filled by device_streams(), further down): which shader engines are short of
-// CUs, and a zeroed counter block per stream for gemm_dynamic_slot
-struct SeBalance { unsigned* counters; unsigned se_cus[8]; int se_max, cus_total, cus_full; };
-static bool se_balance_for_stream(hipStream_t s, SeBalance* out);
 
 static long long count_upper_tiles(int m_off, int n_off, int m_tiles, int n_tiles, int TM, int TN) {
   long long total = 0;
@@ -649,18 +425,6 @@ static int launch_gemm(GemmArgs g, hipStream_t s) {
               g.total_tiles >= 512) ? 1 : 0;
   long long chunks = (g.total_tiles + g.chunk - 1) / g.chunk;
   long long blocks = ((chunks + 7) / 8) * 8 * g.chunk;
-  g.dyn = nullptr;
-  if constexpr (TM == 128 && TN == 128) {
-    SeBalance sb;
-    // (launches with K = 256 are too short for the extra atomics to pay: 40.1 vs 42.1 TFLOP/s, profiles/r02_se_balance_ab.txt)
-    if (g.K >= 512 && se_balance_for_stream(s, &sb) && g.total_tiles >= 2 * sb.cus_total) {
-      g.dyn = sb.counters; g.se_max = sb.se_max;
-      for (int i = 0; i < 8; ++i) g.se_cus[i] = sb.se_cus[i];
-      // oversubscribed by (all CUs of the complete SEs) / (CUs available), plus the workgroups that arrive after the last tile
-      blocks = (g.total_tiles * sb.cus_full + sb.cus_total - 1) / sb.cus_total + 64;
-      g.skip_budget = (unsigned)(blocks - g.total_tiles - 32);
-    }
-  }
   hipLaunchKernelGGL((k_gemm_atb<TM, TN, WM, WN, SUB>), dim3((unsigned)blocks), dim3(256), 0, s, g);
   CBA_HIP(hipGetLastError());
   return CBA_OK;
@@ -736,51 +500,18 @@ int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const doubl
   g.C = C; g.ldc = ld; g.Cin = Cin; g.ldcin = ld;
   g.m_tiles = n_pad / 128; g.n_tiles = n_pad / 128; g.m_off = 0; g.n_off = 0; g.upper = 1;
   g.n_real = n_real; g.diag = add_diag; g.diag_add_ptr = nullptr; g.diag_add = lambda;
-  g.C2 = nullptr; g.ldc2 = 0; g.rowscale_inv = nullptr;
   return launch_gemm<128, 128, 64, 64, true>(g, s);
 }
 
 // ------------------------------------------------------------------------------------------------
-// blocked LDL^T, lower/column-major view of "upper in row-major" storage.
-//   kInner = 64 : diagonal blocks factored (and their unit-lower factors inverted) by one workgroup
-//   kPanel = 256: panel width of the chain-bound tail and of the back substitution
-//   kPanelWide = 512: panel width while the bulk update is the bottleneck (the leading part of the matrix):
-//                the GEMM reaches 53 instead of 46 TFLOP/s at K = 512 because the read+write of the C
-//                tile is amortised over twice the flops
+// LDL^T, lower/column-major view of "upper in row-major" storage.
+//   kInner = 64 : diagonal blocks factored (and their unit-lower factors inverted) by the chain workgroup of a dataflow launch
+//   kPanel = 256: panel width of the panel version of the back substitution
 // ------------------------------------------------------------------------------------------------
 constexpr int kInner = 64;
-// two pivots per barrier in the 64 x 64 diagonal factorisation (ldlt_diag_pair); the bench harness can build the one-pivot loop
-#ifdef CBA_DIAG_SINGLE
-constexpr bool kDiagPairs = false;
-#else
-constexpr bool kDiagPairs = true;
-#endif
 constexpr int kPanel = 256;
-constexpr int kPanelWide = 512;
 constexpr int kSuperMax = 4096;              // widest super-panel (rows factored by one dataflow launch in front of a bulk update)
 constexpr int kTailMaxBlockRows = 192;      // the persistent tail launch covers at most this many 64-row blocks (flag storage)
-// panels are kPanelWide wide while more than this many rows remain (env CBA_WIDE_ROWS overrides; 0 = never)
-static int wide_rows_threshold() {
-  static int v = -1;
-  if (v < 0) { const char* e = CBA_GETENV("CBA_WIDE_ROWS"); v = e ? atoi(e) : 6144; if (v < 0) v = 6144; }
-  return v;
-}
-static int panel_width_at(int k0, int n_fact) {
-  const int thr = wide_rows_threshold();
-  // nothing overlaps the first panel's chain, and a 256-panel's chain is a third of a 512-panel's
-  static const bool narrow_first = CBA_GETENV("CBA_WIDE_FIRST") == nullptr;
-  if (k0 == 0 && narrow_first) return kPanel;
-  return (thr > 0 && n_fact - k0 > thr && n_fact - k0 >= kPanelWide) ? kPanelWide : kPanel;
-}
-
-// Factor the 64x64 diagonal block at (j0,j0): T = L D L^T, and invert the unit-lower factor.
-// Writes L (L(p,q), p>q, at M[j0+q][j0+p]), d into the diagonal and dvec, and invLt[q][p] = (L^-1)(p,q).
-// One workgroup; every lane keeps a cyclic 4x4 sub-grid of T and of X = L^-1 in registers
-// (element (i,j) with i = ti + 16a, j = tj + 16b).  Step s reads column s of T and row s of X
-// from LDS and applies the two rank-1 updates
-//     T[i][j] -= l_i d l_j   (i,j > s),        X[i][c] -= l_i X[s][c]   (i > s, c <= s)
-// -- the second is the product form L^-1 = (I - l_62 e_62^T) ... (I - l_0 e_0^T).  One barrier per step.
-
 // Reciprocal of a pivot: v_rcp_f64 refined by two Newton steps (the IEEE division expands to ~3x as
 // many dependent instructions, and 1/d sits on the critical path of every elimination step).
 __device__ __forceinline__ double pivot_rcp(double d) {
@@ -792,425 +523,8 @@ __device__ __forceinline__ double pivot_rcp(double d) {
   return r;
 }
 
-// One elimination step s = 16*SA + SR-or-sr of the register-resident 64x64 LDL^T.  Column s of T and
-// row s of X were published to colbuf/rowbuf[s & 1] by the previous step.  The step first updates the
-// entries of column s+1 / row s+1 (register index SAN of the cyclic sub-grid, owners tj / ti == nsr),
-// publishes them for the next step, and only then applies the rest of the rank-1 updates, which
-// therefore overlap the LDS round trip and the barrier.
-template <int SA, int SAN>
-__device__ __forceinline__ void ldlt_diag_step(double (&T)[4][4], double (&X)[4][4], double (*colbuf)[kInner],
-                                               double (*rowbuf)[kInner], int ti, int tj, int sr, int nsr, bool& bad) {
-  const int s = 16 * SA + sr, pb = s & 1;
-  // Only part of the cyclic sub-grid is still live in segment SA (s in [16 SA, 16 SA + 16)): rows and columns of
-  // T in groups a, b < SA are eliminated (their l_i / d l_j are zero), and row s of X = L^-1 is zero right of column
-  // s, i.e. in groups b > SA.  The dead groups are skipped statically: on average 12.5 of the 32 FMAs and 8.5 of the
-  // 13 LDS reads per step remain -- the step is instruction-issue bound, so this is where its time goes.
-  const double d = colbuf[pb][s];
-  double li[4], lj[4], xr[4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a) if (a >= SA) li[a] = colbuf[pb][ti + 16 * a];
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    if (b >= SA) lj[b] = colbuf[pb][tj + 16 * b];
-    if (b <= SA) xr[b] = rowbuf[pb][tj + 16 * b];
-  }
-  if (!(fabs(d) > 0.0)) bad = true;
-  const double invd = pivot_rcp(d);
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    if (a == SA) li[a] = (ti + 16 * a > s) ? li[a] * invd : 0.0;      // the group that contains row s needs the mask
-    else if (a > SA) li[a] = li[a] * invd;
-  }
-#pragma unroll
-  for (int b = 0; b < 4; ++b) if (b == SA) lj[b] = (tj + 16 * b > s) ? lj[b] : 0.0;
-  if constexpr (SAN < 4) {
-#pragma unroll
-    for (int a = 0; a < 4; ++a) if (a >= SA) T[a][SAN] -= li[a] * lj[SAN];
-    if constexpr (SAN >= SA) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b) if (b <= SA) X[SAN][b] -= li[SAN] * xr[b];
-    }
-    // branch-free publish: non-owners write to a scratch row behind the buffers (an exec-masked branch per
-    // publish costs a VALU -> SALU -> branch round trip on the critical path of every step)
-    {
-      double* cdst = (tj == nsr) ? &colbuf[pb ^ 1][ti] : &colbuf[2][ti];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) cdst[16 * a] = T[a][SAN];
-      double* rdst = (ti == nsr) ? &rowbuf[pb ^ 1][tj] : &rowbuf[2][tj];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) rdst[16 * b] = X[SAN][b];
-    }
-  }
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      if (a >= SA && b >= SA && b != SAN) T[a][b] -= li[a] * lj[b];               // l_i d l_j with lj holding d*l_j
-      if (a >= SA && b <= SA && a != SAN) X[a][b] -= li[a] * xr[b];
-    }
-#pragma unroll
-  for (int a = 0; a < 4; ++a)                               // store column s of L in place of T[:,s] (select, no branch)
-    if (a >= SA) T[a][SA] = (tj == sr && ti + 16 * a > s) ? li[a] : T[a][SA];
-  __syncthreads();
-}
-
-// One segment of 16 elimination steps s = 16*SA + sr.  SA is a compile-time constant so that the
-// registers holding column / row s (index SA of the cyclic 4x4 sub-grid) are addressed statically --
-// a run-time register index costs 3x per step (measured: 0.38 us vs 1.05 us).  The last step of a
-// segment publishes into the next segment's register index and is peeled.
-template <int SA>
-__device__ __forceinline__ void ldlt_diag_segment(double (&T)[4][4], double (&X)[4][4], double (*colbuf)[kInner],
-                                                  double (*rowbuf)[kInner], int ti, int tj, int nsteps, bool& bad) {
-#pragma nounroll
-  for (int sr = 0; sr < 15; ++sr) {
-    if (16 * SA + sr >= nsteps) return;
-    ldlt_diag_step<SA, SA>(T, X, colbuf, rowbuf, ti, tj, sr, sr + 1, bad);
-  }
-  if (16 * SA + 15 >= nsteps) return;
-  ldlt_diag_step<SA, SA + 1>(T, X, colbuf, rowbuf, ti, tj, 15, 0, bad);
-}
-
-// ---- two elimination steps per barrier -------------------------------------------------------------------------
-// Steps s (even) and s + 1 from the columns s, s + 1 of T and the rows s, s + 1 of X as they are BEFORE step s (published
-// to cb[2 pb + 0 / 1], rb[2 pb + 0 / 1]).  Every lane derives what step s makes of column / row s + 1 itself,
-//     T[i][s+1] -= l_i(s) T[s+1][s],      X[s+1][c] -= l_{s+1}(s) X[s][c],
-// with the very expressions the owning lanes would use, so the two rank-1 updates are the same arithmetic as two single
-// steps -- one barrier and one LDS round trip fewer per pair, and two independent update streams per register.
-template <int SA, int SAN>
-__device__ __forceinline__ void ldlt_diag_pair(double (&T)[4][4], double (&X)[4][4], double (*cb)[kInner], double (*rb)[kInner],
-                                               int ti, int tj, int sr /* even */, bool& bad) {
-  const int s = 16 * SA + sr, pb = (s >> 1) & 1;
-  const double* C0 = cb[2 * pb], *C1 = cb[2 * pb + 1];
-  const double* R0 = rb[2 * pb], *R1 = rb[2 * pb + 1];
-  const double d0 = C0[s], e = C0[s + 1], f = C1[s + 1];
-  double li0[4], lj0[4], li1[4], lj1[4], xr0[4], xr1[4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a) if (a >= SA) { li0[a] = C0[ti + 16 * a]; li1[a] = C1[ti + 16 * a]; }
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    if (b >= SA) { lj0[b] = C0[tj + 16 * b]; lj1[b] = C1[tj + 16 * b]; }
-    if (b <= SA) { xr0[b] = R0[tj + 16 * b]; xr1[b] = R1[tj + 16 * b]; }
-  }
-  if (!(fabs(d0) > 0.0)) bad = true;
-  const double inv0 = pivot_rcp(d0);
-  const double l0n = e * inv0;                                 // l_{s+1}(s)
-  const double d1 = f - l0n * e;                               // T[s+1][s+1] after step s
-  if (!(fabs(d1) > 0.0)) bad = true;
-  const double inv1 = pivot_rcp(d1);
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    if (a < SA) continue;
-    const int row = ti + 16 * a;
-    const double l0 = (a == SA) ? ((row > s) ? li0[a] * inv0 : 0.0) : li0[a] * inv0;
-    const double c1 = li1[a] - l0 * e;                         // column s + 1 after step s, at this lane's rows
-    li0[a] = l0;
-    li1[a] = (a == SA) ? ((row > s + 1) ? c1 * inv1 : 0.0) : c1 * inv1;
-  }
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    if (b < SA) continue;
-    const int col = tj + 16 * b;
-    const double l0 = lj0[b] * inv0;                           // l_col(s), as the lane that owns (col, s + 1) forms it
-    const double c1 = lj1[b] - l0 * e;                         // column s + 1 after step s, at this lane's columns (raw = d l)
-    if (b == SA) { lj0[b] = (col > s) ? lj0[b] : 0.0; lj1[b] = (col > s + 1) ? c1 : 0.0; }
-    else lj1[b] = c1;
-  }
-#pragma unroll
-  for (int b = 0; b < 4; ++b) if (b <= SA) xr1[b] = xr1[b] - l0n * xr0[b];     // row s + 1 of X after step s
-  if constexpr (SAN < 4) {
-    // the register column / row that holds the NEXT pair's columns and rows first, then publish it
-#pragma unroll
-    for (int a = 0; a < 4; ++a) if (a >= SA) { T[a][SAN] -= li0[a] * lj0[SAN]; T[a][SAN] -= li1[a] * lj1[SAN]; }
-#pragma unroll
-    for (int b = 0; b < 4; ++b) if (b <= SA) { X[SAN][b] -= li0[SAN] * xr0[b]; X[SAN][b] -= li1[SAN] * xr1[b]; }
-    const int n0 = (sr + 2) & 15, n1 = (sr + 3) & 15;
-    {
-      double* cdst = (tj == n0) ? &cb[2 * (pb ^ 1)][ti] : (tj == n1) ? &cb[2 * (pb ^ 1) + 1][ti] : &cb[4][ti];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) cdst[16 * a] = T[a][SAN];
-      double* rdst = (ti == n0) ? &rb[2 * (pb ^ 1)][tj] : (ti == n1) ? &rb[2 * (pb ^ 1) + 1][tj] : &rb[4][tj];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) rdst[16 * b] = X[SAN][b];
-    }
-  }
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      if (a >= SA && b >= SA && b != SAN) { T[a][b] -= li0[a] * lj0[b]; T[a][b] -= li1[a] * lj1[b]; }
-      if (a >= SA && b <= SA && a != SAN) { X[a][b] -= li0[a] * xr0[b]; X[a][b] -= li1[a] * xr1[b]; }
-    }
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {                               // columns s and s + 1 of L in place of T[:,s], T[:,s+1]
-    if (a < SA) continue;
-    const int row = ti + 16 * a;
-    T[a][SA] = (tj == sr && row > s) ? li0[a] : (tj == sr + 1 && row > s + 1) ? li1[a] : T[a][SA];
-  }
-  __syncthreads();
-}
-template <int SA>
-__device__ __forceinline__ void ldlt_diag_segment_pairs(double (&T)[4][4], double (&X)[4][4], double (*cb)[kInner],
-                                                        double (*rb)[kInner], int ti, int tj, bool& bad) {
-#pragma nounroll
-  for (int sr = 0; sr < 14; sr += 2) ldlt_diag_pair<SA, SA>(T, X, cb, rb, ti, tj, sr, bad);
-  ldlt_diag_pair<SA, SA + 1>(T, X, cb, rb, ti, tj, 14, bad);
-}
-
-// Factor the 64x64 diagonal block at (j0,j0): T = L D L^T, and invert the unit-lower factor.
-// Writes L (L(p,q), p>q, at M[j0+q][j0+p]), d into the diagonal and dvec, and invLt[q][p] = (L^-1)(p,q).
-// One workgroup; every lane keeps a cyclic 4x4 sub-grid of T and of X = L^-1 in registers
-// (element (i,j) with i = ti + 16a, j = tj + 16b).  Step s broadcasts column s of T and row s of X
-// through LDS and applies the two rank-1 updates
-//     T[i][j] -= l_i d l_j   (i,j > s),        X[i][c] -= l_i X[s][c]   (i > s, c <= s)
-// -- the second is the product form L^-1 = (I - l_62 e_62^T) ... (I - l_0 e_0^T).  One barrier per step.
-// `tile` == nullptr: T is read from the stored upper triangle of M; otherwise from a 64 x 64 tile in LDS (row stride
-// tile_ld, upper triangle valid) -- the fused chain kernel hands over the block it has just updated.
-// The elimination loop itself: T (symmetric, cyclic 4 x 4 sub-grid per lane) -> L below / d on the diagonal, X (identity on
-// entry) -> L^-1.  colbuf / rowbuf: 5 x 64 doubles of LDS each.  Returns true when a pivot was zero or NaN.
-template <int NSTEPS>
-__device__ __forceinline__ bool ldlt_diag_core(double (&T)[4][4], double (&X)[4][4], double (*colbuf)[kInner],
-                                               double (*rowbuf)[kInner]) {
-  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
-  bool bad = false;
-  if constexpr (kDiagPairs && NSTEPS == kInner) {
-    if (tj < 2) {
-#pragma unroll
-      for (int a = 0; a < 4; ++a) colbuf[tj][ti + 16 * a] = T[a][0];
-    }
-    if (ti < 2) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b) rowbuf[ti][tj + 16 * b] = X[0][b];
-    }
-    __syncthreads();
-    ldlt_diag_segment_pairs<0>(T, X, colbuf, rowbuf, ti, tj, bad);
-    ldlt_diag_segment_pairs<1>(T, X, colbuf, rowbuf, ti, tj, bad);
-    ldlt_diag_segment_pairs<2>(T, X, colbuf, rowbuf, ti, tj, bad);
-    ldlt_diag_segment_pairs<3>(T, X, colbuf, rowbuf, ti, tj, bad);
-  } else {
-    if (tj == 0) {
-#pragma unroll
-      for (int a = 0; a < 4; ++a) colbuf[0][ti + 16 * a] = T[a][0];
-    }
-    if (ti == 0) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b) rowbuf[0][tj + 16 * b] = X[0][b];
-    }
-    __syncthreads();
-    ldlt_diag_segment<0>(T, X, colbuf, rowbuf, ti, tj, NSTEPS, bad);
-    ldlt_diag_segment<1>(T, X, colbuf, rowbuf, ti, tj, NSTEPS, bad);
-    ldlt_diag_segment<2>(T, X, colbuf, rowbuf, ti, tj, NSTEPS, bad);
-    ldlt_diag_segment<3>(T, X, colbuf, rowbuf, ti, tj, NSTEPS, bad);
-  }
-  return bad;
-}
-
-template <int NSTEPS>
-__device__ __forceinline__ void ldlt_diag_body(double* __restrict__ M, int ld, int j0, double* __restrict__ dvec,
-                                               double* __restrict__ invLt_all, int* __restrict__ status,
-                                               const double* tile, int tile_ld, double (*colbuf)[kInner],
-                                               double (*rowbuf)[kInner]) {
-  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
-  double T[4][4], X[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      int i = ti + 16 * a, j = tj + 16 * b;
-      int lo = i < j ? i : j, hi = i < j ? j : i;           // symmetric fill from the upper triangle
-      T[a][b] = tile ? tile[lo * tile_ld + hi] : M[(size_t)(j0 + lo) * ld + j0 + hi];
-      X[a][b] = (i == j) ? 1.0 : 0.0;
-    }
-  bool bad = ldlt_diag_core<NSTEPS>(T, X, colbuf, rowbuf);
-  if (bad && tid == 0) atomicExch(status, 2);
-  double* invLt = invLt_all + (size_t)(j0 / kInner) * kInner * kInner;
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      int i = ti + 16 * a, j = tj + 16 * b;
-      // memory row q = j, column p = i holds L(p,q) for p > q and d for p == q
-      if (i >= j) M[(size_t)(j0 + j) * ld + j0 + i] = T[a][b];
-      invLt[j * kInner + i] = (i >= j) ? X[a][b] : 0.0;     // invLt[q][p] = invL(p,q)
-      if (i == j) dvec[j0 + i] = T[a][b];
-    }
-}
-
-template <int NSTEPS = kInner>
-__global__ void __launch_bounds__(256) k_ldlt_diag(double* __restrict__ M, int ld, int j0, double* __restrict__ dvec,
-                                                   double* __restrict__ invLt_all, int* __restrict__ status) {
-  __shared__ double colbuf[5][kInner];   // two columns per parity + a scratch row for the branch-free publish
-  __shared__ double rowbuf[5][kInner];
-  __builtin_amdgcn_s_setprio(3);   // latency-critical: runs underneath the bulk trailing-update GEMM
-  tlog_begin((j0 / kInner) * kTlKinds + kTlDiag);
-  ldlt_diag_body<NSTEPS>(M, ld, j0, dvec, invLt_all, status, nullptr, 0, colbuf, rowbuf);
-  tlog_end((j0 / kInner) * kTlKinds + kTlDiag);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Panel row right of the look-ahead columns: forward substitution through the whole panel, fused.
-// One workgroup per 64-column tile walks the panel's 64-blocks top to bottom,
-//   X_j = invL_jj (U_j - sum_{e<j} L_je X_e),
-// reading U once and writing X (panel buffer) and L = X / d (in place) once.  The per-block launches
-// this replaces (a K = 64 solve and a K = 64 update over all remaining columns per block) were
-// latency-bound at ~1 TFLOP/s and, in the leading panels, took longer than the bulk update they fed.
-// ------------------------------------------------------------------------------------------------
 constexpr int TS = kInner + 16;   // LDS row stride (doubles) of a staged K-slab / 64x64 tile
 
-// loads that must observe global stores made earlier by this same launch go to L2 (agent scope)
-template <bool COH>
-__device__ __forceinline__ double ldg(const double* p) {
-  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else return *p;
-}
-
-// acc (64x64 tile, 4 waves x 32x32) += sum_{k<K} A[k][m] B[k][n];  A, B K-major in global memory, or B
-// already in LDS as Bl[k][TS].  K multiple of 16.  Register-staged, three slabs in flight; ends with a barrier.
-// A_DIV: A[k][m] is divided by adiv[k] while staged (L = X / d taken from the panel buffer).
-template <bool COH_A, bool COH_B, bool B_LDS, bool A_DIV = false>
-__device__ __forceinline__ void tile_mma(v4f64 (&acc)[2][2], const double* __restrict__ A, int lda,
-                                         const double* __restrict__ B, int ldb, int K, double* sA, double* sB,
-                                         const double* Bl, const double* __restrict__ adiv = nullptr) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
-  const int r = tid >> 5, c2 = 2 * (tid & 31);
-  const int nk = K / KT;
-  constexpr int kDepth = 3;     // K slabs in flight (see the small-tile variant of k_gemm_atb)
-  // staging registers written out as scalars, one set per slot (arrays here end up in scratch memory)
-  double ra0_00, ra0_01, ra0_10, ra0_11, ra1_00, ra1_01, ra1_10, ra1_11, ra2_00, ra2_01, ra2_10, ra2_11;
-  double rb0_00, rb0_01, rb0_10, rb0_11, rb1_00, rb1_01, rb1_10, rb1_11, rb2_00, rb2_01, rb2_10, rb2_11;
-  double rd0_0 = 1.0, rd0_1 = 1.0, rd1_0 = 1.0, rd1_1 = 1.0, rd2_0 = 1.0, rd2_1 = 1.0;
-#define CBA_TLOAD(slot_, k0_)                                                                    \
-  {                                                                                              \
-    const double* pa = A + (size_t)((k0_) + r) * lda + c2;                                       \
-    ra##slot_##_00 = ldg<COH_A>(pa); ra##slot_##_01 = ldg<COH_A>(pa + 1);                        \
-    ra##slot_##_10 = ldg<COH_A>(pa + (size_t)8 * lda); ra##slot_##_11 = ldg<COH_A>(pa + (size_t)8 * lda + 1); \
-    if constexpr (A_DIV) { rd##slot_##_0 = adiv[(k0_) + r]; rd##slot_##_1 = adiv[(k0_) + r + 8]; }  \
-    if constexpr (!B_LDS) {                                                                      \
-      const double* pb = B + (size_t)((k0_) + r) * ldb + c2;                                     \
-      rb##slot_##_00 = ldg<COH_B>(pb); rb##slot_##_01 = ldg<COH_B>(pb + 1);                      \
-      rb##slot_##_10 = ldg<COH_B>(pb + (size_t)8 * ldb); rb##slot_##_11 = ldg<COH_B>(pb + (size_t)8 * ldb + 1); \
-    }                                                                                            \
-  }
-#define CBA_TSTORE(buf_, slot_)                                                                  \
-  {                                                                                              \
-    double* qa = sA + (buf_) * KT * TS + r * TS + c2;                                            \
-    if constexpr (A_DIV) {                                                                       \
-      ra##slot_##_00 /= rd##slot_##_0; ra##slot_##_01 /= rd##slot_##_0;                          \
-      ra##slot_##_10 /= rd##slot_##_1; ra##slot_##_11 /= rd##slot_##_1;                          \
-    }                                                                                            \
-    qa[0] = ra##slot_##_00; qa[1] = ra##slot_##_01; qa[8 * TS] = ra##slot_##_10; qa[8 * TS + 1] = ra##slot_##_11; \
-    if constexpr (!B_LDS) {                                                                      \
-      double* qb = sB + (buf_) * KT * TS + r * TS + c2;                                          \
-      qb[0] = rb##slot_##_00; qb[1] = rb##slot_##_01; qb[8 * TS] = rb##slot_##_10; qb[8 * TS + 1] = rb##slot_##_11; \
-    }                                                                                            \
-  }
-  CBA_TLOAD(0, 0);
-  CBA_TLOAD(1, (1 < nk ? 1 : nk - 1) * KT);
-  CBA_TLOAD(2, (2 < nk ? 2 : nk - 1) * KT);
-  CBA_TSTORE(0, 0);
-  __syncthreads();
-#define CBA_TSTEP(slot_, next_slot_)                                                                       \
-  if (kb0 + (slot_) < nk) {                                                                                  \
-    const int kb = kb0 + (slot_);                                                                            \
-    const int buf = kb & 1;                                                                                  \
-    CBA_TLOAD(slot_, (kb + kDepth < nk ? kb + kDepth : nk - 1) * KT);                                        \
-    const double* a_s = sA + buf * KT * TS;                                                                  \
-    const double* b_s = B_LDS ? Bl + kb * KT * TS : sB + buf * KT * TS;                                      \
-    _Pragma("unroll") for (int kk = 0; kk < KT; kk += 4) {                                                   \
-      double af[2], bf[2];                                                                                   \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) af[i] = a_s[(kk + lk) * TS + wm0 + i * 16 + li];         \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j) bf[j] = b_s[(kk + lk) * TS + wn0 + j * 16 + li];         \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);                \
-    }                                                                                                        \
-    CBA_TSTORE(buf ^ 1, next_slot_);                                                                         \
-    __syncthreads();                                                                                         \
-  }
-  static_assert(kDepth == 3, "CBA_TSTEP sequence below is written for three slots");
-#pragma nounroll
-  for (int kb0 = 0; kb0 < nk; kb0 += kDepth) {
-    CBA_TSTEP(0, 1)
-    CBA_TSTEP(1, 2)
-    CBA_TSTEP(2, 0)
-  }
-#undef CBA_TSTEP
-#undef CBA_TLOAD
-#undef CBA_TSTORE
-}
-
-// INV = true: U is the identity (generated, not read) and nothing is written into S -- Xk then receives the inverse of the
-// panel's unit-lower factor, Xk[p][c] = (L_panel^-1)(p, c), c in [0, nb): what the distributed driver multiplies the block row
-// with (ldlt_factor_distributed).
-template <bool INV>
-__global__ void __launch_bounds__(256) k_panel_solve_t(double* __restrict__ S, int ld, int k0, int nb, int col0,
-                                                       double* __restrict__ Xk, int ldx, const double* __restrict__ dvec,
-                                                       const double* __restrict__ invLt_all) {
-  __shared__ double sA[2 * KT * TS];
-  __shared__ double sB[2 * KT * TS];
-  __shared__ double sV[kInner * TS];
-  __builtin_amdgcn_s_setprio(2);
-  tlog_begin((k0 / kInner) * kTlKinds + kTlPanelSolve);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
-  const int n0 = col0 + kInner * (int)blockIdx.x;
-  const int nblk = nb / kInner;
-  for (int j = 0; j < nblk; ++j) {
-    v4f64 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    // sum_{e<j} L_je X_e: rows 0 .. 64 j of the panel are one K range (A = L in place, B = X written above)
-    if (j > 0)
-      tile_mma<false, true, false>(acc, S + (size_t)k0 * ld + (k0 + kInner * j), ld, Xk + n0, ldx, kInner * j, sA, sB, nullptr);
-    double* Urow = S + (size_t)(k0 + kInner * j) * ld + n0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = wm0 + i * 16 + lk + 4 * r, n = wn0 + jj * 16 + li;
-          const double u = INV ? ((kInner * j + m == n0 + n) ? 1.0 : 0.0) : Urow[(size_t)m * ld + n];
-          sV[m * TS + n] = u - acc[i][jj][r];
-        }
-    __syncthreads();
-    v4f64 x[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) x[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    tile_mma<false, false, true>(x, invLt_all + (size_t)((k0 + kInner * j) / kInner) * kInner * kInner, kInner, nullptr, 0,
-                                 kInner, sA, sB, sV);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = wm0 + i * 16 + lk + 4 * r;
-        const double d = dvec[k0 + kInner * j + m];
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          const int n = wn0 + jj * 16 + li;
-          const double v = x[i][jj][r];
-          Xk[(size_t)(kInner * j + m) * ldx + n0 + n] = v;
-          if (!INV) Urow[(size_t)m * ld + n] = v / d;
-        }
-      }
-    __syncthreads();   // the stores are acknowledged by L2 (vmcnt) before any lane re-reads X with agent-scope loads
-  }
-  tlog_end((k0 / kInner) * kTlKinds + kTlPanelSolve);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Chain step of a 256-panel, fused: the solve of the block row inside the panel and its update of the
-// rest of the panel's diagonal block in ONE launch (was: a K = 64 solve launch followed by a K = 64
-// update launch, ~12 + ~9 us of mostly launch and pipeline-fill latency on the critical path).
-// One workgroup per upper 64x64 tile (r, c) of the remaining diagonal block; it recomputes the two
-// solved tiles it needs, X_r = invL_jj U_j[:, r] and X_c, and applies T_rc -= (X_r / d)^T X_c.  The
-// diagonal tiles also publish X_c.  U_j is only read here: L = X / d is written in place by
-// k_scale_rows on the mid stream, off the critical path.
-// ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void tile_mma_lds(v4f64 (&acc)[2][2], const double* Al, const double* Bl) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
@@ -1228,324 +542,13 @@ __device__ __forceinline__ void tile_mma_lds(v4f64 (&acc)[2][2], const double* A
   }
 }
 
-//
-// Workgroups: first the nblk (nblk + 1) / 2 upper tiles (r, c) of the panel's remaining diagonal block, then -- when
-// the caller passes lag = 1 and nx > e0 -- one workgroup per 64-column block cn of the NEXT panel's columns [e0, nx) that
-// does the look-ahead of the PREVIOUS block row (j0 - 64, factored and published by the previous launch): X_cn =
-// invL U[cn], published, and T[r][cn] -= L_r^T X_cn for every later block row r of the panel, with L_r = X_r / d read
-// from the panel buffer.  This keeps the whole look-ahead of a 256-panel on the chain stream (no second stream, no
-// cross-stream hops of ~17 us each), one block row behind the pivot chain so that it never delays it.
-//
-// FUSE_DIAG: workgroup 0 owns tile (0, 0), the next diagonal block.  Instead of writing it back it factors it
-// right away (same code as k_ldlt_diag, fed from LDS) while the other workgroups finish their tiles: the chain is
-// one launch per 64-block instead of two, and the near step hides behind the 64 pivot steps.
-template <bool FUSE_DIAG>
-__global__ void __launch_bounds__(256) k_near_fused(double* __restrict__ S, int ld, int k0, int j0, int e0, int nx,
-                                                    double* __restrict__ Xk, int ldx, double* __restrict__ dvec,
-                                                    double* __restrict__ invLt_all, int* __restrict__ status, int lag) {
-  __shared__ double sA[2 * KT * TS];
-  __shared__ double sB[2 * KT * TS];
-  __shared__ double sV[kInner * TS];    // X_c           [p][n]
-  __shared__ double sL[kInner * TS];    // X_r / d = L^T [p][m]
-  __builtin_amdgcn_s_setprio(3);
-  tlog_begin((j0 / kInner) * kTlKinds + kTlNear);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
-  const int c0 = j0 + kInner, nblk = (e0 - c0) / kInner;
-  const int n_tri = nblk * (nblk + 1) / 2;
-  int r, colc;
-  bool same;
-  // Workgroup b is dispatched to XCD b % 8 and the chain stream owns one CU per XCD (a workgroup fills the CU's
-  // LDS), so with FUSE_DIAG the slots 8, 16, ... stay empty: nothing queues behind workgroup 0's pivot steps.
-  int tile = blockIdx.x;
-  if (FUSE_DIAG && tile > 0) {
-    if ((tile & 7) == 0) return;
-    tile -= tile >> 3;
-  }
-  const int ncn = lag ? (nx - e0) / kInner : 0;
-  if (tile >= n_tri + ncn) return;
-  if (tile >= n_tri) {
-    // ---- look-ahead of block row j0 - 64 on column block cn of the next panel ----
-    const int pj0 = j0 - kInner, cn0 = e0 + kInner * (tile - n_tri);
-    v4f64 xa[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) xa[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    tile_mma<false, false, false>(xa, invLt_all + (size_t)(pj0 / kInner) * kInner * kInner, kInner, S + (size_t)pj0 * ld + cn0, ld,
-                                  kInner, sA, sB, nullptr);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const int p = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
-          sV[p * TS + n] = xa[i][jj][r4];
-          Xk[(size_t)(pj0 - k0 + p) * ldx + cn0 + n] = xa[i][jj][r4];
-        }
-    for (int colr = j0; colr < e0; colr += kInner) {
-      __syncthreads();                     // sV written / the previous block row's reads of sL done
-      for (int e = threadIdx.x; e < kInner * kInner; e += 256) {
-        const int p = e >> 6, m = e & 63;
-        sL[p * TS + m] = Xk[(size_t)(pj0 - k0 + p) * ldx + colr + m] / dvec[pj0 + p];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) xa[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
-      tile_mma_lds(xa, sL, sV);
-      double* Tn = S + (size_t)colr * ld + cn0;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
-            Tn[(size_t)m * ld + n] -= xa[i][jj][r4];
-          }
-    }
-    tlog_end((j0 / kInner) * kTlKinds + kTlNear);
-    return;
-  }
-  {
-    int t = tile;
-    for (r = 0; r < nblk; ++r) { const int cnt = nblk - r; if (t < cnt) break; t -= cnt; }
-    colc = c0 + kInner * (r + t);
-    same = (t == 0);
-  }
-  const int colr = c0 + kInner * r;
-  const double* invLt = invLt_all + (size_t)(j0 / kInner) * kInner * kInner;
-  const double* Uj = S + (size_t)j0 * ld;
-  v4f64 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
-  tile_mma<false, false, false>(acc, invLt, kInner, Uj + colr, ld, kInner, sA, sB, nullptr);
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      const int p = wm0 + i * 16 + lk + 4 * r4;
-      const double d = dvec[j0 + p];
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int n = wn0 + jj * 16 + li;
-        const double v = acc[i][jj][r4];
-        sL[p * TS + n] = v / d;
-        if (same) { sV[p * TS + n] = v; Xk[(size_t)(j0 - k0 + p) * ldx + colr + n] = v; }
-      }
-    }
-  if (!same) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    tile_mma<false, false, false>(acc, invLt, kInner, Uj + colc, ld, kInner, sA, sB, nullptr);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const int p = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
-          sV[p * TS + n] = acc[i][jj][r4];
-        }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
-  tile_mma_lds(acc, sL, sV);
-  double* T = S + (size_t)colr * ld + colc;
-  if (FUSE_DIAG && tile == 0) {
-    // tile (0, 0): updated block -> LDS -> factor it (block j0 + 64) without a round trip through memory
-    __syncthreads();                       // every wave is done reading sV / sL
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
-          sV[m * TS + n] = T[(size_t)m * ld + n] - acc[i][jj][r4];
-        }
-    __syncthreads();
-    tlog_begin((c0 / kInner) * kTlKinds + kTlDiag);
-    double (*colbuf)[kInner] = reinterpret_cast<double (*)[kInner]>(sA);
-    double (*rowbuf)[kInner] = reinterpret_cast<double (*)[kInner]>(sA + 5 * kInner);
-    ldlt_diag_body<kInner>(S, ld, c0, dvec, invLt_all, status, sV, TS, colbuf, rowbuf);
-    tlog_end((c0 / kInner) * kTlKinds + kTlDiag);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
-          T[(size_t)m * ld + n] -= acc[i][jj][r4];
-        }
-  }
-  tlog_end((j0 / kInner) * kTlKinds + kTlNear);
-}
-
-// Last step of a 256-panel's look-ahead (after the last k_near_fused<true>, which has factored the panel's last block):
-// one workgroup per 64-column block cn of the next panel's columns finishes the second-to-last block row,
-//   X_2 = invL_2 U_2[cn]   (published),        U_3' = U_3[cn] - L_23^T X_2,
-// and solves the last one, X_3 = invL_3 U_3' (published).  S is only read: L = X / d is written in place later, off
-// the chain (k_scale_rows on the far stream), and (a') / (a''n) take L from the panel buffer (GemmArgs::a_rowdiv).
-__global__ void __launch_bounds__(256) k_next_last(const double* __restrict__ S, int ld, int k0, int e0, double* __restrict__ Xk,
-                                                   int ldx, const double* __restrict__ dvec, const double* __restrict__ invLt_all) {
-  __shared__ double sA[2 * KT * TS];
-  __shared__ double sB[2 * KT * TS];
-  __shared__ double sV[kInner * TS];
-  __shared__ double sL[kInner * TS];
-  __builtin_amdgcn_s_setprio(3);
-  const int j2 = e0 - 2 * kInner, j3 = e0 - kInner, cn0 = e0 + kInner * (int)blockIdx.x;
-  tlog_begin((j3 / kInner) * kTlKinds + kTlXn);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
-  v4f64 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
-  for (int e = threadIdx.x; e < kInner * kInner; e += 256) {     // L_23^T from the panel buffer (published by the near step)
-    const int p = e >> 6, m = e & 63;
-    sL[p * TS + m] = Xk[(size_t)(j2 - k0 + p) * ldx + j3 + m] / dvec[j2 + p];
-  }
-  tile_mma<false, false, false>(acc, invLt_all + (size_t)(j2 / kInner) * kInner * kInner, kInner, S + (size_t)j2 * ld + cn0, ld, kInner,
-                                sA, sB, nullptr);
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int p = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
-        sV[p * TS + n] = acc[i][jj][r4];
-        Xk[(size_t)(j2 - k0 + p) * ldx + cn0 + n] = acc[i][jj][r4];
-      }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
-  tile_mma_lds(acc, sL, sV);
-  __syncthreads();                         // every wave is done reading sV
-  const double* U3 = S + (size_t)j3 * ld + cn0;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
-        sV[m * TS + n] = U3[(size_t)m * ld + n] - acc[i][jj][r4];
-      }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
-  tile_mma<false, false, true>(acc, invLt_all + (size_t)(j3 / kInner) * kInner * kInner, kInner, nullptr, 0, kInner, sA, sB, sV);
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
-        Xk[(size_t)(j3 - k0 + m) * ldx + cn0 + n] = acc[i][jj][r4];
-      }
-  tlog_end((j3 / kInner) * kTlKinds + kTlXn);
-}
-
-// (a') of a 256-panel fused with the next panel's first diagonal factor: one workgroup per upper 64x64 tile (r, c)
-// of the next panel's diagonal block [r0, r0 + 64 nt),
-//   T_rc -= sum_{p < nb} (X[p][r] / d_p) X[p][c]        (X = panel buffer, complete after k_next_last),
-// and workgroup 0 (tile (0, 0), the next panel's first diagonal block) factors its tile right away, like
-// k_near_fused<true>: the next panel's chain starts ~20 us before the other tiles are done.
-__global__ void __launch_bounds__(256) k_aprime_fused(double* __restrict__ S, int ld, int k0, int nb, int r0, int nt,
-                                                      const double* __restrict__ Xk, int ldx, double* __restrict__ dvec,
-                                                      double* __restrict__ invLt_all, int* __restrict__ status) {
-  __shared__ double sA[2 * KT * TS];
-  __shared__ double sB[2 * KT * TS];
-  __shared__ double sV[kInner * TS];
-  __builtin_amdgcn_s_setprio(3);
-  int tile = blockIdx.x;
-  if (tile > 0) {                          // slots 8, 16, ... stay empty (see k_near_fused)
-    if ((tile & 7) == 0) return;
-    tile -= tile >> 3;
-  }
-  if (tile >= nt * (nt + 1) / 2) return;
-  tlog_begin((k0 / kInner) * kTlKinds + kTlAPrime);
-  int r = 0, t = tile;
-  for (; r < nt; ++r) { const int cnt = nt - r; if (t < cnt) break; t -= cnt; }
-  const int colr = r0 + kInner * r, colc = r0 + kInner * (r + t);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
-  v4f64 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
-  tile_mma<false, false, false, true>(acc, Xk + colr, ldx, Xk + colc, ldx, nb, sA, sB, nullptr, dvec + k0);
-  double* T = S + (size_t)colr * ld + colc;
-  if (tile == 0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
-          sV[m * TS + n] = T[(size_t)m * ld + n] - acc[i][jj][r4];
-        }
-    __syncthreads();
-    tlog_begin((r0 / kInner) * kTlKinds + kTlDiag);
-    double (*colbuf)[kInner] = reinterpret_cast<double (*)[kInner]>(sA);
-    double (*rowbuf)[kInner] = reinterpret_cast<double (*)[kInner]>(sA + 5 * kInner);
-    ldlt_diag_body<kInner>(S, ld, r0, dvec, invLt_all, status, sV, TS, colbuf, rowbuf);
-    tlog_end((r0 / kInner) * kTlKinds + kTlDiag);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const int m = wm0 + i * 16 + lk + 4 * r4, n = wn0 + jj * 16 + li;
-          T[(size_t)m * ld + n] -= acc[i][jj][r4];
-        }
-  }
-  tlog_end((k0 / kInner) * kTlKinds + kTlAPrime);
-}
-
-// L = X / d in place for the panel-internal columns [c0, e0) of block row j0 (see k_near_fused)
-__global__ void __launch_bounds__(256) k_scale_rows(double* __restrict__ S, int ld, int k0, int j0, int c0, int e0,
-                                                    const double* __restrict__ Xk, int ldx, const double* __restrict__ dvec) {
-  const int p = blockIdx.x;                 // row j0 + p; the launch may span several 64-blocks of the panel
-  tlog_begin((j0 / kInner) * kTlKinds + kTlScale);
-  const double d = dvec[j0 + p];
-  const int own = j0 + kInner * (p / kInner + 1);        // first column right of the row's own diagonal block
-  for (int col = (c0 > own ? c0 : own) + threadIdx.x; col < e0; col += blockDim.x)
-    S[(size_t)(j0 + p) * ld + col] = Xk[(size_t)(j0 - k0 + p) * ldx + col] / d;
-  tlog_end((j0 / kInner) * kTlKinds + kTlScale);
-}
-
 // ------------------------------------------------------------------------------------------------
-// Tail of the factorisation: ONE persistent dataflow launch for the last rows (ldlt_tail, k_ldlt_tail).
+// Dataflow factorisation of a block-row range in ONE persistent launch (ldlt_tail, k_ldlt_tail).
 //
-// Below ~6000 remaining rows the blocked schedule above is bound by its pivot chain: per 64-block 18 us of pivots plus
-// 25-30 us of near step, launch gaps, waits for the last workgroup of the previous launch and cross-stream stalls
-// (profiles/r02_factor_timeline_pairs.txt: 5.1 ms for 12 % of the flops at config 2).  Here the whole trailing block is
-// factored by one launch in which every 64 x 64 tile is a task and tasks synchronise through device-scope flags:
+// A blocked schedule of separate launches (rounds 1-2: per 64-block a diagonal factor, a near step, solves and updates on four
+// streams) is bound by its pivot chain below ~6000 remaining rows: launch gaps, waits for the last workgroup of the previous
+// launch and cross-stream stalls (profiles/r02_factor_timeline_pairs.txt: 5.1 ms for 12 % of the flops at config 2).  Here the
+// whole range is factored by one launch in which every 64 x 64 tile is a task and tasks synchronise through device-scope flags:
 //
 //   chain workgroup (the first one to arrive): for r = r0, r0 + 1, ...: X = invL_{r-1} U_{r-1,r} (both operands in LDS: the
 //       inverse it has just computed never leaves the CU), L_{r-1,r} = X / d published, T_rr = P_r - L^T X, 64 pivots
@@ -1865,12 +868,6 @@ __device__ unsigned long long* g_taillog = nullptr;
 #define HELP_NOW() 0ull
 #endif
 
-// The chain's diagonal blocks: blocked panels (round 4, default) or the barrier-per-pivot-pair loop of round 3 (bench harness: -DCBA_CHAIN_OLD)
-#ifdef CBA_CHAIN_OLD
-constexpr bool kChainBlocked = false;
-#else
-constexpr bool kChainBlocked = true;
-#endif
 // tile_mma_lds with an A operand that is a transposed unit-lower-triangular inverse carrying junk in the 16 x 16 tiles below
 // its block diagonal (chain_factor_blocked): row block I of the result takes the k blocks <= I only
 __device__ __forceinline__ void tile_mma_lds_lowerA(v4f64 (&acc)[2][2], const double* Al, const double* Bl) {
@@ -2148,9 +1145,6 @@ __device__ __forceinline__ bool chain_factor_blocked(double* sW, double* sV, dou
 __device__ __forceinline__ void tail_chain(const TailArgs& t, double* sV, double* sW) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
-  const int ti = tid >> 4, tj = tid & 15;
-  double (*colbuf)[kInner] = reinterpret_cast<double (*)[kInner]>(sV);                  // the pivot loop's buffers live in sV
-  double (*rowbuf)[kInner] = reinterpret_cast<double (*)[kInner]>(sV + 5 * kInner);
   double* s_rd = sW + kInner;                     // 1 / d of the block factored last: padding columns of rows 0 .. 3 of sW
   volatile int* slot = reinterpret_cast<volatile int*>(sW + 4 * TS + kInner);            // padding of row 4
   const int ld = t.ld;
@@ -2192,8 +1186,7 @@ __device__ __forceinline__ void tail_chain(const TailArgs& t, double* sV, double
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) X[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
-      if constexpr (kChainBlocked) tile_mma_lds_lowerA(X, sW, sV);   // (sW carries junk below its block diagonal)
-      else tile_mma_lds(X, sW, sV);              // X[p][n] = sum_q invLt[q][p] U[q][n]
+      tile_mma_lds_lowerA(X, sW, sV);            // X[p][n] = sum_q invLt[q][p] U[q][n]  (sW carries junk below its block diagonal)
       __syncthreads();                           // every wave is done reading sW (inverse) and sV (U)
       TAIL_STAMP(b, 3);
 #pragma unroll
@@ -2239,7 +1232,7 @@ __device__ __forceinline__ void tail_chain(const TailArgs& t, double* sV, double
       }
       __syncthreads();
     }
-    if constexpr (kChainBlocked) {
+    {
       // four panels of 16 columns: wave 0 pivots in registers, waves 1-3 update with MFMA and build the inverse
       TAIL_STAMP(b, 7);
       const bool bad = chain_factor_blocked(sW, sV, s_rd);
@@ -2267,57 +1260,6 @@ __device__ __forceinline__ void tail_chain(const TailArgs& t, double* sV, double
       if (tid < kInner) {
         const __amdgpu_buffer_rsrc_t rv = tail_rsrc(t.dvec + j0);
         tail_st1(rv, tid * 8, 0, sV[tid * TS + tid]);
-      }
-    } else {
-      double T[4][4], Xi[4][4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-          const int i = ti + 16 * a, j = tj + 16 * bb;
-          const int lo = i < j ? i : j, hi = i < j ? j : i;
-          T[a][bb] = sW[lo * TS + hi];
-          Xi[a][bb] = (i == j) ? 1.0 : 0.0;
-        }
-      __syncthreads();                             // sW is read; sV (colbuf / rowbuf) is free since the barrier after the second product
-      TAIL_STAMP(b, 7);
-      const bool bad = ldlt_diag_core<kInner>(T, Xi, colbuf, rowbuf);
-      TAIL_STAMP(b, 8);
-      if (bad && tid == 0) atomicExch(t.status, 2);
-      {
-        // L_rr / d (memory row j, column i: transposed) -> sV, invLt -> sW, then both tiles leave row by row.  No global store
-        // is issued before the barrier: a store followed by anything that makes the compiler wait for vmcnt(0) (a register
-        // reload, here) costs a full write-through acknowledgement, ~1 us each.
-        int tid2 = threadIdx.x;
-        asm volatile("" : "+v"(tid2));               // lane indices are re-derived here instead of staying live across the pivots
-        const int ti2 = tid2 >> 4, tj2 = tid2 & 15;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int bb = 0; bb < 4; ++bb) {
-            const int i = ti2 + 16 * a, j = tj2 + 16 * bb;
-            sV[j * TS + i] = (i >= j) ? T[a][bb] : 0.0;       // below the diagonal of a diagonal tile nothing is ever read
-            sW[j * TS + i] = (i >= j) ? Xi[a][bb] : 0.0;      // invLt[q][p], the K-major operand of the next step's first product
-            if (a == bb && ti2 == tj2) s_rd[(i >> 4) * TS + (i & 15)] = pivot_rcp(T[a][bb]);
-          }
-        __syncthreads();
-        const int lane2 = tid2 & 63, wv2 = tid2 >> 6;
-        const int rw2 = 16 * wv2 + (lane2 >> 5), cw2 = 2 * (lane2 & 31);
-        const int s_voff = (rw2 * ld + cw2) * 8, i_voff = (rw2 * kInner + cw2) * 8;
-        const __amdgpu_buffer_rsrc_t rs = tail_rsrc(t.S + (size_t)j0 * ld + j0);
-        const __amdgpu_buffer_rsrc_t ri = tail_rsrc(t.invLt + (size_t)r * kInner * kInner);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          v2f64_t v, w;
-          v.x = sV[(rw2 + 2 * k) * TS + cw2]; v.y = sV[(rw2 + 2 * k) * TS + cw2 + 1];
-          w.x = sW[(rw2 + 2 * k) * TS + cw2]; w.y = sW[(rw2 + 2 * k) * TS + cw2 + 1];
-          tail_st2(rs, s_voff, 2 * k * ld * 8, v);
-          tail_st2(ri, i_voff, 2 * k * kInner * 8, w);
-        }
-        if (tid2 < kInner) {
-          const __amdgpu_buffer_rsrc_t rv = tail_rsrc(t.dvec + j0);
-          tail_st1(rv, tid2 * 8, 0, sV[tid2 * TS + tid2]);
-        }
       }
     }
     TAIL_STAMP(b, 9);
@@ -2487,56 +1429,16 @@ __global__ void __launch_bounds__(256, 2) k_ldlt_tail(TailArgs t) {
   }
 }
 
-int panel_cu_count() {
-  static int n = -1;
-  if (n < 0) {
-    // Round 3: no CUs are reserved any more.  The two-level schedule (super-panels factored by the dataflow launch + one
-    // exclusive bulk update each) has no pivot chain running next to a GEMM, and a CU mask costs every launch on the masked
-    // stream 5-15 % (in-order, per-shader-engine dispatch).  CBA_PANEL_CUS=8 restores the round-2 setup
-    // for the blocked multi-stream schedule (CBA_SUPER_W=0) in the bench harness.
-    const char* e = CBA_GETENV("CBA_PANEL_CUS");
-    n = e ? atoi(e) : 0;
-    if (n < 0 || n > 128) n = 0;
-  }
-  return n;
-}
-void panel_cu_mask(uint32_t* mask8, bool panel) {
-  const int n = panel_cu_count();
-  for (int i = 0; i < 8; ++i) mask8[i] = 0;
-  for (int bit = 0; bit < 256; ++bit) {
-    bool is_panel = bit < n;
-    if (is_panel == panel) mask8[bit >> 5] |= (1u << (bit & 31));
-  }
-}
 // The engine's four HIP streams per device are created ONCE, as early as possible in the life of the process, and
-// never destroyed.  Measured on MI355X / ROCm 7.2 (tools/stream_mask_test.hip): the same GEMM launch runs at
-// 60 TFLOP/s on a stream that was created before the process launched its first kernel and at 52-53 TFLOP/s on a
-// stream created afterwards (and that late stream also slows the older ones down).  cba_prepare_device() is the
-// hook for hosts to call first thing; cba_create calls it as a fallback.
-//   main  : bulk work; CU mask without the CUs reserved for the pivot chain
-//   chain : the latency-bound pivot chain of the factorisation.  It ran ~1.5x slower when its small kernels shared
-//           CUs with the bulk GEMM, so it gets CUs of its own: CBA_PANEL_CUS compute units (default 8 = one per
-//           XCD; mask bits are interleaved over the XCDs)
-//   mid   : look-ahead work of the wide panels, on the same reserved CUs
-//   far   : wide launches next to the bulk update (and the Jacobian pass' stragglers); same mask as main
+// never destroyed.  Measured on MI355X / ROCm 7.2 (round 2): the same GEMM launch runs at 60 TFLOP/s on a stream that was created
+// before the process launched its first kernel and at 52-53 TFLOP/s on a stream created afterwards (and that late stream also
+// slows the older ones down).  cba_prepare_device() is the hook for hosts to call first thing; cba_create calls it as a fallback.
+//   main  : everything on the critical path of a step, the whole factorisation included
+//   chain / mid / far : side work (the stragglers of the Jacobian pass, memsets, the distributed solve's exchanges)
+// No CU masks: a masked stream costs every launch on it 13-17 % (in-order dispatch, even over the shader engines: DESIGN.md).
 struct DeviceStreams {
   hipStream_t main = nullptr, chain = nullptr, mid = nullptr, far = nullptr;
-  // shader-engine census of the main / far mask (k_cu_census) and the counter blocks of gemm_dynamic_slot
-  bool short_se = false;
-  unsigned se_cus[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int se_max = 0, cus_total = 0, cus_full = 0;
-  unsigned* counters = nullptr;      // [2][80]: main, far
 };
-// every workgroup marks the CU it runs on: out[8 xcc + se] |= 1 << cu_id
-__global__ void k_cu_census(unsigned* __restrict__ out) {
-  if (threadIdx.x == 0) {
-    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7u;
-    const unsigned hw = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);
-    atomicOr(&out[8 * xcc + ((hw >> 13) & 7u)], 1u << ((hw >> 8) & 15u));
-    const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < 300) {}          // 3 us: long enough for the launch to spread over every CU
-  }
-}
 static std::mutex g_streams_mutex;
 static std::map<int, DeviceStreams> g_streams;
 static int device_streams(DeviceStreams* out) {
@@ -2546,67 +1448,18 @@ static int device_streams(DeviceStreams* out) {
   auto it = g_streams.find(dev);
   if (it == g_streams.end()) {
     DeviceStreams d;
-    uint32_t panel[8], rest[8];
-    panel_cu_mask(panel, /*panel=*/true);
-    panel_cu_mask(rest, /*panel=*/false);
-    if (panel_cu_count() > 0) {
-      CBA_HIP(hipExtStreamCreateWithCUMask(&d.main, 8, rest));
-      CBA_HIP(hipExtStreamCreateWithCUMask(&d.chain, 8, panel));
-      CBA_HIP(hipExtStreamCreateWithCUMask(&d.mid, 8, panel));
-      CBA_HIP(hipExtStreamCreateWithCUMask(&d.far, 8, rest));
-      // census of the CUs the main / far mask leaves, per (XCD, shader engine)
-      CBA_HIP(hipMalloc(&d.counters, sizeof(unsigned) * 160));
-      CBA_HIP(hipMemset(d.counters, 0, sizeof(unsigned) * 160));
-      hipLaunchKernelGGL(k_cu_census, dim3(32768), dim3(64), 0, d.main, d.counters);
-      unsigned seen[64];
-      CBA_HIP(hipStreamSynchronize(d.main));
-      CBA_HIP(hipMemcpy(seen, d.counters, sizeof(seen), hipMemcpyDeviceToHost));
-      CBA_HIP(hipMemset(d.counters, 0, sizeof(unsigned) * 160));
-      int n_se = 0;
-      for (int x = 0; x < 8; ++x)
-        for (int e = 0; e < 8; ++e) {
-          const int c = __builtin_popcount(seen[8 * x + e]);
-          if (c > 15) { d.se_max = 0; break; }
-          d.se_cus[x] |= (unsigned)c << (4 * e);
-          d.cus_total += c;
-          if (c > 0) ++n_se;
-          if (c > d.se_max) d.se_max = c;
-        }
-      d.cus_full = n_se * d.se_max;
-      d.short_se = d.se_max > 0 && d.cus_total < d.cus_full;
-      // SEs that the mask leaves empty get no workgroups at all: they must not count as "short"
-      for (int x = 0; x < 8; ++x)
-        for (int e = 0; e < 8; ++e)
-          if (((d.se_cus[x] >> (4 * e)) & 15u) == 0) d.se_cus[x] |= (unsigned)(d.se_max & 15) << (4 * e);
-    } else {
-      int lo = 0, hi = 0;
-      CBA_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      CBA_HIP(hipStreamCreateWithFlags(&d.main, hipStreamNonBlocking));
-      CBA_HIP(hipStreamCreateWithPriority(&d.chain, hipStreamNonBlocking, hi));
-      CBA_HIP(hipStreamCreateWithFlags(&d.mid, hipStreamNonBlocking));
-      CBA_HIP(hipStreamCreateWithFlags(&d.far, hipStreamNonBlocking));
-    }
+    int lo = 0, hi = 0;
+    CBA_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    CBA_HIP(hipStreamCreateWithFlags(&d.main, hipStreamNonBlocking));
+    CBA_HIP(hipStreamCreateWithPriority(&d.chain, hipStreamNonBlocking, hi));
+    CBA_HIP(hipStreamCreateWithFlags(&d.mid, hipStreamNonBlocking));
+    CBA_HIP(hipStreamCreateWithFlags(&d.far, hipStreamNonBlocking));
     it = g_streams.emplace(dev, d).first;
   }
   *out = it->second;
   return CBA_OK;
 }
 int prepare_device_streams() { DeviceStreams d; return device_streams(&d); }
-static bool se_balance_for_stream(hipStream_t s, SeBalance* out) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return false;
-  std::lock_guard<std::mutex> lock(g_streams_mutex);
-  auto it = g_streams.find(dev);
-  if (it == g_streams.end() || !it->second.short_se || s == nullptr) return false;
-  static const bool off = CBA_GETENV("CBA_NO_SE_BALANCE") != nullptr;      // developer switch (bench harness only)
-  if (off) return false;
-  const DeviceStreams& d = it->second;
-  if (s != d.main && s != d.far) return false;
-  out->counters = d.counters + (s == d.far ? 80 : 0);
-  for (int i = 0; i < 8; ++i) out->se_cus[i] = d.se_cus[i];
-  out->se_max = d.se_max; out->cus_total = d.cus_total; out->cus_full = d.cus_full;
-  return true;
-}
 
 int make_main_stream(hipStream_t* s) {
   DeviceStreams d;
@@ -2618,8 +1471,8 @@ int make_main_stream(hipStream_t* s) {
 
 int ldlt_workspace_alloc(LdltWorkspace& w, int n_pad) {
   ldlt_workspace_free(w);
-  // two panel buffers of the blocked schedule (look-ahead) = one X buffer of a super-panel (kSuperMax rows)
-  CBA_HIP(hipMalloc(&w.X, sizeof(double) * (size_t)(2 * kPanelWide > kSuperMax ? 2 * kPanelWide : kSuperMax) * n_pad));
+  // X = D L of a super-panel's row strip (kSuperMax rows): the K-major B operand of the bulk update
+  CBA_HIP(hipMalloc(&w.X, sizeof(double) * (size_t)kSuperMax * n_pad));
   CBA_HIP(hipMalloc(&w.invLt, sizeof(double) * (size_t)(n_pad / kInner) * kInner * kInner));
   CBA_HIP(hipMalloc(&w.dvec, sizeof(double) * (size_t)n_pad));
   CBA_HIP(hipMalloc(&w.status, sizeof(int)));
@@ -2629,14 +1482,8 @@ int ldlt_workspace_alloc(LdltWorkspace& w, int n_pad) {
     if (rc != CBA_OK) return rc;
     w.panel_stream = d.chain; w.mid_stream = d.mid; w.far_stream = d.far;     // shared, not owned
   }
-  CBA_HIP(hipEventCreateWithFlags(&w.ev_panel, hipEventDisableTiming | hipEventDisableSystemFence));
   CBA_HIP(hipEventCreateWithFlags(&w.ev_strip, hipEventDisableTiming | hipEventDisableSystemFence));
   CBA_HIP(hipEventCreateWithFlags(&w.ev_mid, hipEventDisableTiming | hipEventDisableSystemFence));
-  CBA_HIP(hipEventCreateWithFlags(&w.ev_diag, hipEventDisableTiming | hipEventDisableSystemFence));
-  CBA_HIP(hipEventCreateWithFlags(&w.ev_xn, hipEventDisableTiming | hipEventDisableSystemFence));
-  CBA_HIP(hipEventCreateWithFlags(&w.ev_aa, hipEventDisableTiming | hipEventDisableSystemFence));
-  CBA_HIP(hipEventCreateWithFlags(&w.ev_chain, hipEventDisableTiming | hipEventDisableSystemFence));
-  CBA_HIP(hipEventCreateWithFlags(&w.ev_bulk, hipEventDisableTiming | hipEventDisableSystemFence));
   {
     const int ntc = n_pad / kInner;
     const int rows = ntc < kTailMaxBlockRows ? ntc : kTailMaxBlockRows;
@@ -2661,83 +1508,15 @@ void ldlt_workspace_free(LdltWorkspace& w) {
   if (w.invLt) hipFree(w.invLt);
   if (w.dvec) hipFree(w.dvec);
   if (w.status) hipFree(w.status);
-  if (w.ev_panel) hipEventDestroy(w.ev_panel);
   if (w.ev_strip) hipEventDestroy(w.ev_strip);
   if (w.ev_mid) hipEventDestroy(w.ev_mid);
-  if (w.ev_diag) hipEventDestroy(w.ev_diag);
   for (auto& sp : w.spans) { hipEventDestroy(sp.e0); hipEventDestroy(sp.e1); }
-  if (w.ev_xn) hipEventDestroy(w.ev_xn);
-  if (w.ev_aa) hipEventDestroy(w.ev_aa);
-  if (w.ev_chain) hipEventDestroy(w.ev_chain);
-  if (w.ev_bulk) hipEventDestroy(w.ev_bulk);
   if (w.tail_flags) hipFree(w.tail_flags);
   if (w.tail_ctrl) hipFree(w.tail_ctrl);
   if (w.back_xe) hipFree(w.back_xe);
   if (w.tail_e0) hipEventDestroy(w.tail_e0);
   if (w.tail_e1) hipEventDestroy(w.tail_e1);
   w = LdltWorkspace();
-}
-
-// Factor rows [0, n_fact) of the n_pad x n_pad matrix S (ld = n_pad). Columns up to n_pad take part
-// in the panel solves / updates, so a right-hand side stored in a trailing column is forward-
-// substituted and scaled on the fly (it ends up holding D^-1 L^-1 b).
-//
-// Four streams:
-//   chain : the latency-bound pivot chain -- per 64-block: diagonal factor, then the solve / update
-//           restricted to the panel's own 256 columns ("near", 1-6 workgroups each); after the last
-//           block it also solves that block for the next panel's columns and applies (a'), the update of
-//           the next panel's diagonal block, so that the next panel starts without a stream hop;
-//   mid   : the same solve / update for the next panel's 256 columns (what (a') needs);
-//   far   : after the panel's chain: the fused forward substitution of everything right of that
-//           (k_panel_solve), plus (a''), the update of the rest of the next panel's rows;
-//   main  : (b) the bulk trailing update with K = 256 on the MFMA GEMM.  The next panel is factored
-//           underneath (b) (look-ahead).
-static int trsm_cols(double* S, int ld, int j0, int k0, int col_begin, int col_end, double* Xk, LdltWorkspace& w, hipStream_t s,
-                     int tl_kind) {
-  // X[p][i] = sum_q invLt[q][p] * S[j0+q][i], i in [col_begin, col_end); L = X / d written in place
-  if (col_begin >= col_end) return CBA_OK;
-  GemmArgs g{};
-  g.A = w.invLt + (size_t)(j0 / kInner) * kInner * kInner; g.lda = kInner;
-  g.B = S + (size_t)j0 * ld; g.ldb = ld; g.K = kInner;
-  g.C = Xk + (size_t)(j0 - k0) * ld; g.ldc = ld; g.Cin = nullptr; g.ldcin = 0;
-  g.m_tiles = 1; g.m_off = 0; g.upper = 0; g.diag = 0;
-  g.rowscale_inv = w.dvec + j0;
-  g.C2 = S + (size_t)j0 * ld; g.ldc2 = ld;
-  g.tlog_tag = (j0 / kInner) * kTlKinds + tl_kind + 1;
-  int c = col_begin;
-  if (c % 128 != 0) {  // unaligned 64-column head
-    GemmArgs h = g; h.n_tiles = 1; h.n_off = c;
-    int rc = launch_gemm<64, 64, 32, 32, false>(h, s);
-    if (rc) return rc;
-    c += 64;
-  }
-  const int n128 = (col_end - c) / 128;
-  if (n128 > 0) {
-    GemmArgs h = g; h.n_tiles = n128; h.n_off = c;
-    int rc = launch_gemm<64, 128, 32, 64, false>(h, s);
-    if (rc) return rc;
-    c += 128 * n128;
-  }
-  if (c < col_end) {   // 64-column tail
-    GemmArgs h = g; h.n_tiles = 1; h.n_off = c;
-    int rc = launch_gemm<64, 64, 32, 32, false>(h, s);
-    if (rc) return rc;
-  }
-  return CBA_OK;
-}
-// S[m][n] -= sum_p L[p][m] X[p][n] for rows m in [m_begin, m_end), cols n in [n_begin, n_end) (64-tiles)
-static int update_block(double* S, int ld, int j0, int k0, int m_begin, int m_end, int n_begin, int n_end, int upper,
-                        double* Xk, hipStream_t s, int tl_kind) {
-  if (m_begin >= m_end || n_begin >= n_end) return CBA_OK;
-  GemmArgs u{};
-  u.A = S + (size_t)j0 * ld; u.lda = ld;       // L values (rows j0..j0+63)
-  u.B = Xk + (size_t)(j0 - k0) * ld; u.ldb = ld; u.K = kInner;
-  u.C = S; u.ldc = ld; u.Cin = S; u.ldcin = ld;
-  u.m_off = m_begin; u.m_tiles = (m_end - m_begin) / 64;
-  u.n_off = n_begin; u.n_tiles = (n_end - n_begin) / 64;
-  u.upper = upper; u.diag = 0;
-  u.tlog_tag = (j0 / kInner) * kTlKinds + tl_kind + 1;
-  return launch_gemm<64, 64, 32, 32, true>(u, s);
 }
 
 static int span_begin(LdltWorkspace& w, hipStream_t s) {
@@ -2775,12 +1554,12 @@ static int timed_gemm128(const GemmArgs& g, hipStream_t s, LdltWorkspace& w, boo
 }
 
 
-// ---- persistent tail: host side ----
-static int g_super_w = 2048;
+// ---- dataflow launches: host side ----
+// Width of the super-panels (rows factored by one dataflow launch in front of a bulk update); the bench harness overrides it
 static int super_width() {
-  static const char* e = CBA_GETENV("CBA_SUPER_W");        // developer switch (bench harness only); 0 = blocked multi-stream schedule in the head
-  int v = e ? atoi(e) : g_super_w;
-  if (v < 0) v = 0;
+  static const char* e = CBA_GETENV("CBA_SUPER_W");        // developer switch (bench harness only)
+  int v = e ? atoi(e) : 2048;
+  if (v < 256) v = 256;
   if (v > kSuperMax) v = kSuperMax;
   return v / 128 * 128;
 }
@@ -2806,27 +1585,20 @@ static int super_width_at(int n_pad, int k0, int sw) {
   }
   return best;
 }
-static int g_tail_rows = 6144;
-void ldlt_set_tail_rows(int rows) { g_tail_rows = rows < 0 ? 0 : rows; }
-int ldlt_tail_rows() {
+// Rows left to the final dataflow launch (LdltWorkspace::tail_rows, cba_solver_options::factor_tail_rows), clamped to what the
+// workspace has flags for: a final launch takes up to tail_rows + sw / 2 rows
+int ldlt_tail_rows(const LdltWorkspace& w) {
   static const char* e = CBA_GETENV("CBA_TAIL_ROWS");      // developer switch (bench harness only)
-  const int v = e ? atoi(e) : g_tail_rows;
-  return v < 0 ? 0 : v;
+  int v = e ? atoi(e) : w.tail_rows;
+  const int cap = w.tail_rows_cap - super_width() / 2;
+  if (v > cap) v = cap;
+  return v < 256 ? 256 : v;
 }
 double ldlt_tail_last_ms(LdltWorkspace& w) {
   if (!w.tail_timed) return 0.0;
   float ms = 0;
   if (hipEventSynchronize(w.tail_e1) != hipSuccess || hipEventElapsedTime(&ms, w.tail_e0, w.tail_e1) != hipSuccess) return 0.0;
   return ms;
-}
-// first row of the tail: the first panel boundary of the blocked schedule with at most ldlt_tail_rows() rows left (n_fact = none)
-static int tail_start_row(int n_fact, const LdltWorkspace& w) {
-  int rows = ldlt_tail_rows();
-  if (rows > w.tail_rows_cap) rows = w.tail_rows_cap;
-  if (rows <= 0 || !w.tail_flags) return n_fact;
-  int k0 = 0;
-  while (k0 < n_fact && n_fact - k0 > rows) k0 += panel_width_at(k0, n_fact);
-  return k0 < n_fact ? k0 : n_fact;
 }
 // Factors rows [t0, n_fact) of S, whose trailing block [t0, n_pad)^2 carries every update of the rows above, with one launch
 // on stream s.  t0 and n_fact are multiples of 64.
@@ -2875,286 +1647,39 @@ static int ldlt_tail(double* S, int n_fact, int ld, int t0, LdltWorkspace& w, hi
   return CBA_OK;
 }
 
+// Factor rows [0, n_fact) of the n_pad x n_pad matrix S (ld = n_pad).  Columns up to n_pad take part, so a right-hand side stored
+// in a trailing column is forward-substituted and scaled on the fly (it ends up holding D^-1 L^-1 b).
+//
+// Two-level right-looking schedule on ONE stream: super-panels of ~2048 rows are factored -- diagonal part AND the whole row strip
+// right of it -- by the dataflow launch (ldlt_tail with X output), each followed by ONE trailing update with K = the super-panel's
+// width on the 128 x 128 MFMA GEMM, alone on the chip; the last tail_rows rows by one more dataflow launch.  No side streams, no
+// look-ahead: the chain of a super-panel hides behind its own row-strip tiles, and the bulk update runs at its stand-alone rate.
+// (Round 4 built two alternatives and dropped both, DESIGN.md section 3: the next super-panel's dataflow launch NEXT TO the bulk
+// update -- its hand-offs through L2 take 5x as long under the GEMM's memory traffic -- and the far columns of a strip as one
+// product with the explicit inverse of the super-panel's unit factor.)
 int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, GemmStats* st) {
   const int n_pad = ld;
-  hipStream_t s2 = w.panel_stream, s3 = w.far_stream, s4 = w.mid_stream;
-  if (CBA_GETENV("CBA_SERIAL")) { s2 = s; s3 = s; s4 = s; }   // developer switch: one stream (profiling the bulk GEMM alone)
-  // the side streams may start once everything queued on the main stream so far (assembly of S) is done
+  // the side streams (users: the distributed variant, the Jacobian pass) may start once everything queued on the main stream so
+  // far (assembly of S) is done
   CBA_HIP(hipEventRecord(w.ev_strip, s));
-  CBA_HIP(hipStreamWaitEvent(s2, w.ev_strip, 0));
-  CBA_HIP(hipStreamWaitEvent(s3, w.ev_strip, 0));
-  CBA_HIP(hipStreamWaitEvent(s4, w.ev_strip, 0));
-  CBA_HIP(hipEventRecord(w.ev_bulk, s));
-  int kidx = 0;
-  int prefactored = -1;          // first column of a diagonal block that the previous panel's (a') launch has already factored
-  // rows [t0, n_fact) are left to the persistent tail launch (ldlt_tail); the panel that ends at t0 ("junction") applies its
-  // whole trailing update in one launch, without look-ahead pieces
-  int t0 = tail_start_row(n_fact, w);
-  // Two-level schedule (default): super-panels of `super_w` rows are factored -- diagonal part AND the whole row strip right of
-  // it -- by the dataflow launch (ldlt_tail with X output), each followed by ONE trailing update with K = super_w on the
-  // 128 x 128 MFMA GEMM, alone on the chip; the last tail_rows rows by the dataflow launch as before.  No side streams, no
-  // look-ahead: the chain of a super-panel (super_w / 64 x 28 us) is hidden behind its own row-strip tiles, and the bulk
-  // update runs at its stand-alone rate with a quarter of the C-tile traffic of the 512-wide panels.
-  const int sw = super_width();
-  if (sw > 0 && t0 < n_fact) {
-    int k0 = 0;
-    while (n_fact - k0 > ldlt_tail_rows() + sw / 2 && n_pad - (k0 + sw) >= 1024) {
-      const int wk = super_width_at(n_pad, k0, sw);
-      int rc = ldlt_tail(S, k0 + wk, ld, k0, w, s, st, w.X);
-      if (rc) return rc;
-      GemmArgs u{};
-      u.A = S + (size_t)k0 * ld; u.lda = ld; u.B = w.X; u.ldb = n_pad; u.K = wk;
-      u.C = S; u.ldc = ld; u.Cin = S; u.ldcin = ld; u.diag = 0; u.upper = 1;
-      const int tl = (n_pad - (k0 + wk)) / 128;
-      u.m_off = k0 + wk; u.m_tiles = tl; u.n_off = k0 + wk; u.n_tiles = tl;
-      if ((rc = timed_gemm128(u, s, w, st != nullptr, (double)tl * (tl + 1) / 2))) return rc;
-      if (st) { const double rows = (double)(n_pad - (k0 + wk)); st->flops += rows * rows * wk; st->launches += 1; }
-      k0 += wk;
-    }
-    int rc = ldlt_tail(S, n_fact, ld, k0, w, s, st);
-    if (rc) return rc;
-    CBA_HIP(hipGetLastError());
-    return CBA_OK;
+  CBA_HIP(hipStreamWaitEvent(w.panel_stream, w.ev_strip, 0));
+  CBA_HIP(hipStreamWaitEvent(w.far_stream, w.ev_strip, 0));
+  CBA_HIP(hipStreamWaitEvent(w.mid_stream, w.ev_strip, 0));
+  const int sw = super_width(), tail_rows = ldlt_tail_rows(w);
+  int k0 = 0, rc;
+  while (n_fact - k0 > tail_rows + sw / 2 && n_pad - (k0 + sw) >= 1024) {
+    const int wk = super_width_at(n_pad, k0, sw);
+    if ((rc = ldlt_tail(S, k0 + wk, ld, k0, w, s, st, w.X))) return rc;
+    GemmArgs u{};
+    u.A = S + (size_t)k0 * ld; u.lda = ld; u.B = w.X; u.ldb = n_pad; u.K = wk;
+    u.C = S; u.ldc = ld; u.Cin = S; u.ldcin = ld; u.diag = 0; u.upper = 1;
+    const int tl = (n_pad - (k0 + wk)) / 128;
+    u.m_off = k0 + wk; u.m_tiles = tl; u.n_off = k0 + wk; u.n_tiles = tl;
+    if ((rc = timed_gemm128(u, s, w, st != nullptr, (double)tl * (tl + 1) / 2))) return rc;
+    if (st) { const double rows = (double)(n_pad - (k0 + wk)); st->flops += rows * rows * wk; st->launches += 1; }
+    k0 += wk;
   }
-  for (int k0 = 0, pw = 0; k0 < n_fact && k0 < t0; k0 += pw, ++kidx) {
-    pw = panel_width_at(k0, n_fact);
-    const int nb = (n_fact - k0 < pw) ? (n_fact - k0) : pw;
-    const int e0 = k0 + nb;   // first column right of the panel
-    double* Xk = w.X + (size_t)(kidx & 1) * kPanelWide * n_pad;
-    const int pw_next = e0 < n_fact ? panel_width_at(e0, n_fact) : kPanel;
-    const int r0 = e0;
-    // look-ahead structure: the next panel's columns [e0, nx) are kept ahead of the rest
-    const bool more = e0 < n_fact;                 // the last panel needs no trailing update
-    const bool junction = more && e0 == t0;
-    const bool la = more && !junction && (r0 < n_pad) && (r0 % 128 == 0);
-    const int mt = la ? (n_pad - r0) / 128 : 0;
-    const int head = mt < pw_next / 128 ? mt : pw_next / 128;   // 128-tile rows of the next panel
-    const int nx = la ? r0 + head * 128 : e0;
-    int rc;
-    GemmArgs u{};                                  // trailing update with the whole panel
-    u.A = S + (size_t)k0 * ld; u.lda = ld;
-    u.B = Xk; u.ldb = n_pad; u.K = nb;
-    u.C = S; u.ldc = ld; u.Cin = S; u.ldcin = ld;
-    u.diag = 0;
-    // A full 256-panel with look-ahead runs its whole chain on the chain stream: one launch per 64-block (near step
-    // on the panel's own AND the next panel's columns + the next diagonal factor, k_near_fused<true>).
-    static const bool no_chain_only = CBA_GETENV("CBA_NO_CHAIN_ONLY") != nullptr;      // developer switch
-    const bool chain_only = !no_chain_only && pw == kPanel && nb == kPanel && la && nx > e0;
-    if (chain_only) {
-      const int ncn = (nx - e0) / kInner, nblocks = kPanel / kInner;
-      if (prefactored != k0)
-        hipLaunchKernelGGL(k_ldlt_diag<kInner>, dim3(1), dim3(256), 0, s2, S, ld, k0, w.dvec, w.invLt, w.status);
-      for (int b = 0; b + 1 < nblocks; ++b) {
-        const int nbk = nblocks - 1 - b;
-        // from the second launch on, the look-ahead workgroups update this panel's rows in the next panel's columns,
-        // which (a''n) of the previous panel (far stream) wrote last
-        if (b == 1) CBA_HIP(hipStreamWaitEvent(s2, w.ev_aa, 0));
-        const int tiles = nbk * (nbk + 1) / 2 + (b > 0 ? ncn : 0);
-        hipLaunchKernelGGL(k_near_fused<true>, dim3(tiles + (tiles + 5) / 7), dim3(256), 0, s2, S, ld, k0, k0 + kInner * b, e0,
-                           nx, Xk, n_pad, w.dvec, w.invLt, w.status, b > 0 ? 1 : 0);
-      }
-      CBA_HIP(hipEventRecord(w.ev_chain, s2));
-      // chain: the look-ahead of the last two block rows, then (a') with L taken from the panel buffer
-      hipLaunchKernelGGL(k_next_last, dim3(ncn), dim3(256), 0, s2, S, ld, k0, e0, Xk, n_pad, w.dvec, w.invLt);
-      CBA_HIP(hipEventRecord(w.ev_xn, s2));
-      CBA_HIP(hipStreamWaitEvent(s2, w.ev_bulk, 0));     // the previous bulk update wrote the same block
-      {
-        // (a') + the next panel's first diagonal factor in one launch
-        const int nt = head * 2, tiles = nt * (nt + 1) / 2;
-        hipLaunchKernelGGL(k_aprime_fused, dim3(tiles + (tiles + 5) / 7), dim3(256), 0, s2, S, ld, k0, nb, r0, nt, Xk, n_pad, w.dvec,
-                           w.invLt, w.status);
-        prefactored = r0;
-      }
-      GemmArgs v = u;
-      v.A = Xk; v.lda = n_pad; v.a_rowdiv = w.dvec + k0;
-      CBA_HIP(hipEventRecord(w.ev_strip, s2));
-      // far: L in place inside the panel, the fused forward substitution right of the look-ahead columns (the bulk
-      // update waits for it), then (a''n) -- the next panel's chain waits for that -- and the rest of (a'').  (Solving
-      // only the columns (a''n) needs first and the rest after it was measured as well: 0.2 ms slower per
-      // factorisation, the forward substitution then sits behind (a''n)'s wait for the previous bulk update.)
-      const int h2 = (mt - head) < head ? (mt - head) : head;
-      CBA_HIP(hipStreamWaitEvent(s3, w.ev_chain, 0));
-      hipLaunchKernelGGL(k_scale_rows, dim3(kPanel - kInner), dim3(256), 0, s3, S, ld, k0, k0, k0 + kInner, e0, Xk, n_pad, w.dvec);
-      if (n_pad > nx)
-        hipLaunchKernelGGL(k_panel_solve_t<false>, dim3((n_pad - nx) / kInner), dim3(256), 0, s3, S, ld, k0, nb, nx, Xk, n_pad, w.dvec, w.invLt);
-      CBA_HIP(hipEventRecord(w.ev_panel, s3));
-      CBA_HIP(hipStreamWaitEvent(s, w.ev_panel, 0));
-      if (mt > head) {
-        CBA_HIP(hipStreamWaitEvent(s3, w.ev_xn, 0));
-        CBA_HIP(hipStreamWaitEvent(s3, w.ev_bulk, 0));
-        v.upper = 0; v.m_off = r0; v.m_tiles = head * 2; v.n_off = r0 + head * 128; v.n_tiles = h2 * 2;
-        v.tlog_tag = (k0 / kInner) * kTlKinds + kTlAA_n + 1;
-        if ((rc = launch_gemm<64, 64, 32, 32, true>(v, s3))) return rc;       // A = panel buffer / d, like (a')
-      }
-      CBA_HIP(hipEventRecord(w.ev_aa, s3));
-      CBA_HIP(hipStreamWaitEvent(s4, w.ev_aa, 0));
-      // L in place in the next panel's columns (the 128 x 128 launches below and the back substitution read it)
-      CBA_HIP(hipStreamWaitEvent(s3, w.ev_xn, 0));
-      hipLaunchKernelGGL(k_scale_rows, dim3(kPanel), dim3(256), 0, s3, S, ld, k0, k0, e0, nx, Xk, n_pad, w.dvec);
-      v.A = u.A; v.lda = u.lda; v.a_rowdiv = nullptr;
-      // Near the end of the matrix a launch has fewer 128 x 128 tiles than the chip has CUs and its duration is one
-      // tile's K loop (16 slabs, ~30-60 us): 64 x 64 tiles are four times as many and a quarter as long.
-      constexpr long long kFewTiles = 200;
-      if (mt - head > h2) {
-        v.upper = 0; v.m_off = r0; v.m_tiles = head; v.n_off = r0 + (head + h2) * 128; v.n_tiles = mt - head - h2;
-        v.tlog_tag = (k0 / kInner) * kTlKinds + kTlAA_rest + 1;
-        if ((long long)v.m_tiles * v.n_tiles < kFewTiles) {
-          v.m_tiles *= 2; v.n_tiles *= 2;
-          if ((rc = launch_gemm<64, 64, 32, 32, true>(v, s3))) return rc;
-        } else if ((rc = timed_gemm128(v, s3, w, st != nullptr, (double)head * (mt - head - h2)))) return rc;
-      }
-      if (mt > head) {
-        // In this (chain-bound) part of the matrix the bulk update has time to spare, but (a''n) -- 16 small tiles that
-        // the NEXT panel's chain waits for after its first block -- took 50-110 us when it started together with the
-        // bulk launch, queued behind its ~100-us workgroups.  The bulk update therefore starts after (a''n).
-        // (Only while the bulk launch is short next to the panel's chain: with more than ~3000 rows left it is itself on
-        // the critical path and the delay costs more than it saves -- 262 vs 231 us per panel at 5900 rows.)
-        static const int aa_first_rows = CBA_GETENV("CBA_AA_FIRST_ROWS") ? atoi(CBA_GETENV("CBA_AA_FIRST_ROWS")) : 3072;   // developer switch
-        if (n_pad - r0 <= aa_first_rows) CBA_HIP(hipStreamWaitEvent(s, w.ev_aa, 0));
-        u.upper = 1; u.m_off = r0 + head * 128; u.m_tiles = mt - head; u.n_off = r0 + head * 128; u.n_tiles = mt - head;
-        u.tlog_tag = (k0 / kInner) * kTlKinds + kTlBulk + 1;
-        if ((long long)u.m_tiles * (u.m_tiles + 1) / 2 < kFewTiles) {
-          u.m_tiles *= 2; u.n_tiles *= 2;
-          if ((rc = launch_gemm<64, 64, 32, 32, true>(u, s))) return rc;
-        } else if ((rc = timed_gemm128(u, s, w, st != nullptr, (double)(mt - head) * (mt - head + 1) / 2))) return rc;
-      }
-      CBA_HIP(hipEventRecord(w.ev_bulk, s));
-      if (st) {
-        double rows = (double)(n_pad - r0);
-        st->flops += rows * rows * nb;
-        st->launches += 1;
-      }
-      continue;
-    }
-    for (int j0 = k0; j0 < e0; j0 += kInner) {
-      const int c0 = j0 + kInner;
-      const bool last = (c0 == e0);
-      // ---- chain: factor the diagonal block, near solve, near update ----
-      if (prefactored != j0)
-        hipLaunchKernelGGL(k_ldlt_diag<kInner>, dim3(1), dim3(256), 0, s2, S, ld, j0, w.dvec, w.invLt, w.status);
-      const bool mid_work = !last && nx > e0;
-      if (mid_work) {
-        // mid: the block row's solve on the next panel's columns needs only the diagonal factor, so it runs next to
-        // the chain's near step instead of behind it (the mid stream's tail is what the last block's solve waits for)
-        CBA_HIP(hipEventRecord(w.ev_diag, s2));
-        CBA_HIP(hipStreamWaitEvent(s4, w.ev_diag, 0));
-        if ((rc = trsm_cols(S, ld, j0, k0, e0, nx, Xk, w, s4, kTlMidTrsm))) return rc;
-      }
-      const bool fused_near = (pw == kPanel) && (c0 < e0);
-      if (fused_near) {
-        const int nbk = (e0 - c0) / kInner;
-        hipLaunchKernelGGL(k_near_fused<false>, dim3(nbk * (nbk + 1) / 2), dim3(256), 0, s2, S, ld, k0, j0, e0, e0, Xk, n_pad, w.dvec,
-                           w.invLt, w.status, 0);
-      } else {
-        if ((rc = trsm_cols(S, ld, j0, k0, c0, e0, Xk, w, s2, kTlChainTrsm))) return rc;
-        if ((rc = update_block(S, ld, j0, k0, c0, e0, c0, e0, /*upper*/ 1, Xk, s2, kTlChainUpd))) return rc;
-      }
-      CBA_HIP(hipEventRecord(w.ev_chain, s2));
-      if (fused_near) {      // L in place for the panel-internal columns, off the critical path
-        CBA_HIP(hipStreamWaitEvent(s4, w.ev_chain, 0));
-        hipLaunchKernelGGL(k_scale_rows, dim3(kInner), dim3(256), 0, s4, S, ld, k0, j0, c0, e0, Xk, n_pad, w.dvec);
-        if (last || nx <= e0) CBA_HIP(hipEventRecord(w.ev_mid, s4));
-      }
-      if (last && la) {
-        // the last block's solve on the next panel's columns and (a') stay on the chain stream
-        CBA_HIP(hipStreamWaitEvent(s2, w.ev_mid, 0));      // mid updates of the earlier blocks
-        if ((rc = trsm_cols(S, ld, j0, k0, e0, nx, Xk, w, s2, kTlXn))) return rc;
-        CBA_HIP(hipStreamWaitEvent(s2, w.ev_bulk, 0));     // the previous bulk update wrote the same block
-        // (a') diagonal block of the next panel.  64x64 tiles: ten small tiles on ten CUs finish several
-        // times sooner than three 128x128 tiles, and this launch is on the critical path.
-        GemmArgs v = u;
-        v.upper = 1; v.m_off = r0; v.m_tiles = head * 2; v.n_off = r0; v.n_tiles = head * 2;
-        v.tlog_tag = (k0 / kInner) * kTlKinds + kTlAPrime + 1;
-        if ((rc = launch_gemm<64, 64, 32, 32, true>(v, s2))) return rc;
-        CBA_HIP(hipEventRecord(w.ev_strip, s2));
-      }
-      // ---- mid: the next panel's columns ----
-      if (mid_work) {
-        CBA_HIP(hipStreamWaitEvent(s4, w.ev_chain, 0));    // L of the panel-internal columns (near step / k_scale_rows)
-        if ((rc = update_block(S, ld, j0, k0, c0, e0, e0, nx, /*upper*/ 0, Xk, s4, kTlMidUpd))) return rc;
-        CBA_HIP(hipEventRecord(w.ev_mid, s4));
-      }
-    }
-    // ---- far: everything right of the look-ahead columns, one fused forward substitution per 64-column tile ----
-    CBA_HIP(hipStreamWaitEvent(s3, w.ev_chain, 0));          // the panel's last block is factored
-    CBA_HIP(hipStreamWaitEvent(s3, w.ev_mid, 0));            // ... and L is in place inside the panel
-    if (n_pad > nx)
-      hipLaunchKernelGGL(k_panel_solve_t<false>, dim3((n_pad - nx) / kInner), dim3(256), 0, s3, S, ld, k0, nb, nx, Xk, n_pad,
-                         w.dvec, w.invLt);
-    CBA_HIP(hipEventRecord(w.ev_panel, s3));
-    CBA_HIP(hipStreamWaitEvent(s, w.ev_panel, 0));
-    if (more && r0 < n_pad) {
-      if (la) {
-        // (a'') rest of the next panel's rows, on the far stream (it is what the next panel's mid / far
-        // work waits for) so that it runs next to the bulk update instead of in front of it.  It writes
-        // rows that the previous bulk update also wrote, hence the wait on ev_bulk.
-        CBA_HIP(hipStreamWaitEvent(s3, w.ev_strip, 0));    // the chain's solve on the next panel's columns
-        if (mt > head) {
-          CBA_HIP(hipStreamWaitEvent(s3, w.ev_bulk, 0));
-          // first the block the next panel's mid stream reads (its own next-panel columns), in small tiles,
-          // then the rest of the strip: the mid stream is released ~50 us earlier in the chain-bound tail
-          const int h2 = (mt - head) < head ? (mt - head) : head;
-          GemmArgs v = u;
-          v.upper = 0; v.m_off = r0; v.m_tiles = head * 2; v.n_off = r0 + head * 128; v.n_tiles = h2 * 2;
-          v.tlog_tag = (k0 / kInner) * kTlKinds + kTlAA_n + 1;
-          if ((rc = launch_gemm<64, 64, 32, 32, true>(v, s3))) return rc;
-          CBA_HIP(hipEventRecord(w.ev_aa, s3));
-          CBA_HIP(hipStreamWaitEvent(s4, w.ev_aa, 0));
-          if (mt - head > h2) {
-            v.m_tiles = head; v.n_off = r0 + (head + h2) * 128; v.n_tiles = mt - head - h2;
-            v.tlog_tag = (k0 / kInner) * kTlKinds + kTlAA_rest + 1;
-            static const bool aa_main = CBA_GETENV("CBA_AA_MAIN") != nullptr;     // developer switch: row strip in front of the bulk update, same stream
-            if (aa_main) {
-              CBA_HIP(hipStreamWaitEvent(s, w.ev_strip, 0));
-              if ((rc = timed_gemm128(v, s, w, st != nullptr, (double)head * (mt - head - h2)))) return rc;
-              CBA_HIP(hipEventRecord(w.ev_diag, s));
-              CBA_HIP(hipStreamWaitEvent(s3, w.ev_diag, 0));
-            } else if ((rc = timed_gemm128(v, s3, w, st != nullptr, (double)head * (mt - head - h2)))) return rc;
-          }
-        } else {
-          CBA_HIP(hipEventRecord(w.ev_aa, s3));
-          CBA_HIP(hipStreamWaitEvent(s4, w.ev_aa, 0));
-        }
-        // (b) bulk
-        if (mt > head) {
-          u.upper = 1; u.m_off = r0 + head * 128; u.m_tiles = mt - head; u.n_off = r0 + head * 128; u.n_tiles = mt - head;
-          u.tlog_tag = (k0 / kInner) * kTlKinds + kTlBulk + 1;
-          if ((rc = timed_gemm128(u, s, w, st != nullptr, (double)(mt - head) * (mt - head + 1) / 2))) return rc;
-        }
-        CBA_HIP(hipEventRecord(w.ev_bulk, s));
-      } else {
-        u.upper = 1;
-        if (r0 % 128 == 0 && n_pad - r0 >= 1024) {
-          const int tl = (n_pad - r0) / 128;
-          u.m_off = r0; u.m_tiles = tl; u.n_off = r0; u.n_tiles = tl;
-          u.tlog_tag = (k0 / kInner) * kTlKinds + kTlBulk + 1;
-          if ((rc = timed_gemm128(u, s, w, st != nullptr, (double)tl * (tl + 1) / 2))) return rc;
-        } else {
-          u.m_off = r0; u.m_tiles = (n_pad - r0) / 64; u.n_off = r0; u.n_tiles = (n_pad - r0) / 64;
-          if ((rc = launch_gemm<64, 64, 32, 32, true>(u, s))) return rc;
-        }
-        CBA_HIP(hipEventRecord(w.ev_strip, s));
-        CBA_HIP(hipStreamWaitEvent(s2, w.ev_strip, 0));
-        CBA_HIP(hipStreamWaitEvent(s3, w.ev_strip, 0));
-        CBA_HIP(hipStreamWaitEvent(s4, w.ev_strip, 0));
-      }
-      if (st) {
-        double rows = (double)(n_pad - r0);
-        st->flops += rows * rows * nb;  // 2 * (rows^2 / 2) * nb
-        st->launches += 1;
-      }
-    }
-  }
-  if (t0 < n_fact) {
-    // the junction panel's update (main stream) is the last thing the head did; the side streams are idle by then
-    int rc = ldlt_tail(S, n_fact, ld, t0, w, s, st);
-    if (rc) return rc;
-  }
-  // everything the side streams did is ordered before whatever follows on the main stream
-  CBA_HIP(hipEventRecord(w.ev_strip, s2));
-  CBA_HIP(hipStreamWaitEvent(s, w.ev_strip, 0));
-  CBA_HIP(hipEventRecord(w.ev_mid, s4));
-  CBA_HIP(hipStreamWaitEvent(s, w.ev_mid, 0));
+  if ((rc = ldlt_tail(S, n_fact, ld, k0, w, s, st))) return rc;
   CBA_HIP(hipGetLastError());
   return CBA_OK;
 }
@@ -3295,7 +1820,7 @@ int ldlt_factor_distributed(double* S, int n_fact, int ld, LdltWorkspace& w, hip
   if (c.world < 1 || c.rank < 0 || c.rank >= c.world || !c.send || !c.recv) return CBA_ERR_ARG;
   hipStream_t s2 = w.far_stream;
   int nsp = 0;
-  for (int k0 = 0; n_fact - k0 > ldlt_tail_rows() + W / 2 && n_pad - (k0 + W) >= 1024; k0 += W) ++nsp;
+  for (int k0 = 0; n_fact - k0 > ldlt_tail_rows(w) + W / 2 && n_pad - (k0 + W) >= 1024; k0 += W) ++nsp;
   int rc;
   if (nsp == 0) {
     // small systems: one dataflow launch on everything -- sum the packed upper triangle, factor replicated
@@ -3518,12 +2043,9 @@ __global__ void __launch_bounds__(256) k_back_dataflow(BackArgs a) {
   }
 }
 
-static bool g_back_dataflow = true;
-void ldlt_set_back_dataflow(int on) { g_back_dataflow = on != 0; }
-
 int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWorkspace& w, double* x, hipStream_t s) {
   static const bool no_df = CBA_GETENV("CBA_BACK_PANELS") != nullptr;       // developer switch (bench harness only)
-  if (g_back_dataflow && !no_df && w.back_xe && n_fact % kInner == 0) {
+  if (w.back_dataflow && !no_df && w.back_xe && n_fact % kInner == 0) {
     BackArgs a{};
     a.S = S; a.ld = ld; a.n_fact = n_fact; a.zcol = zcol; a.invLt = w.invLt; a.x = x; a.xe = w.back_xe; a.status = w.status;
     LdltWorkspace& wm = const_cast<LdltWorkspace&>(w);

@@ -36,6 +36,14 @@ COLLECTIVE_FN = C.CFUNCTYPE(C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_int6
 COLL_ALLREDUCE_SUM, COLL_REDUCE_SCATTER_SUM, COLL_ALLGATHER = 0, 1, 2
 
 
+class CbaSolverOptions(C.Structure):
+    """cba_solver_options: scheduling options of the reduced solve (all zero = defaults)."""
+    _fields_ = [("factor_tail_rows", C.c_int32), ("back_substitution", C.c_int32)]
+
+
+DEFAULT_FACTOR_TAIL_ROWS = 6144      # what factor_tail_rows = 0 selects (include/cba.h)
+
+
 class CbaConfig(C.Structure):
     _fields_ = [("n_cameras", C.c_int32), ("cameras", C.POINTER(CbaCamera)),
                 ("n_images", C.c_int32), ("n_points", C.c_int32),
@@ -45,7 +53,7 @@ class CbaConfig(C.Structure):
                 ("n_images_global", C.c_int32),
                 ("reduce_buffer", C.c_void_p), ("reduce_buffer_doubles", C.c_int64),
                 ("deterministic", C.c_int32), ("distributed_solve", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
-                ("collective", COLLECTIVE_FN), ("collective_user", C.c_void_p)]
+                ("collective", COLLECTIVE_FN), ("collective_user", C.c_void_p), ("solver", CbaSolverOptions)]
 
 
 class CbaFitReport(C.Structure):
@@ -69,7 +77,7 @@ EXPORTED_SYMBOLS = [
     "cba_total_dof", "cba_dense_dof", "cba_jacobian_record_doubles", "cba_reduce_buffer_doubles",
     "cba_kernel_stats", "cba_fit_grid_to_directions", "cba_prepare_device",
     "cba_model_create", "cba_model_destroy", "cba_model_set_grid", "cba_model_project", "cba_model_unproject",
-    "cba_fd_redo_overflow", "cba_set_factor_tail_rows", "cba_factor_tail_rows", "cba_debug_fd_redo_counts", "cba_debug_set_back_substitution",
+    "cba_fd_redo_overflow", "cba_debug_fd_redo_counts", "cba_schur_solve_opt",
 ]
 
 DUMP_COST_VECTOR, DUMP_PIXELS, DUMP_FLAGS, DUMP_JACOBIANS = 1, 2, 3, 4
@@ -138,30 +146,10 @@ def load() -> C.CDLL:
     return L
 
 
-def set_factor_tail_rows(rows: int) -> None:
-    """cba_set_factor_tail_rows (process-wide): rows factored by the persistent tail launch; 0 = blocked schedule only."""
-    L = load()
-    L.cba_set_factor_tail_rows.argtypes = [C.c_int32]
-    L.cba_set_factor_tail_rows(int(rows))
-
-
-def set_back_substitution(dataflow: bool) -> None:
-    """cba_debug_set_back_substitution (process-wide): one dataflow launch (default) or panels of 256 rows."""
-    L = load()
-    L.cba_debug_set_back_substitution.argtypes = [C.c_int32]
-    L.cba_debug_set_back_substitution(int(bool(dataflow)))
-
-
-def factor_tail_rows() -> int:
-    L = load()
-    L.cba_factor_tail_rows.restype = C.c_int32
-    return int(L.cba_factor_tail_rows())
-
-
 def prepare(device: int = 0) -> None:
     """Creates the engine's HIP streams for `device` now (cba_prepare_device).  Call it before the process launches
     its first GPU kernel: streams created that early run the dominant GEMM ~15 % faster than streams created later
-    (measured on MI355X / ROCm 7.2, tools/stream_mask_test.hip).  Optional -- cba_create does it on demand."""
+    (measured on MI355X / ROCm 7.2 in round 2).  Optional -- cba_create does it on demand."""
     _check(load().cba_prepare_device(int(device)), "cba_prepare_device")
 
 
@@ -206,7 +194,8 @@ class Engine:
                  n_images_global: int = 0, reduce_buffer_ptr: int = 0, reduce_buffer_doubles: int = 0,
                  last_projection: Optional[np.ndarray] = None, deterministic: bool = False,
                  allreduce_native: Optional[tuple] = None, distributed_solve: bool = False, rank: int = 0, world_size: int = 1,
-                 collective: Optional[Callable[[int, int, int, int], int]] = None, collective_native: Optional[tuple] = None):
+                 collective: Optional[Callable[[int, int, int, int], int]] = None, collective_native: Optional[tuple] = None,
+                 factor_tail_rows: int = 0, back_substitution_panels: bool = False):
         self.L = load()
         self.problem = problem
         self._cams = (CbaCamera * problem.n_cameras)(*[_cam_struct(c) for c in problem.cameras])
@@ -241,7 +230,7 @@ class Engine:
                         int(problem.localize_only), int(problem.eliminate_points), device,
                         cb, user, n_images_global,
                         reduce_buffer_ptr or None, reduce_buffer_doubles, int(deterministic), int(distributed_solve), int(rank), int(world_size),
-                        ccb, cuser)
+                        ccb, cuser, CbaSolverOptions(int(factor_tail_rows), int(bool(back_substitution_panels))))
         self._cfg = cfg
         self._h = C.c_void_p()
         _check(self.L.cba_create(C.byref(cfg), C.byref(self._h)), "cba_create")
@@ -258,7 +247,7 @@ class Engine:
         cams = (CbaCamera * problem.n_cameras)(*[_cam_struct(c) for c in problem.cameras])
         cfg = CbaConfig(problem.n_cameras, cams, problem.n_images, problem.n_points, problem.fd_delta,
                         int(problem.localize_only), int(problem.eliminate_points), 0, ALLREDUCE_FN(0), None, 0, None, 0, 0,
-                        int(distributed_solve), 0, int(world_size), COLLECTIVE_FN(0), None)
+                        int(distributed_solve), 0, int(world_size), COLLECTIVE_FN(0), None, CbaSolverOptions(0, 0))
         return int(load().cba_reduce_buffer_doubles(C.byref(cfg)))
 
     def close(self) -> None:
@@ -436,8 +425,9 @@ def unproject(cam: Camera, grid: np.ndarray, pixels: np.ndarray, with_jacobian: 
 
 
 def schur_solve(block_diag_H: np.ndarray, off_diag_H: np.ndarray, dense_H: np.ndarray, block_diag_b: np.ndarray,
-                dense_b: np.ndarray, device: int = 0) -> np.ndarray:
-    """LMOptimizer::SolveWithSchurComplementDenseOffDiag on host arrays (reference layout)."""
+                dense_b: np.ndarray, device: int = 0, factor_tail_rows: int = 0, back_substitution_panels: bool = False) -> np.ndarray:
+    """LMOptimizer::SolveWithSchurComplementDenseOffDiag on host arrays (reference layout); the two keyword options are
+    cba_solver_options (scheduling only)."""
     L = load()
     bD = np.ascontiguousarray(block_diag_H, dtype=np.float64)
     nb, bs = bD.shape[0], bD.shape[1]
@@ -447,7 +437,12 @@ def schur_solve(block_diag_H: np.ndarray, off_diag_H: np.ndarray, dense_H: np.nd
     db = np.ascontiguousarray(dense_b, dtype=np.float64)
     dd = dH.shape[0]
     x = np.zeros(nb * bs + dd)
-    _check(L.cba_schur_solve(bs, nb, dd, _dp(bD), _dp(oH), _dp(dH), _dp(bb), _dp(db), _dp(x), device), "cba_schur_solve")
+    if factor_tail_rows or back_substitution_panels:
+        opt = CbaSolverOptions(int(factor_tail_rows), int(bool(back_substitution_panels)))
+        L.cba_schur_solve_opt.argtypes = [C.c_int32, C.c_int32, C.c_int32] + [C.POINTER(C.c_double)] * 6 + [C.POINTER(CbaSolverOptions), C.c_int32]
+        _check(L.cba_schur_solve_opt(bs, nb, dd, _dp(bD), _dp(oH), _dp(dH), _dp(bb), _dp(db), _dp(x), C.byref(opt), device), "cba_schur_solve_opt")
+    else:
+        _check(L.cba_schur_solve(bs, nb, dd, _dp(bD), _dp(oH), _dp(dH), _dp(bb), _dp(db), _dp(x), device), "cba_schur_solve")
     return x
 
 

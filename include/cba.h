@@ -36,7 +36,9 @@ enum {
   CBA_ERR_HIP = -2,        /* HIP runtime error; cba_last_error() has the text */
   CBA_ERR_STATE = -3,      /* call sequence error (e.g. step before set_state) */
   CBA_ERR_NUMERIC = -4,    /* factorisation broke down (zero pivot) */
-  CBA_ERR_UNSUPPORTED = -5
+  CBA_ERR_UNSUPPORTED = -5,
+  CBA_ERR_TIMEOUT = -6     /* a dataflow launch of the reduced solve gave up waiting for another workgroup (3 s): device fault or a
+                              launch that could not become resident; nothing was written to the state */
 };
 
 /* CameraModel::Type of the two generic models (APP/models/camera_model.h:44-52) */
@@ -65,6 +67,15 @@ typedef int (*cba_allreduce_fn)(void* device_ptr, int64_t count, void* user);
  * Returns 0 on success. */
 enum { CBA_COLL_ALLREDUCE_SUM = 0, CBA_COLL_REDUCE_SCATTER_SUM = 1, CBA_COLL_ALLGATHER = 2 };
 typedef int (*cba_collective_fn)(int32_t op, void* sendbuf, void* recvbuf, int64_t count, void* user);
+
+/* Scheduling options of the reduced solve (LV/lm_optimizer.h:1361, Eigen's LDLT there).  They select between equivalent schedules:
+ * results change only in the last bits.  All zero = defaults.  Per problem / per call -- nothing here is process-wide. */
+typedef struct {
+  int32_t factor_tail_rows;   /* rows left to the FINAL dataflow launch of the two-level factorisation;
+                                 0 = default (6144), clamped to what the launch has flags for.  Smaller values give small systems
+                                 the super-panel structure of large ones (the tests use that) */
+  int32_t back_substitution;  /* 0 = one dataflow launch (default); 1 = panels of 256 rows (98 launches at BASELINE configs[1]) */
+} cba_solver_options;
 
 typedef struct {
   int32_t n_cameras;
@@ -109,6 +120,7 @@ typedef struct {
    * results, 2-world x the bytes) */
   cba_collective_fn collective;
   void* collective_user;
+  cba_solver_options solver;     /* scheduling options of the reduced solve (all zero = defaults) */
 } cba_config;
 
 /* OptimizationReport (LV/lm_optimizer.h:55-77) + what OptimizeJointly returns through pointers */
@@ -179,16 +191,6 @@ int64_t cba_fd_redo_overflow(cba_problem* p);
 /* Diagnostics: out[0] / out[1] = tasks of the last Jacobian pass that went to the gather-path follow-up list of the main /
  * side-stream finite-difference launch, out[2] = the overflow count above. */
 int cba_debug_fd_redo_counts(cba_problem* p, int64_t out[3]);
-/* Diagnostics (process-wide): 1 = back substitution of the reduced solve as ONE dataflow launch (default), 0 = by panels of 256
- * rows (98 launches at BASELINE configs[1]); same result to rounding.  Lets the tests keep the fallback path alive. */
-void cba_debug_set_back_substitution(int32_t dataflow);
-
-/* Scheduling knob of the reduced-system factorisation (process-wide; results change only in the last bits): the last `rows`
- * rows are factored by ONE persistent dataflow launch instead of the blocked multi-stream schedule.
- * Default 6144; 0 = off.  (No reference counterpart: Eigen's LDLT, LV/lm_optimizer.h:1361.) */
-void cba_set_factor_tail_rows(int32_t rows);
-int32_t cba_factor_tail_rows(void);
-
 /* ---- stateless model-level entry points (CameraModel API) ---- */
 /* CameraModel::Project / ProjectWithInitialEstimate for n local points (APP/models/central_grid.h:79-97,
  * central_generic.cc:433-519, noncentral_generic.cc:156-264). init_pixels NULL = start at the centre
@@ -217,6 +219,10 @@ int cba_model_unproject(cba_model* m, int64_t n, const double* pixels, double* l
 int cba_schur_solve(int32_t block_size, int32_t n_blocks, int32_t dense_dof, const double* block_diag_H,
                     const double* off_diag_H, const double* dense_H, const double* block_diag_b,
                     const double* dense_b, double* x, int32_t device);
+/* the same with explicit scheduling options (NULL = defaults) */
+int cba_schur_solve_opt(int32_t block_size, int32_t n_blocks, int32_t dense_dof, const double* block_diag_H,
+                        const double* off_diag_H, const double* dense_H, const double* block_diag_b,
+                        const double* dense_b, double* x, const cba_solver_options* options, int32_t device);
 
 /* ---- grid-only LM ---- */
 /* OptimizationReport of the fit + the optimizer's final lambda */

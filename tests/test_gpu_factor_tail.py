@@ -1,7 +1,7 @@
-"""The persistent tail launch of the reduced-system factorisation (k_ldlt_tail, cba_set_factor_tail_rows) against the blocked
-multi-stream schedule and against LAPACK: same solution, whatever share of the matrix the tail takes -- nothing (0), the last
-panels (1024), everything (the system is smaller than the default 6144), and sizes that put the junction on every kind of
-panel boundary."""
+"""The dataflow launches of the reduced-system factorisation (k_ldlt_tail) against the oracle's pivoted LDL^T: same solution
+whatever share of the matrix the final launch takes -- the last 1024 rows (super-panels in front of it at the larger sizes),
+everything (the system is smaller than the default 6144) -- at sizes that put the junctions on every kind of block boundary, and
+the two back substitutions against each other.  Scheduling options travel per call (cba_solver_options)."""
 import numpy as np
 import pytest
 
@@ -27,23 +27,18 @@ def _system(n_blocks, dense_dof, seed):
 
 
 @pytest.mark.parametrize("dense_dof", [63, 64, 65, 700, 1089, 2240, 3500])
-def test_tail_launch_matches_blocked_schedule_and_lapack(dense_dof):
+def test_dataflow_factorisation_matches_the_oracle_for_every_tail_size(dense_dof):
     case = f"factorisation tail, D = {dense_dof}"
     s = _system(12, dense_dof, seed=dense_dof)
-    default_rows = eng.factor_tail_rows()
-    try:
-        xs = {}
-        for rows in (0, 1024, default_rows):
-            eng.set_factor_tail_rows(rows)
-            xs[rows] = eng.schur_solve(s.block_diag_H, s.off_diag_H, s.dense_H, s.block_diag_b, s.dense_b)
-            check_equal(case, f"tail rows {rows}: finite", int(np.count_nonzero(~np.isfinite(xs[rows]))))
-    finally:
-        eng.set_factor_tail_rows(default_rows)
+    xs = {}
+    for rows in (512, 1024, 0):                    # 0 = default (6144): one launch at these sizes
+        xs[rows] = eng.schur_solve(s.block_diag_H, s.off_diag_H, s.dense_H, s.block_diag_b, s.dense_b, factor_tail_rows=rows)
+        check_equal(case, f"tail rows {rows}: finite", int(np.count_nonzero(~np.isfinite(xs[rows]))))
     x_ref = orc.schur_solve(s)                     # Eigen's pivoted LDLT restated (oracle)
     scale = np.abs(x_ref).max()
     for rows, x in xs.items():
         check(case, f"tail rows {rows}: x vs oracle / |x|max", np.abs(x - x_ref).max() / scale, 5e-11)
-    check(case, "tail (default) vs blocked schedule / |x|max", np.abs(xs[default_rows] - xs[0]).max() / scale, 5e-12)
+    check(case, "super-panels + tail 512 vs one launch / |x|max", np.abs(xs[512] - xs[0]).max() / scale, 5e-12)
 
 
 @pytest.mark.parametrize("dense_dof", [65, 1089, 3500, 7000])
@@ -51,13 +46,8 @@ def test_back_substitution_dataflow_launch_matches_the_panel_version(dense_dof):
     """k_back_dataflow (one launch, {value, tag} pairs, agent-scope polling) against the panel kernels on the same factor."""
     case = f"back substitution, D = {dense_dof}"
     s = _system(12, dense_dof, seed=1000 + dense_dof)
-    try:
-        eng.set_back_substitution(False)
-        x_panels = eng.schur_solve(s.block_diag_H, s.off_diag_H, s.dense_H, s.block_diag_b, s.dense_b)
-        eng.set_back_substitution(True)
-        x_flow = eng.schur_solve(s.block_diag_H, s.off_diag_H, s.dense_H, s.block_diag_b, s.dense_b)
-    finally:
-        eng.set_back_substitution(True)
+    x_panels = eng.schur_solve(s.block_diag_H, s.off_diag_H, s.dense_H, s.block_diag_b, s.dense_b, back_substitution_panels=True)
+    x_flow = eng.schur_solve(s.block_diag_H, s.off_diag_H, s.dense_H, s.block_diag_b, s.dense_b)
     check_equal(case, "finite", int(np.count_nonzero(~np.isfinite(x_flow)) + np.count_nonzero(~np.isfinite(x_panels))))
     check(case, "dataflow vs panels / |x|max", np.abs(x_flow - x_panels).max() / np.abs(x_panels).max(), 5e-13)
 

@@ -50,8 +50,7 @@ def _worker(rank, world, port, out_dir, distributed_solve=False, use_collective=
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     eng.prepare(0)
-    if distributed_solve and not full_grid:
-        eng.set_factor_tail_rows(DIST_TAIL_ROWS)
+    tail_rows = DIST_TAIL_ROWS if (distributed_solve and not full_grid) else 0       # cba_solver_options, per problem
     pb, st, _ = _problem_full_grid() if full_grid else _problem(DIST_GRID if distributed_solve else (20, 16))
     shards = dist_mod.shard_images(np.bincount(pb.obs_image, minlength=pb.n_images), world)
     b, e = shards[rank]
@@ -59,7 +58,7 @@ def _worker(rank, world, port, out_dir, distributed_solve=False, use_collective=
     allreduce = dist_mod.make_allreduce_host_staged()
     en = eng.Engine(sub, device=0, allreduce=allreduce, n_images_global=pb.n_images, deterministic=True,
                     last_projection=sub.obs_xy.astype(np.float64), distributed_solve=distributed_solve, rank=rank, world_size=world,
-                    collective=dist_mod.make_collective_host_staged() if use_collective else None)
+                    collective=dist_mod.make_collective_host_staged() if use_collective else None, factor_tail_rows=tail_rows)
     en.set_state(sst)
     lam = -1.0
     reps = []
@@ -123,9 +122,7 @@ def test_two_ranks_with_the_distributed_factorisation(tmp_path, world, use_colle
     the single-process engine: same decisions, results equal to the rounding of two different summation orders."""
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True, use_collective), nprocs=world, join=True)
     pb, st, _ = _problem(DIST_GRID)
-    en = eng.Engine(pb, deterministic=True, last_projection=pb.obs_xy.astype(np.float64))
-    default_rows = eng.factor_tail_rows()
-    eng.set_factor_tail_rows(DIST_TAIL_ROWS)
+    en = eng.Engine(pb, deterministic=True, last_projection=pb.obs_xy.astype(np.float64), factor_tail_rows=DIST_TAIL_ROWS)
     try:
         en.set_state(st)
         lam = -1.0
@@ -136,7 +133,6 @@ def test_two_ranks_with_the_distributed_factorisation(tmp_path, world, use_colle
             reps.append([r.initial_cost, r.final_cost, r.final_lambda, r.lm_attempts, float(r.accepted), r.n_residuals_valid])
         ref = en.get_state(st)
     finally:
-        eng.set_factor_tail_rows(default_rows)
         en.close()
     reps = np.array(reps)
     case = f"{world} ranks on 1 GPU, distributed factorisation (cfg-3-shaped, 24 imagesets, 30x24 grids) vs single process"
@@ -180,12 +176,10 @@ def test_native_rccl_collective_world_of_one_distributed_solve(tmp_path):
     single-GPU factorisation of the same system -- all columns owned, every transfer a copy through RCCL."""
     pb, st, _ = _problem(DIST_GRID)
     rc = dist_mod.NativeRccl(0, 1, str(tmp_path / "rccl_id"), 0)
-    default_rows = eng.factor_tail_rows()
-    eng.set_factor_tail_rows(DIST_TAIL_ROWS)
     try:
-        e1 = eng.Engine(pb, deterministic=True)
+        e1 = eng.Engine(pb, deterministic=True, factor_tail_rows=DIST_TAIL_ROWS)
         e2 = eng.Engine(pb, deterministic=True, allreduce_native=(rc.fn, rc.user), n_images_global=pb.n_images, distributed_solve=True,
-                        rank=0, world_size=1, collective_native=(rc.collective_fn, rc.user))
+                        rank=0, world_size=1, collective_native=(rc.collective_fn, rc.user), factor_tail_rows=DIST_TAIL_ROWS)
         e1.set_state(st); e2.set_state(st)
         l1 = l2 = -1.0
         for _ in range(3):
@@ -197,7 +191,6 @@ def test_native_rccl_collective_world_of_one_distributed_solve(tmp_path):
         check("native RCCL collectives, world 1, distributed solve", "points abs", np.abs(s1.points - s2.points).max(), 2e-7)
         e1.close(); e2.close()
     finally:
-        eng.set_factor_tail_rows(default_rows)
         rc.close()
 
 

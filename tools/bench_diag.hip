@@ -1,7 +1,7 @@
 // Developer harness (not shipped): the chain's 64 x 64 diagonal-block factorisation in isolation -- the blocked panels of round 4
-// (chain_factor_blocked: one wavefront pivots in registers, three update with MFMA and build the inverse) against the
-// barrier-per-pivot-pair loop of round 3 (ldlt_diag_core), both checked against a long-double LDL^T on the host and timed with the
-// 100 MHz wall clock inside one workgroup.
+// (chain_factor_blocked: one wavefront pivots in registers, three update with MFMA and build the inverse), checked against a
+// long-double LDL^T on the host and timed with the 100 MHz wall clock inside one workgroup, phase by phase.  (The
+// barrier-per-pivot-pair loop of round 3 it replaced measured 17.9 us per block in this harness against 9.9: profiles/r04_diag.txt.)
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -mllvm -amdgpu-mfma-vgpr-form tools/bench_diag.hip -o tools/bin/bench_diag
 #define CBA_DEV_SWITCHES 1
 #define CBA_DIAGLOG 1
@@ -13,7 +13,6 @@
 namespace cba { void set_error(const std::string& m) { fprintf(stderr, "error: %s\n", m.c_str()); } }
 using namespace cba;
 
-// mode 0: blocked panels; mode 1: round-3 pivot loop (T -> registers, ldlt_diag_core, registers -> LDS as tail_chain did it)
 __global__ void __launch_bounds__(256) k_diag_test(const double* __restrict__ Tin, double* __restrict__ Lout, double* __restrict__ Iout,
                                                    double* __restrict__ rdout, int iters, unsigned long long* __restrict__ ticks, int mode,
                                                    int* __restrict__ status) {
@@ -35,34 +34,7 @@ __global__ void __launch_bounds__(256) k_diag_test(const double* __restrict__ Ti
     __syncthreads();
     const unsigned long long t0 = wall_clock64();
     bool bad;
-    if (mode == 0) bad = chain_factor_blocked(sW, sV, s_rd);
-    else {
-      const int ti = tid >> 4, tj = tid & 15;
-      double (*colbuf)[kInner] = reinterpret_cast<double (*)[kInner]>(sV);
-      double (*rowbuf)[kInner] = reinterpret_cast<double (*)[kInner]>(sV + 5 * kInner);
-      double T[4][4], Xi[4][4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-          const int i = ti + 16 * a, j = tj + 16 * bb;
-          const int lo = i < j ? i : j, hi = i < j ? j : i;
-          T[a][bb] = sW[lo * TS + hi];
-          Xi[a][bb] = (i == j) ? 1.0 : 0.0;
-        }
-      __syncthreads();
-      bad = ldlt_diag_core<kInner>(T, Xi, colbuf, rowbuf);
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-          const int i = ti + 16 * a, j = tj + 16 * bb;
-          sV[j * TS + i] = (i >= j) ? T[a][bb] : 0.0;
-          sW[j * TS + i] = (i >= j) ? Xi[a][bb] : 0.0;
-          if (a == bb && ti == tj) s_rd[(i >> 4) * TS + (i & 15)] = pivot_rcp(T[a][bb]);
-        }
-      __syncthreads();
-    }
+    bad = chain_factor_blocked(sW, sV, s_rd);
     total += wall_clock64() - t0;
     bad_any |= bad;
     __syncthreads();
@@ -105,7 +77,7 @@ int main(int argc, char** argv) {
   hipMalloc(&dT, 8 * n * n); hipMalloc(&dL, 8 * n * n); hipMalloc(&dI, 8 * n * n); hipMalloc(&dr, 8 * n); hipMalloc(&dt, 8); hipMalloc(&dst, 4);
   hipMemcpy(dT, T.data(), 8 * n * n, hipMemcpyHostToDevice);
   unsigned long long* dlog; hipMalloc(&dlog, 8 * 32);
-  for (int mode = 0; mode < 2; ++mode) {
+  for (int mode = 0; mode < 1; ++mode) {
     hipMemset(dst, 0, 4);
     for (int rep = 0; rep < 2; ++rep) {
       // second repetition of the blocked variant with the phase stamps on

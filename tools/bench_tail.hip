@@ -1,5 +1,6 @@
-// Developer harness (not shipped): the persistent tail launch of the factorisation (ldlt_tail) against the blocked
-// multi-stream schedule -- same matrix, factors / solution compared, both timed.
+// Developer harness (not shipped): the two-level factorisation (super-panels + final dataflow launch) for several sizes of the
+// final launch -- same matrix, solutions compared with the first setting, all timed; chain timeline of the final launch (TAILLOG),
+// helper-task breakdown (HELPLOG), the helpers' K loop alone (MMA_ONLY).
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -mllvm -amdgpu-mfma-vgpr-form tools/bench_tail.hip -o tools/bin/bench_tail
 #define CBA_DEV_SWITCHES 1
 #define CBA_TAILLOG 1
@@ -184,7 +185,7 @@ int main(int argc, char** argv) {
     }
     LdltWorkspace w; ldlt_workspace_alloc(w, n);
     auto run = [&](int tail, std::vector<double>* hx, std::vector<double>* hS, std::vector<double>* hd, double* best_ms, double* tail_ms) {
-      ldlt_set_tail_rows(tail);
+      w.tail_rows = tail;
       *best_ms = 1e30; *tail_ms = 0;
       int st = 0;
       for (int rep = 0; rep < reps; ++rep) {
@@ -208,10 +209,10 @@ int main(int argc, char** argv) {
         std::vector<double> xa(n_fact), xb(n_fact);
         float tp = 1e30f, td = 1e30f;
         for (int rep = 0; rep < 3; ++rep) {
-          ldlt_set_back_dataflow(0);
+          w.back_dataflow = false;
           hipEventRecord(e0, ms); ldlt_back_solve(S, n_fact, n, n - 1, w, x, ms); hipEventRecord(e1, ms); tp = std::min(tp, timeit(e0, e1));
           hipMemcpy(xa.data(), x, sizeof(double) * n_fact, hipMemcpyDeviceToHost);
-          ldlt_set_back_dataflow(1);
+          w.back_dataflow = true;
           hipEventRecord(e0, ms); ldlt_back_solve(S, n_fact, n, n - 1, w, x, ms); hipEventRecord(e1, ms); td = std::min(td, timeit(e0, e1));
         }
         hipMemcpy(xb.data(), x, sizeof(double) * n_fact, hipMemcpyDeviceToHost);
@@ -226,8 +227,8 @@ int main(int argc, char** argv) {
     };
     std::vector<double> xr, Sr, dr;
     double ms_ref, tms;
-    int st = run(0, &xr, n <= 4096 ? &Sr : nullptr, &dr, &ms_ref, &tms);
-    printf("blocked schedule (tail off): %.3f ms  status %d   [128x128 GEMM launches: %d at %.1f TFLOP/s per launch]\n", ms_ref, st, g_launches, g_rate);
+    int st = run(tails.back(), &xr, n <= 4096 ? &Sr : nullptr, &dr, &ms_ref, &tms);
+    printf("reference (tail %d): %.3f ms  status %d   [128x128 GEMM launches: %d at %.1f TFLOP/s per launch]\n", tails.back(), ms_ref, st, g_launches, g_rate);
     double xmax = 0; for (double v : xr) xmax = std::max(xmax, std::fabs(v));
     for (int tail : tails) {
       std::vector<double> xt, St, dt;
@@ -241,7 +242,8 @@ int main(int argc, char** argv) {
           const double a = St[(size_t)r * n + c], b = Sr[(size_t)r * n + c];
           dS = std::max(dS, std::fabs(a - b)); smax = std::max(smax, std::fabs(b));
         }
-      const int t0 = tail_start_row(n_fact, w);
+      int t0 = 0;                                  // first row of the final launch (the loop of ldlt_factor)
+      { const int sw = super_width(), tr = ldlt_tail_rows(w); while (n_fact - t0 > tr + sw / 2 && n - (t0 + sw) >= 1024) t0 += super_width_at(n, t0, sw); }
       if (getenv("TAILLOG") && n_fact - t0 >= 512) {
         // one more run with the chain timeline
         const int nb = (n_fact - t0) / 64;
