@@ -8,6 +8,7 @@ namespace vis {
 using namespace Eigen;
 typedef Matrix<double, 2, 1> Vec2d; typedef Matrix<double, 3, 1> Vec3d; typedef Matrix<double, 4, 1> Vec4d;
 typedef Matrix<float, 2, 1> Vec2f;  typedef Matrix<float, 3, 1> Vec3f;
+typedef Matrix<int, 2, 1> Vec2i;
 typedef Matrix<double, 2, 2> Mat2d; typedef Matrix<double, 3, 3> Mat3d;
 }
 #endif

@@ -6,6 +6,9 @@
 #include <cstddef>
 #include <cstdint>
 #include <iostream>
+#include <memory>
+#include <string>
+#include <unordered_map>
 #include <vector>
 // LOG(severity) << ...: the real header pulls in the loguru-based logging (LV/logging.h); messages go to stderr here.
 #ifndef LOG

@@ -42,3 +42,39 @@ def test_patch_applies_cleanly_to_the_reference_tree():
     assert r.returncode == 0, r.stdout + r.stderr
     assert "FAILED" not in r.stdout and "fuzz" not in r.stdout, r.stdout
     assert r.stdout.count("checking file") == len(EXPECTED)
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "applications")) or shutil.which("patch") is None or shutil.which("g++") is None,
+                    reason="needs /root/reference, patch(1) and g++")
+def test_patched_adapter_compiles_against_the_reference_s_own_types(tmp_path):
+    """Compile proof of the drop-in boundary: the patch is applied to a scratch copy of the reference's application and the adapter
+    it adds (bundle_adjustment/joint_optimization_hip.cc) is type-checked (g++ -fsyntax-only) against the reference's REAL
+    dataset.h, bundle_adjustment/ba_state.h, models/camera_model.h and bundle_adjustment/joint_optimization.h -- Dataset, Imageset,
+    PointFeature, BAState, CameraModel and SchurMode are the reference's own declarations (APP/dataset.h:57-212,
+    ba_state.h:46-97, joint_optimization.h:53-70).  Only the third-party headers underneath (Eigen, Sophus, libvis' image /
+    logging) come from oracle/ref_shim, which is searched first.  A second translation unit type-checks the packing hooks the
+    patch adds to central_generic.h / noncentral_generic.h (GetGridForHIP / SetGridFromHIP overrides)."""
+    scratch = tmp_path / "ref"
+    shutil.copytree(os.path.join(REFERENCE, "applications", "camera_calibration", "src"),
+                    scratch / "applications" / "camera_calibration" / "src")
+    shutil.copy(os.path.join(REFERENCE, "applications", "camera_calibration", "CMakeLists.txt"),
+                scratch / "applications" / "camera_calibration" / "CMakeLists.txt")
+    r = subprocess.run(["patch", "-p1", "--batch", "-s", "-d", str(scratch), "-i", PATCH], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    app = scratch / "applications" / "camera_calibration" / "src"
+    adapter = app / "camera_calibration" / "bundle_adjustment" / "joint_optimization_hip.cc"
+    assert adapter.exists()
+    flags = ["g++", "-std=c++14", "-fsyntax-only", "-DCBA_HAVE_HIP", "-I", os.path.join(ROOT, "oracle", "ref_shim"), "-I", str(app),
+             "-I", os.path.join(ROOT, "include")]
+    r = subprocess.run(flags + [str(adapter)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    # the translation unit really saw the reference's declarations (not stand-ins): they are part of its preprocessed text
+    pre = subprocess.run(["g++", "-std=c++14", "-E", "-DCBA_HAVE_HIP"] + flags[4:] + [str(adapter)], capture_output=True, text=True).stdout
+    for needle in ("struct BAState", "class Dataset", "class Imageset", "struct PointFeature", "class CameraModel", "SchurMode"):
+        assert needle in pre, needle
+    assert str(app / "camera_calibration" / "dataset.h") in pre and str(app / "camera_calibration" / "bundle_adjustment" / "ba_state.h") in pre
+    hooks = tmp_path / "hooks_tu.cc"
+    hooks.write_text('#include "camera_calibration/models/central_generic.h"\n#include "camera_calibration/models/noncentral_generic.h"\n'
+                     '#include "camera_calibration/bundle_adjustment/joint_optimization.h"\nint main() { return 0; }\n')
+    r = subprocess.run(flags + [str(hooks)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
