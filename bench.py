@@ -47,8 +47,15 @@ def parse_args():
                     help="exercise only the self-launch path (spawn --gpus ranks, one gloo all-reduce on CPU, rank 0 prints a JSON "
                          "line); needs no GPU -- tests/test_bench_launcher.py")
     ap.add_argument("--distributed-solve", type=int, default=-1,
-                    help="1 / 0: distribute the factorisation of the reduced system over the ranks (cba_config.distributed_solve, "
-                         "DESIGN.md section 6); default: on with more than one rank")
+                    help="1 / 0: only the distributed / only the replicated factorisation of the reduced system (cba_config."
+                         "distributed_solve, DESIGN.md section 6); default with more than one rank: BOTH legs are timed in this one "
+                         "invocation -- replicated (one packed-upper all-reduce, the design north_star names) first, distributed "
+                         "second -- and the line reports the better one and carries both")
+    ap.add_argument("--both-legs", action="store_true",
+                    help="time both reduced solves even with one rank (with --force-allreduce: 1-GPU validation of the two-leg path)")
+    ap.add_argument("--leg-timeout", type=float, default=0.0,
+                    help="watchdog of the second (distributed) leg in seconds; 0 = max(120, 30 x the first leg).  When it "
+                         "expires, the first leg's line is printed and every rank exits")
     return ap.parse_args()
 
 
@@ -239,20 +246,6 @@ def main():
     pb, st0, gt = syn.baseline_config(args.config, proj, n_imagesets=n_img, image_offset=rank * n_img)
     t_gen = time.time() - t_gen
 
-    allreduce = None
-    reduce_ptr, reduce_n, keep = 0, 0, None
-    # distributed reduced solve: on by default with more than one rank; with one rank only on request (times the driver alone)
-    dist_solve = bool(use_dist and (args.distributed_solve == 1 or (args.distributed_solve < 0 and world > 1)))
-    if use_dist:
-        reduce_n = eng.Engine.reduce_buffer_doubles(pb, dist_solve, world)
-        keep = torch.zeros(reduce_n, dtype=torch.float64, device=f"cuda:{local_rank}")
-        reduce_ptr = keep.data_ptr()
-        allreduce = make_allreduce(keep, local_rank)
-    e = eng.Engine(pb, device=local_rank, allreduce=allreduce, n_images_global=n_img * world,
-                   reduce_buffer_ptr=reduce_ptr, reduce_buffer_doubles=reduce_n, distributed_solve=dist_solve, rank=rank, world_size=world,
-                   collective=make_collective(local_rank) if dist_solve else None)
-    e.set_state(st0)
-
     n_obs_local = pb.n_obs
     n_obs_t = torch.tensor([n_obs_local], dtype=torch.float64, device=f"cuda:{local_rank}")
     if use_dist:
@@ -264,52 +257,95 @@ def main():
     # calibration converges after ~8 iterations and its last iterations burn dozens of rejected LM attempts
     # (24 full solves in one "iteration"), which would make the figure depend on K.
     RESTART = 4
-    lam = -1.0
-    reports = []
-    it_index = 0
 
-    def one_step():
-        nonlocal lam, it_index
-        if it_index % RESTART == 0:
-            e.set_state(st0)
-            lam = -1.0
-        it_index += 1
-        r = e.step(lam)
-        lam = r.final_lambda
-        return r
+    def open_engine(dist_solve: bool):
+        allreduce = None
+        reduce_ptr, reduce_n, keep = 0, 0, None
+        if use_dist:
+            reduce_n = eng.Engine.reduce_buffer_doubles(pb, dist_solve, world)
+            keep = torch.zeros(reduce_n, dtype=torch.float64, device=f"cuda:{local_rank}")
+            reduce_ptr = keep.data_ptr()
+            allreduce = make_allreduce(keep, local_rank)
+        e = eng.Engine(pb, device=local_rank, allreduce=allreduce, n_images_global=n_img * world,
+                       reduce_buffer_ptr=reduce_ptr, reduce_buffer_doubles=reduce_n, distributed_solve=dist_solve, rank=rank, world_size=world,
+                       collective=make_collective(local_rank) if dist_solve else None)
+        return e, keep
 
-    for _ in range(args.warmup):
-        one_step()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    agg = {k: {"seconds": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0} for k in range(5)}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rep = one_step()
-        reports.append(rep)
-        for k in range(5):
-            s = e.kernel_stats(k)
-            for f in agg[k]:
-                agg[k][f] += s[f]
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-    if use_dist:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-    # every rank holds the same replicated state and takes the same LM decisions: the last report must agree bit for bit
-    ranks_consistent = None
-    if use_dist and reports:
-        mine = torch.tensor([reports[-1].final_cost, reports[-1].final_lambda, float(reports[-1].lm_attempts)], dtype=torch.float64,
-                            device=f"cuda:{local_rank}")
-        lo, hi = mine.clone(), mine.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        ranks_consistent = bool(torch.equal(lo, hi))
+    def run_leg(dist_solve: bool) -> dict:
+        """One complete measurement with its own engine: warm-up, barrier + synchronize, exactly --steps timed steps, barrier +
+        synchronize, MAX over ranks.  The engine stays open in the result (the caller closes it)."""
+        e, keep = open_engine(dist_solve)
+        e.set_state(st0)
+        state = {"lam": -1.0, "it": 0}
+        reports = []
 
+        def one_step():
+            if state["it"] % RESTART == 0:
+                e.set_state(st0)
+                state["lam"] = -1.0
+            state["it"] += 1
+            r = e.step(state["lam"])
+            state["lam"] = r.final_lambda
+            return r
+
+        for _ in range(args.warmup):
+            one_step()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        agg = {k: {"seconds": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0} for k in range(5)}
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            rep = one_step()
+            reports.append(rep)
+            for k in range(5):
+                st_k = e.kernel_stats(k)
+                for f in agg[k]:
+                    agg[k][f] += st_k[f]
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        el = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        if use_dist:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+        # every rank holds the same replicated state and takes the same LM decisions: the last report must agree bit for bit
+        ranks_consistent = None
+        if use_dist and reports:
+            mine = torch.tensor([reports[-1].final_cost, reports[-1].final_lambda, float(reports[-1].lm_attempts)], dtype=torch.float64,
+                                device=f"cuda:{local_rank}")
+            lo, hi = mine.clone(), mine.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            ranks_consistent = bool(torch.equal(lo, hi))
+        return {"engine": e, "keep": keep, "dist_solve": dist_solve, "elapsed": elapsed, "reports": reports, "agg": agg,
+                "ranks_consistent": ranks_consistent}
+
+    def leg_summary(leg: dict) -> dict:
+        reps = leg["reports"]
+        return {"solve": "distributed" if leg["dist_solve"] else "replicated",
+                "ms_per_step": leg["elapsed"] / max(1, args.steps) * 1e3,
+                "value": sum(r.n_residuals_valid for r in reps) / leg["elapsed"] / 1e6,
+                "t_factor_ms": sum(r.t_factor for r in reps) / max(1, len(reps)) * 1e3,
+                "t_solve_ms": sum(r.t_solve for r in reps) / max(1, len(reps)) * 1e3,
+                "ranks_consistent": leg["ranks_consistent"], "status": "ok"}
+
+    # Which legs: one rank (or an explicit --distributed-solve) -> one leg.  More than one rank -> the replicated solve first (one
+    # packed-upper ncclAllReduce per Gauss-Newton step: the design north_star names, and the path with the most test coverage),
+    # then the distributed solve under a watchdog.  The line reports the better leg; if the second leg fails or hangs the first
+    # one's line is still printed -- the first multi-GPU run cannot be lost to the less proven path.
+    if not use_dist:
+        leg_kinds = [False]
+    elif args.distributed_solve >= 0:
+        leg_kinds = [bool(args.distributed_solve)]
+    elif world > 1 or args.both_legs:
+        leg_kinds = [False, True]
+    else:
+        leg_kinds = [False]
+    legs_info = []
+    best = run_leg(leg_kinds[0])
+    legs_info.append(leg_summary(best))
     # the library's DGEMM on the same device, measured once outside the timed region: the in-situ gap of the hand-written GEMM
     # (roofline.frac_vs_library) is visible in the line itself
     lib_tflops = None
@@ -321,19 +357,20 @@ def main():
             B_l = torch.randn(K_l, n_l, dtype=torch.float64, device=f"cuda:{local_rank}")
             torch.mm(A_l.t(), B_l)
             torch.cuda.synchronize()
-            best = None
+            best_ms = None
             for _ in range(5):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(); torch.mm(A_l.t(), B_l); e1.record()
                 torch.cuda.synchronize()
                 t_ms = e0.elapsed_time(e1)
-                best = t_ms if best is None or t_ms < best else best
-            lib_tflops = 2.0 * n_l * n_l * K_l / (best * 1e-3) / 1e12
+                best_ms = t_ms if best_ms is None or t_ms < best_ms else best_ms
+            lib_tflops = 2.0 * n_l * n_l * K_l / (best_ms * 1e-3) / 1e12
             del A_l, B_l
         except Exception:
             lib_tflops = None
-    out = None
-    if rank == 0:
+    def build_output(leg: dict) -> dict:
+        """The JSON line of one leg (rank 0)."""
+        reports, agg, elapsed, dist_solve, ranks_consistent = leg["reports"], leg["agg"], leg["elapsed"], leg["dist_solve"], leg["ranks_consistent"]
         ms_per_step = elapsed / max(1, args.steps) * 1e3
         # SURVEY 8(d): n_valid / t_iter.  n_residuals_valid is the whole job's count (the 8-double scalar all-reduce of the
         # Jacobian pass sums it over the ranks); invalid residuals (projection failed, APP joint_optimization.cc:334-342) do not count
@@ -450,6 +487,64 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(pb, st0, min(args.cpu_sample_images, pb.n_images), n_obs_total, n_img)
             except Exception as ex:  # the baseline is a reported extra, never a reason to lose the line
                 out["cpu_baseline"] = {"error": repr(ex)}
+        return out
+
+    out = build_output(best) if rank == 0 else None
+
+    # ---- second leg under a watchdog ----
+    import threading
+    watchdog = {"timer": None, "fired": False}
+
+    def emit(line_out):
+        # RCCL prints its version banner through C stdio; flush it first so the JSON line is the last line
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(line_out), flush=True)
+
+    def on_timeout(first_line, seconds):
+        watchdog["fired"] = True
+        if rank == 0 and first_line is not None:
+            first_line["config"]["legs"] = first_line["config"].get("legs", []) + [
+                {"solve": "distributed", "status": f"abandoned: no result after {seconds:.0f} s (watchdog); the line is the replicated leg"}]
+            emit(first_line)
+        os._exit(0)       # a rank stuck inside a collective cannot be unwound; every rank runs the same watchdog
+
+    if len(leg_kinds) > 1:
+        first_line = None
+        if rank == 0:
+            first_line = json.loads(json.dumps(out))
+            first_line["config"]["legs"] = [dict(legs_info[0])]
+        limit = args.leg_timeout if args.leg_timeout > 0 else max(120.0, 30.0 * (best["elapsed"] + 1.0))
+        watchdog["timer"] = threading.Timer(limit, on_timeout, args=(first_line, limit))
+        watchdog["timer"].daemon = True
+        watchdog["timer"].start()
+        second = None
+        try:
+            best["engine"].close()                       # the replicated leg's buffers go first (S / H_dd are 2 x 14.7 GB at config 5)
+            best["engine"] = None
+            second = run_leg(leg_kinds[1])
+            legs_info.append(leg_summary(second))
+        except Exception as ex:                        # e.g. CBA_ERR_TIMEOUT from a dataflow launch: reported, not fatal
+            legs_info.append({"solve": "distributed", "status": "failed: " + repr(ex)[:300]})
+            second = None
+        if second is not None:
+            ok = second["ranks_consistent"] is not False
+            if ok and legs_info[-1]["value"] > legs_info[0]["value"]:
+                best = second
+                out = build_output(best) if rank == 0 else None
+            else:
+                second["engine"].close()
+                second["engine"] = None
+        if rank == 0:
+            out["config"]["legs"] = legs_info
+            out["config"]["legs_note"] = ("both reduced solves timed in this invocation (replicated first); value / ms_per_step are the "
+                                          "better leg's (config.parallelism names it)")
+    if best["engine"] is None:                           # the winner was the replicated leg: a fresh engine for the convergence run
+        best["engine"], best["keep"] = open_engine(best["dist_solve"])
+    e = best["engine"]
     # second BASELINE metric: wall-clock to converged calibration under the reference's stopping rule
     # (RunBundleAdjustment, APP/calibration.cc:298: cost >= last_cost - 1e-4, at most 100 iterations),
     # from the same perturbed start; reported next to the headline metric, outside the timed region.
@@ -468,6 +563,8 @@ def main():
                 "seconds_in_cost_passes": sum(r.t_cost for r in reps),
                 "initial_cost": reps[0].initial_cost}
     e.close()
+    if watchdog["timer"] is not None:
+        watchdog["timer"].cancel()
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
@@ -476,13 +573,7 @@ def main():
             # the headline value restarts the trajectory every RESTART steps (single-attempt iterations); this is the
             # average over the WHOLE calibration run incl. the last iterations' rejected LM attempts
             out["trajectory_avg_mobs"] = n_obs_total * conv["outer_iterations"] / conv["seconds"] / 1e6
-        # RCCL prints its version banner through C stdio; flush it first so the JSON line is the last line
-        try:
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        emit(out)
 
 
 if __name__ == "__main__":

@@ -115,6 +115,11 @@ class NativeRccl:
         self.fn = ctypes.cast(self.lib.cba_rccl_allreduce, ctypes.c_void_p)
         self.collective_fn = ctypes.cast(self.lib.cba_rccl_collective, ctypes.c_void_p)      # cba_config.collective
 
+    def comm_count(self) -> int:
+        """ncclCommCount of the communicator (what bench.py reports as rccl_ranks on the native path)."""
+        self.lib.cba_rccl_comm_count.argtypes = [ctypes.c_void_p]
+        return int(self.lib.cba_rccl_comm_count(self.user))
+
     def close(self):
         if self.user:
             self.lib.cba_rccl_destroy(self.user)

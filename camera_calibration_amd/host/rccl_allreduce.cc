@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <ctime>
+#include <cstdlib>
 #include <string>
 #include <thread>
 
@@ -76,13 +77,21 @@ int cba_rccl_debug_read_id_file(const char* path, char id[CBA_RCCL_ID_BYTES], in
 // atomically (rename), every rank joins, a one-element all-reduce proves that ALL ranks have read the file, and rank 0 removes
 // it again.  A later launch with the same path therefore never finds this run's id; the leftover of a run that crashed in
 // between is recognised by its age (ranks start within seconds of each other, a stale file is minutes old or older).
-int cba_rccl_create_via_file(int rank, int world, const char* path, int device, cba_rccl** out) {
-  if (!path) return fail("cba_rccl_create_via_file", "null path");
+int cba_rccl_create_via_file(int rank, int world, const char* path_in, int device, cba_rccl** out) {
+  if (!path_in || !out) return fail("cba_rccl_create_via_file", "null argument");
+  *out = nullptr;
+  // launch nonce in the file name: a rank that starts before rank 0 must never accept the leftover of an earlier launch that is
+  // still young enough for the age test (crash + quick relaunch, clock skew).  CBA_RCCL_NONCE, or MASTER_PORT (the same on every
+  // rank of one torchrun / mpirun launch, different between launches), is appended when set.
+  std::string eff(path_in);
+  if (const char* n = std::getenv("CBA_RCCL_NONCE")) eff += std::string(".") + n;
+  else if (const char* mp = std::getenv("MASTER_PORT")) eff += std::string(".") + mp;
+  const char* path = eff.c_str();
   char id[CBA_RCCL_ID_BYTES];
   if (rank == 0) {
     ::unlink(path);
     if (cba_rccl_unique_id(id) != 0) return -1;
-    const std::string tmp = std::string(path) + ".tmp";
+    const std::string tmp = eff + ".tmp";
     FILE* f = std::fopen(tmp.c_str(), "wb");
     if (!f || std::fwrite(id, 1, sizeof(id), f) != sizeof(id)) { if (f) std::fclose(f); return fail("cba_rccl_create_via_file", "cannot write the id file"); }
     std::fclose(f);
@@ -95,13 +104,23 @@ int cba_rccl_create_via_file(int rank, int world, const char* path, int device, 
   if (rc != 0) { if (rank == 0) ::unlink(path); return rc; }
   // handshake: when it returns on rank 0, every rank has passed ncclCommInitRank, i.e. has read the file
   double* one = nullptr;
-  if (hipMalloc(&one, sizeof(double)) == hipSuccess) {
+  if (hipMalloc(&one, sizeof(double)) != hipSuccess) rc = fail("cba_rccl_create_via_file", "hipMalloc failed (handshake)");
+  else {
     hipMemset(one, 0, sizeof(double));
     rc = cba_rccl_allreduce(one, 1, *out);
     hipFree(one);
   }
   if (rank == 0) ::unlink(path);
+  if (rc != 0) { cba_rccl_destroy(*out); *out = nullptr; }       // no half-initialised communicator reaches the caller
   return rc;
+}
+
+// ncclCommCount of the communicator (-1 on error): what a host reports as the number of ranks its collectives really span
+int cba_rccl_comm_count(cba_rccl* c) {
+  if (!c || !c->comm) return -1;
+  int n = -1;
+  if (ncclCommCount(c->comm, &n) != ncclSuccess) return -1;
+  return n;
 }
 
 void cba_rccl_destroy(cba_rccl* c) {

@@ -27,6 +27,8 @@ int cba_rccl_create_via_file(int rank, int world, const char* path, int device, 
 /* the reader half of the above (tests): 0 = id read, -1 = no fresh file within timeout_ms */
 int cba_rccl_debug_read_id_file(const char* path, char id[CBA_RCCL_ID_BYTES], int timeout_ms, int max_age_s);
 void cba_rccl_destroy(cba_rccl* c);
+/* ncclCommCount of the communicator (-1 on error) */
+int cba_rccl_comm_count(cba_rccl* c);
 /* cba_allreduce_fn: in-place fp64 sum of a DEVICE buffer over all ranks; `user` is the cba_rccl*.  Enqueues
  * ncclAllReduce on the communicator's own stream and waits for THAT stream only (no device-wide synchronisation). */
 int cba_rccl_allreduce(void* device_ptr, int64_t count, void* user);

@@ -194,12 +194,13 @@ def test_native_rccl_collective_world_of_one_distributed_solve(tmp_path):
         rc.close()
 
 
-def test_distributed_factorisation_at_the_benchmarked_size(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_distributed_factorisation_at_the_benchmarked_size(tmp_path, world):
     """The distributed schedule with its DEFAULT parameters at the size of BASELINE configs[1] (D = 12 525, n_pad = 12 672: first band
     of 2048 rows all-reduced, 10 624 rows reduce-scattered into 25 column groups, three super-panels, 6400 rows gathered for the
-    final launch), two processes on one GPU with the collectives through a cba_collective_fn (host-staged gloo), three LM
-    iterations against the single-process engine."""
-    world = 2
+    final launch), two and EIGHT processes on one GPU (eight: 7-8 imagesets per rank, the 25 column groups dealt 4 / 3 to the ranks
+    -- the ownership the first real 8-GPU run will have) with the collectives through a cba_collective_fn (host-staged gloo),
+    three LM iterations against the single-process engine."""
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True, True, True), nprocs=world, join=True)
     pb, st, _ = _problem_full_grid()
     en = eng.Engine(pb, deterministic=True, last_projection=pb.obs_xy.astype(np.float64))
@@ -213,7 +214,7 @@ def test_distributed_factorisation_at_the_benchmarked_size(tmp_path):
     ref = en.get_state(st)
     en.close()
     reps = np.array(reps)
-    case = "2 ranks on 1 GPU, distributed factorisation at cfg-2 size (60 imagesets, 84x60 grid) vs single process"
+    case = f"{world} ranks on 1 GPU, distributed factorisation at cfg-2 size (60 imagesets, 84x60 grid) vs single process"
     rk = [np.load(os.path.join(str(tmp_path), f"rank{k}.npz")) for k in range(world)]
     for k in range(world):
         check_equal(case, f"rank {k}: LM attempts / accept decisions / valid counts", int(np.count_nonzero(rk[k]["reps"][:, 3:] != reps[:, 3:])))
@@ -223,5 +224,72 @@ def test_distributed_factorisation_at_the_benchmarked_size(tmp_path):
         check(case, f"rank {k}: points abs", np.abs(rk[k]["points"] - ref.points).max(), 5e-8)
         check(case, f"rank {k}: grid abs", np.abs(rk[k]["grid0"] - ref.grids[0]).max(), 1e-7)
     for key in ("points", "grid0"):
-        check_equal(case, f"replicated state identical on both ranks: {key}", int(np.count_nonzero(rk[0][key] != rk[1][key])))
+        for k in range(1, world):
+            check_equal(case, f"replicated state identical on ranks 0 and {k}: {key}", int(np.count_nonzero(rk[0][key] != rk[k][key])))
 
+
+
+def _rccl_worker(rank, world, port, out_dir, distributed_solve):
+    import torch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    eng.prepare(rank)
+    pb, st, _ = _problem(DIST_GRID)
+    shards = dist_mod.shard_images(np.bincount(pb.obs_image, minlength=pb.n_images), world)
+    b, e = shards[rank]
+    sub, sst = pb.image_slice(b, e), st.image_slice(b, e)
+    rc = dist_mod.NativeRccl(rank, world, os.path.join(out_dir, f"rccl_id_{port}"), rank)
+    en = eng.Engine(sub, device=rank, allreduce_native=(rc.fn, rc.user), n_images_global=pb.n_images, deterministic=True,
+                    last_projection=sub.obs_xy.astype(np.float64), distributed_solve=distributed_solve, rank=rank, world_size=world,
+                    collective_native=(rc.collective_fn, rc.user) if distributed_solve else None, factor_tail_rows=DIST_TAIL_ROWS)
+    en.set_state(sst)
+    lam = -1.0
+    reps = []
+    for _ in range(STEPS):
+        r = en.step(lam)
+        lam = r.final_lambda
+        reps.append([r.initial_cost, r.final_cost, r.final_lambda, r.lm_attempts, float(r.accepted), r.n_residuals_valid])
+    out = en.get_state(sst)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), b=b, e=e, reps=np.array(reps), poses=out.rig_tr_global, points=out.points,
+             grid0=out.grids[0], comm=rc.comm_count())
+    en.close()
+    rc.close()
+
+
+def _device_count():
+    try:
+        import torch
+        return torch.cuda.device_count() if torch.cuda.is_available() else 0
+    except Exception:
+        return 0
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs (skips on the 1-GPU lease, runs on a multi-GPU node)")
+@pytest.mark.parametrize("distributed_solve", [False, True])
+def test_native_rccl_two_ranks_on_two_gpus(tmp_path, distributed_solve):
+    """The C++ host's path with a real communicator: libcalib_ba_rccl.so (ncclAllReduce, and ncclReduceScatter / ncclAllGather
+    for the distributed solve) between two processes on two devices, three LM iterations against the single-process engine."""
+    world = 2
+    mp.spawn(_rccl_worker, args=(world, _free_port(), str(tmp_path), distributed_solve), nprocs=world, join=True)
+    pb, st, _ = _problem(DIST_GRID)
+    en = eng.Engine(pb, deterministic=True, last_projection=pb.obs_xy.astype(np.float64), factor_tail_rows=DIST_TAIL_ROWS)
+    en.set_state(st)
+    lam = -1.0
+    reps = []
+    for _ in range(STEPS):
+        r = en.step(lam)
+        lam = r.final_lambda
+        reps.append([r.initial_cost, r.final_cost, r.final_lambda, r.lm_attempts, float(r.accepted), r.n_residuals_valid])
+    ref = en.get_state(st)
+    en.close()
+    reps = np.array(reps)
+    case = f"native RCCL, 2 ranks on 2 GPUs, {'distributed' if distributed_solve else 'replicated'} solve vs single process"
+    rk = [np.load(os.path.join(str(tmp_path), f"rank{k}.npz")) for k in range(world)]
+    for k in range(world):
+        check_equal(case, f"rank {k}: communicator size", int(rk[k]["comm"]) - world)
+        check_equal(case, f"rank {k}: LM attempts / accept decisions / valid counts", int(np.count_nonzero(rk[k]["reps"][:, 3:] != reps[:, 3:])))
+        check(case, f"rank {k}: costs rel", (np.abs(rk[k]["reps"][:, :2] - reps[:, :2]) / reps[:, :2]).max(), 5e-7)
+        check(case, f"rank {k}: points abs", np.abs(rk[k]["points"] - ref.points).max(), 5e-8)
+        check(case, f"rank {k}: grid abs", np.abs(rk[k]["grid0"] - ref.grids[0]).max(), 1e-7)
+    check_equal(case, "replicated state identical on both ranks", int(np.count_nonzero(rk[0]["points"] != rk[1]["points"])))
