@@ -52,6 +52,35 @@ def test_back_substitution_dataflow_launch_matches_the_panel_version(dense_dof):
     check(case, "dataflow vs panels / |x|max", np.abs(x_flow - x_panels).max() / np.abs(x_panels).max(), 5e-13)
 
 
+@pytest.mark.parametrize("dense_dof,poison,tail_rows", [(700, "nan", 0), (3500, "nan", 1024), (3500, "zero", 1024), (3500, "zero", 0)])
+def test_poisoned_diagonal_is_reported_not_hung(dense_dof, poison, tail_rows):
+    """Error path of the dataflow launches: a NaN on the diagonal, or a row / column of exact zeros (a zero pivot), in the middle of
+    the reduced system.  The chain flags the pivot (status 2), every flag of the launch is still published -- k_ldlt_tail and
+    k_back_dataflow run to their end on NaNs instead of waiting for tiles that never come -- and the call returns
+    CBA_ERR_NUMERIC in well under the 3-s spin limit; the LM loop treats that like the reference's NaN update (lambda x 2,
+    LV/lm_optimizer.h:905-958)."""
+    import time
+    case = f"error path, D = {dense_dof}, {poison}, tail rows {tail_rows}"
+    s = _system(12, dense_dof, seed=77 + dense_dof)
+    k = dense_dof // 2 + 3
+    if poison == "nan":
+        s.dense_H[k, k] = np.nan
+    else:
+        s.dense_H[k, :] = 0.0
+        s.dense_H[:, k] = 0.0
+        s.off_diag_H[:, k] = 0.0
+    t0 = time.perf_counter()
+    with pytest.raises(eng.EngineError) as ei:
+        eng.schur_solve(s.block_diag_H, s.off_diag_H, s.dense_H, s.block_diag_b, s.dense_b, factor_tail_rows=tail_rows)
+    dt = time.perf_counter() - t0
+    check_equal(case, "error code is CBA_ERR_NUMERIC (-4)", int("code -4" not in str(ei.value)))
+    check(case, "seconds until the error is returned (spin limit 3 s per wait)", dt, 2.5)
+    # the engine is usable afterwards: the same system without the poison solves
+    s2 = _system(12, dense_dof, seed=77 + dense_dof)
+    x = eng.schur_solve(s2.block_diag_H, s2.off_diag_H, s2.dense_H, s2.block_diag_b, s2.dense_b, factor_tail_rows=tail_rows)
+    check_equal(case, "next solve finite", int(np.count_nonzero(~np.isfinite(x))))
+
+
 def test_follow_up_list_of_the_finite_difference_kernel_does_not_overflow():
     from camera_calibration_amd import synthetic as syn
     pb, st, _ = syn.baseline_config(4, lambda cam, grid, pts: eng.project(cam, grid, pts), n_imagesets=30)
