@@ -23,7 +23,9 @@ int launch_gemv_t_strided(const double* M, int K, int n, int ld, const double* v
                           int ystride, double* partial_ws, hipStream_t s);
 int gemv_t_workspace_doubles(int n);
 int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const double* Cin, double* C, int n_pad, int ld,
-               int n_real, int add_diag, double lambda, const unsigned long long* kmask, hipStream_t s);
+               int n_real, int add_diag, double lambda, const unsigned long long* kmask, hipStream_t s, const int* chunk_order = nullptr);
+int schur_chunk_count(int n_pad);
+void schur_chunk_order(const unsigned long long* mask_host, int n_pad, int Kpad, int* order);
 int schur_mask_words(int Kpad);
 int launch_touch_mask(const double* B, int Kpad, int n_pad, int ld, unsigned long long* mask, hipStream_t s);
 int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWorkspace& w, double* x, hipStream_t s);
@@ -155,6 +157,9 @@ struct cba_problem {
   double* x = nullptr; double* scal = nullptr; double* gemv_ws = nullptr;
   unsigned long long* kmask = nullptr;   // block-sparsity of B per (column tile, K slab), rebuilt after every accumulation
   unsigned long long* kmask_host = nullptr; size_t kmask_host_words = 0;   // pinned copy (flop count of the Schur product)
+  // chunk order of the Schur launch (heaviest first) from the masks of the PREVIOUS solve: the sparsity of B only changes with
+  // the validity flags, and the order is a scheduling hint (any permutation is correct)
+  int* chunk_order = nullptr; int* chunk_order_host = nullptr; bool chunk_order_valid = false; unsigned chunk_order_age = 0;
   int* status = nullptr;
   LdltWorkspace ldlt;
   KernelTimer timers[5];     // see cba_kernel_stats
@@ -417,7 +422,12 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
   // lambda on the diagonal / ones on the padding diagonal: single GPU: in the product; replicated multi-GPU solve: after the
   // all-reduce; distributed solve: rank 0 adds them to its partial system, the reduction carries them to the owners
   const bool dist = multi && p->cfg.distributed_solve && p->cfg.world_size >= 1;
-  CBA_TRY(schur_gemm(p->B, p->W, p->Kpad, ld, p->Hdd, p->S, p->n_pad, ld, dd, (!multi || (dist && p->cfg.rank == 0)) ? 1 : 0, lambda, p->kmask, p->stream));
+  const int* chunk_order = nullptr;
+  if (p->chunk_order && p->chunk_order_valid) {
+    CBA_HIP(hipMemcpyAsync(p->chunk_order, p->chunk_order_host, sizeof(int) * schur_chunk_count(p->n_pad), hipMemcpyHostToDevice, p->stream));
+    chunk_order = p->chunk_order;
+  }
+  CBA_TRY(schur_gemm(p->B, p->W, p->Kpad, ld, p->Hdd, p->S, p->n_pad, ld, dd, (!multi || (dist && p->cfg.rank == 0)) ? 1 : 0, lambda, p->kmask, p->stream, chunk_order));
   CBA_TRY(timer_end(p, 0, 0, 0, 1));
   // algorithmic flops of this launch = K slabs actually multiplied (block-sparse loop): the touch masks go to pinned
   // host memory now and are counted after the solve (no host wait in the middle of the step)
@@ -466,6 +476,11 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
         for (int w = 0; w < mask_words; ++w)
           slabs += __builtin_popcountll(p->kmask_host[(size_t)tm * mask_words + w] & p->kmask_host[(size_t)tn * mask_words + w]);
     const double tiles = mask_tiles * (mask_tiles + 1) / 2.0;
+    // (host work while the device idles: only for the first solve and then every 16th -- the pattern hardly moves)
+    if (p->chunk_order_host && (!p->chunk_order_valid || (++p->chunk_order_age & 15) == 0)) {
+      schur_chunk_order(p->kmask_host, p->n_pad, p->Kpad, p->chunk_order_host);
+      p->chunk_order_valid = true;
+    }
     p->timers[0].flops += slabs * 2.0 * 128 * 128 * 16;
     p->timers[0].bytes += tiles * 2.0 * 128 * 128 * 8 + slabs * 2.0 * 16 * 128 * 8;
   }
@@ -632,6 +647,10 @@ int cba_create(const cba_config* config, cba_problem** out) {
   CBA_HIP(hipMemset(p->x, 0, sizeof(double) * ((size_t)L.block_dof + p->n_pad)));
   CBA_TRY(dev_alloc(&p->scal, 16));
   CBA_TRY(dev_alloc(&p->kmask, (size_t)(p->n_pad / 128) * schur_mask_words(p->Kpad)));
+  if (schur_chunk_count(p->n_pad) > 0) {
+    CBA_TRY(dev_alloc(&p->chunk_order, (size_t)schur_chunk_count(p->n_pad)));
+    CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->chunk_order_host), sizeof(int) * (size_t)schur_chunk_count(p->n_pad)));
+  }
   CBA_TRY(dev_alloc(&p->gemv_ws, (size_t)gemv_t_workspace_doubles(p->n_pad)));
   CBA_TRY(dev_alloc(&p->status, 1));
   CBA_TRY(ldlt_workspace_alloc(p->ldlt, p->n_pad));
@@ -665,6 +684,8 @@ void cba_destroy(cba_problem* p) {
   ldlt_workspace_free(p->ldlt);
   for (auto& t : p->timers) for (auto& sp : t.spans) { hipEventDestroy(sp.e0); hipEventDestroy(sp.e1); }
   if (p->kmask_host) hipHostFree(p->kmask_host);
+  if (p->chunk_order_host) hipHostFree(p->chunk_order_host);
+  if (p->chunk_order) hipFree(p->chunk_order);
   F(p->slow_skip); F(p->fd_slow); F(p->slow_list); F(p->slow_count); F(p->img_start); F(p->band_mask); F(p->det_bits); F(p->det_scale); F(p->fd_redo[0]); F(p->fd_redo[1]); F(p->fd_redo_count);
   if (p->ev_aux0) hipEventDestroy(p->ev_aux0);
   if (p->ev_aux1) hipEventDestroy(p->ev_aux1);

@@ -131,6 +131,7 @@ int launch_gemv_n(const double* M, int K, int n, int ld, const double* v, const 
 // tiles of the same tile row and share its A panel in that XCD's L2.
 // ------------------------------------------------------------------------------------------------
 constexpr int KT = 16;
+constexpr int kSchurChunk = 64;   // tiles per XCD chunk of a block-sparse launch
 
 struct GemmArgs {
   const double* A; int lda;     // K x lda, column offset already applied for m_begin = 0 of this call
@@ -149,6 +150,8 @@ struct GemmArgs {
   int chunk;                    // tiles per XCD chunk (set by launch_gemm)
   const unsigned long long* kmask;  // optional block-sparsity mask [column tile][kmask_words], bit = K slab of 16 rows
   int kmask_words;
+  const int* chunk_order;           // block-sparse launches: permutation of the 64-tile chunks, heaviest first (null = as enumerated)
+  int n_chunks;
   int strips;                   // set by launch_gemm: strip-blocked tile order (square upper dense launches)
   int col_group, col_stride;    // distributed factorisation: owned column groups (tiles per group, group stride); 0 = all columns
 };
@@ -165,7 +168,14 @@ struct GemmArgs {
 __device__ __forceinline__ long long gemm_slot_tile(const GemmArgs& g, long long b) {
   const long long q = b >> 3;
   const long long cq = q / g.chunk;
-  return (cq * 8 + (b & 7)) * g.chunk + (q - cq * g.chunk);
+  long long c = cq * 8 + (b & 7);
+  if (g.chunk_order) {
+    // the eight chunks of a round (one per XCD) are neighbours in the order by executed K slabs: the XCDs finish together and
+    // the light chunks of the sparse grid x grid region come last instead of leaving CUs idle behind dense ones
+    if (c >= g.n_chunks) return g.total_tiles;
+    c = g.chunk_order[c];
+  }
+  return c * g.chunk + (q - cq * g.chunk);
 }
 
 // col_group launches (distributed factorisation): first column of owned tile column tn, and the number of tile rows of the
@@ -419,11 +429,13 @@ static int launch_gemm(GemmArgs g, hipStream_t s) {
   long long per = (g.total_tiles + 7) / 8;
   // dense launches: one contiguous range per XCD (best L2 reuse); block-sparse launches: chunks of 64
   // interleaved over the XCDs so that dense and sparse regions of the matrix are spread evenly
-  g.chunk = (int)((g.kmask && per > 64) ? 64 : (per < 1 ? 1 : per));   // col_group launches are dense: the few skipped tiles sit at the end of every strip
+  g.chunk = (int)((g.kmask && per > kSchurChunk) ? kSchurChunk : (per < 1 ? 1 : per));   // col_group launches are dense: the few skipped tiles sit at the end of every strip
   static const int use_strips = CBA_GETENV("CBA_NO_STRIPS") ? 0 : 1;
   g.strips = (use_strips && TM == 128 && TN == 128 && g.upper && !g.kmask && g.m_off == g.n_off && g.m_tiles == g.n_tiles &&
               g.total_tiles >= 512) ? 1 : 0;
   long long chunks = (g.total_tiles + g.chunk - 1) / g.chunk;
+  g.n_chunks = (int)chunks;
+  if (g.chunk != kSchurChunk) g.chunk_order = nullptr;            // the order was built for chunks of kSchurChunk tiles
   long long blocks = ((chunks + 7) / 8) * 8 * g.chunk;
   hipLaunchKernelGGL((k_gemm_atb<TM, TN, WM, WN, SUB>), dim3((unsigned)blocks), dim3(256), 0, s, g);
   CBA_HIP(hipGetLastError());
@@ -484,6 +496,27 @@ __global__ void __launch_bounds__(256) k_touch_mask(const double* __restrict__ B
   if (threadIdx.x == 0 && any) atomicOr(mask + (size_t)tile * words + (slab >> 6), 1ull << (slab & 63));
 }
 int schur_mask_words(int Kpad) { return (Kpad / 16 + 63) / 64; }
+// Chunks of the block-sparse Schur launch (kSchurChunk consecutive upper tiles in row-major order) sorted by the K slabs they
+// execute, heaviest first; `order` gets schur_chunk_count(n_pad) entries, or is left alone when the launch would not use chunks
+int schur_chunk_count(int n_pad) {
+  const long long tiles = (long long)(n_pad / 128) * (n_pad / 128 + 1) / 2;
+  return ((tiles + 7) / 8 > kSchurChunk) ? (int)((tiles + kSchurChunk - 1) / kSchurChunk) : 0;
+}
+void schur_chunk_order(const unsigned long long* mask_host, int n_pad, int Kpad, int* order) {
+  const int nt = n_pad / 128, words = schur_mask_words(Kpad), nc = schur_chunk_count(n_pad);
+  if (nc == 0) return;
+  std::vector<std::pair<long long, int>> work(nc);
+  for (int c = 0; c < nc; ++c) work[c] = {0, c};
+  long long t = 0;
+  for (int tm = 0; tm < nt; ++tm)
+    for (int tn = tm; tn < nt; ++tn, ++t) {
+      long long slabs = 0;
+      for (int w = 0; w < words; ++w) slabs += __builtin_popcountll(mask_host[(size_t)tm * words + w] & mask_host[(size_t)tn * words + w]);
+      work[t / kSchurChunk].first += slabs + 2;            // + the C tile's read / write
+    }
+  std::stable_sort(work.begin(), work.end(), [](const std::pair<long long, int>& a, const std::pair<long long, int>& b) { return a.first > b.first; });
+  for (int c = 0; c < nc; ++c) order[c] = work[c].second;
+}
 int launch_touch_mask(const double* B, int Kpad, int n_pad, int ld, unsigned long long* mask, hipStream_t s) {
   const int words = schur_mask_words(Kpad);
   CBA_HIP(hipMemsetAsync(mask, 0, sizeof(unsigned long long) * (size_t)(n_pad / 128) * words, s));
@@ -493,9 +526,10 @@ int launch_touch_mask(const double* B, int Kpad, int n_pad, int ld, unsigned lon
 }
 
 int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const double* Cin, double* C, int n_pad, int ld,
-               int n_real, int add_diag, double lambda, const unsigned long long* kmask, hipStream_t s) {
+               int n_real, int add_diag, double lambda, const unsigned long long* kmask, hipStream_t s, const int* chunk_order) {
   GemmArgs g{};
   g.kmask = kmask; g.kmask_words = schur_mask_words(Kpad);
+  g.chunk_order = chunk_order;
   g.A = A; g.lda = ldab; g.B = B; g.ldb = ldab; g.K = Kpad;
   g.C = C; g.ldc = ld; g.Cin = Cin; g.ldcin = ld;
   g.m_tiles = n_pad / 128; g.n_tiles = n_pad / 128; g.m_off = 0; g.n_off = 0; g.upper = 1;
