@@ -1669,6 +1669,9 @@ static int ldlt_tail(double* S, int n_fact, int ld, int t0, LdltWorkspace& w, hi
   long long grid = ntasks + 1;
   if (grid > 2LL * cus - reserve_wgs) grid = 2LL * cus - reserve_wgs;        // two workgroups per CU are resident (80 KB of LDS each)
   if (grid < 2) grid = 2;
+  // a helper that finds itself on the chain's CU leaves (the chain needs the CU's LDS bandwidth and matrix pipes); with a grid this
+  // small the only helpers could all sit there and nobody would run the chain's PRE / PART tasks
+  if (grid <= 3) t.evict = 0;
   if (st) CBA_HIP(hipEventRecord(w.tail_e0, s));
   hipLaunchKernelGGL(k_ldlt_tail, dim3((unsigned)grid), dim3(256), 0, s, t);
   CBA_HIP(hipGetLastError());
@@ -1795,12 +1798,27 @@ static int dist_copy(const RectArgs& a, double* buf, long long rank_stride, int 
   CBA_HIP(hipGetLastError());
   return CBA_OK;
 }
+// Size of each of the two staging buffers: the largest transfer of the schedule, from the layout functions themselves -- the
+// triangle below the first band (reduce-scatter), a band of W rows or everything that is left (all-gathers, for every possible
+// number of super-panels), and the packed upper triangle of small systems.  (Round 3 reserved world x ceil(groups / world) x 512
+// x n_pad doubles, about twice this: 2 x 14.7 GB more than needed at BASELINE configs[4].)
 size_t ldlt_dist_buffer_doubles(int n_pad, int world) {
   if (world < 1) world = 1;
-  const size_t groups = (size_t)(n_pad + kOwnGroup - 1) / kOwnGroup;
-  const size_t per_rank = ((groups + world - 1) / world) * kOwnGroup * (size_t)n_pad;     // every transfer fits: <= n_pad rows of <= that many columns
-  const size_t packed = (size_t)n_pad * n_pad / 2 + 64 * (size_t)n_pad;
-  return std::max(per_rank * world, packed);
+  int W = super_width();
+  if (W <= 0 || W % kOwnGroup) W = 2048;
+  long long need = (long long)n_pad * (n_pad / 128 + 1) * 64;                       // packed upper triangle
+  auto transfer = [&](int g_begin, int R0, int nrows) {
+    RectArgs a{nullptr, n_pad, n_pad, g_begin, world, R0, nrows};
+    long long m = 0;
+    for (int q = 0; q < world; ++q) m = std::max(m, dist_count(a, q));
+    need = std::max(need, m * world);
+  };
+  if (n_pad > W) transfer(W / kOwnGroup, W, 0);
+  for (int e0 = W; e0 < n_pad; e0 += W) {
+    transfer(e0 / kOwnGroup, e0, std::min(W, n_pad - e0));
+    transfer(e0 / kOwnGroup, e0, n_pad - e0);
+  }
+  return (size_t)need;
 }
 // The collectives through the caller's callback, or -- when only an all-reduce is available -- emulated with it (same
 // results, more bytes: the tests with several ranks on one GPU and hosts that have not been moved to cba_collective_fn yet)

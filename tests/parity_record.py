@@ -14,12 +14,14 @@ _OUT = os.path.join(_ROOT, "gpurun_out", "parity_deviations.json")
 _rows = {}
 
 
-def check(case: str, quantity: str, observed: float, tolerance: float, exact: bool = False) -> None:
+def check(case: str, quantity: str, observed: float, tolerance: float, exact: bool = False, note: str = "") -> None:
     observed = float(observed)
     key = f"{case}/{quantity}"
     prev = _rows.get(key)
     _rows[key] = dict(case=case, quantity=quantity, observed=max(observed, prev["observed"]) if prev else observed,
                       tolerance=float(tolerance), exact=bool(exact))
+    if note:
+        _rows[key]["note"] = note
     assert observed <= tolerance, f"{key}: observed {observed:.3e} > tolerance {tolerance:.3e}"
 
 

@@ -169,7 +169,14 @@ def _full_size_case(case, cfg, n_imagesets, grid_wh=None, lapack=True, eliminate
         c2, nv2, v2 = e.cost(want_vector=True)
         check_equal(case, "cost-pass validity mask", int(np.count_nonzero((v2 >= 0) != (v2_ref >= 0))))
         both = v2_ref >= 0
-        check(case, "cost-pass cost vector rel", (np.abs(v2[both] - v2_ref[both]) / np.maximum(1e-3, v2_ref[both])).max(), 8e-7)
+        # per-case tolerance: the single-camera cases agree to 4e-11; in the rigs ONE observation per ~1e6 stops its projection LM one
+        # iterate apart from the oracle (cost change < 1e-12 decides the stop, APP/models/central_generic.cc:433-519; the composed
+        # camera_tr_rig x rig_tr_global pose differs in the last bit after the update) -- its pixel moves by ~1e-7 px
+        rig = pb.n_cameras > 1
+        check(case, "cost-pass cost vector rel", (np.abs(v2[both] - v2_ref[both]) / np.maximum(1e-3, v2_ref[both])).max(),
+              8e-7 if rig else 1e-9,
+              note="rig: one lane of ~1e6 stops its projection one LM iterate apart from the oracle (last-bit difference of the composed "
+                   "pose after the state update); every other lane agrees to ~4e-11, which is what the single-camera tolerance states" if rig else "")
         # the sum inherits the few lanes whose projection stops one LM iterate apart (the vector check above); it moves with the
         # engine's own x (atomics order), observed 8e-16 ... 2.7e-12 over the runs of this round
         check(case, "cost-pass total rel", abs(c2 - c2_ref) / c2_ref, 3e-11)
