@@ -526,7 +526,7 @@ int launch_touch_mask(const double* B, int Kpad, int n_pad, int ld, unsigned lon
 }
 
 int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const double* Cin, double* C, int n_pad, int ld,
-               int n_real, int add_diag, double lambda, const unsigned long long* kmask, hipStream_t s, const int* chunk_order) {
+               int n_real, int add_diag, double lambda, const unsigned long long* kmask, hipStream_t s, const int* chunk_order = nullptr) {
   GemmArgs g{};
   g.kmask = kmask; g.kmask_words = schur_mask_words(Kpad);
   g.chunk_order = chunk_order;
