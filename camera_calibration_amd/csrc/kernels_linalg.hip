@@ -705,54 +705,59 @@ __device__ __forceinline__ int tail_wait_rows(const TailArgs& t, int k, int kend
 
 // acc (64 x 64, 4 waves x 32 x 32) += sum_{k < K} (dk[k] A[k][m]) B[k][n]; A, B: K rows of `ld` doubles, written by other workgroups
 // of this launch (agent-scope loads).  SYM: B == A (loaded once).  Register-staged, three slabs in flight; ends with a barrier.
+// Round 4: slabs of 32 rows (kTailKT), two in flight.  The loop is bound by its synchronisation, not by memory (plain instead of
+// agent-scope loads, three or six slabs of 16 rows in flight: 48-49 TFLOP/s over the chip every time, profiles/r04_helper_kloop_*):
+// per barrier a wavefront now issues 32 MFMAs instead of 16.  sA and sB are 2 x 32 x TS doubles each -- one whole 64 x TS tile.
+constexpr int kTailKT = 32;
 template <bool SYM>
 __device__ __forceinline__ void tail_mma(v4f64 (&acc)[2][2], const double* A, const double* B, int ld, const double* dk, int K,
                                          double* sA, double* sB) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
-  const int r = tid >> 5, c2 = 2 * (tid & 31);
-  const int nk = K / KT;
+  const int r = tid >> 5, c2 = 2 * (tid & 31);          // rows r, r + 8, r + 16, r + 24 of a slab
+  const int nk = K / kTailKT;                             // K is a multiple of 64
   const __amdgpu_buffer_rsrc_t ra = tail_rsrc(A), rb = tail_rsrc(B), rd = tail_rsrc(dk);
   const int rowb = ld * 8;
-  v2f64_t a0_0, a0_1, a1_0, a1_1, a2_0, a2_1;
-  v2f64_t b0_0 = {0, 0}, b0_1 = {0, 0}, b1_0 = {0, 0}, b1_1 = {0, 0}, b2_0 = {0, 0}, b2_1 = {0, 0};
-  double d0_0, d0_1, d1_0, d1_1, d2_0, d2_1;
-#define CBA_XLOAD(slot_, k0_)                                                                    \
+  // staging registers written out as scalars, one set per slot (arrays here end up in scratch memory)
+  v2f64_t a0_0, a0_1, a0_2, a0_3, a1_0, a1_1, a1_2, a1_3;
+  v2f64_t b0_0 = {0, 0}, b0_1 = {0, 0}, b0_2 = {0, 0}, b0_3 = {0, 0}, b1_0 = {0, 0}, b1_1 = {0, 0}, b1_2 = {0, 0}, b1_3 = {0, 0};
+  double d0_0, d0_1, d0_2, d0_3, d1_0, d1_1, d1_2, d1_3;
+#define CBA_XLOAD1(slot_, q_, k0_)                                                               \
   {                                                                                              \
-    const int o = ((k0_) + r) * rowb + c2 * 8;                                                   \
-    a##slot_##_0 = tail_ld2(ra, o); a##slot_##_1 = tail_ld2(ra, o + 8 * rowb);                   \
-    if constexpr (!SYM) { b##slot_##_0 = tail_ld2(rb, o); b##slot_##_1 = tail_ld2(rb, o + 8 * rowb); } \
-    d##slot_##_0 = tail_ld1(rd, ((k0_) + r) * 8); d##slot_##_1 = tail_ld1(rd, ((k0_) + r + 8) * 8); \
+    const int o = ((k0_) + r + 8 * (q_)) * rowb + c2 * 8;                                        \
+    a##slot_##_##q_ = tail_ld2(ra, o);                                                           \
+    if constexpr (!SYM) b##slot_##_##q_ = tail_ld2(rb, o);                                       \
+    d##slot_##_##q_ = tail_ld1(rd, ((k0_) + r + 8 * (q_)) * 8);                                  \
   }
-#define CBA_XSTORE(buf_, slot_)                                                                  \
+#define CBA_XLOAD(slot_, k0_) { CBA_XLOAD1(slot_, 0, k0_) CBA_XLOAD1(slot_, 1, k0_) CBA_XLOAD1(slot_, 2, k0_) CBA_XLOAD1(slot_, 3, k0_) }
+#define CBA_XSTORE1(buf_, slot_, q_)                                                             \
   {                                                                                              \
-    double* qa = sA + (buf_) * KT * TS + r * TS + c2;                                            \
-    double* qb = sB + (buf_) * KT * TS + r * TS + c2;                                            \
-    qa[0] = a##slot_##_0.x * d##slot_##_0; qa[1] = a##slot_##_0.y * d##slot_##_0;                \
-    qa[8 * TS] = a##slot_##_1.x * d##slot_##_1; qa[8 * TS + 1] = a##slot_##_1.y * d##slot_##_1;  \
-    if constexpr (SYM) { qb[0] = a##slot_##_0.x; qb[1] = a##slot_##_0.y; qb[8 * TS] = a##slot_##_1.x; qb[8 * TS + 1] = a##slot_##_1.y; } \
-    else { qb[0] = b##slot_##_0.x; qb[1] = b##slot_##_0.y; qb[8 * TS] = b##slot_##_1.x; qb[8 * TS + 1] = b##slot_##_1.y; } \
+    double* qa = sA + (buf_) * kTailKT * TS + (r + 8 * (q_)) * TS + c2;                          \
+    double* qb = sB + (buf_) * kTailKT * TS + (r + 8 * (q_)) * TS + c2;                          \
+    qa[0] = a##slot_##_##q_.x * d##slot_##_##q_; qa[1] = a##slot_##_##q_.y * d##slot_##_##q_;    \
+    if constexpr (SYM) { qb[0] = a##slot_##_##q_.x; qb[1] = a##slot_##_##q_.y; }                 \
+    else { qb[0] = b##slot_##_##q_.x; qb[1] = b##slot_##_##q_.y; }                               \
   }
+#define CBA_XSTORE(buf_, slot_) { CBA_XSTORE1(buf_, slot_, 0) CBA_XSTORE1(buf_, slot_, 1) CBA_XSTORE1(buf_, slot_, 2) CBA_XSTORE1(buf_, slot_, 3) }
   CBA_XLOAD(0, 0);
-  CBA_XLOAD(1, (1 < nk ? 1 : nk - 1) * KT);
-  CBA_XLOAD(2, (2 < nk ? 2 : nk - 1) * KT);
+  CBA_XLOAD(1, (1 < nk ? 1 : nk - 1) * kTailKT);
   CBA_XSTORE(0, 0);
   __syncthreads();
 #define CBA_XSTEP(slot_, next_slot_)                                                                         \
   if (kb0 + (slot_) < nk) {                                                                                  \
     const int kb = kb0 + (slot_);                                                                            \
     const int buf = kb & 1;                                                                                  \
-    CBA_XLOAD(slot_, (kb + 3 < nk ? kb + 3 : nk - 1) * KT);                                                  \
-    const double* a_s = sA + buf * KT * TS;                                                                  \
-    const double* b_s = sB + buf * KT * TS;                                                                  \
+    CBA_XLOAD(slot_, (kb + 2 < nk ? kb + 2 : nk - 1) * kTailKT);                                             \
+    const double* a_s = sA + buf * kTailKT * TS;                                                             \
+    const double* b_s = sB + buf * kTailKT * TS;                                                             \
     /* operands of k-step kk + 4 are read before the MFMAs of step kk are issued (the compiler's own order, read -> wait -> */ \
     /* 4 MFMAs, left the matrix pipe idle for an LDS round trip per step) */                                 \
     double af[2][2], bf[2][2];                                                                               \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) af[0][i] = a_s[lk * TS + wm0 + i * 16 + li];               \
     _Pragma("unroll") for (int j = 0; j < 2; ++j) bf[0][j] = b_s[lk * TS + wn0 + j * 16 + li];               \
-    _Pragma("unroll") for (int kk = 0; kk < KT; kk += 4) {                                                   \
+    _Pragma("unroll") for (int kk = 0; kk < kTailKT; kk += 4) {                                              \
       const int cur = (kk >> 2) & 1, nxt = cur ^ 1;                                                          \
-      if (kk + 4 < KT) {                                                                                     \
+      if (kk + 4 < kTailKT) {                                                                                \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) af[nxt][i] = a_s[(kk + 4 + lk) * TS + wm0 + i * 16 + li]; \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) bf[nxt][j] = b_s[(kk + 4 + lk) * TS + wn0 + j * 16 + li]; \
       }                                                                                                      \
@@ -766,14 +771,15 @@ __device__ __forceinline__ void tail_mma(v4f64 (&acc)[2][2], const double* A, co
     __syncthreads();                                                                                         \
   }
 #pragma nounroll
-  for (int kb0 = 0; kb0 < nk; kb0 += 3) {
+  for (int kb0 = 0; kb0 < nk; kb0 += 2) {
     CBA_XSTEP(0, 1)
-    CBA_XSTEP(1, 2)
-    CBA_XSTEP(2, 0)
+    CBA_XSTEP(1, 0)
   }
 #undef CBA_XSTEP
 #undef CBA_XLOAD
+#undef CBA_XLOAD1
 #undef CBA_XSTORE
+#undef CBA_XSTORE1
 }
 
 // The same product for TWO adjacent column blocks: acc (64 x 128, 4 waves x 32 x 64) += sum_k (dk[k] A[k][m]) B[k][n], B 128 columns
@@ -1306,8 +1312,8 @@ __device__ __forceinline__ void tail_chain(const TailArgs& t, double* sV, double
 __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, double* sAB) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
-  double* sA = sAB;
-  double* sB = sAB + 2 * KT * TS;
+  double* sA = sAB;                              // K-loop staging: the whole sAB tile for A, the whole sV tile for B (2 x 32 x TS doubles
+  double* sB = sV;                               // each; only columns < 64 are written: the slots in sV's padding survive)
   volatile int* slot = reinterpret_cast<volatile int*>(sV + kInner);          // padding of row 0 of sV
   volatile int* slot2 = reinterpret_cast<volatile int*>(sV + TS + kInner);    // padding of row 1
   volatile int* slot3 = reinterpret_cast<volatile int*>(sV + 2 * TS + kInner);

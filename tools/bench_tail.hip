@@ -32,28 +32,12 @@ __global__ void __launch_bounds__(256, 2) k_mma2_only(const double* S, int ld, c
   double v = 0; for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) for (int q = 0; q < 4; ++q) v += acc[i][j][q];
   if (v == 1.2345e300) out[blockIdx.x] = v;
 }
-// the same K loop at 3 / 4 workgroups per CU (only the 40 KB of K-loop staging in LDS): what a helper kernel split from the chain could reach
-template <int WGS>
-__global__ void __launch_bounds__(256, WGS) k_mma_only_occ(const double* S, int ld, const double* dvec, int K, int ntc, double* out) {
-  __shared__ double smem[4 * KT * TS];
-  double* sA = smem;
-  double* sB = sA + 2 * KT * TS;
-  const int c = blockIdx.x % ntc, r = (blockIdx.x / ntc) % ntc;
-  v4f64 acc[2][2];
-  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
-  for (int k = 0; k < K; k += 1024) {
-    const int kk = K - k < 1024 ? K - k : 1024;
-    tail_mma<false>(acc, S + (size_t)k * ld + r * kInner, S + (size_t)k * ld + c * kInner, ld, dvec + k, kk, sA, sB);
-  }
-  double v = 0; for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int q = 0; q < 4; ++q) v += acc[i][j][q];
-  if (v == 1.2345e300) out[blockIdx.x] = v;
-}
 // synthetic ceiling of the helpers' inner loop: every workgroup accumulates one 64 x 64 tile over K rows, no flags
 template <bool SYM>
 __global__ void __launch_bounds__(256, 2) k_mma_only(const double* S, int ld, const double* dvec, int K, int ntc, double* out) {
   __shared__ double smem[2 * kInner * TS];
   double* sA = smem + kInner * TS;
-  double* sB = sA + 2 * KT * TS;
+  double* sB = smem;
   const int c = blockIdx.x % ntc, r = (blockIdx.x / ntc) % ntc;
   v4f64 acc[2][2];
   for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
@@ -141,20 +125,6 @@ int main(int argc, char** argv) {
       hipEventRecord(e1, ms);
       const float t = timeit(e0, e1);
       printf("mma_only grid %d K %d: %.3f ms  %.2f TFLOP/s\n", grid, K, t, grid * 2.0 * 64 * 64 * K / t / 1e9);
-    }
-    for (int grid : {768, 1536, 3072}) for (int rep = 0; rep < 2; ++rep) {
-      hipEventRecord(e0, ms);
-      hipLaunchKernelGGL(k_mma_only_occ<3>, dim3(grid), dim3(256), 0, ms, S, n, dv, K, ntc, out);
-      hipEventRecord(e1, ms);
-      const float t = timeit(e0, e1);
-      printf("mma_only 3 WGs/CU grid %d K %d: %.3f ms  %.2f TFLOP/s\n", grid, K, t, grid * 2.0 * 64 * 64 * K / t / 1e9);
-    }
-    for (int grid : {1024, 2048, 4096}) for (int rep = 0; rep < 2; ++rep) {
-      hipEventRecord(e0, ms);
-      hipLaunchKernelGGL(k_mma_only_occ<4>, dim3(grid), dim3(256), 0, ms, S, n, dv, K, ntc, out);
-      hipEventRecord(e1, ms);
-      const float t = timeit(e0, e1);
-      printf("mma_only 4 WGs/CU grid %d K %d: %.3f ms  %.2f TFLOP/s\n", grid, K, t, grid * 2.0 * 64 * 64 * K / t / 1e9);
     }
     return 0;
   }
