@@ -391,7 +391,7 @@ def main():
         # committed measurement (tools/rocprof_pmc.py) is quoted when the workload is the one it was taken on.
         pmc_traffic = {}
         pmc_path = ""
-        for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for cand in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", cand)
             if os.path.exists(pmc_path):
                 break

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 R=$GRAFT_REPO_ROOT
 O=gpurun_out; mkdir -p $O
-WHAT=${1:-suite}; TAG=${2:-r03}
+WHAT=${1:-suite}; TAG=${2:-r04}
 summary() { python - "$1" <<'PY'
 import json, sys
 try:
@@ -21,11 +21,9 @@ PY
 }
 case $WHAT in
   chain)
-    # round 4: the chain's blocked diagonal factorisation alone, then the dataflow launches with it (and with the round-3 loop)
+    # round 4: the chain's blocked diagonal factorisation alone (phase by phase), then the dataflow launches with the chain timeline
     timeout 120 tools/bin/bench_diag 200 2>&1 | tee $O/${TAG}_diag.txt
-    TAILLOG=1 TAILS=${TAILS:-6144} timeout 300 tools/bin/bench_tail 2304 2240 2>&1 | tee $O/${TAG}_tail_small.txt
-    TAILLOG=1 TAILS=${TAILS:-6144} timeout 300 tools/bin/bench_tail 12672 12544 2>&1 | tee $O/${TAG}_tail.txt
-    [ -x tools/bin/bench_tail_old ] && TAILLOG=1 TAILS=${TAILS:-6144} timeout 300 tools/bin/bench_tail_old 12672 12544 2>&1 | tee $O/${TAG}_tail_old.txt ;;
+    TAILLOG=1 TAILS=${TAILS:-6144} timeout 300 tools/bin/bench_tail 12672 12544 2>&1 | tee $O/${TAG}_tail.txt ;;
   tail)
     TAILLOG=1 TAILS=${TAILS:-1024,6144,8192} timeout 300 tools/bin/bench_tail 12672 12544 2>&1 | tee $O/${TAG}_tail.txt ;;
   suite|record|profile)
@@ -38,9 +36,8 @@ case $WHAT in
     if [ "$WHAT" != suite ]; then
       timeout 400 python bench.py --config 3 --steps 4 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench_cfg3.log 2>&1; tail -1 $O/${TAG}_bench_cfg3.log > $O/${TAG}_bench_cfg3.json; summary $O/${TAG}_bench_cfg3.json
       timeout 300 python bench.py --config 4 --steps 8 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_cfg4.log 2>&1; tail -1 $O/${TAG}_bench_cfg4.log > $O/${TAG}_bench_cfg4.json; summary $O/${TAG}_bench_cfg4.json
-      # one rank's driver of the distributed solve against the replicated one (cfg 2, and one rank's share of cfg 5)
-      timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-convergence --force-allreduce --distributed-solve 0 > $O/${TAG}_bench_cfg2_forced_replicated.log 2>&1; tail -1 $O/${TAG}_bench_cfg2_forced_replicated.log > $O/${TAG}_bench_cfg2_forced_replicated.json; summary $O/${TAG}_bench_cfg2_forced_replicated.json
-      timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-convergence --force-allreduce --distributed-solve 1 > $O/${TAG}_bench_cfg2_forced_distributed.log 2>&1; tail -1 $O/${TAG}_bench_cfg2_forced_distributed.log > $O/${TAG}_bench_cfg2_forced_distributed.json; summary $O/${TAG}_bench_cfg2_forced_distributed.json
+      # both reduced solves in one invocation with one rank (the two-leg path of bench.py --gpus N: replicated first, distributed second)
+      timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-convergence --force-allreduce --both-legs > $O/${TAG}_bench_cfg2_both_legs.log 2>&1; tail -1 $O/${TAG}_bench_cfg2_both_legs.log > $O/${TAG}_bench_cfg2_both_legs.json; summary $O/${TAG}_bench_cfg2_both_legs.json
       timeout 600 python bench.py --config 5 --imagesets 500 --steps 3 --warmup 1 --no-cpu-baseline --no-convergence > $O/${TAG}_bench_cfg5_share.log 2>&1; tail -1 $O/${TAG}_bench_cfg5_share.log > $O/${TAG}_bench_cfg5_share.json; summary $O/${TAG}_bench_cfg5_share.json
       timeout 600 python bench.py --config 5 --imagesets 500 --steps 3 --warmup 1 --no-cpu-baseline --no-convergence --force-allreduce --distributed-solve 1 > $O/${TAG}_bench_cfg5_share_distributed.log 2>&1; tail -1 $O/${TAG}_bench_cfg5_share_distributed.log > $O/${TAG}_bench_cfg5_share_distributed.json; summary $O/${TAG}_bench_cfg5_share_distributed.json
       cd /tmp
@@ -56,6 +53,13 @@ case $WHAT in
         timeout 400 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o pmc -- python $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-convergence > $R/$O/${TAG}_pmc_$c.log 2>&1
         db=$(find /tmp/pmc_$c -name "*.db" | head -1); [ -n "$db" ] && python $R/tools/rocprof_pmc.py $db > $R/$O/${TAG}_pmc_$c.txt 2>&1
       done
-      cd $R; head -6 $O/${TAG}_pmc_FETCH_SIZE.txt $O/${TAG}_pmc_WRITE_SIZE.txt; head -30 $O/${TAG}_bench_cfg2_kernel_stats.txt
+      # MFMA-busy counters of the GEMM and of the dataflow launches (two more passes: busy cycles, instruction counts)
+      rm -rf /tmp/pmc_m1 /tmp/pmc_m2
+      timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d /tmp/pmc_m1 -o pmc -- python $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-convergence > $R/$O/${TAG}_pmc_mfma1.log 2>&1
+      timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_ACTIVE_INST_ANY -d /tmp/pmc_m2 -o pmc -- python $R/bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-convergence > $R/$O/${TAG}_pmc_mfma2.log 2>&1
+      : > $R/$O/${TAG}_pmc_mfma.txt
+      for d in /tmp/pmc_m1 /tmp/pmc_m2; do db=$(find $d -name "*.db" | head -1); [ -n "$db" ] && python $R/tools/rocprof_pmc_generic.py $db gemm_atb,ldlt_tail,back_dataflow,fd_tasks >> $R/$O/${TAG}_pmc_mfma.txt 2>&1; done
+      cd $R; python tools/make_pmc_traffic.py $O/${TAG}_pmc_FETCH_SIZE.txt $O/${TAG}_pmc_WRITE_SIZE.txt $O/${TAG}_pmc_traffic.json ${TAG}
+      head -6 $O/${TAG}_pmc_FETCH_SIZE.txt $O/${TAG}_pmc_WRITE_SIZE.txt; cat $O/${TAG}_pmc_mfma.txt; head -30 $O/${TAG}_bench_cfg2_kernel_stats.txt
     fi ;;
 esac

@@ -1,0 +1,28 @@
+#!/usr/bin/env python
+"""profiles/<tag>_pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE tables of tools/rocprof_pmc.py (two separate --pmc passes):
+HBM bytes per launch of the dominant kernel, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950.
+  python tools/make_pmc_traffic.py <fetch table> <write table> <out json> <tag>"""
+import json, sys
+
+
+def per_call(path, counter):
+    for line in open(path):
+        if "k_gemm_atb<128" in line.replace(" ", "") or "k_gemm_atbILi128" in line or "k_gemm_atb<128, 128" in line:
+            f = line.split()
+            # ... counter calls sum_KiB per_call_MiB
+            i = f.index(counter)
+            return int(f[i + 1]), float(f[i + 2]) * 1024.0 / int(f[i + 1])
+    raise SystemExit(f"{path}: no k_gemm_atb row")
+
+
+n_f, fetch = per_call(sys.argv[1], "FETCH_SIZE")
+n_w, write = per_call(sys.argv[2], "WRITE_SIZE")
+tag = sys.argv[4] if len(sys.argv) > 4 else "r04"
+out = {"kernel": "cba::k_gemm_atb<128,128,64,64,true>", "launches": n_f,
+       "fetch_size_raw_bytes_per_launch": fetch, "fetch_bytes_per_launch": 2.0 * fetch, "write_bytes_per_launch": write,
+       "traffic_bytes_per_launch": 2.0 * fetch + write,
+       "source": f"profiles/{tag}_pmc_FETCH_SIZE.txt + {tag}_pmc_WRITE_SIZE.txt: two separate `rocprofv3 --kernel-trace --pmc <counter>` passes over "
+                 "`bench.py --steps 2 --warmup 0`; FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section), WRITE_SIZE as "
+                 "reported; average over all launches of the kernel (4 per step: the Schur product and the three K = 2048 super-panel updates)"}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out))
