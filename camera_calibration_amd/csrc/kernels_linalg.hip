@@ -782,6 +782,97 @@ __device__ __forceinline__ void tail_mma(v4f64 (&acc)[2][2], const double* A, co
 #undef CBA_XSTORE1
 }
 
+// The same loop with LDS-DMA (global_load_lds_dwordx4, agent scope): no staging registers, no ds_write, no per-slab v_mul of the
+// staged rows -- the A fragments are scaled by d_k after their ds_read (2 v_mul_f64 per 4 MFMAs).  One DMA instruction moves 1 KiB
+// = two 64-column rows to CONSECUTIVE LDS addresses, so slab row k sits in "pair" k & 15, half k >> 4, pairs 144 doubles apart:
+// the four K rows 4 j + lk of an MFMA step then fall into both halves of the LDS banks (288 dwords = 32 mod 64 per pair).
+// The DMA is issued from inline asm: issued through the builtin, the compiler's wait-count insertion cannot tell the two stage
+// buffers inside one __shared__ array apart and puts s_waitcnt vmcnt(0) in front of every ds_read (k_gemm_atb solves that with
+// four separate arrays; here the two 64 x TS tiles of the chain have to stay one array).  The waits are explicit, as there.
+// sm: 4 slabs of kDmaSlab doubles (A0, B0, A1, B1) + 2 x 32 doubles of d; ends with a barrier.
+constexpr int kDmaPair = 2 * kInner + 16;
+constexpr int kDmaSlab = (kTailKT / 2) * kDmaPair;
+constexpr int kDmaDoubles = 4 * kDmaSlab + 2 * kTailKT;
+__device__ __forceinline__ void tail_dma16(const double* base, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ void tail_dma4(const double* base, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 sc1" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ const double* tail_uniform(const double* p) {      // a wave-uniform pointer the compiler keeps in VGPRs
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const double*>(((unsigned long long)hi << 32) | lo);
+}
+template <bool SYM>
+__device__ __forceinline__ void tail_mma_dma(v4f64 (&acc)[2][2], const double* A_, const double* B_, int ld_, const double* dk_, int K,
+                                             double* sm) {
+  const double* A = tail_uniform(A_);
+  const double* B = tail_uniform(B_);
+  const double* dk = tail_uniform(dk_);
+  const int ld = __builtin_amdgcn_readfirstlane(ld_);
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
+  const int nk = K / kTailKT;                             // K is a multiple of 64
+  const unsigned lds0 = (unsigned)(size_t)sm;
+  // wavefront wv moves pairs 4 wv ... 4 wv + 3 of each operand: lanes 0-31 slab row p, lanes 32-63 slab row p + 16
+  const unsigned rowb = (unsigned)ld * 8u;
+  const unsigned vo = (unsigned)(4 * wv + (lane >> 5) * 16) * rowb + (unsigned)(lane & 31) * 16u;
+  const unsigned la = lds0 + (unsigned)(4 * wv * kDmaPair) * 8u;
+#define CBA_DSTAGE(buf_, k0_)                                                                                 \
+  {                                                                                                           \
+    const double* ga = A + (size_t)(k0_) * ld;                                                                \
+    const double* gb = B + (size_t)(k0_) * ld;                                                                \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                           \
+      tail_dma16(ga, vo + q * rowb, la + (unsigned)((buf_) * 2 * kDmaSlab + q * kDmaPair) * 8u);              \
+      if constexpr (!SYM) tail_dma16(gb, vo + q * rowb, la + (unsigned)((buf_) * 2 * kDmaSlab + kDmaSlab + q * kDmaPair) * 8u); \
+    }                                                                                                         \
+    if (wv == 0) tail_dma4(dk + (k0_), (unsigned)lane * 4u, lds0 + (unsigned)(4 * kDmaSlab + (buf_) * kTailKT) * 8u); \
+  }
+#define CBA_DOFF(j_) ((((4 * (j_)) & 15) * kDmaPair) + ((j_) >> 2) * kInner)
+#define CBA_DMMA(buf_)                                                                                        \
+  {                                                                                                           \
+    const double* a_s = sm + (buf_) * 2 * kDmaSlab + lk * kDmaPair + wm0 + li;                                \
+    const double* b_s = sm + (buf_) * 2 * kDmaSlab + (SYM ? 0 : kDmaSlab) + lk * kDmaPair + wn0 + li;         \
+    const double* d_s = sm + 4 * kDmaSlab + (buf_) * kTailKT + lk;                                            \
+    double af[2][2], bf[2][2], dv[2];                                                                         \
+    dv[0] = d_s[0];                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) af[0][i] = a_s[CBA_DOFF(0) + i * 16];                       \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) bf[0][j] = b_s[CBA_DOFF(0) + j * 16];                       \
+    _Pragma("unroll") for (int s = 0; s < kTailKT / 4; ++s) {                                                 \
+      const int cur = s & 1, nxt = cur ^ 1;                                                                   \
+      if (s + 1 < kTailKT / 4) {                                                                              \
+        dv[nxt] = d_s[4 * (s + 1)];                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) af[nxt][i] = a_s[CBA_DOFF(s + 1) + i * 16];             \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) bf[nxt][j] = b_s[CBA_DOFF(s + 1) + j * 16];             \
+      }                                                                                                       \
+      af[cur][0] *= dv[cur]; af[cur][1] *= dv[cur];                                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                           \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);       \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+    }                                                                                                         \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
+    __syncthreads();                                                                                          \
+  }
+  CBA_DSTAGE(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma nounroll
+  for (int kb = 0; kb < nk; kb += 2) {
+    if (kb + 1 < nk) CBA_DSTAGE(1, (kb + 1) * kTailKT);
+    CBA_DMMA(0)
+    if (kb + 1 < nk) {
+      if (kb + 2 < nk) CBA_DSTAGE(0, (kb + 2) * kTailKT);
+      CBA_DMMA(1)
+    }
+  }
+#undef CBA_DMMA
+#undef CBA_DOFF
+#undef CBA_DSTAGE
+}
+
 // The same product for TWO adjacent column blocks: acc (64 x 128, 4 waves x 32 x 64) += sum_k (dk[k] A[k][m]) B[k][n], B 128 columns
 // wide.  One barrier per 2048 MFMA-cycles per wave instead of 1024 (the 64 x 64 loop keeps the MFMA pipe 49 % busy with two
 // workgroups per CU, tools/bench_tail.hip MMA_ONLY), and the A slab is staged once for both tiles.
@@ -1312,11 +1403,12 @@ __device__ __forceinline__ void tail_chain(const TailArgs& t, double* sV, double
 __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, double* sAB) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
-  double* sA = sAB;                              // K-loop staging: the whole sAB tile for A, the whole sV tile for B (2 x 32 x TS doubles
-  double* sB = sV;                               // each; only columns < 64 are written: the slots in sV's padding survive)
-  volatile int* slot = reinterpret_cast<volatile int*>(sV + kInner);          // padding of row 0 of sV
-  volatile int* slot2 = reinterpret_cast<volatile int*>(sV + TS + kInner);    // padding of row 1
-  volatile int* slot3 = reinterpret_cast<volatile int*>(sV + 2 * TS + kInner);
+  // K-loop staging (LDS-DMA): kDmaDoubles from the start of sV, running over into sAB (the two tiles are one array); the slots
+  // sit behind it, in the padding of sAB's last row
+  static_assert(kDmaDoubles <= kInner * TS + (kInner - 1) * TS + kInner, "the K-loop staging overruns the slots");
+  volatile int* slot = reinterpret_cast<volatile int*>(sAB + (kInner - 1) * TS + kInner);
+  volatile int* slot2 = reinterpret_cast<volatile int*>(sAB + (kInner - 1) * TS + kInner + 2);
+  volatile int* slot3 = reinterpret_cast<volatile int*>(sAB + (kInner - 1) * TS + kInner + 4);
   const int ld = t.ld;
   const unsigned my_cu = tail_cu_id();
   const int nl = t.xcd_lists ? 8 : 1;
@@ -1357,8 +1449,8 @@ __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, doubl
       const unsigned long long h1 = HELP_NOW();
       const double* A = t.S + (size_t)k * kInner * ld + (size_t)ca * kInner;
       const double* B = t.S + (size_t)k * kInner * ld + (size_t)c * kInner;
-      if (kind == 1) tail_mma<true>(acc, A, A, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sA, sB);
-      else tail_mma<false>(acc, A, B, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sA, sB);
+      if (kind == 1) tail_mma_dma<true>(acc, A, A, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sV);
+      else tail_mma_dma<false>(acc, A, B, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sV);
       k += nrows;
       h_wait += h1 - h0; h_mma += HELP_NOW() - h1;
     }

@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(256, 2) k_mma2_only(const double* S, int ld, c
 }
 // synthetic ceiling of the helpers' inner loop: every workgroup accumulates one 64 x 64 tile over K rows, no flags
 template <bool SYM>
-__global__ void __launch_bounds__(256, 2) k_mma_only(const double* S, int ld, const double* dvec, int K, int ntc, double* out) {
+__global__ void __launch_bounds__(256, 2) k_mma_only(const double* S, int ld, const double* dvec, int K, int ntc, double* out, int variant) {
   __shared__ double smem[2 * kInner * TS];
   double* sA = smem + kInner * TS;
   double* sB = smem;
@@ -43,10 +43,12 @@ __global__ void __launch_bounds__(256, 2) k_mma_only(const double* S, int ld, co
   for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
   for (int k = 0; k < K; k += 1024) {
     const int kk = K - k < 1024 ? K - k : 1024;
-    tail_mma<SYM>(acc, S + (size_t)k * ld + r * kInner, S + (size_t)k * ld + c * kInner, ld, dvec + k, kk, sA, sB);
+    if (variant == 0) tail_mma<SYM>(acc, S + (size_t)k * ld + r * kInner, S + (size_t)k * ld + c * kInner, ld, dvec + k, kk, sA, sB);
+    else tail_mma_dma<SYM>(acc, S + (size_t)k * ld + r * kInner, S + (size_t)k * ld + c * kInner, ld, dvec + k, kk, smem);
   }
-  double v = 0; for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int q = 0; q < 4; ++q) v += acc[i][j][q];
-  if (v == 1.2345e300) out[blockIdx.x] = v;
+  double v = 0; for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int q = 0; q < 4; ++q) v += acc[i][j][q] * (1 + i + 2 * j + 4 * q);
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + (threadIdx.x >> 6)] = v;
 }
 
 int main(int argc, char** argv) {
@@ -114,17 +116,26 @@ int main(int argc, char** argv) {
     return 0;
   }
   if (getenv("MMA_ONLY")) {
-    const int n = 12672, K = 4096, ntc = 96;
-    double *S, *dv, *out; hipMalloc(&S, sizeof(double) * (size_t)K * n); hipMalloc(&dv, sizeof(double) * K); hipMalloc(&out, 8 * 4096);
+    const int n = 12672, K = 4096, ntc = getenv("MMA_NTC") ? atoi(getenv("MMA_NTC")) : 96;
+    double *S, *dv, *out; hipMalloc(&S, sizeof(double) * (size_t)K * n); hipMalloc(&dv, sizeof(double) * K); hipMalloc(&out, 8 * 8192);
     std::vector<double> h((size_t)K * n); for (size_t i = 0; i < h.size(); ++i) h[i] = ((double)((i * 2654435761u) % 2001) / 1000.0 - 1.0) * 0.05;
     hipMemcpy(S, h.data(), h.size() * 8, hipMemcpyHostToDevice);
-    std::vector<double> hd(K, 1.5); hipMemcpy(dv, hd.data(), K * 8, hipMemcpyHostToDevice);
+    std::vector<double> hd(K); for (int i = 0; i < K; ++i) hd[i] = 1.0 + 0.001 * (i % 97); hipMemcpy(dv, hd.data(), K * 8, hipMemcpyHostToDevice);
+    std::vector<double> ref(8192), got(8192);
+    for (int variant = 0; variant < 2; ++variant)
     for (int grid : {256, 512, 1024, 2048}) for (int rep = 0; rep < 2; ++rep) {
+      hipMemset(out, 0, 8 * 8192);
       hipEventRecord(e0, ms);
-      hipLaunchKernelGGL(k_mma_only<false>, dim3(grid), dim3(256), 0, ms, S, n, dv, K, ntc, out);
+      if (getenv("MMA_SYM")) hipLaunchKernelGGL(k_mma_only<true>, dim3(grid), dim3(256), 0, ms, S, n, dv, K, ntc, out, variant);
+      else hipLaunchKernelGGL(k_mma_only<false>, dim3(grid), dim3(256), 0, ms, S, n, dv, K, ntc, out, variant);
       hipEventRecord(e1, ms);
       const float t = timeit(e0, e1);
-      printf("mma_only grid %d K %d: %.3f ms  %.2f TFLOP/s\n", grid, K, t, grid * 2.0 * 64 * 64 * K / t / 1e9);
+      hipMemcpy(got.data(), out, 8 * 8192, hipMemcpyDeviceToHost);
+      if (variant == 0 && grid == 2048) ref = got;
+      double dev = 0, mx = 0; for (int i = 0; i < grid * 4 && i < 8192; ++i) { dev = std::max(dev, std::fabs(got[i] - ref[i])); mx = std::max(mx, std::fabs(ref[i])); }
+      printf("mma_only %s grid %d K %d: %.3f ms  %.2f TFLOP/s%s\n", variant ? "LDS-DMA" : "register-staged", grid, K, t, grid * 2.0 * 64 * 64 * K / t / 1e9,
+             variant ? (dev == 0 ? "  [bit-identical to the register-staged loop]" : "  [DIFFERS]") : "");
+      if (variant && dev != 0) printf("   max dev %.3e of %.3e\n", dev, mx);
     }
     return 0;
   }
