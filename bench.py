@@ -37,6 +37,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config id (1-5)")
+    ap.add_argument("--factor-tail-rows", type=int, default=0, help="cba_solver_options.factor_tail_rows (0 = the library default); schedule sweeps only")
     ap.add_argument("--imagesets", type=int, default=0, help="imagesets per GPU (0 = the config's count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-allreduce", action="store_true",
@@ -267,7 +268,7 @@ def main():
             reduce_ptr = keep.data_ptr()
             allreduce = make_allreduce(keep, local_rank)
         e = eng.Engine(pb, device=local_rank, allreduce=allreduce, n_images_global=n_img * world,
-                       reduce_buffer_ptr=reduce_ptr, reduce_buffer_doubles=reduce_n, distributed_solve=dist_solve, rank=rank, world_size=world,
+                       reduce_buffer_ptr=reduce_ptr, reduce_buffer_doubles=reduce_n, distributed_solve=dist_solve, rank=rank, world_size=world, factor_tail_rows=args.factor_tail_rows,
                        collective=make_collective(local_rank) if dist_solve else None)
         return e, keep
 

@@ -140,7 +140,7 @@ struct LdltWorkspace {
   double* X = nullptr;       // X = D L of a super-panel's row strip [kSuperMax][ld]
   double* invLt = nullptr;   // per 64-block: transposed inverse of the unit factor [kInner][kInner]
   // scheduling options (cba_solver_options): rows left to the final dataflow launch; back substitution as one dataflow launch
-  int tail_rows = 6144;
+  int tail_rows = 8192;
   bool back_dataflow = true;
   double* dvec = nullptr;    // n
   int* status = nullptr;

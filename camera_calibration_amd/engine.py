@@ -41,7 +41,7 @@ class CbaSolverOptions(C.Structure):
     _fields_ = [("factor_tail_rows", C.c_int32), ("back_substitution", C.c_int32)]
 
 
-DEFAULT_FACTOR_TAIL_ROWS = 6144      # what factor_tail_rows = 0 selects (include/cba.h)
+DEFAULT_FACTOR_TAIL_ROWS = 8192      # what factor_tail_rows = 0 selects (include/cba.h)
 
 
 class CbaConfig(C.Structure):

@@ -1,6 +1,6 @@
 """The dataflow launches of the reduced-system factorisation (k_ldlt_tail) against the oracle's pivoted LDL^T: same solution
 whatever share of the matrix the final launch takes -- the last 1024 rows (super-panels in front of it at the larger sizes),
-everything (the system is smaller than the default 6144) -- at sizes that put the junctions on every kind of block boundary, and
+everything (the system is smaller than the default 8192) -- at sizes that put the junctions on every kind of block boundary, and
 the two back substitutions against each other.  Scheduling options travel per call (cba_solver_options)."""
 import numpy as np
 import pytest
@@ -31,7 +31,7 @@ def test_dataflow_factorisation_matches_the_oracle_for_every_tail_size(dense_dof
     case = f"factorisation tail, D = {dense_dof}"
     s = _system(12, dense_dof, seed=dense_dof)
     xs = {}
-    for rows in (512, 1024, 0):                    # 0 = default (6144): one launch at these sizes
+    for rows in (512, 1024, 0):                    # 0 = default (8192): one launch at these sizes
         xs[rows] = eng.schur_solve(s.block_diag_H, s.off_diag_H, s.dense_H, s.block_diag_b, s.dense_b, factor_tail_rows=rows)
         check_equal(case, f"tail rows {rows}: finite", int(np.count_nonzero(~np.isfinite(xs[rows]))))
     x_ref = orc.schur_solve(s)                     # Eigen's pivoted LDLT restated (oracle)

@@ -40,7 +40,7 @@ DIST_TAIL_ROWS = 512
 
 
 def _problem_full_grid():
-    """BASELINE configs[1] with its full 84 x 60 grid (D = 12 525: three super-panels of 2048 rows and the 6144-row final launch
+    """BASELINE configs[1] with its full 84 x 60 grid (D = 12 525: super-panels of ~2048 rows and the ~9000-row final launch
     at the DEFAULT schedule parameters) and 60 imagesets."""
     return syn.baseline_config(2, lambda cam, grid, pts: eng.project(cam, grid, pts), n_imagesets=60)
 
