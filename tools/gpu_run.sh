@@ -3,6 +3,7 @@
 #   suite   whole GPU test suite + smoke + default bench line                      -> gpurun_out/<tag>_*
 #   record  suite + bench lines of configs 2 / 3 / 4 + kernel stats + PMC traffic  -> gpurun_out/<tag>_*
 #   profile record without the test suite / smoke
+#   timeline kernel trace of five cfg-2 steps -> step timeline + kernel stats
 #   tail    tools/bin/bench_tail (factorisation tail vs blocked schedule, chain timeline)
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
@@ -20,6 +21,12 @@ except Exception as e:
 PY
 }
 case $WHAT in
+  timeline)
+    cd /tmp
+    rm -rf /tmp/prof_c2; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_c2 -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-convergence > $R/$O/${TAG}_prof_cfg2.log 2>&1
+    db=$(find /tmp/prof_c2 -name "*.db" | head -1); [ -n "$db" ] && python $R/tools/rocprof_summary.py $db > $R/$O/${TAG}_bench_cfg2_kernel_stats.txt 2>&1
+    [ -n "$db" ] && python $R/tools/step_timeline.py $db 15 > $R/$O/${TAG}_step_timeline_cfg2.txt 2>&1
+    cat $R/$O/${TAG}_step_timeline_cfg2.txt ;;
   chain)
     # round 4: the chain's blocked diagonal factorisation alone (phase by phase), then the dataflow launches with the chain timeline
     timeout 120 tools/bin/bench_diag 200 2>&1 | tee $O/${TAG}_diag.txt
