@@ -672,13 +672,14 @@ __device__ __forceinline__ bool tail_wait(const TailArgs& t, const unsigned* f0,
   const int ok = *slot;
   return ok != 0;
 }
-// Number of consecutive block rows k, k + 1, ... (< kend, at most 16) whose tiles (row, ca) and (row, cb) are published; waits for
-// at least one.  0 = aborted.  One wavefront polls 32 flags per round.
+// Number of consecutive block rows k, k + 1, ... (< kend, at most 32) whose tiles (row, ca) and (row, cb) are published; waits for
+// at least one.  0 = aborted.  One wavefront polls 64 flags per round (a round costs an L2 round trip, ~2 us: with 16 rows per
+// round the polling alone was 10 % of a helper's time in the final launch).
 __device__ __forceinline__ int tail_wait_rows(const TailArgs& t, int k, int kend, int ca, int cb, volatile int* slot) {
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     const int row = k + (lane >> 1);
-    const bool in = lane < 32 && row < kend;
+    const bool in = row < kend;
     const unsigned* f = t.tile_flag + (size_t)((in ? row : k) - t.rt0) * t.ntc + ((lane & 1) ? cb : ca);
     const unsigned long long t0 = wall_clock64();
     int n = 0;
@@ -688,7 +689,7 @@ __device__ __forceinline__ int tail_wait_rows(const TailArgs& t, int k, int kend
       const unsigned long long m = __ballot(ok);
       const unsigned long long both = m & (m >> 1) & 0x5555555555555555ull;
       n = 0;
-      while (n < 16 && ((both >> (2 * n)) & 1ull)) ++n;
+      while (n < 32 && ((both >> (2 * n)) & 1ull)) ++n;
       if (n > 0) break;
       __builtin_amdgcn_s_sleep(1);
       if ((++spins & 63u) == 0) {
@@ -1442,6 +1443,17 @@ __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, doubl
       for (int jj = 0; jj < 2; ++jj) acc[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
     const unsigned long long h_start = HELP_NOW();
     unsigned long long h_wait = 0, h_mma = 0;
+    // the tile itself (written before this launch) is fetched now, underneath the K loop
+    const int row0 = (kind == 1 ? c : r) * kInner;
+    const __amdgpu_buffer_rsrc_t rt = tail_rsrc(t.S + (size_t)row0 * ld + (size_t)c * kInner);
+    const int acc_voff = ((wm0 + lk) * ld + wn0 + li) * 8;
+    double a_rc[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) a_rc[i][jj][r4] = tail_ld1(rt, acc_voff, ((16 * i + 4 * r4) * ld + 16 * jj) * 8);
     for (int k = t.rt0; k < r;) {
       const unsigned long long h0 = HELP_NOW();
       const int nrows = tail_wait_rows(t, k, r, ca, c, slot);
@@ -1455,17 +1467,7 @@ __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, doubl
       h_wait += h1 - h0; h_mma += HELP_NOW() - h1;
     }
     const unsigned long long h_kend = HELP_NOW();
-    // U = A_rc - acc.  The tile itself was written before this launch.
-    const int row0 = (kind == 1 ? c : r) * kInner;
-    const __amdgpu_buffer_rsrc_t rt = tail_rsrc(t.S + (size_t)row0 * ld + (size_t)c * kInner);
-    const int acc_voff = ((wm0 + lk) * ld + wn0 + li) * 8;
-    double a_rc[2][2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) a_rc[i][jj][r4] = tail_ld1(rt, acc_voff, ((16 * i + 4 * r4) * ld + 16 * jj) * 8);
+    // U = A_rc - acc
     if (kind != 2) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
