@@ -705,88 +705,17 @@ __device__ __forceinline__ int tail_wait_rows(const TailArgs& t, int k, int kend
 }
 
 // acc (64 x 64, 4 waves x 32 x 32) += sum_{k < K} (dk[k] A[k][m]) B[k][n]; A, B: K rows of `ld` doubles, written by other workgroups
-// of this launch (agent-scope loads).  SYM: B == A (loaded once).  Register-staged, three slabs in flight; ends with a barrier.
-// Round 4: slabs of 32 rows (kTailKT), two in flight.  The loop is bound by its synchronisation, not by memory (plain instead of
-// agent-scope loads, three or six slabs of 16 rows in flight: 48-49 TFLOP/s over the chip every time, profiles/r04_helper_kloop_*):
-// per barrier a wavefront now issues 32 MFMAs instead of 16.  sA and sB are 2 x 32 x TS doubles each -- one whole 64 x TS tile.
+// of this launch (agent-scope loads).  SYM: B == A (loaded once).  Slabs of kTailKT = 32 rows, the next one in flight while the
+// MFMAs consume the current one; one s_waitcnt vmcnt(0) + barrier per slab.
+// Operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write, no per-slab v_mul of the
+// staged rows -- the A fragments are scaled by d_k after their ds_read (2 v_mul_f64 per 4 MFMAs).  Rounds 2-4 staged the slabs
+// through registers (load, scale, ds_write): that loop sat at 48-50 TFLOP/s over the chip whatever the prefetch depth, slab height
+// or cache policy (profiles/r04_helper_kloop_*); this one reaches 56-60 in the same harness with bit-identical sums
+// (profiles/r04_helper_kloop_lds_dma.txt; the register-staged loop lives on in tools/bench_tail.hip as the reference).
+// One DMA instruction moves 1 KiB = two 64-column rows to CONSECUTIVE LDS addresses, so slab row k sits in "pair" k & 15, half
+// k >> 4, pairs 144 doubles apart: the four K rows 4 j + lk of an MFMA step then fall into both halves of the LDS banks (288 dwords
+// = 32 mod 64 per pair).
 constexpr int kTailKT = 32;
-template <bool SYM>
-__device__ __forceinline__ void tail_mma(v4f64 (&acc)[2][2], const double* A, const double* B, int ld, const double* dk, int K,
-                                         double* sA, double* sB) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
-  const int r = tid >> 5, c2 = 2 * (tid & 31);          // rows r, r + 8, r + 16, r + 24 of a slab
-  const int nk = K / kTailKT;                             // K is a multiple of 64
-  const __amdgpu_buffer_rsrc_t ra = tail_rsrc(A), rb = tail_rsrc(B), rd = tail_rsrc(dk);
-  const int rowb = ld * 8;
-  // staging registers written out as scalars, one set per slot (arrays here end up in scratch memory)
-  v2f64_t a0_0, a0_1, a0_2, a0_3, a1_0, a1_1, a1_2, a1_3;
-  v2f64_t b0_0 = {0, 0}, b0_1 = {0, 0}, b0_2 = {0, 0}, b0_3 = {0, 0}, b1_0 = {0, 0}, b1_1 = {0, 0}, b1_2 = {0, 0}, b1_3 = {0, 0};
-  double d0_0, d0_1, d0_2, d0_3, d1_0, d1_1, d1_2, d1_3;
-#define CBA_XLOAD1(slot_, q_, k0_)                                                               \
-  {                                                                                              \
-    const int o = ((k0_) + r + 8 * (q_)) * rowb + c2 * 8;                                        \
-    a##slot_##_##q_ = tail_ld2(ra, o);                                                           \
-    if constexpr (!SYM) b##slot_##_##q_ = tail_ld2(rb, o);                                       \
-    d##slot_##_##q_ = tail_ld1(rd, ((k0_) + r + 8 * (q_)) * 8);                                  \
-  }
-#define CBA_XLOAD(slot_, k0_) { CBA_XLOAD1(slot_, 0, k0_) CBA_XLOAD1(slot_, 1, k0_) CBA_XLOAD1(slot_, 2, k0_) CBA_XLOAD1(slot_, 3, k0_) }
-#define CBA_XSTORE1(buf_, slot_, q_)                                                             \
-  {                                                                                              \
-    double* qa = sA + (buf_) * kTailKT * TS + (r + 8 * (q_)) * TS + c2;                          \
-    double* qb = sB + (buf_) * kTailKT * TS + (r + 8 * (q_)) * TS + c2;                          \
-    qa[0] = a##slot_##_##q_.x * d##slot_##_##q_; qa[1] = a##slot_##_##q_.y * d##slot_##_##q_;    \
-    if constexpr (SYM) { qb[0] = a##slot_##_##q_.x; qb[1] = a##slot_##_##q_.y; }                 \
-    else { qb[0] = b##slot_##_##q_.x; qb[1] = b##slot_##_##q_.y; }                               \
-  }
-#define CBA_XSTORE(buf_, slot_) { CBA_XSTORE1(buf_, slot_, 0) CBA_XSTORE1(buf_, slot_, 1) CBA_XSTORE1(buf_, slot_, 2) CBA_XSTORE1(buf_, slot_, 3) }
-  CBA_XLOAD(0, 0);
-  CBA_XLOAD(1, (1 < nk ? 1 : nk - 1) * kTailKT);
-  CBA_XSTORE(0, 0);
-  __syncthreads();
-#define CBA_XSTEP(slot_, next_slot_)                                                                         \
-  if (kb0 + (slot_) < nk) {                                                                                  \
-    const int kb = kb0 + (slot_);                                                                            \
-    const int buf = kb & 1;                                                                                  \
-    CBA_XLOAD(slot_, (kb + 2 < nk ? kb + 2 : nk - 1) * kTailKT);                                             \
-    const double* a_s = sA + buf * kTailKT * TS;                                                             \
-    const double* b_s = sB + buf * kTailKT * TS;                                                             \
-    /* operands of k-step kk + 4 are read before the MFMAs of step kk are issued (the compiler's own order, read -> wait -> */ \
-    /* 4 MFMAs, left the matrix pipe idle for an LDS round trip per step) */                                 \
-    double af[2][2], bf[2][2];                                                                               \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) af[0][i] = a_s[lk * TS + wm0 + i * 16 + li];               \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) bf[0][j] = b_s[lk * TS + wn0 + j * 16 + li];               \
-    _Pragma("unroll") for (int kk = 0; kk < kTailKT; kk += 4) {                                              \
-      const int cur = (kk >> 2) & 1, nxt = cur ^ 1;                                                          \
-      if (kk + 4 < kTailKT) {                                                                                \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) af[nxt][i] = a_s[(kk + 4 + lk) * TS + wm0 + i * 16 + li]; \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) bf[nxt][j] = b_s[(kk + 4 + lk) * TS + wn0 + j * 16 + li]; \
-      }                                                                                                      \
-      __builtin_amdgcn_sched_barrier(0);                                                                     \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);      \
-      __builtin_amdgcn_sched_barrier(0);                                                                     \
-    }                                                                                                        \
-    CBA_XSTORE(buf ^ 1, next_slot_);                                                                         \
-    __syncthreads();                                                                                         \
-  }
-#pragma nounroll
-  for (int kb0 = 0; kb0 < nk; kb0 += 2) {
-    CBA_XSTEP(0, 1)
-    CBA_XSTEP(1, 0)
-  }
-#undef CBA_XSTEP
-#undef CBA_XLOAD
-#undef CBA_XLOAD1
-#undef CBA_XSTORE
-#undef CBA_XSTORE1
-}
-
-// The same loop with LDS-DMA (global_load_lds_dwordx4, agent scope): no staging registers, no ds_write, no per-slab v_mul of the
-// staged rows -- the A fragments are scaled by d_k after their ds_read (2 v_mul_f64 per 4 MFMAs).  One DMA instruction moves 1 KiB
-// = two 64-column rows to CONSECUTIVE LDS addresses, so slab row k sits in "pair" k & 15, half k >> 4, pairs 144 doubles apart:
-// the four K rows 4 j + lk of an MFMA step then fall into both halves of the LDS banks (288 dwords = 32 mod 64 per pair).
 // The DMA is issued from inline asm: issued through the builtin, the compiler's wait-count insertion cannot tell the two stage
 // buffers inside one __shared__ array apart and puts s_waitcnt vmcnt(0) in front of every ds_read (k_gemm_atb solves that with
 // four separate arrays; here the two 64 x TS tiles of the chain have to stay one array).  The waits are explicit, as there.
@@ -874,83 +803,6 @@ __device__ __forceinline__ void tail_mma_dma(v4f64 (&acc)[2][2], const double* A
 #undef CBA_DSTAGE
 }
 
-// The same product for TWO adjacent column blocks: acc (64 x 128, 4 waves x 32 x 64) += sum_k (dk[k] A[k][m]) B[k][n], B 128 columns
-// wide.  One barrier per 2048 MFMA-cycles per wave instead of 1024 (the 64 x 64 loop keeps the MFMA pipe 49 % busy with two
-// workgroups per CU, tools/bench_tail.hip MMA_ONLY), and the A slab is staged once for both tiles.
-// sA: 2 x KT x TS doubles, sB: 2 x KT x TSB doubles.
-constexpr int TSB = 2 * kInner + 16;
-__device__ __forceinline__ void tail_mma2(v4f64 (&acc)[2][4], const double* A, const double* B, int ld, const double* dk, int K,
-                                          double* sA, double* sB) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 64, li = lane & 15, lk = lane >> 4;
-  const int r = tid >> 5, c2 = 2 * (tid & 31);          // A: rows r, r + 8
-  const int rb = tid >> 6, cb = 2 * (tid & 63);         // B: rows rb, rb + 4, rb + 8, rb + 12 (one full 1 KB row per wave-instruction)
-  const int nk = K / KT;
-  const __amdgpu_buffer_rsrc_t ra = tail_rsrc(A), rbs = tail_rsrc(B), rd = tail_rsrc(dk);
-  const int rowb = ld * 8;
-  v2f64_t a0_0, a0_1, a1_0, a1_1, a2_0, a2_1;
-  v2f64_t b0_0, b0_1, b0_2, b0_3, b1_0, b1_1, b1_2, b1_3, b2_0, b2_1, b2_2, b2_3;
-  double d0_0, d0_1, d1_0, d1_1, d2_0, d2_1;
-#define CBA_YLOAD(slot_, k0_)                                                                    \
-  {                                                                                              \
-    const int oa = ((k0_) + r) * rowb + c2 * 8;                                                  \
-    const int ob = ((k0_) + rb) * rowb + cb * 8;                                                 \
-    a##slot_##_0 = tail_ld2(ra, oa); a##slot_##_1 = tail_ld2(ra, oa, 8 * rowb);                  \
-    b##slot_##_0 = tail_ld2(rbs, ob); b##slot_##_1 = tail_ld2(rbs, ob, 4 * rowb);                \
-    b##slot_##_2 = tail_ld2(rbs, ob, 8 * rowb); b##slot_##_3 = tail_ld2(rbs, ob, 12 * rowb);     \
-    d##slot_##_0 = tail_ld1(rd, ((k0_) + r) * 8); d##slot_##_1 = tail_ld1(rd, ((k0_) + r + 8) * 8); \
-  }
-#define CBA_YSTORE(buf_, slot_)                                                                  \
-  {                                                                                              \
-    double* qa = sA + (buf_) * KT * TS + r * TS + c2;                                            \
-    double* qb = sB + (buf_) * KT * TSB + rb * TSB + cb;                                         \
-    qa[0] = a##slot_##_0.x * d##slot_##_0; qa[1] = a##slot_##_0.y * d##slot_##_0;                \
-    qa[8 * TS] = a##slot_##_1.x * d##slot_##_1; qa[8 * TS + 1] = a##slot_##_1.y * d##slot_##_1;  \
-    qb[0] = b##slot_##_0.x; qb[1] = b##slot_##_0.y;                                              \
-    qb[4 * TSB] = b##slot_##_1.x; qb[4 * TSB + 1] = b##slot_##_1.y;                              \
-    qb[8 * TSB] = b##slot_##_2.x; qb[8 * TSB + 1] = b##slot_##_2.y;                              \
-    qb[12 * TSB] = b##slot_##_3.x; qb[12 * TSB + 1] = b##slot_##_3.y;                            \
-  }
-  CBA_YLOAD(0, 0);
-  CBA_YLOAD(1, (1 < nk ? 1 : nk - 1) * KT);
-  CBA_YLOAD(2, (2 < nk ? 2 : nk - 1) * KT);
-  CBA_YSTORE(0, 0);
-  __syncthreads();
-#define CBA_YSTEP(slot_, next_slot_)                                                                         \
-  if (kb0 + (slot_) < nk) {                                                                                  \
-    const int kb = kb0 + (slot_);                                                                            \
-    const int buf = kb & 1;                                                                                  \
-    CBA_YLOAD(slot_, (kb + 3 < nk ? kb + 3 : nk - 1) * KT);                                                  \
-    const double* a_s = sA + buf * KT * TS;                                                                  \
-    const double* b_s = sB + buf * KT * TSB;                                                                 \
-    double af[2][2], bf[2][4];                                                                               \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) af[0][i] = a_s[lk * TS + wm0 + i * 16 + li];               \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) bf[0][j] = b_s[lk * TSB + wn0 + j * 16 + li];              \
-    _Pragma("unroll") for (int kk = 0; kk < KT; kk += 4) {                                                   \
-      const int cur = (kk >> 2) & 1, nxt = cur ^ 1;                                                          \
-      if (kk + 4 < KT) {                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) af[nxt][i] = a_s[(kk + 4 + lk) * TS + wm0 + i * 16 + li]; \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) bf[nxt][j] = b_s[(kk + 4 + lk) * TSB + wn0 + j * 16 + li]; \
-      }                                                                                                      \
-      __builtin_amdgcn_sched_barrier(0);                                                                     \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                        \
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);      \
-      __builtin_amdgcn_sched_barrier(0);                                                                     \
-    }                                                                                                        \
-    CBA_YSTORE(buf ^ 1, next_slot_);                                                                         \
-    __syncthreads();                                                                                         \
-  }
-#pragma nounroll
-  for (int kb0 = 0; kb0 < nk; kb0 += 3) {
-    CBA_YSTEP(0, 1)
-    CBA_YSTEP(1, 2)
-    CBA_YSTEP(2, 0)
-  }
-#undef CBA_YSTEP
-#undef CBA_YLOAD
-#undef CBA_YSTORE
-}
 
 // ticket of list x -> task.  kind 0 = PRE(r), 1 = PART(r + 1), 2 = REG(r, c).  List x (of `nl` lists) holds the tasks whose column
 // block c has c % nl == x, rows in increasing order -- a task only waits for tiles of earlier rows, so every list is in

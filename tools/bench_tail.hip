@@ -10,6 +10,83 @@
 #include <cmath>
 #include <algorithm>
 namespace cba { void set_error(const std::string& m) { fprintf(stderr, "error: %s\n", m.c_str()); } }
+// The helpers' K loop of rounds 2-4 (register-staged: buffer loads -> scale by d -> ds_write -> barrier -> MFMA), kept here as the
+// reference of the LDS-DMA loop the product uses now (tail_mma_dma): same sums bit for bit, 48-50 vs 56-60 TFLOP/s.
+namespace cba {
+template <bool SYM>
+__device__ __forceinline__ void tail_mma_regstaged(v4f64 (&acc)[2][2], const double* A, const double* B, int ld, const double* dk, int K,
+                                         double* sA, double* sB) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
+  const int r = tid >> 5, c2 = 2 * (tid & 31);          // rows r, r + 8, r + 16, r + 24 of a slab
+  const int nk = K / kTailKT;                             // K is a multiple of 64
+  const __amdgpu_buffer_rsrc_t ra = tail_rsrc(A), rb = tail_rsrc(B), rd = tail_rsrc(dk);
+  const int rowb = ld * 8;
+  // staging registers written out as scalars, one set per slot (arrays here end up in scratch memory)
+  v2f64_t a0_0, a0_1, a0_2, a0_3, a1_0, a1_1, a1_2, a1_3;
+  v2f64_t b0_0 = {0, 0}, b0_1 = {0, 0}, b0_2 = {0, 0}, b0_3 = {0, 0}, b1_0 = {0, 0}, b1_1 = {0, 0}, b1_2 = {0, 0}, b1_3 = {0, 0};
+  double d0_0, d0_1, d0_2, d0_3, d1_0, d1_1, d1_2, d1_3;
+#define CBA_XLOAD1(slot_, q_, k0_)                                                               \
+  {                                                                                              \
+    const int o = ((k0_) + r + 8 * (q_)) * rowb + c2 * 8;                                        \
+    a##slot_##_##q_ = tail_ld2(ra, o);                                                           \
+    if constexpr (!SYM) b##slot_##_##q_ = tail_ld2(rb, o);                                       \
+    d##slot_##_##q_ = tail_ld1(rd, ((k0_) + r + 8 * (q_)) * 8);                                  \
+  }
+#define CBA_XLOAD(slot_, k0_) { CBA_XLOAD1(slot_, 0, k0_) CBA_XLOAD1(slot_, 1, k0_) CBA_XLOAD1(slot_, 2, k0_) CBA_XLOAD1(slot_, 3, k0_) }
+#define CBA_XSTORE1(buf_, slot_, q_)                                                             \
+  {                                                                                              \
+    double* qa = sA + (buf_) * kTailKT * TS + (r + 8 * (q_)) * TS + c2;                          \
+    double* qb = sB + (buf_) * kTailKT * TS + (r + 8 * (q_)) * TS + c2;                          \
+    qa[0] = a##slot_##_##q_.x * d##slot_##_##q_; qa[1] = a##slot_##_##q_.y * d##slot_##_##q_;    \
+    if constexpr (SYM) { qb[0] = a##slot_##_##q_.x; qb[1] = a##slot_##_##q_.y; }                 \
+    else { qb[0] = b##slot_##_##q_.x; qb[1] = b##slot_##_##q_.y; }                               \
+  }
+#define CBA_XSTORE(buf_, slot_) { CBA_XSTORE1(buf_, slot_, 0) CBA_XSTORE1(buf_, slot_, 1) CBA_XSTORE1(buf_, slot_, 2) CBA_XSTORE1(buf_, slot_, 3) }
+  CBA_XLOAD(0, 0);
+  CBA_XLOAD(1, (1 < nk ? 1 : nk - 1) * kTailKT);
+  CBA_XSTORE(0, 0);
+  __syncthreads();
+#define CBA_XSTEP(slot_, next_slot_)                                                                         \
+  if (kb0 + (slot_) < nk) {                                                                                  \
+    const int kb = kb0 + (slot_);                                                                            \
+    const int buf = kb & 1;                                                                                  \
+    CBA_XLOAD(slot_, (kb + 2 < nk ? kb + 2 : nk - 1) * kTailKT);                                             \
+    const double* a_s = sA + buf * kTailKT * TS;                                                             \
+    const double* b_s = sB + buf * kTailKT * TS;                                                             \
+    /* operands of k-step kk + 4 are read before the MFMAs of step kk are issued (the compiler's own order, read -> wait -> */ \
+    /* 4 MFMAs, left the matrix pipe idle for an LDS round trip per step) */                                 \
+    double af[2][2], bf[2][2];                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) af[0][i] = a_s[lk * TS + wm0 + i * 16 + li];               \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) bf[0][j] = b_s[lk * TS + wn0 + j * 16 + li];               \
+    _Pragma("unroll") for (int kk = 0; kk < kTailKT; kk += 4) {                                              \
+      const int cur = (kk >> 2) & 1, nxt = cur ^ 1;                                                          \
+      if (kk + 4 < kTailKT) {                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) af[nxt][i] = a_s[(kk + 4 + lk) * TS + wm0 + i * 16 + li]; \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) bf[nxt][j] = b_s[(kk + 4 + lk) * TS + wn0 + j * 16 + li]; \
+      }                                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);      \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }                                                                                                        \
+    CBA_XSTORE(buf ^ 1, next_slot_);                                                                         \
+    __syncthreads();                                                                                         \
+  }
+#pragma nounroll
+  for (int kb0 = 0; kb0 < nk; kb0 += 2) {
+    CBA_XSTEP(0, 1)
+    CBA_XSTEP(1, 0)
+  }
+#undef CBA_XSTEP
+#undef CBA_XLOAD
+#undef CBA_XLOAD1
+#undef CBA_XSTORE
+#undef CBA_XSTORE1
+}
+
+}  // namespace cba
 using namespace cba;
 namespace cba { int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWorkspace& w, double* x, hipStream_t s); }
 
@@ -18,20 +95,6 @@ static float timeit(hipEvent_t e0, hipEvent_t e1) { float ms; hipEventSynchroniz
 struct Case { int n, n_fact; };
 static double g_rate = 0; static int g_launches = 0;
 
-__global__ void __launch_bounds__(256, 2) k_mma2_only(const double* S, int ld, const double* dvec, int K, int ntc, double* out) {
-  __shared__ double smem[2 * kInner * TS];
-  double* sA = smem;
-  double* sB = smem + 2 * KT * TS;
-  const int c = blockIdx.x % ntc, r = (blockIdx.x / ntc) % (2 * ntc);
-  v4f64 acc[2][4];
-  for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
-  for (int k = 0; k < K; k += 1024) {
-    const int kk = K - k < 1024 ? K - k : 1024;
-    tail_mma2(acc, S + (size_t)k * ld + r * kInner, S + (size_t)k * ld + c * 2 * kInner, ld, dvec + k, kk, sA, sB);
-  }
-  double v = 0; for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) for (int q = 0; q < 4; ++q) v += acc[i][j][q];
-  if (v == 1.2345e300) out[blockIdx.x] = v;
-}
 // synthetic ceiling of the helpers' inner loop: every workgroup accumulates one 64 x 64 tile over K rows, no flags
 template <bool SYM>
 __global__ void __launch_bounds__(256, 2) k_mma_only(const double* S, int ld, const double* dvec, int K, int ntc, double* out, int variant) {
@@ -43,7 +106,7 @@ __global__ void __launch_bounds__(256, 2) k_mma_only(const double* S, int ld, co
   for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
   for (int k = 0; k < K; k += 1024) {
     const int kk = K - k < 1024 ? K - k : 1024;
-    if (variant == 0) tail_mma<SYM>(acc, S + (size_t)k * ld + r * kInner, S + (size_t)k * ld + c * kInner, ld, dvec + k, kk, sA, sB);
+    if (variant == 0) tail_mma_regstaged<SYM>(acc, S + (size_t)k * ld + r * kInner, S + (size_t)k * ld + c * kInner, ld, dvec + k, kk, sA, sB);
     else tail_mma_dma<SYM>(acc, S + (size_t)k * ld + r * kInner, S + (size_t)k * ld + c * kInner, ld, dvec + k, kk, smem);
   }
   double v = 0; for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int q = 0; q < 4; ++q) v += acc[i][j][q] * (1 + i + 2 * j + 4 * q);
@@ -98,21 +161,6 @@ int main(int argc, char** argv) {
     printf("REG tasks logged: %ld, span %.1f us; workgroup-time: total %.0f us = wait rows %.1f %% + k-loop %.1f %% + wait diag %.1f %% + epilogue/other %.1f %%\n",
            cnt, (double)(tmax - tmin) / 100.0, tot, 100 * wait / tot, 100 * mma / tot, 100 * dwait / tot, 100 * epi / tot);
     printf("per REG task: %.1f us (wait rows %.1f, k-loop %.1f, wait diag %.1f, rest %.1f)\n", tot / cnt, wait / cnt, mma / cnt, dwait / cnt, epi / cnt);
-    return 0;
-  }
-  if (getenv("MMA2_ONLY")) {
-    const int n = 12672, K = 4096, ntc = 48;
-    double *S, *dv, *out; hipMalloc(&S, sizeof(double) * (size_t)K * n); hipMalloc(&dv, sizeof(double) * K); hipMalloc(&out, 8 * 4096);
-    std::vector<double> h((size_t)K * n); for (size_t i = 0; i < h.size(); ++i) h[i] = ((double)((i * 2654435761u) % 2001) / 1000.0 - 1.0) * 0.05;
-    hipMemcpy(S, h.data(), h.size() * 8, hipMemcpyHostToDevice);
-    std::vector<double> hd(K, 1.5); hipMemcpy(dv, hd.data(), K * 8, hipMemcpyHostToDevice);
-    for (int grid : {256, 512, 1024, 2048}) for (int rep = 0; rep < 2; ++rep) {
-      hipEventRecord(e0, ms);
-      hipLaunchKernelGGL(k_mma2_only, dim3(grid), dim3(256), 0, ms, S, n, dv, K, ntc, out);
-      hipEventRecord(e1, ms);
-      const float t = timeit(e0, e1);
-      printf("mma2_only (64x128) grid %d K %d: %.3f ms  %.2f TFLOP/s\n", grid, K, t, grid * 2.0 * 64 * 128 * K / t / 1e9);
-    }
     return 0;
   }
   if (getenv("MMA_ONLY")) {
