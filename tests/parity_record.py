@@ -47,7 +47,9 @@ def _flush():
         policy = ("one tolerance per quantity (per case where the cases differ by construction -- a row's note says why): 10x ... 30x "
                   "the largest value seen over the cases AND over the GPU runs of rounds 3 and 4 (the default accumulation uses "
                   "floating-point atomics, so the same row moves by up to two orders of magnitude from run to run; the solver-only "
-                  "rows are deterministic and sit at ~25x); rows whose quantity names a bound (fp32 ulp of sinf / cosf, the "
+                  "rows are deterministic and sit at ~25x; rows that compare two LM TRAJECTORIES of several iterations are heavy-tailed -- an "
+                  "occasional projection stops one LM iterate apart and the iterations amplify it -- and carry a note with the "
+                  "spread seen); rows whose quantity names a bound (fp32 ulp of sinf / cosf, the "
                   "reference's own criterion, a time limit) are checked against that bound; exact = true rows must be 0")
         with open(_OUT, "w") as f:
             json.dump(dict(host=host, tolerance_policy=policy, rows=sorted(old.values(), key=lambda r: (r["case"], r["quantity"]))), f, indent=1)

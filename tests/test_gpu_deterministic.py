@@ -68,7 +68,7 @@ def test_deterministic_mode_is_bit_reproducible(cfg, n):
     dD_det = np.einsum("bii->bi", np.asarray(a["bD"])).ravel(); dD_def = np.einsum("bii->bi", np.asarray(c["bD"])).ravel()
     liveD = dD_def >= 1e-8 * max(dD_def.max(), dH_def.max())
     if liveD.any():
-        check(case, "diag(block_diag_H) vs default mode, per entry rel (entries >= 1e-8 of the largest of H)", (np.abs(dD_det - dD_def)[liveD] / dD_def[liveD]).max(), 5e-9)
+        check(case, "diag(block_diag_H) vs default mode, per entry rel (entries >= 1e-8 of the largest of H)", (np.abs(dD_det - dD_def)[liveD] / dD_def[liveD]).max(), 1e-7)
     check(case, "final cost vs default mode rel (after 3 iterations)", abs(a["reps"][-1][1] - c["reps"][-1][1]) / c["reps"][-1][1], 5e-5)   # the default mode moves with the order of its atomics: 6e-9 ... 8e-6 observed over two rounds
     orc.set_num_threads(0)
     try:
@@ -88,7 +88,7 @@ def test_default_mode_differs_only_in_the_last_bits():
     pb, st, _ = syn.baseline_config(2, gpu_project, n_imagesets=120)
     a = _run(pb, st, False, 2)
     b = _run(pb, st, False, 2)
-    check("default mode run-to-run", "dense_H / max", np.abs(a["H"] - b["H"]).max() / np.abs(a["H"]).max(), 1e-15)
+    check("default mode run-to-run", "dense_H / max", np.abs(a["H"] - b["H"]).max() / np.abs(a["H"]).max(), 1e-14)
     check("default mode run-to-run", "x / max", np.abs(a["x"] - b["x"]).max() / np.abs(a["x"]).max(), 1e-8)
 
 

@@ -118,10 +118,14 @@ def test_cpp_run_bundle_adjustment_session_matches_per_call_loop():
         assert rc == 0
         out[mode] = dict(rig=rig, camrig=camrig, pts=pts, grid=g_out[0], lastp=lastp, seconds=secs.value, iterations=iters.value)
     case = "C++ RunBundleAdjustment: session vs per-call loop (cfg 2 grid, 120 imagesets, 4 iterations)"
-    check(case, "poses abs", np.abs(out[0]["rig"] - out[1]["rig"]).max(), 5e-10)
-    check(case, "points abs", np.abs(out[0]["pts"] - out[1]["pts"]).max(), 2e-10)
-    check(case, "grid abs", np.abs(out[0]["grid"] - out[1]["grid"]).max(), 1e-9)
-    check(case, "last_projection abs [px]", np.abs(out[0]["lastp"] - out[1]["lastp"]).max(), 1e-7)
+    # two runs of the SAME code: they differ by the order of the floating-point atomics of the accumulation and, from there, by the
+    # occasional projection that stops one LM iterate apart (~1e-7 px in one residual); four LM iterations amplify that.  The spread
+    # is heavy-tailed: poses 5e-12, 3e-11 and 1.2e-9 over three recorded runs of rounds 3-4 -- hence tolerances ~20x the largest
+    note = "run-to-run spread of the default (atomic) accumulation after 4 LM iterations, heavy-tailed: 5e-12 ... 1.2e-9 seen for the poses"
+    check(case, "poses abs", np.abs(out[0]["rig"] - out[1]["rig"]).max(), 2e-8, note=note)
+    check(case, "points abs", np.abs(out[0]["pts"] - out[1]["pts"]).max(), 2e-8, note=note)
+    check(case, "grid abs", np.abs(out[0]["grid"] - out[1]["grid"]).max(), 2e-8, note=note)
+    check(case, "last_projection abs [px]", np.abs(out[0]["lastp"] - out[1]["lastp"]).max(), 1e-6, note=note)
     # measurement, not a bound (recorded in profiles/r02_parity_deviations.json): seconds of the whole loop
     check(case, "seconds, session (mode 0) (bound: one minute)", out[0]["seconds"], 60.0)
     check(case, "seconds, per-call OptimizeJointly (mode 1) (bound: one minute)", out[1]["seconds"], 60.0)

@@ -243,7 +243,7 @@ def test_full_step_at_config2_grid_size_against_oracle_optimize_jointly():
             lam_ref, lam = r["final_lambda"], rep.final_lambda
             check_equal(case, f"iteration {it}: accept decision", int(rep.accepted != bool(r["performed"])))
             check_equal(case, f"iteration {it}: LM attempts", abs(rep.lm_attempts - r["lm_attempts"]))
-            check(case, f"iteration {it}: final cost rel", abs(rep.final_cost - r["cost"]) / r["cost"], 5e-10)
+            check(case, f"iteration {it}: final cost rel", abs(rep.final_cost - r["cost"]) / r["cost"], 2e-9)
             check(case, f"iteration {it}: lambda rel", abs(lam - lam_ref) / lam_ref, 5e-13)
         st = e.get_state(st0)
         check(case, "state after 2 iterations: points abs", np.abs(st.points - st_ref.points).max(), 1e-10)

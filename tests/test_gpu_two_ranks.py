@@ -102,9 +102,9 @@ def test_two_ranks_on_one_gpu_match_the_single_process_engine(tmp_path):
         check(case, f"rank {k}: lambda rel", (np.abs(rk[k]["reps"][:, 2] - reps[:, 2]) / reps[:, 2]).max(), 5e-13)
         b, e = int(rk[k]["b"]), int(rk[k]["e"])
         check(case, f"rank {k}: own poses abs", np.abs(rk[k]["poses"] - ref.rig_tr_global[b:e]).max(), 5e-8)     # observed 2e-9
-        check(case, f"rank {k}: points abs", np.abs(rk[k]["points"] - ref.points).max(), 1.5e-8)
+        check(case, f"rank {k}: points abs", np.abs(rk[k]["points"] - ref.points).max(), 5e-8)
         check(case, f"rank {k}: camera_tr_rig abs", np.abs(rk[k]["camrig"] - ref.camera_tr_rig).max(), 5e-8)
-        check(case, f"rank {k}: grids abs", max(np.abs(rk[k]["grid0"] - ref.grids[0]).max(), np.abs(rk[k]["grid1"] - ref.grids[1]).max()), 4e-8)
+        check(case, f"rank {k}: grids abs", max(np.abs(rk[k]["grid0"] - ref.grids[0]).max(), np.abs(rk[k]["grid1"] - ref.grids[1]).max()), 1e-7)
     # the replicated part of the state is bit-identical on both ranks (same reduced system, same factorisation)
     for key in ("points", "camrig", "grid0", "grid1"):
         check_equal(case, f"replicated state identical on both ranks: {key}", int(np.count_nonzero(rk[0][key] != rk[1][key])))
@@ -144,8 +144,8 @@ def test_two_ranks_with_the_distributed_factorisation(tmp_path, world, use_colle
         check(case, f"rank {k}: costs rel", (np.abs(rk[k]["reps"][:, :2] - reps[:, :2]) / reps[:, :2]).max(), 5e-7)     # observed 1.1e-7 (3 iterations)
         b, e = int(rk[k]["b"]), int(rk[k]["e"])
         check(case, f"rank {k}: own poses abs", np.abs(rk[k]["poses"] - ref.rig_tr_global[b:e]).max(), 5e-8)     # observed 2e-9
-        check(case, f"rank {k}: points abs", np.abs(rk[k]["points"] - ref.points).max(), 1.5e-8)
-        check(case, f"rank {k}: grids abs", max(np.abs(rk[k]["grid0"] - ref.grids[0]).max(), np.abs(rk[k]["grid1"] - ref.grids[1]).max()), 4e-8)
+        check(case, f"rank {k}: points abs", np.abs(rk[k]["points"] - ref.points).max(), 5e-8)
+        check(case, f"rank {k}: grids abs", max(np.abs(rk[k]["grid0"] - ref.grids[0]).max(), np.abs(rk[k]["grid1"] - ref.grids[1]).max()), 1e-7)
     for key in ("points", "camrig", "grid0", "grid1"):
         for k in range(1, world):
             check_equal(case, f"replicated state identical on ranks 0 and {k}: {key}", int(np.count_nonzero(rk[0][key] != rk[k][key])))
@@ -166,7 +166,7 @@ def test_native_rccl_callback_world_of_one(tmp_path):
         assert r1.accepted == r2.accepted and r1.lm_attempts == r2.lm_attempts
         check("native RCCL callback, world 1", "final cost rel", abs(r1.final_cost - r2.final_cost) / r1.final_cost, 5e-8)   # lambda enters before / after the Schur product
     s1, s2 = e1.get_state(st), e2.get_state(st)
-    check("native RCCL callback, world 1", "points abs", np.abs(s1.points - s2.points).max(), 1e-8)
+    check("native RCCL callback, world 1", "points abs", np.abs(s1.points - s2.points).max(), 5e-8)
     e1.close(); e2.close(); rc.close()
 
 
@@ -188,7 +188,7 @@ def test_native_rccl_collective_world_of_one_distributed_solve(tmp_path):
             assert r1.accepted == r2.accepted and r1.lm_attempts == r2.lm_attempts
             check("native RCCL collectives, world 1, distributed solve", "final cost rel", abs(r1.final_cost - r2.final_cost) / r1.final_cost, 5e-8)
         s1, s2 = e1.get_state(st), e2.get_state(st)
-        check("native RCCL collectives, world 1, distributed solve", "points abs", np.abs(s1.points - s2.points).max(), 1e-8)
+        check("native RCCL collectives, world 1, distributed solve", "points abs", np.abs(s1.points - s2.points).max(), 5e-8)
         e1.close(); e2.close()
     finally:
         rc.close()
@@ -221,7 +221,7 @@ def test_distributed_factorisation_at_the_benchmarked_size(tmp_path, world):
         check(case, f"rank {k}: costs rel", (np.abs(rk[k]["reps"][:, :2] - reps[:, :2]) / reps[:, :2]).max(), 5e-7)
         b, e = int(rk[k]["b"]), int(rk[k]["e"])
         check(case, f"rank {k}: own poses abs", np.abs(rk[k]["poses"] - ref.rig_tr_global[b:e]).max(), 5e-8)
-        check(case, f"rank {k}: points abs", np.abs(rk[k]["points"] - ref.points).max(), 1.5e-8)
+        check(case, f"rank {k}: points abs", np.abs(rk[k]["points"] - ref.points).max(), 5e-8)
         check(case, f"rank {k}: grid abs", np.abs(rk[k]["grid0"] - ref.grids[0]).max(), 1e-7)
     for key in ("points", "grid0"):
         for k in range(1, world):
@@ -290,6 +290,6 @@ def test_native_rccl_two_ranks_on_two_gpus(tmp_path, distributed_solve):
         check_equal(case, f"rank {k}: communicator size", int(rk[k]["comm"]) - world)
         check_equal(case, f"rank {k}: LM attempts / accept decisions / valid counts", int(np.count_nonzero(rk[k]["reps"][:, 3:] != reps[:, 3:])))
         check(case, f"rank {k}: costs rel", (np.abs(rk[k]["reps"][:, :2] - reps[:, :2]) / reps[:, :2]).max(), 5e-7)
-        check(case, f"rank {k}: points abs", np.abs(rk[k]["points"] - ref.points).max(), 1.5e-8)
+        check(case, f"rank {k}: points abs", np.abs(rk[k]["points"] - ref.points).max(), 5e-8)
         check(case, f"rank {k}: grid abs", np.abs(rk[k]["grid0"] - ref.grids[0]).max(), 1e-7)
     check_equal(case, "replicated state identical on both ranks", int(np.count_nonzero(rk[0]["points"] != rk[1]["points"])))
