@@ -140,7 +140,7 @@ struct LdltWorkspace {
   double* X = nullptr;       // X = D L of a super-panel's row strip [kSuperMax][ld]
   double* invLt = nullptr;   // per 64-block: transposed inverse of the unit factor [kInner][kInner]
   // scheduling options (cba_solver_options): rows left to the final dataflow launch; back substitution as one dataflow launch
-  int tail_rows = 8192;
+  int tail_rows = 0;         // rows left to the final dataflow launch; 0 = the schedule's default (ldlt_tail_rows)
   bool back_dataflow = true;
   double* dvec = nullptr;    // n
   int* status = nullptr;
@@ -170,7 +170,7 @@ int ldlt_collect_spans(LdltWorkspace& w, GemmStats* st);
 void ldlt_workspace_free(LdltWorkspace& w);
 int ldlt_factor(double* S, int n, int ld, LdltWorkspace& w, hipStream_t s, GemmStats* trailing_stats);
 // Rows that the final dataflow launch factors (w.tail_rows clamped to the workspace's flag storage)
-int ldlt_tail_rows(const LdltWorkspace& w);
+int ldlt_tail_rows(const LdltWorkspace& w, int world = 1);
 // milliseconds of the last tail launch (waits for it); 0 when there was none
 double ldlt_tail_last_ms(LdltWorkspace& w);
 // Distributed variant (cba_config.distributed_solve): S holds this rank's PARTIAL reduced system on entry; the collectives are

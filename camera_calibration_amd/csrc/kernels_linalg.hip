@@ -1573,9 +1573,14 @@ static int super_width_at(int n_pad, int k0, int sw) {
 }
 // Rows left to the final dataflow launch (LdltWorkspace::tail_rows, cba_solver_options::factor_tail_rows), clamped to what the
 // workspace has flags for: a final launch takes up to tail_rows + sw / 2 rows
-int ldlt_tail_rows(const LdltWorkspace& w) {
+// Default: 8192 on one GPU and for the replicated solve (measured optimum at the cfg-2 and cfg-3 sizes with the LDS-DMA helper
+// loop).  In the distributed solve the final launch is work EVERY rank repeats while the bulk updates in front of it are split, so
+// the optimum moves towards more super-panels: from the single-GPU component times 6144 for 2-3 ranks,
+// 4096 from 4 ranks on.
+int ldlt_tail_rows(const LdltWorkspace& w, int world) {
   static const char* e = CBA_GETENV("CBA_TAIL_ROWS");      // developer switch (bench harness only)
   int v = e ? atoi(e) : w.tail_rows;
+  if (v <= 0) v = world >= 4 ? 4096 : world >= 2 ? 6144 : 8192;
   const int cap = w.tail_rows_cap - super_width() / 2;
   if (v > cap) v = cap;
   return v < 256 ? 256 : v;
@@ -1824,7 +1829,7 @@ int ldlt_factor_distributed(double* S, int n_fact, int ld, LdltWorkspace& w, hip
   if (c.world < 1 || c.rank < 0 || c.rank >= c.world || !c.send || !c.recv) return CBA_ERR_ARG;
   hipStream_t s2 = w.far_stream;
   int nsp = 0;
-  for (int k0 = 0; n_fact - k0 > ldlt_tail_rows(w) + W / 2 && n_pad - (k0 + W) >= 1024; k0 += W) ++nsp;
+  for (int k0 = 0; n_fact - k0 > ldlt_tail_rows(w, c.world) + W / 2 && n_pad - (k0 + W) >= 1024; k0 += W) ++nsp;
   int rc;
   if (nsp == 0) {
     // small systems: one dataflow launch on everything -- sum the packed upper triangle, factor replicated

@@ -41,7 +41,7 @@ class CbaSolverOptions(C.Structure):
     _fields_ = [("factor_tail_rows", C.c_int32), ("back_substitution", C.c_int32)]
 
 
-DEFAULT_FACTOR_TAIL_ROWS = 8192      # what factor_tail_rows = 0 selects (include/cba.h)
+DEFAULT_FACTOR_TAIL_ROWS = 8192      # what factor_tail_rows = 0 selects on one GPU (include/cba.h; 6144 / 4096 in the distributed solve with 2-3 / >= 4 ranks)
 
 
 class CbaConfig(C.Structure):

@@ -72,8 +72,9 @@ typedef int (*cba_collective_fn)(int32_t op, void* sendbuf, void* recvbuf, int64
  * results change only in the last bits.  All zero = defaults.  Per problem / per call -- nothing here is process-wide. */
 typedef struct {
   int32_t factor_tail_rows;   /* rows left to the FINAL dataflow launch of the two-level factorisation;
-                                 0 = default (8192), clamped to what the launch has flags for.  Smaller values give small systems
-                                 the super-panel structure of large ones (the tests use that) */
+                                 0 = default (8192; in the distributed solve, where every rank repeats the final launch, 6144 with
+                                 2-3 ranks and 4096 from 4 ranks on), clamped to what the launch has flags for.  Smaller values
+                                 give small systems the super-panel structure of large ones (the tests use that) */
   int32_t back_substitution;  /* 0 = one dataflow launch (default); 1 = panels of 256 rows (98 launches at BASELINE configs[1]) */
 } cba_solver_options;
 

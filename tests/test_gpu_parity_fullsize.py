@@ -308,8 +308,8 @@ def test_noncentral_bundle_adjustment_trajectory_on_gpu():
 def test_near_singular_reduced_system_with_tiny_lambda(n_imagesets, lambda_factor):
     """Eigen's LDLT pivots on the diagonal (LV/lm_optimizer.h:1289, 1361); the engine's blocked LDL^T does not.  The bundle-adjustment
     normal equations have ~10 gauge directions (global rotation / translation / scale, ...) that only lambda regularises, so
-    with a tiny lambda the reduced system is nearly singular -- the case where pivoting could matter.  At D = 12 525 (512- and
-    256-wide panels, look-ahead, chain stream all active) with lambda = 1e-9 x the automatic value: the engine's solution must
+    with a tiny lambda the reduced system is nearly singular -- the case where pivoting could matter.  At D = 12 525 (super-panels
+    and the final dataflow launch active) with lambda = 1e-9 x the automatic value: the engine's solution must
     satisfy the ORACLE's normal equations as well as the oracle's own pivoted solution does, and agree with it outside the
     near-null space (compared through the predicted decrease b.x, which is insensitive to gauge components).  Round 4: also at the
     FULL BASELINE configs[1] (500 imagesets: the block part at its benchmarked size), and with lambda = 0 -- the exactly singular
