@@ -197,8 +197,8 @@ def test_native_rccl_collective_world_of_one_distributed_solve(tmp_path):
 @pytest.mark.parametrize("world", [2, 8])
 def test_distributed_factorisation_at_the_benchmarked_size(tmp_path, world):
     """The distributed schedule with its DEFAULT parameters at the size of BASELINE configs[1] (D = 12 525, n_pad = 12 672: first band
-    of 2048 rows all-reduced, 10 624 rows reduce-scattered into 25 column groups, three super-panels, 6400 rows gathered for the
-    final launch), two and EIGHT processes on one GPU (eight: 7-8 imagesets per rank, the 25 column groups dealt 4 / 3 to the ranks
+    of 2048 rows all-reduced, 10 624 rows reduce-scattered into 25 column groups; two ranks: three super-panels and 6400 rows gathered
+    for the final launch, eight ranks: four and 4352 -- the rank-dependent default of ldlt_tail_rows), two and EIGHT processes on one GPU (eight: 7-8 imagesets per rank, the 25 column groups dealt 4 / 3 to the ranks
     -- the ownership the first real 8-GPU run will have) with the collectives through a cba_collective_fn (host-staged gloo),
     three LM iterations against the single-process engine."""
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True, True, True), nprocs=world, join=True)
