@@ -30,7 +30,7 @@ case $WHAT in
   chain)
     # round 4: the chain's blocked diagonal factorisation alone (phase by phase), then the dataflow launches with the chain timeline
     timeout 120 tools/bin/bench_diag 200 2>&1 | tee $O/${TAG}_diag.txt
-    TAILLOG=1 TAILS=${TAILS:-6144} timeout 300 tools/bin/bench_tail 12672 12544 2>&1 | tee $O/${TAG}_tail.txt ;;
+    TAILLOG=1 TAILS=${TAILS:-8192} timeout 300 tools/bin/bench_tail 12672 12544 2>&1 | tee $O/${TAG}_tail.txt ;;
   tail)
     TAILLOG=1 TAILS=${TAILS:-1024,6144,8192} timeout 300 tools/bin/bench_tail 12672 12544 2>&1 | tee $O/${TAG}_tail.txt ;;
   suite|record|profile)
