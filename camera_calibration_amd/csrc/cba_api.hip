@@ -145,7 +145,7 @@ struct cba_problem {
   // the side stream is the factorisation's far stream (idle during the Jacobian pass): the process must stay
   // within four HIP streams -- a fifth shares a hardware queue with another one and serialises the LDL^T streams
   // (measured twice, also with GPU_MAX_HW_QUEUES=8)
-  hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr, ev_aux2 = nullptr;
+  hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr, ev_aux2 = nullptr, ev_clear = nullptr;
   // control point -> rank in the engine's tiled order of the grid unknowns, per camera (see build_grid_order)
   int* gperm[kMaxCameras] = {};
   std::vector<int> dense_perm_host;   // reference dense column -> engine dense column (identity outside the grids)
@@ -331,22 +331,11 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
     CBA_TRY(launch_tangents(p->st[w].grids[c], p->tangents[c], p->cams[c].grid_w * p->cams[c].grid_h, p->stream));
   CBA_TRY(launch_compose_poses(p->st[w], L.n_images, L.n_cameras, p->itg, p->stream));
   PassArgs a = pass_args(p, w);
-  // side stream: the accumulation targets are cleared there (1.3 GB for H_dd at cfg 2), underneath the main launches ...
   PassArgs as = a;
   as.obs_list = p->slow_list; as.obs_count = p->slow_count; as.obs_list_cap = p->slow_cap;
   a.skip = p->slow_skip;
-  hipStream_t aux = p->ldlt.far_stream;
-  CBA_HIP(hipEventRecord(p->ev_aux0, p->stream));
-  CBA_HIP(hipStreamWaitEvent(aux, p->ev_aux0, 0));
+  hipStream_t aux = p->ldlt.far_stream, clr = p->ldlt.mid_stream;
   const size_t bs = L.block_size, nb = L.n_blocks;
-  CBA_HIP(hipMemsetAsync(p->Dblk, 0, sizeof(double) * nb * bs * bs, aux));
-  CBA_HIP(hipMemsetAsync(p->bblk, 0, sizeof(double) * nb * bs, aux));
-  if (L.eliminate_points)
-    CBA_HIP(hipMemsetAsync(p->B, 0, sizeof(double) * (size_t)p->Kpad * p->n_pad, aux));
-  else if (p->Kpad > L.block_dof)     // padding rows of B (the strips below overwrite everything else, zeros included)
-    CBA_HIP(hipMemsetAsync(p->B + (size_t)L.block_dof * p->n_pad, 0, sizeof(double) * (size_t)(p->Kpad - L.block_dof) * p->n_pad, aux));
-  CBA_HIP(hipMemsetAsync(p->Hdd, 0, sizeof(double) * (size_t)p->n_pad * p->n_pad, aux));
-  CBA_HIP(hipMemsetAsync(p->bd, 0, sizeof(double) * (size_t)p->n_pad, aux));
   CBA_HIP(hipMemsetAsync(p->fd_redo_count + 2, 0, sizeof(int), p->stream));      // tasks that found a follow-up list full, this pass
   CBA_TRY(launch_base_project(a, p->model_mask, p->cost_ref, p->pixels, p->flags, p->slow_list, p->slow_count, p->slow_cap, p->slow_skip, p->straggler_threshold, p->fd_slow, p->stream));
   // ... and the stragglers of the base projection (long projection chains, see k_base_project_slow) are finished there,
@@ -361,7 +350,22 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   CBA_TRY(launch_fd_tasks(a, p->model_mask, p->tasks_per_obs, L.localize_only, p->pixels, p->flags, p->fd_out, p->fd_ok, p->fd_redo[0], p->fd_redo_count, p->fd_redo_cap,
                           p->fd_redo_count + 2, p->stream));
   CBA_TRY(timer_end(p, 3, 0, 0, 1));
+  // Third stream: the accumulation targets are cleared (1.3 GB for H_dd at cfg 2) underneath the finite-difference launch.  Round 3
+  // issued the memsets first, on the side stream: the 0.2 ms fill of H_dd then held the chip before the base projection of the pass
+  // got a workgroup slot (profiles/r04_v2_step_timeline_cfg2.txt: base projection 0.25 ms after the tangents); queued behind the
+  // VALU-bound FD kernel the fill's workgroups take slots as they come free.
+  CBA_HIP(hipStreamWaitEvent(clr, p->ev_aux2, 0));            // behind the base projection of this pass
+  CBA_HIP(hipMemsetAsync(p->Dblk, 0, sizeof(double) * nb * bs * bs, clr));
+  CBA_HIP(hipMemsetAsync(p->bblk, 0, sizeof(double) * nb * bs, clr));
+  if (L.eliminate_points)
+    CBA_HIP(hipMemsetAsync(p->B, 0, sizeof(double) * (size_t)p->Kpad * p->n_pad, clr));
+  else if (p->Kpad > L.block_dof)     // padding rows of B (the strips below overwrite everything else, zeros included)
+    CBA_HIP(hipMemsetAsync(p->B + (size_t)L.block_dof * p->n_pad, 0, sizeof(double) * (size_t)(p->Kpad - L.block_dof) * p->n_pad, clr));
+  CBA_HIP(hipMemsetAsync(p->Hdd, 0, sizeof(double) * (size_t)p->n_pad * p->n_pad, clr));
+  CBA_HIP(hipMemsetAsync(p->bd, 0, sizeof(double) * (size_t)p->n_pad, clr));
+  CBA_HIP(hipEventRecord(p->ev_clear, clr));
   CBA_HIP(hipStreamWaitEvent(p->stream, p->ev_aux1, 0));
+  CBA_HIP(hipStreamWaitEvent(p->stream, p->ev_clear, 0));
   a.skip = nullptr;
   // (Running the assembly / accumulation of one chunk of imagesets next to the finite-difference launches of the
   // next chunk was measured and gained nothing: the two share the same CUs and the sum stayed the same.)
@@ -554,6 +558,7 @@ int cba_create(const cba_config* config, cba_problem** out) {
   CBA_HIP(hipEventCreateWithFlags(&p->ev_aux0, hipEventDisableTiming));
   CBA_HIP(hipEventCreateWithFlags(&p->ev_aux1, hipEventDisableTiming));
   CBA_HIP(hipEventCreateWithFlags(&p->ev_aux2, hipEventDisableTiming));
+  CBA_HIP(hipEventCreateWithFlags(&p->ev_clear, hipEventDisableTiming));
   CBA_TRY(dev_alloc(&p->slow_count, 1));
   CBA_HIP(hipMemset(p->slow_count, 0, sizeof(int)));
   for (int c = 0; c < L.n_cameras; ++c) p->model_mask |= (p->cams[c].model_type == CBA_CENTRAL_GENERIC) ? 1 : 2;
@@ -690,6 +695,7 @@ void cba_destroy(cba_problem* p) {
   if (p->ev_aux0) hipEventDestroy(p->ev_aux0);
   if (p->ev_aux1) hipEventDestroy(p->ev_aux1);
   if (p->ev_aux2) hipEventDestroy(p->ev_aux2);
+  if (p->ev_clear) hipEventDestroy(p->ev_clear);
   delete p;
 }
 
