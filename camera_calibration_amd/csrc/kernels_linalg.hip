@@ -586,18 +586,19 @@ __device__ __forceinline__ void tile_mma_lds(v4f64 (&acc)[2][2], const double* A
 //
 //   chain workgroup (the first one to arrive): for r = r0, r0 + 1, ...: X = invL_{r-1} U_{r-1,r} (both operands in LDS: the
 //       inverse it has just computed never leaves the CU), L_{r-1,r} = X / d published, T_rr = P_r - L^T X, 64 pivots
-//       (ldlt_diag_core), L_rr / d / invL_rr published.  No launch, no stream event, no other tile on its critical path.
+//       (chain_factor_blocked), L_rr / d / invL_rr published.  No launch, no stream event, no other tile on its critical path.
 //   helper workgroups: tasks drawn from one ticket counter in row-major order (a task only ever waits for tasks with smaller
 //       tickets or for the chain, so the launch cannot deadlock however many workgroups are resident):
 //       PRE(r)    U_{r,r+1} = A_{r,r+1} - sum_{k<r} (d_k L_kr)^T L_{k,r+1}       in place (what the chain's next step reads)
 //       PART(r+1) P_{r+1}   = A_{r+1,r+1} - sum_{k<r} (d_k L_{k,r+1})^T L_{k,r+1}  in place
 //       REG(r,c)  U = A_rc - sum_{k<r} (d_k L_kr)^T L_kc, then (after block r is factored) X = invL_r U, L_rc = X / d_r.
 //   LEFT-looking: a tile is read once, accumulated in registers over all earlier block rows (one K loop that follows the
-//   frontier of finished rows: as many ready rows per batch as there are, at most 16) and written once -- no read-modify-write
-//   of the trailing matrix per panel.  Only S is read: the update uses d_k L_k^T L_k (L scaled while staged), no panel buffer.
+//   frontier of finished rows: as many ready rows per batch as there are, at most 32) and written once -- no read-modify-write
+//   of the trailing matrix per panel.  Only S is read: the update uses d_k L_k^T L_k (the A fragments are scaled by d_k on their
+//   way from LDS to the MFMA), no panel buffer.
 //
 // Cross-workgroup visibility: everything another workgroup reads is written with agent-scope stores (sc1, write-through) and
-// read with agent-scope loads (sc1 buffer loads, 16 B per lane); a flag is raised after s_waitcnt vmcnt(0) + barrier.  Flags hold
+// read with agent-scope loads (sc1 buffer loads / sc1 LDS-DMA, 16 B per lane); a flag is raised after s_waitcnt vmcnt(0) + barrier.  Flags hold
 // the number of the factorisation call ("epoch"), so nothing has to be cleared between calls.  Every spin is bounded
 // (kTailTimeoutTicks of the 100 MHz clock): on a timeout the launch sets status 3, raises the abort flag and ends.
 // ------------------------------------------------------------------------------------------------
