@@ -1981,8 +1981,8 @@ __global__ void __launch_bounds__(256) k_back_panel_update(const double* __restr
 // store instruction, so the consumer needs a single agent-scope load per entry to get value AND validity (a separate flag
 // costs a second L2 round trip per block: the chain is 196 blocks long).  Workgroups are dispatched in index order and only
 // wait for lower indices, so the launch cannot deadlock; every spin is bounded like in the tail launch.
-// Chain per block: one load round trip + two 64 x 64 matrix-vector products out of registers ~ 2.5 us (the 98 launches of
-// the panel version: 6 us per 64 rows).
+// Chain per block: one load round trip + two 64 x 64 matrix-vector products out of registers ~ 1.5 us since round 4 (2.8 in
+// round 3; the 98 launches of the panel version: 6 us per 64 rows).
 struct BackArgs {
   const double* S; int ld; int n_fact; int zcol;
   const double* invLt;
@@ -1991,32 +1991,54 @@ struct BackArgs {
   double tag;
   int* status;
 };
+// Round 4: (1) a lane's 16 columns of a 64-column block are 8 jj + 2 q4 + {0, 1}, jj = 0 ... 7 -- one 16-byte load per jj, the four
+// lanes of a row read 64 contiguous bytes per instruction; with 16 consecutive columns per lane a wavefront-load touched 64 cache
+// lines and the strip loop, not the chain, set the pace: 0.56 -> 0.34 ms at BASELINE configs[1].  (2) x_c is double-buffered in
+// LDS (one barrier per column block) and the strip entries of the next column block are in flight while x_c is polled.
+// (Several 64-blocks per workgroup, handing x over through LDS instead of L2, were built and measured: 0.46 ms with two, 0.76 ms
+// with four blocks -- the barriers of 8 / 16 wavefronts cost more per column block than the saved round trips,
+// profiles/r04_back_substitution_blocks.txt.)
 __global__ void __launch_bounds__(256) k_back_dataflow(BackArgs a) {
-  __shared__ double s_x[kInner];
+  __shared__ double s_x[2][kInner];
   __shared__ double s_t[kInner];
   __shared__ int s_ok;
   const int nblk = (a.n_fact + kInner - 1) / kInner;
   const int r = nblk - 1 - (int)blockIdx.x;
-  const int tid = threadIdx.x, p = tid >> 2, q4 = tid & 3;     // row p of the block, quarter q4 of a 64-column block
+  const int tid = threadIdx.x, p = tid >> 2, q4 = tid & 3;     // row p of the block, lane q4 of the row's four
   const int j0 = r * kInner;
   const int rows = a.n_fact - j0 < kInner ? a.n_fact - j0 : kInner;
-  // this lane's slice of the stored inverse: x_r[p] = sum_{p'} invLt[p][p'] t[p'], p' in [16 q4, 16 q4 + 16)
-  double inv[16];
-  {
-    const double* ip = a.invLt + (size_t)r * kInner * kInner + (size_t)p * kInner + 16 * q4;
+  const bool rlive = p < rows;
+  auto ld16 = [&](const double* base, double (&v)[16], bool on, int cw) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) inv[j] = ip[j];
-  }
-  const double z = (p < rows) ? a.S[(size_t)(j0 + p) * a.ld + a.zcol] : 0.0;
-  const double* row = a.S + (size_t)(j0 + (p < rows ? p : 0)) * a.ld;
+    for (int jj = 0; jj < 8; ++jj) {
+      const int col = 8 * jj + 2 * q4;
+      double2 t = make_double2(0.0, 0.0);
+      if (on && col < cw) t = *reinterpret_cast<const double2*>(base + col);      // cw is even (n_fact is a multiple of 64)
+      v[2 * jj] = t.x; v[2 * jj + 1] = t.y;
+    }
+  };
+  auto dot16 = [&](const double (&v)[16], const double* xs) {
+    double sum = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) sum += v[2 * jj] * xs[8 * jj + 2 * q4] + v[2 * jj + 1] * xs[8 * jj + 2 * q4 + 1];
+    return sum;
+  };
+  // this lane's slice of the stored inverse: x_r[p] = sum_{p'} invLt[p][p'] t[p'] over the lane's 16 columns p'
+  double inv[16];
+  ld16(a.invLt + (size_t)r * kInner * kInner + (size_t)p * kInner, inv, true, kInner);
+  const double* row = a.S + (size_t)(j0 + (rlive ? p : 0)) * a.ld;
+  const double z = rlive ? row[a.zcol] : 0.0;
   double acc = 0.0;
   const __amdgpu_buffer_rsrc_t rx = tail_rsrc(a.xe);
+  double l[16], ln[16];
+  {
+    const int c = nblk - 1;
+    ld16(row + (size_t)c * kInner, l, rlive && c > r, a.n_fact - c * kInner < kInner ? a.n_fact - c * kInner : kInner);
+  }
   for (int c = nblk - 1; c > r; --c) {
-    // the strip's entries do not depend on x: in flight while the pair is polled
-    double l[16];
-    const int cw = a.n_fact - c * kInner < kInner ? a.n_fact - c * kInner : kInner;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) l[j] = (16 * q4 + j < cw) ? row[c * kInner + 16 * q4 + j] : 0.0;
+    // the strip's entries do not depend on x: those of the next column block are in flight while this one's x is polled
+    ld16(row + (size_t)(c - 1) * kInner, ln, rlive && c - 1 > r, kInner);
+    double* xs = s_x[c & 1];
     if (tid < kInner) {
       const unsigned long long t0 = wall_clock64();
       v2f64_t v;
@@ -2028,25 +2050,23 @@ __global__ void __launch_bounds__(256) k_back_dataflow(BackArgs a) {
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 255u) == 0 && __builtin_amdgcn_readfirstlane((int)(wall_clock64() - t0 > kTailTimeoutTicks))) { ok = false; break; }
       }
-      s_x[tid] = v.x;
+      xs[tid] = v.x;
       if (tid == 0) { s_ok = ok ? 1 : 0; if (!ok) atomicExch(a.status, 3); }
     }
-    __syncthreads();
+    __syncthreads();            // (the next write to this buffer is two column blocks away: behind the next barrier)
     if (!s_ok) return;
+    acc += dot16(l, xs);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc += l[j] * s_x[16 * q4 + j];
-    __syncthreads();
+    for (int j = 0; j < 16; ++j) l[j] = ln[j];
   }
   acc += __shfl_xor(acc, 1, 64);
   acc += __shfl_xor(acc, 2, 64);
-  if (q4 == 0) s_t[p] = (p < rows) ? z - acc : 0.0;
+  if (q4 == 0) s_t[p] = rlive ? z - acc : 0.0;
   __syncthreads();
-  double xr = 0.0;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) xr += inv[j] * s_t[16 * q4 + j];
+  double xr = dot16(inv, s_t);
   xr += __shfl_xor(xr, 1, 64);
   xr += __shfl_xor(xr, 2, 64);
-  if (q4 == 0 && p < rows) {
+  if (q4 == 0 && rlive) {
     v2f64_t v; v.x = xr; v.y = a.tag;
     tail_st2(rx, (j0 + p) * 16, 0, v);
     a.x[j0 + p] = xr;
