@@ -19,11 +19,14 @@ void set_error(const std::string& msg) { g_error = msg; }
 
 // implemented in kernels_linalg.hip
 int launch_dinv_times_B_ld(const double* Dinv, const double* B, int bs, int nb, int dd, int ld, double* W, hipStream_t s);
+int launch_gemv_t_partial(const double* M, int K, int n, int ld, const double* v, double* partial_ws, hipStream_t s);
+int launch_gemv_t_final(int n, const double* base, double* y, int ystride, const double* partial_ws, int n_zero, hipStream_t s);
 int launch_gemv_t_strided(const double* M, int K, int n, int ld, const double* v, const double* base, double* y,
                           int ystride, double* partial_ws, hipStream_t s);
 int gemv_t_workspace_doubles(int n);
 int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const double* Cin, double* C, int n_pad, int ld,
-               int n_real, int add_diag, double lambda, const unsigned long long* kmask, hipStream_t s, const int* chunk_order = nullptr);
+               int n_real, int add_diag, double lambda, const unsigned long long* kmask, hipStream_t s, const int* chunk_order = nullptr,
+               int keep_col = -1);
 int schur_chunk_count(int n_pad);
 void schur_chunk_order(const unsigned long long* mask_host, int n_pad, int Kpad, int* order);
 int schur_mask_words(int Kpad);
@@ -169,6 +172,7 @@ struct cba_problem {
   int64_t* fd_redo[2] = {nullptr, nullptr}; int* fd_redo_count = nullptr;   // counts: [0] main list, [1] side-stream list, [2] tasks that found a list full
   int fd_redo_cap = 0;
   double last_lambda = 0;
+  double* pin_status = nullptr;   // pinned host memory: {status, ldlt status, x[0]} of the last solve
   double last_x0 = 0;     // x[0] of the last solve (read back with the status words: the NaN test of lm_optimizer.h:905 needs no second wait)
 };
 
@@ -413,6 +417,9 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   return CBA_OK;
 }
 
+__global__ void k_solve_status(const int* __restrict__ s0, const int* __restrict__ s1, const double* __restrict__ x, double* __restrict__ out) {
+  if (threadIdx.x == 0) { out[0] = (double)*s0; out[1] = (double)*s1; out[2] = x[0]; }
+}
 // Builds S (+ right-hand side in its last column) for `lambda`, factors and solves; x (device) = full update.
 static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
   const Layout& L = p->L;
@@ -421,6 +428,27 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
   CBA_HIP(hipMemsetAsync(p->status, 0, sizeof(int), p->stream));
   CBA_HIP(hipMemsetAsync(p->ldlt.status, 0, sizeof(int), p->stream));
   CBA_TRY(launch_block_inverse(p->Dblk, p->bblk, lambda, bs, nb, p->Dinv, p->dinvb, p->status, p->stream));
+  // Side stream, next to W = D^-1 B and the Schur product (MFMA-bound, bandwidth to spare): the partial sums of the right-hand
+  // side B^T D^-1 b (one pass over B), the touch masks on their way to the host, and the control words of the factorisation's first
+  // dataflow launch.  Round 3 had all three between the Schur product and the factorisation: 0.15 ms of small launches and gaps.
+  const int mask_tiles = p->n_pad / 128, mask_words = schur_mask_words(p->Kpad);
+  if (p->kmask_host_words < (size_t)mask_tiles * mask_words) {
+    if (p->kmask_host) CBA_HIP(hipHostFree(p->kmask_host));
+    p->kmask_host_words = (size_t)mask_tiles * mask_words;
+    CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->kmask_host), p->kmask_host_words * sizeof(unsigned long long)));
+  }
+  {
+    hipStream_t side = p->ldlt.far_stream;
+    CBA_HIP(hipEventRecord(p->ev_aux0, p->stream));
+    CBA_HIP(hipStreamWaitEvent(side, p->ev_aux0, 0));
+    // right-hand side: S[j][n_pad-1] = bd[j] - sum_k B[k][j] dinvb[k]; the Schur launch leaves that column alone (keep_col)
+    CBA_TRY(launch_gemv_t_partial(p->B, L.block_dof, dd, ld, p->dinvb, p->gemv_ws, side));
+    CBA_TRY(launch_gemv_t_final(dd, p->bd, p->S + (ld - 1), ld, p->gemv_ws, p->n_pad, side));      // padding rows of the column: zero
+    // (algorithmic flops of the Schur launch = K slabs actually multiplied: counted on the host after the solve)
+    CBA_HIP(hipMemcpyAsync(p->kmask_host, p->kmask, (size_t)mask_tiles * mask_words * sizeof(unsigned long long), hipMemcpyDeviceToHost, side));
+    CBA_TRY(ldlt_clear_ctrl(p->ldlt, side));
+    CBA_HIP(hipEventRecord(p->ev_aux1, side));
+  }
   CBA_TRY(launch_dinv_times_B_ld(p->Dinv, p->B, bs, nb, dd, ld, p->W, p->stream));
   CBA_TRY(timer_begin(p, 0));
   // lambda on the diagonal / ones on the padding diagonal: single GPU: in the product; replicated multi-GPU solve: after the
@@ -431,19 +459,9 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
     CBA_HIP(hipMemcpyAsync(p->chunk_order, p->chunk_order_host, sizeof(int) * schur_chunk_count(p->n_pad), hipMemcpyHostToDevice, p->stream));
     chunk_order = p->chunk_order;
   }
-  CBA_TRY(schur_gemm(p->B, p->W, p->Kpad, ld, p->Hdd, p->S, p->n_pad, ld, dd, (!multi || (dist && p->cfg.rank == 0)) ? 1 : 0, lambda, p->kmask, p->stream, chunk_order));
+  CBA_TRY(schur_gemm(p->B, p->W, p->Kpad, ld, p->Hdd, p->S, p->n_pad, ld, dd, (!multi || (dist && p->cfg.rank == 0)) ? 1 : 0, lambda, p->kmask, p->stream, chunk_order, ld - 1));
   CBA_TRY(timer_end(p, 0, 0, 0, 1));
-  // algorithmic flops of this launch = K slabs actually multiplied (block-sparse loop): the touch masks go to pinned
-  // host memory now and are counted after the solve (no host wait in the middle of the step)
-  const int mask_tiles = p->n_pad / 128, mask_words = schur_mask_words(p->Kpad);
-  if (p->kmask_host_words < (size_t)mask_tiles * mask_words) {
-    if (p->kmask_host) CBA_HIP(hipHostFree(p->kmask_host));
-    p->kmask_host_words = (size_t)mask_tiles * mask_words;
-    CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->kmask_host), p->kmask_host_words * sizeof(unsigned long long)));
-  }
-  CBA_HIP(hipMemcpyAsync(p->kmask_host, p->kmask, (size_t)mask_tiles * mask_words * sizeof(unsigned long long), hipMemcpyDeviceToHost, p->stream));
-  // right-hand side: S[j][n_pad-1] = bd[j] - sum_k B[k][j] dinvb[k]
-  CBA_TRY(launch_gemv_t_strided(p->B, L.block_dof, dd, ld, p->dinvb, p->bd, p->S + (ld - 1), ld, p->gemv_ws, p->stream));
+  CBA_HIP(hipStreamWaitEvent(p->stream, p->ev_aux1, 0));      // the right-hand side column, the masks, the control words
   if (multi && !dist) {
     CBA_TRY(launch_pack_upper(p->S, p->n_pad, p->P, 0, p->stream));
     CBA_TRY(allreduce(p, p->P, packed_upper_doubles(p->n_pad)));
@@ -468,11 +486,14 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
   CBA_TRY(ldlt_back_solve(p->S, p->n_fact, ld, ld - 1, p->ldlt, p->x + L.block_dof, p->stream));
   // block part: x_b = D^-1 b - W x_d      (lm_optimizer.h:1366-1367)
   CBA_TRY(launch_gemv_n(p->W, L.block_dof, dd, ld, p->x + L.block_dof, p->dinvb, p->x, p->stream));
-  int st[2] = {0, 0};
-  CBA_HIP(hipMemcpyAsync(&st[0], p->status, sizeof(int), hipMemcpyDeviceToHost, p->stream));
-  CBA_HIP(hipMemcpyAsync(&st[1], p->ldlt.status, sizeof(int), hipMemcpyDeviceToHost, p->stream));
-  CBA_HIP(hipMemcpyAsync(&p->last_x0, p->x, sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  // the two status words and x[0] reach the host through ONE launch that writes pinned host memory (three device-to-host copies in
+  // a row cost 20 us each in front of the host's decision)
+  if (!p->pin_status) CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->pin_status), 4 * sizeof(double)));
+  hipLaunchKernelGGL(k_solve_status, dim3(1), dim3(64), 0, p->stream, p->status, p->ldlt.status, p->x, p->pin_status);
+  CBA_HIP(hipGetLastError());
   CBA_HIP(hipStreamSynchronize(p->stream));
+  const int st[2] = {(int)p->pin_status[0], (int)p->pin_status[1]};
+  p->last_x0 = p->pin_status[2];
   {
     double slabs = 0;
     for (int tm = 0; tm < mask_tiles; ++tm)
@@ -696,6 +717,7 @@ void cba_destroy(cba_problem* p) {
   if (p->ev_aux1) hipEventDestroy(p->ev_aux1);
   if (p->ev_aux2) hipEventDestroy(p->ev_aux2);
   if (p->ev_clear) hipEventDestroy(p->ev_clear);
+  if (p->pin_status) hipHostFree(p->pin_status);
   delete p;
 }
 

@@ -157,6 +157,7 @@ struct LdltWorkspace {
   // persistent tail launch (ldlt_tail): flags hold the number of the call that set them, nothing is cleared between calls
   unsigned* tail_flags = nullptr;    // tile flags [tail_rows_cap / 64][n / 64], then diag / upre / part flags [n / 64] each
   unsigned* tail_ctrl = nullptr;     // tickets, abort flag, role tickets, chain CU
+  bool tail_ctrl_clean = false;      // the control words are already zero for the next dataflow launch (ldlt_clear_ctrl)
   unsigned tail_epoch = 0;
   int tail_rows_cap = 0;             // largest tail this workspace has flags for
   double* back_xe = nullptr;         // back substitution (k_back_dataflow): {value, tag} pairs, 2 * n doubles
@@ -171,6 +172,7 @@ void ldlt_workspace_free(LdltWorkspace& w);
 int ldlt_factor(double* S, int n, int ld, LdltWorkspace& w, hipStream_t s, GemmStats* trailing_stats);
 // Rows that the final dataflow launch factors (w.tail_rows clamped to the workspace's flag storage)
 int ldlt_tail_rows(const LdltWorkspace& w, int world = 1);
+int ldlt_clear_ctrl(LdltWorkspace& w, hipStream_t s);
 // milliseconds of the last tail launch (waits for it); 0 when there was none
 double ldlt_tail_last_ms(LdltWorkspace& w);
 // Distributed variant (cba_config.distributed_solve): S holds this rank's PARTIAL reduced system on entry; the collectives are

@@ -251,6 +251,7 @@ struct GemmArgs {
   int n_chunks;
   int strips;                   // set by launch_gemm: strip-blocked tile order (square upper dense launches)
   int col_group, col_stride;    // distributed factorisation: owned column groups (tiles per group, group stride); 0 = all columns
+  int keep_col_p1;              // 1 + a column of C the launch must not write (the right-hand side kept in S's last column); 0 = none
 };
 
 // Developer switches are compiled only into the bench harness (tools/bench_tail.hip, tools/bench_diag.hip define CBA_DEV_SWITCHES): the
@@ -488,7 +489,7 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
         const int n = n0 + wn0 + j * 16 + li;
         double v = acc[i][j][r];
         if (SUB) v = -v;
-        g.C[(size_t)m * g.ldc + n] = v;
+        if (n + 1 != g.keep_col_p1) g.C[(size_t)m * g.ldc + n] = v;
       }
   return true;
 }
@@ -559,10 +560,12 @@ __global__ void __launch_bounds__(256) k_gemv_t_partial(const double* __restrict
   for (int k = k0; k < k1; ++k) acc += M[(size_t)k * ld + j] * v[k];
   partial[(size_t)c * n + j] = acc;
 }
+// entries [n, n_zero) of y are set to zero -- the padding rows of the right-hand side column -- except the last one, which is the
+// matrix's last diagonal entry when y is the last column of S (one, like every padding diagonal entry)
 __global__ void __launch_bounds__(256) k_gemv_t_final(const double* __restrict__ partial, int n, const double* __restrict__ base,
-                                                      double* __restrict__ y, int ystride) {
+                                                      double* __restrict__ y, int ystride, int n_zero) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
+  if (j >= n) { if (j < n_zero) y[(size_t)j * ystride] = (j == n_zero - 1) ? 1.0 : 0.0; return; }
   double acc = 0.0;
   for (int c = 0; c < kGemvChunks; ++c) acc += partial[(size_t)c * n + j];
   y[(size_t)j * ystride] = (base ? base[j] : 0.0) - acc;
@@ -571,7 +574,22 @@ int launch_gemv_t_strided(const double* M, int K, int n, int ld, const double* v
                           int ystride, double* partial_ws, hipStream_t s) {
   if (n == 0) return CBA_OK;
   hipLaunchKernelGGL(k_gemv_t_partial, dim3((n + 255) / 256, kGemvChunks), dim3(256), 0, s, M, K, n, ld, v, partial_ws);
-  hipLaunchKernelGGL(k_gemv_t_final, dim3((n + 255) / 256), dim3(256), 0, s, partial_ws, n, base, y, ystride);
+  hipLaunchKernelGGL(k_gemv_t_final, dim3((n + 255) / 256), dim3(256), 0, s, partial_ws, n, base, y, ystride, n);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+// the two stages separately: the partial sums only need M and v, the final stage writes y (solve_system runs the first next to
+// the Schur product and the second behind it)
+int launch_gemv_t_partial(const double* M, int K, int n, int ld, const double* v, double* partial_ws, hipStream_t s) {
+  if (n == 0) return CBA_OK;
+  hipLaunchKernelGGL(k_gemv_t_partial, dim3((n + 255) / 256, kGemvChunks), dim3(256), 0, s, M, K, n, ld, v, partial_ws);
+  CBA_HIP(hipGetLastError());
+  return CBA_OK;
+}
+int launch_gemv_t_final(int n, const double* base, double* y, int ystride, const double* partial_ws, int n_zero, hipStream_t s) {
+  if (n == 0 && n_zero == 0) return CBA_OK;
+  const int m = n > n_zero ? n : n_zero;
+  hipLaunchKernelGGL(k_gemv_t_final, dim3((m + 255) / 256), dim3(256), 0, s, partial_ws, n, base, y, ystride, n_zero);
   CBA_HIP(hipGetLastError());
   return CBA_OK;
 }
@@ -623,8 +641,10 @@ int launch_touch_mask(const double* B, int Kpad, int n_pad, int ld, unsigned lon
 }
 
 int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const double* Cin, double* C, int n_pad, int ld,
-               int n_real, int add_diag, double lambda, const unsigned long long* kmask, hipStream_t s, const int* chunk_order = nullptr) {
+               int n_real, int add_diag, double lambda, const unsigned long long* kmask, hipStream_t s, const int* chunk_order = nullptr,
+               int keep_col = -1) {
   GemmArgs g{};
+  g.keep_col_p1 = keep_col + 1;
   g.kmask = kmask; g.kmask_words = schur_mask_words(Kpad);
   g.chunk_order = chunk_order;
   g.A = A; g.lda = ldab; g.B = B; g.ldb = ldab; g.K = Kpad;
@@ -1683,6 +1703,13 @@ int ldlt_tail_rows(const LdltWorkspace& w, int world) {
   if (v > cap) v = cap;
   return v < 256 ? 256 : v;
 }
+// Clears the control words of the NEXT dataflow launch now (on stream s, which must be ordered in front of that launch): the
+// first launch of a factorisation then starts without a memset between it and the Schur product.
+int ldlt_clear_ctrl(LdltWorkspace& w, hipStream_t s) {
+  CBA_HIP(hipMemsetAsync(w.tail_ctrl, 0, sizeof(unsigned) * 16, s));
+  w.tail_ctrl_clean = true;
+  return CBA_OK;
+}
 double ldlt_tail_last_ms(LdltWorkspace& w) {
   if (!w.tail_timed) return 0.0;
   float ms = 0;
@@ -1718,7 +1745,8 @@ static int ldlt_tail(double* S, int n_fact, int ld, int t0, LdltWorkspace& w, hi
     for (int r = t.rt0; r < t.nr; ++r)
       for (int c = r + 1; c < t.ntc; ++c) t.ntasks_x[c % nl] += (c == r + 1 && r + 1 < t.nr) ? 2 : 1;
   }
-  CBA_HIP(hipMemsetAsync(w.tail_ctrl, 0, sizeof(unsigned) * 16, s));
+  if (w.tail_ctrl_clean) w.tail_ctrl_clean = false;            // cleared ahead of time by the caller (ldlt_clear_ctrl)
+  else CBA_HIP(hipMemsetAsync(w.tail_ctrl, 0, sizeof(unsigned) * 16, s));
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   long long grid = ntasks + 1;
