@@ -165,7 +165,7 @@ struct cba_problem {
   int* chunk_order = nullptr; int* chunk_order_host = nullptr; bool chunk_order_valid = false; unsigned chunk_order_age = 0;
   int* status = nullptr;
   LdltWorkspace ldlt;
-  KernelTimer timers[5];     // see cba_kernel_stats
+  KernelTimer timers[7];     // 0 ... 4: see cba_kernel_stats; 5: Jacobian pass, 6: solves (cba_report.t_jac / t_solve)
   // deterministic mode (cba_config.deterministic): fixed-point scale of the current pass
   unsigned long long* det_bits = nullptr; double* det_scale = nullptr;
   // finite-difference kernel: work lists of the tasks that leave their staged patch (main launch / side-stream launch)
@@ -173,6 +173,7 @@ struct cba_problem {
   int fd_redo_cap = 0;
   double last_lambda = 0;
   double* pin_status = nullptr;   // pinned host memory: {status, ldlt status, x[0]} of the last solve
+  double* pin_cost = nullptr;     // pinned host memory: the 8 reduced scalars of the Jacobian pass when their read is deferred
   double last_x0 = 0;     // x[0] of the last solve (read back with the status words: the NaN test of lm_optimizer.h:905 needs no second wait)
 };
 
@@ -425,6 +426,7 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
   const Layout& L = p->L;
   const int bs = L.block_size, nb = L.n_blocks, dd = L.dense_dof, ld = p->n_pad;
   const bool multi = p->cfg.allreduce != nullptr;
+  CBA_TRY(timer_begin(p, 6));
   CBA_HIP(hipMemsetAsync(p->status, 0, sizeof(int), p->stream));
   CBA_HIP(hipMemsetAsync(p->ldlt.status, 0, sizeof(int), p->stream));
   CBA_TRY(launch_block_inverse(p->Dblk, p->bblk, lambda, bs, nb, p->Dinv, p->dinvb, p->status, p->stream));
@@ -491,6 +493,7 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
   if (!p->pin_status) CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->pin_status), 4 * sizeof(double)));
   hipLaunchKernelGGL(k_solve_status, dim3(1), dim3(64), 0, p->stream, p->status, p->ldlt.status, p->x, p->pin_status);
   CBA_HIP(hipGetLastError());
+  CBA_TRY(timer_end(p, 6, 0, 0, 1));
   CBA_HIP(hipStreamSynchronize(p->stream));
   const int st[2] = {(int)p->pin_status[0], (int)p->pin_status[1]};
   p->last_x0 = p->pin_status[2];
@@ -718,6 +721,7 @@ void cba_destroy(cba_problem* p) {
   if (p->ev_aux2) hipEventDestroy(p->ev_aux2);
   if (p->ev_clear) hipEventDestroy(p->ev_clear);
   if (p->pin_status) hipHostFree(p->pin_status);
+  if (p->pin_cost) hipHostFree(p->pin_cost);
   delete p;
 }
 
@@ -941,18 +945,33 @@ int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double
   // ---- residual + Jacobian pass, accumulation (lm_optimizer.h:706-720) ----
   double t0 = now_s();
   // (the device-side camera descriptions hold pointers and constants only: uploaded once, by cba_create)
+  CBA_TRY(timer_begin(p, 5));
   CBA_TRY(jacobian_pass_and_accumulate(p, &report->t_accumulate));
   CBA_TRY(launch_reduce_costs(p->cost_ref, nullptr, p->flags, p->n_obs, p->red_partials, p->red8, p->stream));
-  CBA_TRY(allreduce(p, p->red8, 8));
-  CBA_TRY(read_scalars(p, p->red8, h, 8));
-  report->t_jac = now_s() - t0;
-  double last_cost = h[0];
-  report->initial_cost = last_cost;
-  report->n_residuals_valid = (int64_t)h[5];
-  report->n_jacobians_dropped = (int64_t)h[7];
-  report->final_cost = last_cost;
+  CBA_TRY(timer_end(p, 5, 0, 0, 1));
+  // One GPU and a given lambda: nothing the host does before the first solve depends on the pass's scalars, so their read rides
+  // on the solve's own wait (one host wait per LM attempt fewer: the device does not idle between the pass and the solve).  The
+  // "cost is already zero" exit of lm_optimizer.h:755-760 is then taken after that solve, whose result is discarded.
+  const bool defer_cost_read = !multi && init_lambda >= 0;
+  double last_cost = 0;
   double lambda = p->last_lambda;
-  if (last_cost == 0) { report->lambda = lambda; return CBA_OK; }   // lm_optimizer.h:755-760
+  auto take_pass_scalars = [&]() {
+    last_cost = h[0];
+    report->initial_cost = last_cost;
+    report->n_residuals_valid = (int64_t)h[5];
+    report->n_jacobians_dropped = (int64_t)h[7];
+    report->final_cost = last_cost;
+  };
+  if (defer_cost_read) {
+    if (!p->pin_cost) CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->pin_cost), 8 * sizeof(double)));
+    CBA_HIP(hipMemcpyAsync(p->pin_cost, p->red8, 8 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+  } else {
+    CBA_TRY(allreduce(p, p->red8, 8));
+    CBA_TRY(read_scalars(p, p->red8, h, 8));
+    take_pass_scalars();
+    if (last_cost == 0) { report->lambda = lambda; return CBA_OK; }   // lm_optimizer.h:755-760
+  }
+  (void)t0;
   if (init_lambda >= 0) {
     lambda = init_lambda;
   } else {  // lm_optimizer.h:766-781
@@ -969,7 +988,17 @@ int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double
     report->lm_attempts += 1;
     t0 = now_s();
     int rc = solve_system(p, lambda, report);
-    report->t_solve += now_s() - t0;
+    if (defer_cost_read && lm == 0) {      // the solve has waited for the stream: the pass's scalars are in pinned memory
+      for (int i = 0; i < 8; ++i) h[i] = p->pin_cost[i];
+      take_pass_scalars();
+      if (last_cost == 0) {                // lm_optimizer.h:755-760 (the solve above is discarded)
+        report->lm_attempts = 0;
+        report->lambda = p->last_lambda;
+        CBA_TRY(timers_collect(p));
+        report->t_jac = p->timers[5].seconds;
+        return CBA_OK;
+      }
+    }
     if (rc != CBA_OK && rc != CBA_ERR_NUMERIC) return rc;
     const double x0 = rc == CBA_OK ? p->last_x0 : NAN;
     bool failed = rc == CBA_ERR_NUMERIC || std::isnan(x0);
@@ -1017,6 +1046,8 @@ int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double
   report->t_gemm = p->timers[0].seconds;
   report->t_factor = p->timers[1].seconds;
   report->t_accumulate = p->timers[2].seconds;
+  report->t_jac = p->timers[5].seconds;       // device-side spans (HIP events), like the other stage times
+  report->t_solve = p->timers[6].seconds;
   return CBA_OK;
 }
 
