@@ -81,6 +81,21 @@ def test_poisoned_diagonal_is_reported_not_hung(dense_dof, poison, tail_rows):
     check_equal(case, "next solve finite", int(np.count_nonzero(~np.isfinite(x))))
 
 
+@pytest.mark.parametrize("dense_dof", [1089, 3500])
+def test_solve_is_bit_identical_run_to_run(dense_dof):
+    """The dataflow launches hand tiles over through device-scope flags (agent-scope stores / loads, LDS-DMA reads): a stale or early
+    read of another workgroup's tile would make the same system give different bits from run to run.  (tools/gpu_det_check.py does
+    the same with 30-40 repeats up to D = 22 617: profiles/r04_solve_determinism.txt.)"""
+    case = f"run-to-run determinism of the reduced solve, D = {dense_dof}"
+    s = _system(12, dense_dof, seed=4242 + dense_dof)
+    xs = [eng.schur_solve(s.block_diag_H, s.off_diag_H, s.dense_H, s.block_diag_b, s.dense_b, factor_tail_rows=rows)
+          for rows in (0, 0, 0, 512, 512, 512)]
+    check_equal(case, "default schedule: entries of x that differ between three runs",
+                int(np.count_nonzero(xs[0] != xs[1]) + np.count_nonzero(xs[0] != xs[2])))
+    check_equal(case, "super-panels + 512-row final launch: entries of x that differ between three runs",
+                int(np.count_nonzero(xs[3] != xs[4]) + np.count_nonzero(xs[3] != xs[5])))
+
+
 def test_follow_up_list_of_the_finite_difference_kernel_does_not_overflow():
     from camera_calibration_amd import synthetic as syn
     pb, st, _ = syn.baseline_config(4, lambda cam, grid, pts: eng.project(cam, grid, pts), n_imagesets=30)
