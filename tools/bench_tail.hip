@@ -87,6 +87,100 @@ __device__ __forceinline__ void tail_mma_regstaged(v4f64 (&acc)[2][2], const dou
 }
 
 }  // namespace cba
+// Experiment: the LDS-DMA K loop for TWO adjacent column blocks (64 x 128 tile, slabs of 16 rows so that two workgroups per CU
+// still fit): acc (4 waves x 32 x 64) += sum_k (d_k A[k][m]) B[k][n], B 128 columns wide.
+namespace cba {
+constexpr int kT2 = 16;                                   // slab height
+constexpr int kA2Slab = (kT2 / 2) * kDmaPair;             // 1152 doubles: pairs of 64-column rows
+constexpr int kB2Row = 2 * kInner + 16;                   // 144
+constexpr int kB2Slab = kT2 * kB2Row;                     // 2304 doubles
+constexpr int kStage2 = kA2Slab + kB2Slab;
+__device__ __forceinline__ void tail_mma_dma2(v4f64 (&acc)[2][4], const double* A_, const double* B_, int ld_, const double* dk_, int K,
+                                              double* sm) {
+  const double* A = tail_uniform(A_);
+  const double* B = tail_uniform(B_);
+  const double* dk = tail_uniform(dk_);
+  const int ld = __builtin_amdgcn_readfirstlane(ld_);
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 64, li = lane & 15, lk = lane >> 4;
+  const int nk = K / kT2;
+  const unsigned lds0 = (unsigned)(size_t)sm;
+  const unsigned rowb = (unsigned)ld * 8u;
+  // A: wave wv moves pairs 2 wv, 2 wv + 1 (lanes 0-31 slab row p, lanes 32-63 slab row p + 8); B: rows 4 wv ... 4 wv + 3, one per instruction
+  const unsigned voa = (unsigned)(2 * wv + (lane >> 5) * 8) * rowb + (unsigned)(lane & 31) * 16u;
+  const unsigned vob = (unsigned)(4 * wv) * rowb + (unsigned)lane * 16u;
+#define X2_STAGE(buf_, k0_)                                                                                    \
+  {                                                                                                            \
+    const double* ga = A + (size_t)(k0_) * ld;                                                                 \
+    const double* gb = B + (size_t)(k0_) * ld;                                                                 \
+    const unsigned base = lds0 + (unsigned)((buf_) * kStage2) * 8u;                                            \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) tail_dma16(ga, voa + q * rowb, base + (unsigned)((2 * wv + q) * kDmaPair) * 8u); \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) tail_dma16(gb, vob + q * rowb, base + (unsigned)(kA2Slab + (4 * wv + q) * kB2Row) * 8u); \
+    if (wv == 0) tail_dma4(dk + (k0_), (unsigned)lane * 4u, lds0 + (unsigned)(2 * kStage2 + (buf_) * 32) * 8u); \
+  }
+#define X2_AOFF(j_) ((((4 * (j_)) & 7) * kDmaPair) + ((j_) >> 1) * kInner)
+#define X2_MMA(buf_)                                                                                           \
+  {                                                                                                            \
+    const double* a_s = sm + (buf_) * kStage2 + lk * kDmaPair + wm0 + li;                                      \
+    const double* b_s = sm + (buf_) * kStage2 + kA2Slab + lk * kB2Row + wn0 + li;                              \
+    const double* d_s = sm + 2 * kStage2 + (buf_) * 32 + lk;                                                   \
+    double af[2][2], bf[2][4], dv[2];                                                                          \
+    dv[0] = d_s[0];                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) af[0][i] = a_s[X2_AOFF(0) + i * 16];                         \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) bf[0][j] = b_s[j * 16];                                      \
+    _Pragma("unroll") for (int s = 0; s < kT2 / 4; ++s) {                                                      \
+      const int cur = s & 1, nxt = cur ^ 1;                                                                    \
+      if (s + 1 < kT2 / 4) {                                                                                   \
+        dv[nxt] = d_s[4 * (s + 1)];                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) af[nxt][i] = a_s[X2_AOFF(s + 1) + i * 16];               \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) bf[nxt][j] = b_s[4 * (s + 1) * kB2Row + j * 16];         \
+      }                                                                                                        \
+      af[cur][0] *= dv[cur]; af[cur][1] *= dv[cur];                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                          \
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);        \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+    }                                                                                                          \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                           \
+    __syncthreads();                                                                                           \
+  }
+  X2_STAGE(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma nounroll
+  for (int kb = 0; kb < nk; kb += 2) {
+    if (kb + 1 < nk) X2_STAGE(1, (kb + 1) * kT2);
+    X2_MMA(0)
+    if (kb + 1 < nk) {
+      if (kb + 2 < nk) X2_STAGE(0, (kb + 2) * kT2);
+      X2_MMA(1)
+    }
+  }
+#undef X2_MMA
+#undef X2_AOFF
+#undef X2_STAGE
+}
+}  // namespace cba
+__global__ void __launch_bounds__(256, 2) k_mma2_only(const double* S, int ld, const double* dvec, int K, int ntc, double* out) {
+  __shared__ double smem[2 * cba::kInner * cba::TS];
+  const int c = blockIdx.x % ntc, r = (blockIdx.x / ntc) % ntc;
+  cba::v4f64 acc[2][4];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = (cba::v4f64){0.0, 0.0, 0.0, 0.0};
+  for (int k = 0; k < K; k += 1024) {
+    const int kk = K - k < 1024 ? K - k : 1024;
+    cba::tail_mma_dma2(acc, S + (size_t)k * ld + r * cba::kInner, S + (size_t)k * ld + c * 2 * cba::kInner, ld, dvec + k, kk, smem);
+  }
+  // same checksum as k_mma_only over the two 64-column halves: half h of this tile = tile (r, 2 c + h) of the 64 x 64 kernel
+  for (int h = 0; h < 2; ++h) {
+    double v = 0;
+    const int wv = threadIdx.x >> 6;
+    // wave wv holds rows wm0 + 32, columns wn0 = (wv & 1) * 64 ... + 64: tiles j = 0..3 -> columns wn0 + 16 j; half h = (wv & 1)
+    if ((wv & 1) == h) for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) for (int q = 0; q < 4; ++q) v += acc[i][j][q];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0 && (wv & 1) == h) atomicAdd(&out[(blockIdx.x * 2 + h)], v);
+  }
+}
 using namespace cba;
 namespace cba { int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWorkspace& w, double* x, hipStream_t s); }
 
@@ -161,6 +255,29 @@ int main(int argc, char** argv) {
     printf("REG tasks logged: %ld, span %.1f us; workgroup-time: total %.0f us = wait rows %.1f %% + k-loop %.1f %% + wait diag %.1f %% + epilogue/other %.1f %%\n",
            cnt, (double)(tmax - tmin) / 100.0, tot, 100 * wait / tot, 100 * mma / tot, 100 * dwait / tot, 100 * epi / tot);
     printf("per REG task: %.1f us (wait rows %.1f, k-loop %.1f, wait diag %.1f, rest %.1f)\n", tot / cnt, wait / cnt, mma / cnt, dwait / cnt, epi / cnt);
+    return 0;
+  }
+  if (getenv("MMA2_ONLY")) {
+    const int n = 12672, K = 4096, ntc = 48;
+    double *S, *dv, *out; hipMalloc(&S, sizeof(double) * (size_t)K * n); hipMalloc(&dv, sizeof(double) * K); hipMalloc(&out, 8 * 8192);
+    std::vector<double> h((size_t)K * n); for (size_t i = 0; i < h.size(); ++i) h[i] = ((double)((i * 2654435761u) % 2001) / 1000.0 - 1.0) * 0.05;
+    hipMemcpy(S, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+    std::vector<double> hd(K); for (int i = 0; i < K; ++i) hd[i] = 1.0 + 0.001 * (i % 97); hipMemcpy(dv, hd.data(), K * 8, hipMemcpyHostToDevice);
+    // reference sums of two tiles from the host (tile (0, 0..1), plain loops) for one workgroup
+    for (int grid : {128, 256, 512, 1024}) for (int rep = 0; rep < 2; ++rep) {
+      hipMemset(out, 0, 8 * 8192);
+      hipEventRecord(e0, ms);
+      hipLaunchKernelGGL(k_mma2_only, dim3(grid), dim3(256), 0, ms, S, n, dv, K, ntc, out);
+      hipEventRecord(e1, ms);
+      const float t = timeit(e0, e1);
+      double got[2]; hipMemcpy(got, out, 16, hipMemcpyDeviceToHost);
+      double ref[2] = {0, 0};
+      if (grid == 128 && rep == 0) {
+        for (int hh = 0; hh < 2; ++hh) for (int k = 0; k < K; ++k) { double sa = 0, sb = 0; for (int m = 0; m < 64; ++m) sa += h[(size_t)k * n + m]; for (int c2 = 0; c2 < 64; ++c2) sb += h[(size_t)k * n + hh * 64 + c2]; ref[hh] += hd[k] * sa * sb; }
+        printf("   tile sums device %.10e %.10e | host %.10e %.10e\n", got[0], got[1], ref[0], ref[1]);
+      }
+      printf("mma2_only (64x128, LDS-DMA, slabs of 16) grid %d K %d: %.3f ms  %.2f TFLOP/s\n", grid, K, t, grid * 2.0 * 64 * 128 * K / t / 1e9);
+    }
     return 0;
   }
   if (getenv("MMA_ONLY")) {
