@@ -133,8 +133,8 @@ typedef struct {
   int32_t lm_attempts;
   int64_t n_residuals_valid;   /* residuals with cost >= 0 in the Jacobian pass (global) */
   int64_t n_jacobians_dropped; /* valid residuals added without Jacobian (joint_optimization.cc:373-376, 446-448) */
-  double t_jac;            /* cost_and_jacobian_evaluation_time of the Jacobian pass [s] */
-  double t_solve;          /* solve_time [s] */
+  double t_jac;            /* cost_and_jacobian_evaluation_time of the Jacobian pass [s]: device-side span (HIP events) */
+  double t_solve;          /* solve_time [s], all LM attempts: device-side spans (HIP events) */
   double t_cost;           /* cost-only passes [s] */
   double t_accumulate;     /* part of t_jac spent in the JtJ accumulation kernel [s] */
   double t_gemm;           /* part of t_solve: Schur complement GEMM [s] */
