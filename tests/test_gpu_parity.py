@@ -259,6 +259,33 @@ def test_cost_pass_matches_oracle_and_invalid_residuals():
     e.close()
 
 
+@pytest.mark.parametrize("init_lambda", [-1.0, 0.5])
+def test_zero_cost_exit_leaves_the_state_alone(init_lambda):
+    """lm_optimizer.h:755-760: a pass whose cost is exactly zero (here: no observation projects -- every point sits far behind the
+    cameras, so there is no valid residual) returns before any LM attempt.  With a given lambda the engine reads the pass's scalars
+    behind its first solve (one host wait fewer per attempt) and has to discard that solve: same report, same state, and the next
+    step on a healthy state works."""
+    pb, st0, gt = syn.reference_test_problem(1, oracle_project, seed=3, num_points=60, num_poses=20)
+    bad = st0.copy()
+    bad.points[:] = bad.points * 0.0 + np.array([0.0, 0.0, -50.0])      # behind every camera
+    op = orc.OracleProblem(pb)
+    c_ref, v_ref = op.cost_pass(bad)
+    assert c_ref == 0.0 and (v_ref < 0).all()
+    e = eng.Engine(pb)
+    e.set_state(bad)
+    rep = e.step(init_lambda)
+    assert rep.initial_cost == 0.0 and rep.final_cost == 0.0
+    assert rep.lm_attempts == 0 and not rep.accepted and rep.n_residuals_valid == 0
+    after = e.get_state(bad)
+    assert np.array_equal(after.points, bad.points) and np.array_equal(after.rig_tr_global, bad.rig_tr_global)
+    for a, b in zip(after.grids, bad.grids):
+        assert np.array_equal(a, b)
+    e.set_state(st0)                               # the engine is fine afterwards
+    rep2 = e.step(-1.0)
+    assert rep2.lm_attempts >= 1 and rep2.initial_cost > 0 and np.isfinite(rep2.final_cost)
+    e.close()
+
+
 @pytest.mark.parametrize("num_cameras", [1, 2])
 def test_optimize_jointly_trajectory_matches_oracle(num_cameras):
     """Restated TestOptimizeJointly (APP/test/util.h:275-571): same iterates as the oracle, cost <= 1e-6*C."""
