@@ -81,6 +81,25 @@ def test_poisoned_diagonal_is_reported_not_hung(dense_dof, poison, tail_rows):
     check_equal(case, "next solve finite", int(np.count_nonzero(~np.isfinite(x))))
 
 
+@pytest.mark.parametrize("poison", ["zero", "nan"])
+def test_singular_pose_block_is_reported(poison):
+    """A 6 x 6 block D_i that cannot be inverted (all zeros: the first pivot is exactly zero; or a NaN on its diagonal): the
+    register-resident block inverse flags it, the call returns CBA_ERR_NUMERIC (the LM loop doubles lambda, lm_optimizer.h:905-913)
+    and the engine is usable afterwards."""
+    case = f"error path, singular pose block ({poison})"
+    s = _system(12, 700, seed=99)
+    if poison == "zero":
+        s.block_diag_H[5][:] = 0.0
+    else:
+        s.block_diag_H[5][2, 2] = np.nan
+    with pytest.raises(eng.EngineError) as ei:
+        eng.schur_solve(s.block_diag_H, s.off_diag_H, s.dense_H, s.block_diag_b, s.dense_b)
+    check_equal(case, "error code is CBA_ERR_NUMERIC (-4)", int("code -4" not in str(ei.value)))
+    s2 = _system(12, 700, seed=99)
+    x = eng.schur_solve(s2.block_diag_H, s2.off_diag_H, s2.dense_H, s2.block_diag_b, s2.dense_b)
+    check_equal(case, "next solve finite", int(np.count_nonzero(~np.isfinite(x))))
+
+
 @pytest.mark.parametrize("dense_dof", [1089, 3500])
 def test_solve_is_bit_identical_run_to_run(dense_dof):
     """The dataflow launches hand tiles over through device-scope flags (agent-scope stores / loads, LDS-DMA reads): a stale or early
