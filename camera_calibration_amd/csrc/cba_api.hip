@@ -148,7 +148,7 @@ struct cba_problem {
   // the side stream is the factorisation's far stream (idle during the Jacobian pass): the process must stay
   // within four HIP streams -- a fifth shares a hardware queue with another one and serialises the LDL^T streams
   // (measured twice, also with GPU_MAX_HW_QUEUES=8)
-  hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr, ev_aux2 = nullptr, ev_clear = nullptr;
+  hipEvent_t ev_aux0 = nullptr, ev_aux1 = nullptr, ev_aux2 = nullptr, ev_clear = nullptr, ev_mask = nullptr;
   // control point -> rank in the engine's tiled order of the grid unknowns, per camera (see build_grid_order)
   int* gperm[kMaxCameras] = {};
   std::vector<int> dense_perm_host;   // reference dense column -> engine dense column (identity outside the grids)
@@ -172,6 +172,7 @@ struct cba_problem {
   int64_t* fd_redo[2] = {nullptr, nullptr}; int* fd_redo_count = nullptr;   // counts: [0] main list, [1] side-stream list, [2] tasks that found a list full
   int fd_redo_cap = 0;
   double last_lambda = 0;
+  bool mask_pending = false;      // a touch-mask launch of the last Jacobian pass may still read B on the side stream
   double* pin_status = nullptr;   // pinned host memory: {status, ldlt status, x[0]} of the last solve
   double* pin_cost = nullptr;     // pinned host memory: the 8 reduced scalars of the Jacobian pass when their read is deferred
   double last_x0 = 0;     // x[0] of the last solve (read back with the status words: the NaN test of lm_optimizer.h:905 needs no second wait)
@@ -340,6 +341,10 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   as.obs_list = p->slow_list; as.obs_count = p->slow_count; as.obs_list_cap = p->slow_cap;
   a.skip = p->slow_skip;
   hipStream_t aux = p->ldlt.far_stream, clr = p->ldlt.mid_stream;
+  if (p->mask_pending) {      // (two passes without a solve in between: the previous pass's mask launch reads the B this one rewrites)
+    CBA_HIP(hipStreamWaitEvent(p->stream, p->ev_mask, 0));
+    p->mask_pending = false;
+  }
   const size_t bs = L.block_size, nb = L.n_blocks;
   CBA_HIP(hipMemsetAsync(p->fd_redo_count + 2, 0, sizeof(int), p->stream));      // tasks that found a follow-up list full, this pass
   CBA_TRY(launch_base_project(a, p->model_mask, p->cost_ref, p->pixels, p->flags, p->slow_list, p->slow_count, p->slow_cap, p->slow_skip, p->straggler_threshold, p->fd_slow, p->stream));
@@ -413,7 +418,13 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   }
   CBA_TRY(timer_end(p, 2, 0, 0, 1));
   if (t_acc) *t_acc += now_s() - t0;
-  CBA_TRY(launch_touch_mask(p->B, p->Kpad, p->n_pad, p->n_pad, p->kmask, p->stream));
+  // The block-sparsity mask of B is only read by the Schur product: it is built on the side stream, underneath the cost reduction,
+  // the block inverses and W = D^-1 B of the solve that follows (solve_system waits for that stream in front of the product).
+  CBA_HIP(hipEventRecord(p->ev_aux2, p->stream));
+  CBA_HIP(hipStreamWaitEvent(aux, p->ev_aux2, 0));
+  CBA_TRY(launch_touch_mask(p->B, p->Kpad, p->n_pad, p->n_pad, p->kmask, aux));
+  CBA_HIP(hipEventRecord(p->ev_mask, aux));
+  p->mask_pending = true;
   p->have_system = true;
   return CBA_OK;
 }
@@ -452,6 +463,8 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
     CBA_HIP(hipEventRecord(p->ev_aux1, side));
   }
   CBA_TRY(launch_dinv_times_B_ld(p->Dinv, p->B, bs, nb, dd, ld, p->W, p->stream));
+  CBA_HIP(hipStreamWaitEvent(p->stream, p->ev_aux1, 0));      // side stream: the touch masks (Jacobian pass), the right-hand side column, the control words
+  p->mask_pending = false;
   CBA_TRY(timer_begin(p, 0));
   // lambda on the diagonal / ones on the padding diagonal: single GPU: in the product; replicated multi-GPU solve: after the
   // all-reduce; distributed solve: rank 0 adds them to its partial system, the reduction carries them to the owners
@@ -463,7 +476,7 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
   }
   CBA_TRY(schur_gemm(p->B, p->W, p->Kpad, ld, p->Hdd, p->S, p->n_pad, ld, dd, (!multi || (dist && p->cfg.rank == 0)) ? 1 : 0, lambda, p->kmask, p->stream, chunk_order, ld - 1));
   CBA_TRY(timer_end(p, 0, 0, 0, 1));
-  CBA_HIP(hipStreamWaitEvent(p->stream, p->ev_aux1, 0));      // the right-hand side column, the masks, the control words
+
   if (multi && !dist) {
     CBA_TRY(launch_pack_upper(p->S, p->n_pad, p->P, 0, p->stream));
     CBA_TRY(allreduce(p, p->P, packed_upper_doubles(p->n_pad)));
@@ -583,6 +596,7 @@ int cba_create(const cba_config* config, cba_problem** out) {
   CBA_HIP(hipEventCreateWithFlags(&p->ev_aux1, hipEventDisableTiming));
   CBA_HIP(hipEventCreateWithFlags(&p->ev_aux2, hipEventDisableTiming));
   CBA_HIP(hipEventCreateWithFlags(&p->ev_clear, hipEventDisableTiming));
+  CBA_HIP(hipEventCreateWithFlags(&p->ev_mask, hipEventDisableTiming));
   CBA_TRY(dev_alloc(&p->slow_count, 1));
   CBA_HIP(hipMemset(p->slow_count, 0, sizeof(int)));
   for (int c = 0; c < L.n_cameras; ++c) p->model_mask |= (p->cams[c].model_type == CBA_CENTRAL_GENERIC) ? 1 : 2;
@@ -720,6 +734,7 @@ void cba_destroy(cba_problem* p) {
   if (p->ev_aux1) hipEventDestroy(p->ev_aux1);
   if (p->ev_aux2) hipEventDestroy(p->ev_aux2);
   if (p->ev_clear) hipEventDestroy(p->ev_clear);
+  if (p->ev_mask) hipEventDestroy(p->ev_mask);
   if (p->pin_status) hipHostFree(p->pin_status);
   if (p->pin_cost) hipHostFree(p->pin_cost);
   delete p;
