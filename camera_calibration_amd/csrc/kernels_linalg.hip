@@ -841,6 +841,8 @@ constexpr int kTailKT = 32;
 constexpr int kDmaPair = 2 * kInner + 16;
 constexpr int kDmaSlab = (kTailKT / 2) * kDmaPair;
 constexpr int kDmaDoubles = 4 * kDmaSlab + 2 * kTailKT;
+// (M0 = LDS base of the DMA is written here without being declared clobbered -- the compiler rejects it as a reserved register.
+// Nothing else in k_ldlt_tail uses M0: every M0 access in its ISA is one of these s_mov_b32, checked with -save-temps.)
 __device__ __forceinline__ void tail_dma16(const double* base, unsigned voff, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
 }
