@@ -51,13 +51,40 @@ def parse_args():
                     help="1 / 0: only the distributed / only the replicated factorisation of the reduced system (cba_config."
                          "distributed_solve, DESIGN.md section 6); default with more than one rank: BOTH legs are timed in this one "
                          "invocation -- replicated (one packed-upper all-reduce, the design north_star names) first, distributed "
-                         "second -- and the line reports the better one and carries both")
+                         "second -- the headline is always the replicated leg, the distributed one is carried in config.legs")
     ap.add_argument("--both-legs", action="store_true",
                     help="time both reduced solves even with one rank (with --force-allreduce: 1-GPU validation of the two-leg path)")
     ap.add_argument("--leg-timeout", type=float, default=0.0,
                     help="watchdog of the second (distributed) leg in seconds; 0 = max(120, 30 x the first leg).  When it "
                          "expires, the first leg's line is printed and every rank exits")
     return ap.parse_args()
+
+
+def _sha256(path):
+    import hashlib
+    try:
+        with open(path, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()
+    except OSError:
+        return None
+
+
+def _model_ceiling(config: int, world: int):
+    """What the N > 1 line should be read against ("the ceiling of this design"): the part of the reduced
+    solve EVERY rank repeats whatever the number of GPUs.  Single-GPU component times of round 4 / 5 at BASELINE configs[1]
+    (D = 12 525 stays fixed under weak scaling of the imagesets): the dataflow launches of the factorisation are replicated,
+    only the bulk updates split N ways; the replicated solve repeats the whole factorisation and adds the packed-upper
+    all-reduce (0.64 GB; ring over xGMI at ~300 GB/s effective)."""
+    if config != 2:
+        return None
+    dataflow = {1: 6.9, 2: 5.6, 3: 5.6}.get(world, 5.0)        # final launch of 8192 / 6144 / 4096 rows by rank count
+    bulk = {1: 5.6, 2: 7.1, 3: 7.1}.get(world, 8.5)
+    return {"per_step_floor_replicated_solve": {"passes": 3.2 + 0.7, "schur_product": 2.6, "factorisation": 12.4, "allreduce_0.64GB": 2 * (world - 1) / world * 0.64 / 0.3,
+                                                "rest_of_solve": 0.6},
+            "distributed_solve_model": {"replicated_dataflow_launches": dataflow, "bulk_updates_split": bulk / world,
+                                        "exposed_exchange": 0.7},
+            "note": "model from single-GPU component times, not a measurement: with D fixed the solve dominates and cannot scale; "
+                    "expect the weak-scaling curve of configs[1] to be set by it (DESIGN.md section 6)"}
 
 
 def _host_description():
@@ -334,7 +361,7 @@ def main():
 
     # Which legs: one rank (or an explicit --distributed-solve) -> one leg.  More than one rank -> the replicated solve first (one
     # packed-upper ncclAllReduce per Gauss-Newton step: the design north_star names, and the path with the most test coverage),
-    # then the distributed solve under a watchdog.  The line reports the better leg; if the second leg fails or hangs the first
+    # then the distributed solve under a watchdog.  The headline is always the first leg; if the second leg fails or hangs the first
     # one's line is still printed -- the first multi-GPU run cannot be lost to the less proven path.
     if not use_dist:
         leg_kinds = [False]
@@ -389,16 +416,22 @@ def main():
         dom_n = agg[0]["launches"] + agg[4]["launches"]
         ach = (dom_f / dom_s / 1e12) if dom_s > 0 else 0.0
         # HBM bytes of the dominant kernel come from PMC passes that cannot run inside the timed region; the last
-        # committed measurement (tools/rocprof_pmc.py) is quoted when the workload is the one it was taken on.
-        pmc_traffic = {}
-        pmc_path = ""
-        for cand in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-            pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", cand)
-            if os.path.exists(pmc_path):
-                break
-        if args.config == 2 and world == 1 and os.path.exists(pmc_path):
-            with open(pmc_path) as fh:
+        # committed measurement (tools/rocprof_pmc.py, tools/make_pmc_traffic.py) is quoted when the workload is the one it was
+        # taken on AND the kernel source is still the one it was taken with: the file records the sha256 of kernels_linalg.hip
+        # (no .git on the GPU box, so the file hash is the provenance).  Otherwise `traffic` is null and `traffic_stale` says why.
+        pmc_traffic, traffic_stale = {}, None
+        prof_dir = os.path.join(ROOT, "profiles")
+        cands = sorted((f for f in os.listdir(prof_dir) if f.endswith("_pmc_traffic.json") and f[0] == "r" and f[1:3].isdigit()
+                        and f[3:4] == "_" and f.count("_") == 2), reverse=True) if os.path.isdir(prof_dir) else []
+        if args.config == 2 and world == 1 and cands:
+            with open(os.path.join(prof_dir, cands[0])) as fh:
                 pmc_traffic = json.load(fh)
+            now_sha = _sha256(os.path.join(ROOT, "camera_calibration_amd", "csrc", "kernels_linalg.hip"))
+            if pmc_traffic.get("kernel_source_sha256") != now_sha:
+                traffic_stale = {"file": "profiles/" + cands[0], "measured_with_sha256": pmc_traffic.get("kernel_source_sha256"),
+                                 "current_sha256": now_sha, "bytes_per_launch_then": pmc_traffic.get("traffic_bytes_per_launch"),
+                                 "note": "kernels_linalg.hip changed since the PMC passes: the figure is not quoted as this build's traffic"}
+                pmc_traffic = {}
         out = {
             "metric": "M observations/sec per LM iteration", "value": value, "unit": "M obs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -413,7 +446,8 @@ def main():
                        "parallelism": (f"image-sharded x{world}" + (", distributed factorisation" if dist_solve else ", replicated factorisation")) if world > 1 else ("single GPU (all-reduce path forced)" if use_dist else "single GPU"),
                        "lm_attempts_per_step": [r.lm_attempts for r in reports],
                        "trajectory_restart_every": RESTART,
-                       "cost": [reports[0].initial_cost, reports[-1].final_cost], "ranks_consistent": ranks_consistent},
+                       "cost": [reports[0].initial_cost, reports[-1].final_cost], "ranks_consistent": ranks_consistent,
+                       "model_ceiling_ms": _model_ceiling(args.config, world) if world > 1 else None},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                          "library_tflops": lib_tflops, "frac_vs_library": (ach / lib_tflops) if lib_tflops else None,
@@ -421,7 +455,7 @@ def main():
                                          "timed region: C[n x n] = A^T[n x K] B[K x n], n = the padded reduced system, K = 2048 (the "
                                          "shape of a super-panel update; the library computes the full square, the kernel its upper triangle), best of 5",
                          "traffic": pmc_traffic.get("traffic_bytes_per_launch"),
-                         "traffic_unit": "bytes/launch", "traffic_source": pmc_traffic.get("source"),
+                         "traffic_unit": "bytes/launch", "traffic_source": pmc_traffic.get("source"), "traffic_stale": traffic_stale,
                          "kernel": "k_gemm_atb<128,128,64,64> (Schur product B^T D^-1 B + the super-panel updates of the LDL^T, K = the super-panel width, ~2048), kernel time",
                          "launches": dom_n, "avg_launch_ms": dom_s / max(1, dom_n) * 1e3,
                          "flops_per_launch": dom_f / max(1, dom_n),
@@ -523,26 +557,35 @@ def main():
         watchdog["timer"].daemon = True
         watchdog["timer"].start()
         second = None
+        second_err = None
         try:
             best["engine"].close()                       # the replicated leg's buffers go first (S / H_dd are 2 x 14.7 GB at config 5)
             best["engine"] = None
             second = run_leg(leg_kinds[1])
-            legs_info.append(leg_summary(second))
         except Exception as ex:                        # e.g. CBA_ERR_TIMEOUT from a dataflow launch: reported, not fatal
-            legs_info.append({"solve": "distributed", "status": "failed: " + repr(ex)[:300]})
-            second = None
-        if second is not None:
-            ok = second["ranks_consistent"] is not False
-            if ok and legs_info[-1]["value"] > legs_info[0]["value"]:
-                best = second
-                out = build_output(best) if rank == 0 else None
-            else:
+            second_err = "failed: " + repr(ex)[:300]
+        # The ranks agree on the outcome: a leg that raised on ONE rank only left the others inside (or in front of) its
+        # collectives -- the watchdog above unwinds those; ranks that did come back compare notes here before anyone goes on.
+        if use_dist:
+            flag = torch.tensor([1.0 if second_err else 0.0], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if flag.item() != 0.0 and second_err is None:
+                second_err = "failed on another rank"
+        if second_err is not None:
+            legs_info.append({"solve": "distributed", "status": second_err})
+            if second is not None and second.get("engine") is not None:
                 second["engine"].close()
-                second["engine"] = None
+            second = None
+        else:
+            legs_info.append(leg_summary(second))
+            second["engine"].close()                     # the headline leg is fixed (below): the second leg's engine is done
+            second["engine"] = None
         if rank == 0:
             out["config"]["legs"] = legs_info
-            out["config"]["legs_note"] = ("both reduced solves timed in this invocation (replicated first); value / ms_per_step are the "
-                                          "better leg's (config.parallelism names it)")
+            out["config"]["legs_note"] = ("both reduced solves timed in this invocation; value / ms_per_step are ALWAYS the first leg's -- the "
+                                          "replicated factorisation behind one packed-upper all-reduce per Gauss-Newton step, the design "
+                                          "BASELINE.json's north_star names -- so the headline is comparable from run to run; the "
+                                          "distributed factorisation is the side figure in config.legs[1]")
     if best["engine"] is None:                           # the winner was the replicated leg: a fresh engine for the convergence run
         best["engine"], best["keep"] = open_engine(best["dist_solve"])
     e = best["engine"]

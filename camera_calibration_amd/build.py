@@ -53,8 +53,68 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(out)
     if failed:
         raise RuntimeError("hipcc compilation failed")
+    check_tail_m0(os.path.join(CSRC, "kernels_linalg.o"))
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
     return LIB
+
+
+def _llvm_tool(name: str) -> str:
+    for d in (os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin"), "/opt/rocm/llvm/bin"):
+        cand = os.path.join(d, name)
+        if os.path.exists(cand):
+            return cand
+    raise RuntimeError(name + " not found")
+
+
+def disassemble_device_code(obj: str) -> str:
+    """gfx950 ISA of a compiled .hip object (llvm-objdump --offloading unpacks next to its input: done in a scratch directory)."""
+    import tempfile
+    objdump = _llvm_tool("llvm-objdump")
+    with tempfile.TemporaryDirectory() as tmp:
+        local = os.path.join(tmp, "k.o")
+        shutil.copy(obj, local)
+        subprocess.check_call([objdump, "--offloading", local], stdout=subprocess.DEVNULL, cwd=tmp)
+        dev = [f for f in os.listdir(tmp) if "gfx950" in f]
+        if len(dev) != 1:
+            raise RuntimeError(f"expected one gfx950 code object in {obj}, found {dev}")
+        return subprocess.check_output([objdump, "-d", os.path.join(tmp, dev[0])], text=True)
+
+
+# instructions that read M0 without naming it as an operand
+_IMPLICIT_M0 = ("s_sendmsg", "s_movrel", "v_movrel", "ds_gws", "s_ttrace", "v_interp", "ds_ordered_count")
+
+
+def check_tail_m0(obj: str) -> int:
+    """Build-time guard for the inline-asm LDS-DMA of k_ldlt_tail (kernels_linalg.hip: tail_dma16 / tail_dma4).
+
+    Those helpers write M0 (the LDS base of global_load_lds) from inline asm and cannot declare it clobbered (the compiler rejects
+    the clobber).  That is only correct while the compiler itself never keeps a value in M0 inside that kernel.  This check
+    disassembles the kernel and fails the build unless EVERY M0 access in it is one of ours: `s_mov_b32 m0, sN`, `s_nop 0`,
+    `global_load_lds_dword[x4]`, in that order, and no instruction with an implicit M0 operand appears.  Returns the number of
+    DMA sites checked."""
+    import re
+    asm = disassemble_device_code(obj)
+    m = re.search(r"^[0-9a-f]+ <[^>]*k_ldlt_tail[^>]*>:\n(.*?)(?=^[0-9a-f]+ <[^>]*>:|\Z)", asm, flags=re.S | re.M)
+    if not m:
+        raise RuntimeError("check_tail_m0: k_ldlt_tail not found in " + obj)
+    ins = [ln.split("//")[0].strip() for ln in m.group(1).splitlines() if ln.strip()]
+    sites = 0
+    for i, text in enumerate(ins):
+        mnem = text.split()[0] if text else ""
+        if any(mnem.startswith(x) for x in _IMPLICIT_M0):
+            raise RuntimeError(f"check_tail_m0: k_ldlt_tail contains `{text}` (implicit M0 operand) next to the inline-asm LDS-DMA")
+        if mnem.startswith("global_load_lds") or (mnem.startswith("buffer_load") and " lds" in text):
+            if i < 2 or not re.fullmatch(r"s_mov_b32 m0, s\d+", ins[i - 2]) or ins[i - 1] != "s_nop 0":
+                raise RuntimeError(f"check_tail_m0: LDS-DMA `{text}` in k_ldlt_tail is not preceded by the helper's own `s_mov_b32 m0` / `s_nop 0`")
+            sites += 1
+        elif re.search(r"\bm0\b", text):
+            ok = re.fullmatch(r"s_mov_b32 m0, s\d+", text) and i + 2 < len(ins) and ins[i + 1] == "s_nop 0" and ins[i + 2].startswith("global_load_lds")
+            if not ok:
+                raise RuntimeError(f"check_tail_m0: k_ldlt_tail uses M0 outside tail_dma16 / tail_dma4: `{text}` -- the inline asm there "
+                                   "writes M0 without a clobber; route that use around M0 or move the DMA to the builtin")
+    if sites == 0:
+        raise RuntimeError("check_tail_m0: no LDS-DMA found in k_ldlt_tail (did the helper loop change? update this check)")
+    return sites
 
 
 HOST_DIR = os.path.join(HERE, "host")

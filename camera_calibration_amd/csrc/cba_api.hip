@@ -984,7 +984,12 @@ int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double
     CBA_TRY(allreduce(p, p->red8, 8));
     CBA_TRY(read_scalars(p, p->red8, h, 8));
     take_pass_scalars();
-    if (last_cost == 0) { report->lambda = lambda; return CBA_OK; }   // lm_optimizer.h:755-760
+    if (last_cost == 0) {                                             // lm_optimizer.h:755-760
+      report->lambda = lambda;
+      CBA_TRY(timers_collect(p));
+      report->t_jac = p->timers[5].seconds;
+      return CBA_OK;
+    }
   }
   (void)t0;
   if (init_lambda >= 0) {
@@ -1003,7 +1008,9 @@ int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double
     report->lm_attempts += 1;
     t0 = now_s();
     int rc = solve_system(p, lambda, report);
+    if (rc != CBA_OK && rc != CBA_ERR_NUMERIC) return rc;      // (before pin_cost is consumed: a solve that failed early never synchronised)
     if (defer_cost_read && lm == 0) {      // the solve has waited for the stream: the pass's scalars are in pinned memory
+      CBA_HIP(hipStreamSynchronize(p->stream));                // (a no-op after a completed solve; a numeric failure may return before its wait)
       for (int i = 0; i < 8; ++i) h[i] = p->pin_cost[i];
       take_pass_scalars();
       if (last_cost == 0) {                // lm_optimizer.h:755-760 (the solve above is discarded)
@@ -1014,7 +1021,6 @@ int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double
         return CBA_OK;
       }
     }
-    if (rc != CBA_OK && rc != CBA_ERR_NUMERIC) return rc;
     const double x0 = rc == CBA_OK ? p->last_x0 : NAN;
     bool failed = rc == CBA_ERR_NUMERIC || std::isnan(x0);
     if (multi) {

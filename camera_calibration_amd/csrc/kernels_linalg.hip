@@ -842,7 +842,10 @@ constexpr int kDmaPair = 2 * kInner + 16;
 constexpr int kDmaSlab = (kTailKT / 2) * kDmaPair;
 constexpr int kDmaDoubles = 4 * kDmaSlab + 2 * kTailKT;
 // (M0 = LDS base of the DMA is written here without being declared clobbered -- the compiler rejects it as a reserved register.
-// Nothing else in k_ldlt_tail uses M0: every M0 access in its ISA is one of these s_mov_b32, checked with -save-temps.)
+// Nothing else in k_ldlt_tail may use M0.  That is enforced at BUILD time: camera_calibration_amd/build.py: check_tail_m0
+// disassembles the kernel after every compile and fails the build unless every M0 access in it is one of these s_mov_b32 directly
+// in front of its s_nop + global_load_lds, and no instruction with an implicit M0 operand appears; tests/test_host_hygiene.py runs
+// the same check and shows that it catches a foreign M0 use.)
 __device__ __forceinline__ void tail_dma16(const double* base, unsigned voff, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1" ::"s"(lds_addr), "v"(voff), "s"(base) : "memory");
 }
@@ -1575,10 +1578,17 @@ int make_main_stream(hipStream_t* s) {
   return CBA_OK;
 }
 
+static int super_width();
 int ldlt_workspace_alloc(LdltWorkspace& w, int n_pad) {
   ldlt_workspace_free(w);
-  // X = D L of a super-panel's row strip (kSuperMax rows): the K-major B operand of the bulk update
-  CBA_HIP(hipMalloc(&w.X, sizeof(double) * (size_t)kSuperMax * n_pad));
+  // X = D L of a super-panel's row strip: the K-major B operand of the bulk update.  A super-panel is at most super_width() + 512
+  // rows wide (super_width_at), never wider than the matrix
+  {
+    int x_rows = super_width() + 512;
+    if (x_rows > kSuperMax) x_rows = kSuperMax;
+    if (x_rows > n_pad) x_rows = n_pad;
+    CBA_HIP(hipMalloc(&w.X, sizeof(double) * (size_t)x_rows * n_pad));
+  }
   CBA_HIP(hipMalloc(&w.invLt, sizeof(double) * (size_t)(n_pad / kInner) * kInner * kInner));
   CBA_HIP(hipMalloc(&w.dvec, sizeof(double) * (size_t)n_pad));
   CBA_HIP(hipMalloc(&w.status, sizeof(int)));

@@ -141,14 +141,14 @@ typedef struct {
   double t_factor;         /* part of t_solve: reduced-system factorisation [s] */
 } cba_report;
 
-typedef struct cba_problem cba_problem; /* Creates the engine's HIP streams for `device` (four per device, shared by every problem on it, alive until the
+typedef struct cba_problem cba_problem; /* opaque, device-resident */
+
+/* Creates the engine's HIP streams for `device` (four per device, shared by every problem on it, alive until the
  * process exits).  Call it as early as possible: on ROCm 7.2 / MI355X a stream created before the process has
  * launched its first kernel runs the dominant GEMM ~15 % faster than one created later.  cba_create() calls it
  * itself, so this is an optimisation hook, not a requirement.  (No reference counterpart: the reference has no
  * device streams on this path.) */
 int cba_prepare_device(int32_t device);
-
-/* opaque, device-resident */
 
 const char* cba_last_error(void);
 const char* cba_version(void);

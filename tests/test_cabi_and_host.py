@@ -43,6 +43,24 @@ def test_library_exports_every_symbol_declared_in_header():
     assert b"gfx950" in L.cba_version()
 
 
+@pytest.mark.parametrize("compiler,std", [("gcc", "-std=c99"), ("g++", "-std=c++14")])
+def test_public_headers_compile_as_c99_and_cxx14(tmp_path, compiler, std):
+    # include/cba.h and include/cba_rccl.h are what a C or C++ host binds: they must stay warning-free plain C
+    import shutil
+    import subprocess
+    if shutil.which(compiler) is None:
+        pytest.skip(f"{compiler} not installed")
+    ext = ".c" if compiler == "gcc" else ".cc"
+    src = tmp_path / ("hdr" + ext)
+    src.write_text('#include "cba.h"\n#include "cba_rccl.h"\n'
+                   'int use(void) { cba_config c; cba_report r; cba_solver_options o; (void)c; (void)r; (void)o; '
+                   'return (int)sizeof(cba_camera) + CBA_ERR_TIMEOUT + CBA_RCCL_ID_BYTES + CBA_COLL_ALLGATHER + CBA_DUMP_X; }\n')
+    cmd = [compiler, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+           "-o", str(tmp_path / "hdr.o")]
+    pr = subprocess.run(cmd, capture_output=True, text=True)
+    assert pr.returncode == 0, pr.stderr
+
+
 @pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
 def test_compute_calls_fail_loudly_without_gpu():
     cam = Camera(CENTRAL_GENERIC, 64, 48, 0, 0, 63, 47, 5, 5)

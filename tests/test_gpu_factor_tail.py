@@ -11,6 +11,17 @@ from parity_record import check, check_equal
 
 pytestmark = pytest.mark.gpu
 
+# Tolerances of the solver-only rows, relative to |x|max.  The test systems are well conditioned by construction (dense part A A^T +
+# n I with 768 random columns: condition number < 10, pose blocks M M^T + 6 I), so x carries a forward error of a few units of
+# c * eps with c growing like sqrt(n) for these random sums.  Observed over rounds 3-5 (profiles/r0*_parity_deviations.json):
+# engine vs the oracle's pivoted LDL^T 1.6e-16 ... 3.8e-16; two schedules / two back substitutions of the engine against each other
+# 0 ... 3.1e-17 (most entries agree bit for bit, the largest |x| entries dominate the norm).  The bounds keep >= 10x headroom over
+# the largest value seen AND stay above what a legitimate reordering of the sums can produce (a few ulp of |x|max): 64 eps against
+# the oracle, 16 eps between schedules -- a real defect (a stale tile, a missed update) shows up at 1e-9 or worse.
+EPS = float(np.finfo(np.float64).eps)
+TOL_VS_ORACLE = 64 * EPS        # 1.4e-14
+TOL_SCHEDULES = 16 * EPS        # 3.6e-15
+
 
 def _system(n_blocks, dense_dof, seed):
     rng = np.random.default_rng(seed)
@@ -37,8 +48,8 @@ def test_dataflow_factorisation_matches_the_oracle_for_every_tail_size(dense_dof
     x_ref = orc.schur_solve(s)                     # Eigen's pivoted LDLT restated (oracle)
     scale = np.abs(x_ref).max()
     for rows, x in xs.items():
-        check(case, f"tail rows {rows}: x vs oracle / |x|max", np.abs(x - x_ref).max() / scale, 1e-14)
-    check(case, "super-panels + tail 512 vs one launch / |x|max", np.abs(xs[512] - xs[0]).max() / scale, 1e-15)
+        check(case, f"tail rows {rows}: x vs oracle / |x|max", np.abs(x - x_ref).max() / scale, TOL_VS_ORACLE)
+    check(case, "super-panels + tail 512 vs one launch / |x|max", np.abs(xs[512] - xs[0]).max() / scale, TOL_SCHEDULES)
 
 
 @pytest.mark.parametrize("dense_dof", [65, 1089, 3500, 7000])
@@ -49,7 +60,7 @@ def test_back_substitution_dataflow_launch_matches_the_panel_version(dense_dof):
     x_panels = eng.schur_solve(s.block_diag_H, s.off_diag_H, s.dense_H, s.block_diag_b, s.dense_b, back_substitution_panels=True)
     x_flow = eng.schur_solve(s.block_diag_H, s.off_diag_H, s.dense_H, s.block_diag_b, s.dense_b)
     check_equal(case, "finite", int(np.count_nonzero(~np.isfinite(x_flow)) + np.count_nonzero(~np.isfinite(x_panels))))
-    check(case, "dataflow vs panels / |x|max", np.abs(x_flow - x_panels).max() / np.abs(x_panels).max(), 1e-15)
+    check(case, "dataflow vs panels / |x|max", np.abs(x_flow - x_panels).max() / np.abs(x_panels).max(), TOL_SCHEDULES)
 
 
 @pytest.mark.parametrize("dense_dof,poison,tail_rows", [(700, "nan", 0), (3500, "nan", 1024), (3500, "zero", 1024), (3500, "zero", 0)])

@@ -47,3 +47,28 @@ def test_distributed_solve_arguments_are_validated_before_any_device_work():
             cfg.allreduce = cb
         out = C.c_void_p()
         assert L.cba_create(C.byref(cfg), C.byref(out)) == -1, (rank, world, with_cb)     # CBA_ERR_ARG (include/cba.h)
+
+
+def test_tail_kernel_uses_m0_only_inside_its_own_lds_dma(tmp_path, monkeypatch):
+    # k_ldlt_tail writes M0 from inline asm without a clobber (kernels_linalg.hip: tail_dma16); the build fails unless the ISA shows
+    # that nothing else in the kernel touches M0.  Here: the check passes on the compiled object, and it catches a foreign M0 use.
+    import shutil
+    from camera_calibration_amd import build as hb
+    obj = os.path.join(ROOT, "camera_calibration_amd", "csrc", "kernels_linalg.o")
+    if not os.path.exists(obj) or shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("kernels_linalg.o / ROCm llvm tools not present")
+    try:
+        sites = hb.check_tail_m0(obj)
+    except RuntimeError as ex:
+        if "not found" in str(ex) and "llvm-objdump" in str(ex):
+            pytest.skip(str(ex))
+        raise
+    assert sites >= 8          # 4 + 4 operand DMAs + the d vector per stage, several inlined copies
+    real = hb.disassemble_device_code(obj)
+    anchor = real.index("k_ldlt_tail")
+    body_start = real.index("\n", anchor) + 1
+    for foreign in ("\ts_mov_b32 m0, 0x100 // 000000000000: BEFC00FF\n", "\tv_readlane_b32 s4, v1, m0 // 0: 0\n", "\ts_sendmsg sendmsg(MSG_INTERRUPT) // 0: 0\n"):
+        doctored = real[:body_start] + foreign + real[body_start:]
+        monkeypatch.setattr(hb, "disassemble_device_code", lambda _o, d=doctored: d)
+        with pytest.raises(RuntimeError, match="check_tail_m0"):
+            hb.check_tail_m0(obj)

@@ -2,7 +2,7 @@
 """profiles/<tag>_pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE tables of tools/rocprof_pmc.py (two separate --pmc passes):
 HBM bytes per launch of the dominant kernel, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950.
   python tools/make_pmc_traffic.py <fetch table> <write table> <out json> <tag>"""
-import json, sys
+import hashlib, json, os, sys
 
 
 def per_call(path, counter):
@@ -24,5 +24,8 @@ out = {"kernel": "cba::k_gemm_atb<128,128,64,64,true>", "launches": n_f,
        "source": f"profiles/{tag}_pmc_FETCH_SIZE.txt + {tag}_pmc_WRITE_SIZE.txt: two separate `rocprofv3 --kernel-trace --pmc <counter>` passes over "
                  "`bench.py --steps 2 --warmup 0`; FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section), WRITE_SIZE as "
                  f"reported; average over all launches of the kernel ({n_f // 2} per step: the Schur product and the super-panel updates of the two-level factorisation)"}
+# provenance: bench.py quotes this file only while kernels_linalg.hip is the source these passes ran with
+src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "camera_calibration_amd", "csrc", "kernels_linalg.hip")
+out["kernel_source_sha256"] = hashlib.sha256(open(src, "rb").read()).hexdigest()
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))
