@@ -997,6 +997,12 @@ double orc_cost_pass(const orc_problem* pb, const orc_state* st, double* cost_ve
   return run_pass(pb, st, 0, NULL, cost_vec, NULL, 0, pb->n_images);
 }
 
+/* Compute<false> with the per-observation records filled (valid, pixel, residual, cost): what a caller needs to drive an
+ * accumulator of its own through the cost-only pass (oracle/ref_lmopt.cc feeds the reference's LMOptimizer with them). */
+double orc_cost_pass_records(const orc_problem* pb, const orc_state* st, double* cost_vec, orc_obs_record* records) {
+  return run_pass(pb, st, 0, NULL, cost_vec, records, 0, pb->n_images);
+}
+
 double orc_jacobian_pass(const orc_problem* pb, const orc_state* st, orc_system* sys, double* cost_vec,
                          orc_obs_record* records, int32_t img_begin, int32_t img_end) {
   if (sys) {

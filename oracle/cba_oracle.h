@@ -136,6 +136,7 @@ int32_t orc_dense_dof(const orc_problem* pb);
 int32_t orc_total_dof(const orc_problem* pb);
 /* Compute<false>: cost-only pass.  cost_vec has n_obs entries (-1 = invalid). */
 double orc_cost_pass(const orc_problem* pb, const orc_state* st, double* cost_vec);
+double orc_cost_pass_records(const orc_problem* pb, const orc_state* st, double* cost_vec, orc_obs_record* records);
 /* Compute<true>: residual+Jacobian pass accumulating into sys (zeroed first).
  * records may be NULL; image range [img_begin,img_end) restricts the pass (cpu_baseline sampling). */
 double orc_jacobian_pass(const orc_problem* pb, const orc_state* st, orc_system* sys,

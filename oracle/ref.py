@@ -277,3 +277,65 @@ def noncentral_grid_subtract_delta(cam, grids, delta):
     if not ok:
         raise ValueError("grid size not compiled into oracle/ref_lm.cc")
     return g.reshape(2, -1, 3)
+
+
+# ---- part 4: LV/lm_optimizer.h itself (oracle/ref_lmopt.cc -> _ref/libcalibref_lm.so) -----------------------------------
+LM_LIB_PATH = os.path.join(_HERE, "_ref", "libcalibref_lm.so")
+_lm_lib: Optional[C.CDLL] = None
+
+
+def lm_available() -> bool:
+    build()
+    return os.path.exists(LM_LIB_PATH)
+
+
+def lm_lib() -> C.CDLL:
+    """The reference's LMOptimizer<double> (OptimizeImpl, CostIsSmallerThan, SolveWithSchurComplementDenseOffDiag) compiled from
+    /root/reference/libvis/src/libvis/lm_optimizer.h; links liboracle.so for the per-observation numbers and Eigen's LDLT."""
+    global _lm_lib
+    if _lm_lib is None:
+        build()
+        if not os.path.exists(LM_LIB_PATH):
+            raise RuntimeError("oracle/_ref/libcalibref_lm.so is missing and /root/reference is not present")
+        from oracle import oracle as orc
+        orc.lib()                               # liboracle.so first (the library resolves it through its rpath as well)
+        L = C.CDLL(LM_LIB_PATH)
+        dp = C.POINTER(C.c_double)
+        L.ref_lmopt_schur_solve.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp]
+        L.ref_lmopt_cost_is_smaller_than.argtypes = [dp, dp, C.c_int]
+        L.ref_lmopt_cost_is_smaller_than.restype = C.c_int
+        L.ref_lmopt_optimize_jointly.argtypes = [C.POINTER(orc.OrcProblem), C.POINTER(orc.OrcState), C.c_int, C.c_double, dp,
+                                                 C.POINTER(C.c_int32), dp]
+        L.ref_lmopt_optimize_jointly.restype = C.c_double
+        _lm_lib = L
+    return _lm_lib
+
+
+def lmopt_schur_solve(system) -> np.ndarray:
+    """LMOptimizer::SolveWithSchurComplementDenseOffDiag (LV/lm_optimizer.h:1247-1369) on an oracle.System (upper triangles; no
+    lambda is added here, as in orc_schur_solve)."""
+    x = np.zeros(system.n_blocks * system.block_size + system.dense_dof)
+    lm_lib().ref_lmopt_schur_solve(system.block_size, system.n_blocks, system.dense_dof, _dp(system.block_diag_H),
+                                   _dp(system.off_diag_H), _dp(system.dense_H), _dp(system.block_diag_b), _dp(system.dense_b), _dp(x))
+    return x
+
+
+def lmopt_cost_is_smaller_than(left: np.ndarray, right: np.ndarray) -> bool:
+    """LMOptimizer::CostIsSmallerThan (LV/lm_optimizer.h:993-1011)."""
+    left = np.ascontiguousarray(left, dtype=np.float64)
+    right = np.ascontiguousarray(right, dtype=np.float64)
+    assert left.shape == right.shape
+    return bool(lm_lib().ref_lmopt_cost_is_smaller_than(_dp(left), _dp(right), int(left.size)))
+
+
+def lmopt_optimize_jointly(oracle_problem, st, max_iteration_count: int = 1, init_lambda: float = -1.0):
+    """OptimizeJointly's optimizer calls (APP/bundle_adjustment/joint_optimization.cc:797-812, :916-940) with the REFERENCE's
+    LMOptimizer<double>::Optimize; in place on st (and on the problem's warm-start cache).  Returns dict(cost, final_lambda,
+    performed, trace) with one trace row per outer iteration: initial_cost, final_cost, lambda, iterations_performed,
+    cost-only passes (= LM attempts that reached the cost test), Jacobian passes."""
+    lam = C.c_double(0)
+    performed = C.c_int32(0)
+    trace = np.zeros((max_iteration_count, 6))
+    cost = lm_lib().ref_lmopt_optimize_jointly(C.byref(oracle_problem.c), C.byref(oracle_problem._state(st)), max_iteration_count,
+                                               init_lambda, C.byref(lam), C.byref(performed), _dp(trace))
+    return dict(cost=cost, final_lambda=lam.value, performed=bool(performed.value), trace=trace)
