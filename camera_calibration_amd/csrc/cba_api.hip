@@ -165,7 +165,7 @@ struct cba_problem {
   int* chunk_order = nullptr; int* chunk_order_host = nullptr; bool chunk_order_valid = false; unsigned chunk_order_age = 0;
   int* status = nullptr;
   LdltWorkspace ldlt;
-  KernelTimer timers[7];     // 0 ... 4: see cba_kernel_stats; 5: Jacobian pass, 6: solves (cba_report.t_jac / t_solve)
+  KernelTimer timers[8];     // 0 ... 4: see cba_kernel_stats; 5: Jacobian pass, 6: solves, 7: cost passes queued behind a solve (cba_report.t_jac / t_solve / t_cost)
   // deterministic mode (cba_config.deterministic): fixed-point scale of the current pass
   unsigned long long* det_bits = nullptr; double* det_scale = nullptr;
   // finite-difference kernel: work lists of the tasks that leave their staged patch (main launch / side-stream launch)
@@ -302,6 +302,7 @@ static PassArgs pass_args(cba_problem* p, int which) {
   a.pose_slot = p->pose_slot;
   a.obs_list = nullptr; a.obs_count = nullptr; a.obs_list_cap = 0; a.skip = nullptr;
   a.jrec = p->jrec; a.rec_doubles = p->rec_doubles;
+  a.guard = nullptr;
   return a;
 }
 
@@ -320,9 +321,10 @@ static int allreduce(cba_problem* p, double* dev, int64_t count) {
 }
 
 // residual pass on state `which`; fills cost vector `cost_vec` and reduces to out8 (host)
-static int residual_pass(cba_problem* p, int which, double* cost_vec) {
+static int residual_pass(cba_problem* p, int which, double* cost_vec, const int* guard = nullptr) {
   CBA_TRY(launch_compose_poses(p->st[which], p->L.n_images, p->L.n_cameras, p->itg, p->stream));
   PassArgs a = pass_args(p, which);
+  a.guard = guard;
   CBA_TRY(launch_base_project(a, p->model_mask, cost_vec, p->pixels, p->flags, p->slow_list, p->slow_count, p->slow_cap, p->slow_skip, p->straggler_threshold, nullptr, p->stream));
   PassArgs as = a;
   as.obs_list = p->slow_list; as.obs_count = p->slow_count; as.obs_list_cap = p->slow_cap;
@@ -429,11 +431,27 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   return CBA_OK;
 }
 
-__global__ void k_solve_status(const int* __restrict__ s0, const int* __restrict__ s1, const double* __restrict__ x, double* __restrict__ out) {
-  if (threadIdx.x == 0) { out[0] = (double)*s0; out[1] = (double)*s1; out[2] = x[0]; }
+// out (pinned host memory): the two status words and x[0]; guard (device): non-zero when the solve broke down or x[0] is NaN (the
+// reference's NaN test, lm_optimizer.h:905) -- read by the cost pass queued behind this launch (PassArgs::guard)
+__global__ void k_solve_status(const int* __restrict__ s0, const int* __restrict__ s1, const double* __restrict__ x, double* __restrict__ out,
+                               int* __restrict__ guard) {
+  if (threadIdx.x == 0) {
+    const double x0 = x[0];
+    out[0] = (double)*s0; out[1] = (double)*s1; out[2] = x0;
+    *guard = (*s0 != 0 || *s1 != 0 || x0 != x0) ? 1 : 0;
+  }
 }
 // Builds S (+ right-hand side in its last column) for `lambda`, factors and solves; x (device) = full update.
+static int solve_finish(cba_problem* p);
+// solve_enqueue queues the whole solve on the stream (no host wait; the status words, x[0] and the guard word are written by its
+// last launch); solve_finish waits for the stream and turns the status into a return code.  cba_step queues the attempt's cost
+// pass BETWEEN the two on one GPU (PassArgs::guard keeps that pass from running behind a broken solve).
+static int solve_enqueue(cba_problem* p, double lambda, cba_report* rep);
 static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
+  CBA_TRY(solve_enqueue(p, lambda, rep));
+  return solve_finish(p);
+}
+static int solve_enqueue(cba_problem* p, double lambda, cba_report* rep) {
   const Layout& L = p->L;
   const int bs = L.block_size, nb = L.n_blocks, dd = L.dense_dof, ld = p->n_pad;
   const bool multi = p->cfg.allreduce != nullptr;
@@ -504,9 +522,14 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
   // the two status words and x[0] reach the host through ONE launch that writes pinned host memory (three device-to-host copies in
   // a row cost 20 us each in front of the host's decision)
   if (!p->pin_status) CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->pin_status), 4 * sizeof(double)));
-  hipLaunchKernelGGL(k_solve_status, dim3(1), dim3(64), 0, p->stream, p->status, p->ldlt.status, p->x, p->pin_status);
+  hipLaunchKernelGGL(k_solve_status, dim3(1), dim3(64), 0, p->stream, p->status, p->ldlt.status, p->x, p->pin_status, p->status + 1);
   CBA_HIP(hipGetLastError());
   CBA_TRY(timer_end(p, 6, 0, 0, 1));
+  (void)rep;
+  return CBA_OK;
+}
+static int solve_finish(cba_problem* p) {
+  const int mask_tiles = p->n_pad / 128, mask_words = schur_mask_words(p->Kpad);
   CBA_HIP(hipStreamSynchronize(p->stream));
   const int st[2] = {(int)p->pin_status[0], (int)p->pin_status[1]};
   p->last_x0 = p->pin_status[2];
@@ -695,7 +718,7 @@ int cba_create(const cba_config* config, cba_problem** out) {
     CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->chunk_order_host), sizeof(int) * (size_t)schur_chunk_count(p->n_pad)));
   }
   CBA_TRY(dev_alloc(&p->gemv_ws, (size_t)gemv_t_workspace_doubles(p->n_pad)));
-  CBA_TRY(dev_alloc(&p->status, 1));
+  CBA_TRY(dev_alloc(&p->status, 2));      // [0] block-inverse status, [1] guard word of the solve (k_solve_status)
   CBA_TRY(ldlt_workspace_alloc(p->ldlt, p->n_pad));
   apply_solver_options(p->ldlt, &config->solver);
   guard.q = nullptr;
@@ -978,7 +1001,7 @@ int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double
     report->final_cost = last_cost;
   };
   if (defer_cost_read) {
-    if (!p->pin_cost) CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->pin_cost), 8 * sizeof(double)));
+    if (!p->pin_cost) CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->pin_cost), 16 * sizeof(double)));
     CBA_HIP(hipMemcpyAsync(p->pin_cost, p->red8, 8 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
   } else {
     CBA_TRY(allreduce(p, p->red8, 8));
@@ -1004,10 +1027,32 @@ int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double
     lambda = init_lambda_factor * sum / dof_global;
   }
   // ---- LM attempts (lm_optimizer.h:802-965) ----
+  // One GPU: the attempt's state update, cost-only pass and cost reduction are queued BEHIND the solve before the host looks at the
+  // solve's status -- one host wait per attempt instead of two (the device no longer idles for a host round trip between the back
+  // substitution and the cost pass).  The kernels of that pass that write the warm-start cache read the solve's guard word and do
+  // nothing behind a broken solve (PassArgs::guard), so a NaN / zero-pivot attempt leaves no trace, as in the reference, which
+  // skips the cost pass for a NaN update (lm_optimizer.h:905-913).  Decisions are unchanged: the same numbers reach the same tests.
+  const bool fused = !multi;
+  if (fused && !p->pin_cost) CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->pin_cost), 16 * sizeof(double)));
   for (int lm = 0; lm < max_lm_attempts; ++lm) {
     report->lm_attempts += 1;
     t0 = now_s();
-    int rc = solve_system(p, lambda, report);
+    const int cand = p->cur ^ 1;
+    int rc;
+    if (fused) {
+      rc = solve_enqueue(p, lambda, report);
+      if (rc == CBA_OK) {
+        CBA_TRY(timer_begin(p, 7));
+        CBA_TRY(launch_apply_update(L, p->cams, p->st[p->cur], p->x, p->st[cand], p->pose_slot, p->gperm, p->stream));
+        CBA_TRY(residual_pass(p, cand, p->cost_test, p->status + 1));
+        CBA_TRY(launch_reduce_costs(p->cost_ref, p->cost_test, nullptr, p->n_obs, p->red_partials, p->red8, p->stream));
+        CBA_HIP(hipMemcpyAsync(p->pin_cost + 8, p->red8, 8 * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+        CBA_TRY(timer_end(p, 7, 0, 0, 1));
+        rc = solve_finish(p);            // the attempt's one host wait
+      }
+    } else {
+      rc = solve_system(p, lambda, report);
+    }
     if (rc != CBA_OK && rc != CBA_ERR_NUMERIC) return rc;      // (before pin_cost is consumed: a solve that failed early never synchronised)
     if (defer_cost_read && lm == 0) {      // the solve has waited for the stream: the pass's scalars are in pinned memory
       CBA_HIP(hipStreamSynchronize(p->stream));                // (a no-op after a completed solve; a numeric failure may return before its wait)
@@ -1038,14 +1083,17 @@ int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double
       lambda = 2.f * lambda;
       continue;
     }
-    t0 = now_s();
-    const int cand = p->cur ^ 1;
-    CBA_TRY(launch_apply_update(L, p->cams, p->st[p->cur], p->x, p->st[cand], p->pose_slot, p->gperm, p->stream));
-    CBA_TRY(residual_pass(p, cand, p->cost_test));
-    CBA_TRY(launch_reduce_costs(p->cost_ref, p->cost_test, nullptr, p->n_obs, p->red_partials, p->red8, p->stream));
-    CBA_TRY(allreduce(p, p->red8, 8));
-    CBA_TRY(read_scalars(p, p->red8, h, 8));
-    report->t_cost += now_s() - t0;
+    if (fused) {
+      for (int i = 0; i < 8; ++i) h[i] = p->pin_cost[8 + i];
+    } else {
+      t0 = now_s();
+      CBA_TRY(launch_apply_update(L, p->cams, p->st[p->cur], p->x, p->st[cand], p->pose_slot, p->gperm, p->stream));
+      CBA_TRY(residual_pass(p, cand, p->cost_test));
+      CBA_TRY(launch_reduce_costs(p->cost_ref, p->cost_test, nullptr, p->n_obs, p->red_partials, p->red8, p->stream));
+      CBA_TRY(allreduce(p, p->red8, 8));
+      CBA_TRY(read_scalars(p, p->red8, h, 8));
+      report->t_cost += now_s() - t0;
+    }
     // CostIsSmallerThan (lm_optimizer.h:993-1011): only residuals valid in both passes
     const bool smaller = h[4] > 0 && h[3] < h[2];
     if (smaller) {
@@ -1069,6 +1117,7 @@ int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double
   report->t_accumulate = p->timers[2].seconds;
   report->t_jac = p->timers[5].seconds;       // device-side spans (HIP events), like the other stage times
   report->t_solve = p->timers[6].seconds;
+  if (fused) report->t_cost = p->timers[7].seconds;       // cost passes queued behind the solves: device-side spans
   return CBA_OK;
 }
 

@@ -69,6 +69,10 @@ struct PassArgs {
   // part of their observation's record (k_assemble fills the header); null outside the Jacobian pass
   double* jrec;
   int rec_doubles;
+  // cost pass behind a solve whose status the host has not read yet (cba_step, one GPU): a non-zero word here means the solve broke
+  // down (zero / NaN pivot, NaN update) -- the kernels that write the warm-start cache then leave at once, so that a rejected-by-NaN
+  // attempt touches nothing, exactly as the reference, which skips the cost pass for a NaN update (LV/lm_optimizer.h:905-913)
+  const int* guard;
 };
 
 // ---- kernels_obs.hip ----

@@ -662,6 +662,7 @@ int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const doubl
 constexpr int kInner = 64;
 constexpr int kPanel = 256;
 constexpr int kSuperMax = 4096;              // widest super-panel (rows factored by one dataflow launch in front of a bulk update)
+constexpr int kTailPairDefault = 0;          // 1: REG tasks of a dataflow launch take two column blocks at a time (tail_task_pair)
 constexpr int kTailMaxBlockRows = 192;      // the persistent tail launch covers at most this many 64-row blocks (flag storage)
 // Reciprocal of a pivot: v_rcp_f64 refined by two Newton steps (the IEEE division expands to ~3x as
 // many dependent instructions, and 1/d sits on the critical path of every elimination step).
@@ -735,6 +736,8 @@ struct TailArgs {
                                     // (the K-major B operand of the bulk update that follows); null = not needed
   int xcd_lists;                    // 1: one task list per XCD (column block c -> XCD c % 8), own list first; 0: one list
   int ntasks_x[8];                  // tasks per list
+  int pair;                         // one list only: REG tasks take TWO adjacent column blocks (64 x 128 tile, kind 3) beyond the first
+                                    // kTailNearSingles columns of a row (tail_task)
 };
 constexpr unsigned long long kTailTimeoutTicks = 300000000ull;   // 3 s
 
@@ -808,6 +811,36 @@ __device__ __forceinline__ int tail_wait_rows(const TailArgs& t, int k, int kend
       const unsigned long long both = m & (m >> 1) & 0x5555555555555555ull;
       n = 0;
       while (n < 32 && ((both >> (2 * n)) & 1ull)) ++n;
+      if (n > 0) break;
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 63u) == 0) {
+        if (tail_ldflag(&t.ctrl[1]) != 0) break;
+        if (__builtin_amdgcn_readfirstlane((int)(wall_clock64() - t0 > kTailTimeoutTicks))) { if (lane == 0) tail_abort(t); break; }
+      }
+    }
+    if (lane == 0) *slot = n;
+  }
+  __syncthreads();
+  const int n = *slot;
+  return n;
+}
+
+// The same for a REG2 task: rows k ... kend - 1 of column blocks ca, cb AND cb + 1 (21 rows x 3 flags per polling round).
+__device__ __forceinline__ int tail_wait_rows3(const TailArgs& t, int k, int kend, int ca, int cb, volatile int* slot) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const int ri = lane / 3, which = lane - 3 * ri;
+    const int row = k + ri;
+    const bool in = lane < 63 && row < kend;
+    const unsigned* f = t.tile_flag + (size_t)((in ? row : k) - t.rt0) * t.ntc + (which == 0 ? ca : cb + which - 1);
+    const unsigned long long t0 = wall_clock64();
+    int n = 0;
+    unsigned spins = 0;
+    for (;;) {
+      const bool ok = in && tail_ldflag(f) == t.epoch;
+      const unsigned long long m = __ballot(ok);
+      n = 0;
+      while (n < 21 && ((m >> (3 * n)) & 7ull) == 7ull) ++n;
       if (n > 0) break;
       __builtin_amdgcn_s_sleep(1);
       if ((++spins & 63u) == 0) {
@@ -927,6 +960,174 @@ __device__ __forceinline__ void tail_mma_dma(v4f64 (&acc)[2][2], const double* A
 }
 
 
+// Ring variant of the 64 x 64 loop (round 5): slabs of 16 K rows in FOUR stages, three slabs in flight.  In situ the operands come
+// over the fabric (L2 hit rate 27 % in the final launch, profiles/r05_tail_traffic.txt) with a latency that one slab of look-ahead
+// (~1.8 us of MFMAs at two workgroups per CU) does not cover: SQ_WAIT_ANY is 24 % of the wave cycles of the final launch against 10 %
+// in the bulk GEMM.  The L2-resident synthetic loop cannot show that (there the deeper ring lost 3 % to its extra barriers).
+// Every wavefront issues the same number of DMA instructions per stage (the 128-byte d slab redundantly, all to the same place), so
+// that `s_waitcnt vmcnt(2 x per stage)` means "my part of the oldest slab in flight has landed" for all of them.
+constexpr int kRingKT = 16, kRingStages = 4;
+constexpr int kRingSlab = (kRingKT / 2) * kDmaPair;       // 1152 doubles
+constexpr int kRingStage = 2 * kRingSlab;
+constexpr int kRingDoubles = kRingStages * kRingStage + kRingStages * 32;
+template <bool SYM>
+__device__ __forceinline__ void tail_mma_ring(v4f64 (&acc)[2][2], const double* A_, const double* B_, int ld_, const double* dk_, int K,
+                                              double* sm) {
+  const double* A = tail_uniform(A_);
+  const double* B = tail_uniform(B_);
+  const double* dk = tail_uniform(dk_);
+  const int ld = __builtin_amdgcn_readfirstlane(ld_);
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
+  const int nk = K / kRingKT;                             // K is a multiple of 64: nk is a multiple of 4
+  const unsigned lds0 = (unsigned)(size_t)sm;
+  const unsigned rowb = (unsigned)ld * 8u;
+  // wavefront wv moves pairs 2 wv, 2 wv + 1 of each operand: lanes 0-31 slab row p, lanes 32-63 slab row p + 8
+  const unsigned vo = (unsigned)(2 * wv + (lane >> 5) * 8) * rowb + (unsigned)(lane & 31) * 16u;
+  const unsigned la = lds0 + (unsigned)(2 * wv * kDmaPair) * 8u;
+#define CBA_RSTAGE(buf_, k0_)                                                                                 \
+  {                                                                                                           \
+    const double* ga = A + (size_t)(k0_) * ld;                                                                \
+    const double* gb = B + (size_t)(k0_) * ld;                                                                \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                           \
+      tail_dma16(ga, vo + q * rowb, la + (unsigned)((buf_) * kRingStage + q * kDmaPair) * 8u);                \
+      if constexpr (!SYM) tail_dma16(gb, vo + q * rowb, la + (unsigned)((buf_) * kRingStage + kRingSlab + q * kDmaPair) * 8u); \
+    }                                                                                                         \
+    tail_dma4(dk + (k0_), (unsigned)(lane & 31) * 4u, lds0 + (unsigned)(kRingStages * kRingStage + (buf_) * 32) * 8u); \
+  }
+#define CBA_ROFF(j_) ((((4 * (j_)) & 7) * kDmaPair) + ((j_) >> 1) * kInner)
+#define CBA_RMMA(buf_)                                                                                        \
+  {                                                                                                           \
+    const double* a_s = sm + (buf_) * kRingStage + lk * kDmaPair + wm0 + li;                                  \
+    const double* b_s = sm + (buf_) * kRingStage + (SYM ? 0 : kRingSlab) + lk * kDmaPair + wn0 + li;          \
+    const double* d_s = sm + kRingStages * kRingStage + (buf_) * 32 + lk;                                     \
+    double af[2][2], bf[2][2], dv[2];                                                                         \
+    dv[0] = d_s[0];                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) af[0][i] = a_s[CBA_ROFF(0) + i * 16];                       \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) bf[0][j] = b_s[CBA_ROFF(0) + j * 16];                       \
+    _Pragma("unroll") for (int s = 0; s < kRingKT / 4; ++s) {                                                 \
+      const int cur = s & 1, nxt = cur ^ 1;                                                                   \
+      if (s + 1 < kRingKT / 4) {                                                                              \
+        dv[nxt] = d_s[4 * (s + 1)];                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) af[nxt][i] = a_s[CBA_ROFF(s + 1) + i * 16];             \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) bf[nxt][j] = b_s[CBA_ROFF(s + 1) + j * 16];             \
+      }                                                                                                       \
+      af[cur][0] *= dv[cur]; af[cur][1] *= dv[cur];                                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                           \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);       \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+    }                                                                                                         \
+  }
+  // DMA instructions per wavefront and stage: 2 (A) + 2 (B, unless SYM) + 1 (d)
+#define CBA_RWAIT(kb_)                                                                                        \
+  {                                                                                                           \
+    if ((kb_) + 2 < nk) { if (SYM) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); } \
+    else if ((kb_) + 1 < nk) { if (SYM) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); } \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
+    __syncthreads();                                                                                          \
+  }
+  CBA_RSTAGE(0, 0);
+  CBA_RSTAGE(1, kRingKT);
+  CBA_RSTAGE(2, 2 * kRingKT);
+#pragma nounroll
+  for (int kb = 0; kb < nk; kb += 4) {
+    CBA_RWAIT(kb)     if (kb + 3 < nk) CBA_RSTAGE(3, (kb + 3) * kRingKT);  CBA_RMMA(0)
+    CBA_RWAIT(kb + 1) if (kb + 4 < nk) CBA_RSTAGE(0, (kb + 4) * kRingKT);  CBA_RMMA(1)
+    CBA_RWAIT(kb + 2) if (kb + 5 < nk) CBA_RSTAGE(1, (kb + 5) * kRingKT);  CBA_RMMA(2)
+    CBA_RWAIT(kb + 3) if (kb + 6 < nk) CBA_RSTAGE(2, (kb + 6) * kRingKT);  CBA_RMMA(3)
+  }
+  __syncthreads();                                       // the staging area is free again
+#undef CBA_RWAIT
+#undef CBA_RMMA
+#undef CBA_ROFF
+#undef CBA_RSTAGE
+}
+
+// The same loop for TWO adjacent column blocks (round 5): acc (64 x 128, 4 waves x 32 x 64) += sum_{k < K} (dk[k] A[k][m]) B[k][n],
+// B 128 columns wide.  Why: the final dataflow launch is bound by what its operands cost on the FABRIC, not by the matrix pipe -- per
+// dispatch PMC (profiles/r05_tail_traffic.txt): 11.1 GiB FETCH_SIZE raw = 23 GB corrected in 5.3 ms = 4.4 TB/s over the whole launch
+// against ~6.3 TB/s a copy reaches, L2 hit rate 27 % (the 64 tasks on an XCD stream 65 different strips through 4 MB), MFMA-busy
+// 65 %.  A 64 x 64 tile moves 2 x 64 x 8 bytes per K row for 2 x 64 x 64 flops (8 flop / byte); a 64 x 128 tile moves 3 x 64 x 8 for
+// twice the flops (10.7 flop / byte): a quarter of the bytes gone, the A strip fetched once for two tiles.
+// Slabs of kT2 = 16 K rows so that two stages fit next to each other in the 80 KB of a workgroup (two workgroups per CU): per
+// stage A = 8 pairs of 64-column rows (as above: rows k and k + 8 share a DMA instruction), B = 16 rows of 128 columns (one DMA
+// instruction each), rows 144 doubles apart (bank-conflict free for the four K rows of an MFMA step).  One barrier per 32 MFMAs of a
+// wavefront, as in the 64 x 64 loop.  (Synthetic, operands L2-resident: 57-61 TFLOP/s against 56-60, tools/bench_tail.hip MMA2_ONLY.)
+constexpr int kT2 = 16;                                   // slab height
+constexpr int kA2Slab = (kT2 / 2) * kDmaPair;             // 1152 doubles: pairs of 64-column rows
+constexpr int kB2Row = 2 * kInner + 16;                   // 144
+constexpr int kB2Slab = kT2 * kB2Row;                     // 2304 doubles
+constexpr int kStage2 = kA2Slab + kB2Slab;
+constexpr int kDma2Doubles = 2 * kStage2 + 64;
+__device__ __forceinline__ void tail_mma_dma2(v4f64 (&acc)[2][4], const double* A_, const double* B_, int ld_, const double* dk_, int K,
+                                              double* sm) {
+  const double* A = tail_uniform(A_);
+  const double* B = tail_uniform(B_);
+  const double* dk = tail_uniform(dk_);
+  const int ld = __builtin_amdgcn_readfirstlane(ld_);
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 64, li = lane & 15, lk = lane >> 4;
+  const int nk = K / kT2;
+  const unsigned lds0 = (unsigned)(size_t)sm;
+  const unsigned rowb = (unsigned)ld * 8u;
+  // A: wave wv moves pairs 2 wv, 2 wv + 1 (lanes 0-31 slab row p, lanes 32-63 slab row p + 8); B: rows 4 wv ... 4 wv + 3, one per instruction
+  const unsigned voa = (unsigned)(2 * wv + (lane >> 5) * 8) * rowb + (unsigned)(lane & 31) * 16u;
+  const unsigned vob = (unsigned)(4 * wv) * rowb + (unsigned)lane * 16u;
+#define CBA_X2_STAGE(buf_, k0_)                                                                                \
+  {                                                                                                            \
+    const double* ga = A + (size_t)(k0_) * ld;                                                                 \
+    const double* gb = B + (size_t)(k0_) * ld;                                                                 \
+    const unsigned base = lds0 + (unsigned)((buf_) * kStage2) * 8u;                                            \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) tail_dma16(ga, voa + q * rowb, base + (unsigned)((2 * wv + q) * kDmaPair) * 8u); \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) tail_dma16(gb, vob + q * rowb, base + (unsigned)(kA2Slab + (4 * wv + q) * kB2Row) * 8u); \
+    if (wv == 0) tail_dma4(dk + (k0_), (unsigned)lane * 4u, lds0 + (unsigned)(2 * kStage2 + (buf_) * 32) * 8u); \
+  }
+#define CBA_X2_AOFF(j_) ((((4 * (j_)) & 7) * kDmaPair) + ((j_) >> 1) * kInner)
+#define CBA_X2_MMA(buf_)                                                                                       \
+  {                                                                                                            \
+    const double* a_s = sm + (buf_) * kStage2 + lk * kDmaPair + wm0 + li;                                      \
+    const double* b_s = sm + (buf_) * kStage2 + kA2Slab + lk * kB2Row + wn0 + li;                              \
+    const double* d_s = sm + 2 * kStage2 + (buf_) * 32 + lk;                                                   \
+    double af[2][2], bf[2][4], dv[2];                                                                          \
+    dv[0] = d_s[0];                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) af[0][i] = a_s[CBA_X2_AOFF(0) + i * 16];                     \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) bf[0][j] = b_s[j * 16];                                      \
+    _Pragma("unroll") for (int s = 0; s < kT2 / 4; ++s) {                                                      \
+      const int cur = s & 1, nxt = cur ^ 1;                                                                    \
+      if (s + 1 < kT2 / 4) {                                                                                   \
+        dv[nxt] = d_s[4 * (s + 1)];                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) af[nxt][i] = a_s[CBA_X2_AOFF(s + 1) + i * 16];           \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) bf[nxt][j] = b_s[4 * (s + 1) * kB2Row + j * 16];         \
+      }                                                                                                        \
+      af[cur][0] *= dv[cur]; af[cur][1] *= dv[cur];                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                          \
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);        \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+    }                                                                                                          \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                           \
+    __syncthreads();                                                                                           \
+  }
+  CBA_X2_STAGE(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma nounroll
+  for (int kb = 0; kb < nk; kb += 2) {
+    if (kb + 1 < nk) CBA_X2_STAGE(1, (kb + 1) * kT2);
+    CBA_X2_MMA(0)
+    if (kb + 1 < nk) {
+      if (kb + 2 < nk) CBA_X2_STAGE(0, (kb + 2) * kT2);
+      CBA_X2_MMA(1)
+    }
+  }
+#undef CBA_X2_MMA
+#undef CBA_X2_AOFF
+#undef CBA_X2_STAGE
+}
+
 // ticket of list x -> task.  kind 0 = PRE(r), 1 = PART(r + 1), 2 = REG(r, c).  List x (of `nl` lists) holds the tasks whose column
 // block c has c % nl == x, rows in increasing order -- a task only waits for tiles of earlier rows, so every list is in
 // dependency order and the launch makes progress as long as each list's pending head is held by a running workgroup or nobody
@@ -939,7 +1140,39 @@ __device__ __forceinline__ int tail_row_count(const TailArgs& t, int r, int x, i
   if (r + 1 < t.nr && (r + 1) % nl == x) cnt += 1;
   return cnt;
 }
+// Pair mode (t.pair, one list): row r hands out PRE(r), PART(r + 1), the REG tasks of the first kTailNearSingles columns right of
+// them one tile at a time (they feed the chain's next steps: latency matters), then REG2 tasks (kind 3) of two adjacent column blocks
+// each, and a last single tile when the count is odd.  The last block row (nothing below it) keeps single tiles.
+constexpr int kTailNearSingles = 2;
+__host__ __device__ inline int tail_pair_row_count(int rt0, int nr, int ntc, int r) {
+  (void)rt0;
+  if (r + 1 >= nr) return ntc - nr;
+  const int ncols = ntc - r - 2;
+  const int s1 = ncols < kTailNearSingles ? ncols : kTailNearSingles;
+  const int rem = ncols - s1;
+  return 2 + s1 + rem / 2 + (rem & 1);
+}
+__device__ __forceinline__ void tail_task_pair(const TailArgs& t, int ticket, int* kind, int* r_out, int* c_out) {
+  int r = t.rt0;
+  for (; r < t.nr; ++r) {
+    const int cnt = tail_pair_row_count(t.rt0, t.nr, t.ntc, r);
+    if (ticket < cnt) break;
+    ticket -= cnt;
+  }
+  *r_out = r;
+  if (r + 1 >= t.nr) { *kind = 2; *c_out = r + 1 + ticket; return; }
+  if (ticket < 2) { *kind = ticket; *c_out = r + 1; return; }
+  int q = ticket - 2;
+  const int ncols = t.ntc - r - 2;
+  const int s1 = ncols < kTailNearSingles ? ncols : kTailNearSingles;
+  if (q < s1) { *kind = 2; *c_out = r + 2 + q; return; }
+  q -= s1;
+  const int rem = ncols - s1;
+  if (q < rem / 2) { *kind = 3; *c_out = r + 2 + s1 + 2 * q; return; }
+  *kind = 2; *c_out = t.ntc - 1;
+}
 __device__ __forceinline__ void tail_task(const TailArgs& t, int ticket, int x, int nl, int* kind, int* r_out, int* c_out) {
+  if (t.pair) { tail_task_pair(t, ticket, kind, r_out, c_out); return; }
   int r = t.rt0;
   for (; r < t.nr; ++r) {
     const int cnt = tail_row_count(t, r, x, nl);
@@ -1376,12 +1609,125 @@ __device__ __forceinline__ void tail_chain(const TailArgs& t, double* sV, double
 }
 
 // ---- helper workgroups ----
+// REG2 task (round 5): tiles (r, c) and (r, c + 1) in one go -- the K loop on the 64 x 128 tile (tail_mma_dma2: the A strip is
+// fetched once for both), then the 64 x 64 epilogue of a REG task twice with ONE load of invL_r.  false = the launch was aborted.
+__device__ __forceinline__ bool tail_helper_pair(const TailArgs& t, double* sV, double* sAB, int r, int c, volatile int* slot) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int ld = t.ld;
+  static_assert(kDma2Doubles <= kInner * TS + (kInner - 1) * TS + kInner, "the 64 x 128 K-loop staging overruns the slots");
+  v4f64 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
+  for (int k = t.rt0; k < r;) {
+    const int nrows = tail_wait_rows3(t, k, r, r, c, slot);
+    if (nrows <= 0) return false;
+    const double* A = t.S + (size_t)k * kInner * ld + (size_t)r * kInner;
+    const double* B = t.S + (size_t)k * kInner * ld + (size_t)c * kInner;
+    tail_mma_dma2(acc, A, B, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sV);
+    k += nrows;
+  }
+  // accumulator layout of the 64 x 128 tile: wave wv holds rows 32 (wv >> 1) + 16 i + lk + 4 r4, columns 64 (wv & 1) + 16 j + li,
+  // i.e. waves 0 / 2 hold tile (r, c) and waves 1 / 3 hold tile (r, c + 1)
+  const int wm0 = (wv >> 1) * 32, half = wv & 1;
+  {
+    // U = A_rc - acc, straight into the accumulator registers (the tiles were written before this launch: fetched now, one round trip
+    // per task; prefetching them underneath the K loop would cost 64 more live registers)
+    const __amdgpu_buffer_rsrc_t rt = tail_rsrc(t.S + (size_t)r * kInner * ld + (size_t)(c + half) * kInner);
+    const int voff = ((wm0 + lk) * ld + li) * 8;
+    double a[2][4][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) a[i][j][r4] = tail_ld1(rt, voff, ((16 * i + 4 * r4) * ld + 16 * j) * 8);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) acc[i][j][r4] = a[i][j][r4] - acc[i][j][r4];
+  }
+  if (!tail_wait(t, &t.diag_flag[r - t.rt0], nullptr, slot)) return false;     // (its barrier: every wave is done with the K-loop staging)
+  // invL_r (K-major, [q][p]) -> sAB; 1 / d_r of the rows of the 64 x 64 product layout
+  const int pm0 = (wv >> 1) * 32, pn0 = (wv & 1) * 32;                         // 64 x 64 product: 4 waves x 32 x 32
+  double rdr[2][4];
+  {
+    const __amdgpu_buffer_rsrc_t ri = tail_rsrc(t.invLt + (size_t)r * kInner * kInner);
+    const __amdgpu_buffer_rsrc_t rd = tail_rsrc(t.dvec + (size_t)r * kInner);
+    const int rw = 16 * wv + (lane >> 5), cw = 2 * (lane & 31);
+    v2f64_t u[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) u[k] = tail_ld2(ri, (rw * kInner + cw) * 8, 2 * k * kInner * 8);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) rdr[i][r4] = tail_ld1(rd, (pm0 + lk) * 8, (16 * i + 4 * r4) * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sAB[(rw + 2 * k) * TS + cw] = u[k].x; sAB[(rw + 2 * k) * TS + cw + 1] = u[k].y; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) rdr[i][r4] = 1.0 / rdr[i][r4];
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h == 1) __syncthreads();                 // every wave is done reading tile 0's U from sV
+    if (half == h) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) sV[(wm0 + 16 * i + lk + 4 * r4) * TS + 16 * j + li] = acc[i][j][r4];
+    }
+    __syncthreads();                             // U (and, for h = 0, invL_r) complete in LDS
+    v4f64 x[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) x[i][jj] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    tile_mma_lds(x, sAB, sV);                    // X[p][n] = sum_q invLt[q][p] U[q][n]
+    const __amdgpu_buffer_rsrc_t rt = tail_rsrc(t.S + (size_t)r * kInner * ld + (size_t)(c + h) * kInner);
+    const int acc_voff = ((pm0 + lk) * ld + pn0 + li) * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+          tail_st1(rt, acc_voff, ((16 * i + 4 * r4) * ld + 16 * jj) * 8, x[i][jj][r4] * rdr[i][r4]);
+    if (t.X && c + h >= t.x_c0) {
+      double* Xt = t.X + (size_t)(r - t.rt0) * kInner * t.ldx + (size_t)(c + h) * kInner;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+            Xt[(size_t)(pm0 + i * 16 + lk + 4 * r4) * t.ldx + pn0 + jj * 16 + li] = x[i][jj][r4];
+    }
+  }
+  // both tiles with one acknowledgement wait: tail_publish = vmcnt(0) + barrier + flag store by one lane
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    tail_stflag(&t.tile_flag[(size_t)(r - t.rt0) * t.ntc + c], t.epoch);
+    tail_stflag(&t.tile_flag[(size_t)(r - t.rt0) * t.ntc + c + 1], t.epoch);
+  }
+  return true;
+}
+
 __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, double* sAB) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
   // K-loop staging (LDS-DMA): kDmaDoubles from the start of sV, running over into sAB (the two tiles are one array); the slots
   // sit behind it, in the padding of sAB's last row
   static_assert(kDmaDoubles <= kInner * TS + (kInner - 1) * TS + kInner, "the K-loop staging overruns the slots");
+  static_assert(kRingDoubles <= kInner * TS + (kInner - 1) * TS + kInner, "the ring K-loop staging overruns the slots");
   volatile int* slot = reinterpret_cast<volatile int*>(sAB + (kInner - 1) * TS + kInner);
   volatile int* slot2 = reinterpret_cast<volatile int*>(sAB + (kInner - 1) * TS + kInner + 2);
   volatile int* slot3 = reinterpret_cast<volatile int*>(sAB + (kInner - 1) * TS + kInner + 4);
@@ -1409,7 +1755,11 @@ __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, doubl
     if (tk < 0) return;
     int kind, r, c;
     tail_task(t, tk, *slot3, nl, &kind, &r, &c);
-    if (kind == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3);
+    if (kind >= 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3);
+    if (kind == 3) {
+      if (!tail_helper_pair(t, sV, sAB, r, c, slot)) return;
+      continue;
+    }
     const int ca = (kind == 1) ? c : r;          // column block of the A operand: PART is L_{k,r+1}^T d L_{k,r+1}
     v4f64 acc[2][2];
 #pragma unroll
@@ -1436,8 +1786,13 @@ __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, doubl
       const unsigned long long h1 = HELP_NOW();
       const double* A = t.S + (size_t)k * kInner * ld + (size_t)ca * kInner;
       const double* B = t.S + (size_t)k * kInner * ld + (size_t)c * kInner;
+#ifdef CBA_TAIL_RING
+      if (kind == 1) tail_mma_ring<true>(acc, A, A, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sV);
+      else tail_mma_ring<false>(acc, A, B, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sV);
+#else
       if (kind == 1) tail_mma_dma<true>(acc, A, A, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sV);
       else tail_mma_dma<false>(acc, A, B, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sV);
+#endif
       k += nrows;
       h_wait += h1 - h0; h_mma += HELP_NOW() - h1;
     }
@@ -1744,8 +2099,12 @@ static int ldlt_tail(double* S, int n_fact, int ld, int t0, LdltWorkspace& w, hi
   t.part_flag = t.upre_flag + t.ntc;
   t.ctrl = w.tail_ctrl;
   t.epoch = ++w.tail_epoch;
+  const char* pair_env = CBA_GETENV("CBA_TAIL_PAIR");                      // developer switch (bench harness only; read per call)
+  static const bool one_list_sw = CBA_GETENV("CBA_TAIL_XCD_LISTS") == nullptr;
+  t.pair = (pair_env ? atoi(pair_env) : kTailPairDefault) && one_list_sw ? 1 : 0;
   long long ntasks = 0;
-  for (int r = t.rt0; r < t.nr; ++r) ntasks += (r + 1 < t.nr) ? t.ntc - r : t.ntc - t.nr;
+  for (int r = t.rt0; r < t.nr; ++r)
+    ntasks += t.pair ? tail_pair_row_count(t.rt0, t.nr, t.ntc, r) : ((r + 1 < t.nr) ? t.ntc - r : t.ntc - t.nr);
   t.ntasks = (int)ntasks;
   static const bool no_evict = CBA_GETENV("CBA_TAIL_NO_EVICT") != nullptr;     // developer switches (bench harness only)
   static const bool one_list = CBA_GETENV("CBA_TAIL_XCD_LISTS") == nullptr;   // per-XCD lists measured: no gain (the helpers are not operand-bandwidth bound)
@@ -1756,6 +2115,7 @@ static int ldlt_tail(double* S, int n_fact, int ld, int t0, LdltWorkspace& w, hi
     for (int x = 0; x < 8; ++x) t.ntasks_x[x] = 0;
     for (int r = t.rt0; r < t.nr; ++r)
       for (int c = r + 1; c < t.ntc; ++c) t.ntasks_x[c % nl] += (c == r + 1 && r + 1 < t.nr) ? 2 : 1;
+    if (t.pair) t.ntasks_x[0] = t.ntasks;
   }
   if (w.tail_ctrl_clean) w.tail_ctrl_clean = false;            // cleared ahead of time by the caller (ldlt_clear_ctrl)
   else CBA_HIP(hipMemsetAsync(w.tail_ctrl, 0, sizeof(unsigned) * 16, s));

@@ -192,6 +192,7 @@ __global__ void __launch_bounds__(256) k_base_project(PassArgs a, double* __rest
                                                       const uint8_t* __restrict__ fd_slow) {
   const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= a.n_obs) return;
+  if (a.guard && *a.guard != 0) return;                     // the solve in front of this cost pass broke down: touch nothing
   const int cam = a.obs_camera[o];
   const CamDev c = a.cams[cam];
   if (c.model_type != MODEL) return;
@@ -230,6 +231,7 @@ __global__ void __launch_bounds__(256) k_base_project_slow(PassArgs a, double* _
   constexpr double kEpsilon = 1e-12;
   const int tid = blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63;
+  if (a.guard && *a.guard != 0) return;                     // (wave-uniform) the solve in front of this cost pass broke down
   const int cnt = min(*a.obs_count, a.obs_list_cap);
   if (((tid & ~63) >> 4) >= cnt) return;                    // wave-uniform
   const int g = tid >> 4;

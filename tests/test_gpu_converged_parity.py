@@ -1,0 +1,56 @@
+"""Converged-calibration parity (BASELINE.json north_star: "converged intrinsics, poses and pattern geometry match the reference
+CPU path ... to a stated fp64 tolerance"): HIP engine and CPU oracle run side by side UNDER THE REFERENCE'S STOPPING RULE
+(RunBundleAdjustment, APP/calibration.cc:298: cost >= last_cost - 1e-4 or no update performed; <= 100 iterations, :1123-1125) from
+the same perturbed start on BASELINE configs[0] (30 imagesets, 16x12 grid, D = 1 413) -- the reference's own CPU-runnable case.
+
+Checked: outer-iteration count, per-iteration LM attempt counts and accept decisions (LV/lm_optimizer.h:943-977) identical; final
+cost; points / poses / grids after gauge alignment (the reference's test leaves them unchecked because of the gauge freedom,
+APP/test/util.h:557-565; acceptance there: APP/test/util.h:432, 567-568).  The cfg-2-grid run of the same comparison (all-core
+oracle, minutes) is tools/converged_parity.py -> profiles/r05_converged_parity.json.
+
+Tolerances: BASELINE.md section 2 names the targets (final cost 1e-9 relative, state 1e-7 relative after gauge alignment).
+Observed on the GPU (round 5, default fp64-atomic accumulation): final cost 2.5e-10, aligned state 2.9e-9, raw state 3.7e-9.  This
+is a comparison of two LM TRAJECTORIES of ten iterations (heavy-tailed run to run: atomics reorder sums, the gauge directions
+amplify it), so the bounds keep ~30x over the observation: 1e-8 for the cost, the 1e-7 target for the state."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from camera_calibration_amd import engine as eng
+from camera_calibration_amd import synthetic as syn
+from oracle import oracle as orc
+from parity_record import check, check_equal
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import converged_parity as cp  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_baseline_config1_converges_like_the_oracle_under_the_reference_stopping_rule(deterministic):
+    pb, st0, _ = syn.baseline_config(1, lambda cam, grid, pts: orc.project(cam, grid, pts))
+    assert pb.dense_dof == 1413 and pb.n_images == 30
+    rec = cp.run_pair(eng, orc, pb, st0, max_iterations=100, threshold=1e-4, threads=0, deterministic=deterministic)
+    case = "converged calibration, BASELINE configs[0], " + ("deterministic accumulation" if deterministic else "default accumulation")
+    print(case, rec["outer_iterations"], rec["lm_attempts_per_iteration"], rec["achieved_tolerance"], rec["state"])
+    assert rec["outer_iterations"]["engine"] >= 5, rec["outer_iterations"]          # the case is meant to converge over several iterations
+    check_equal(case, "outer iterations until the stopping rule fires (engine - oracle)",
+                abs(rec["outer_iterations"]["engine"] - rec["outer_iterations"]["oracle"]))
+    check_equal(case, "iterations whose LM attempt count or accept decision differs",
+                0 if rec["decisions_identical"] else 1 + len(rec["lm_attempts_per_iteration"]["engine"]) - int(rec["first_divergence"]["iteration"]))
+    check(case, "per-iteration cost rel (max over the trajectory)", max(rec["cost_rel_per_iteration"]), 1e-8,
+          note="trajectory comparison (heavy-tailed run to run); observed 2.5e-10")
+    check(case, "lambda rel (max over the trajectory)", max(rec["lambda_rel_per_iteration"]), 1e-9,
+          note="lambda is a function of the accept decisions after the first iteration; the first one is a sum over the diagonal of H")
+    check(case, "final cost rel (target 1e-9, BASELINE.md section 2)", rec["final_cost"]["rel"], 1e-8,
+          note="observed 2.5e-10; bound = 10x the target because this row compares two ten-iteration trajectories")
+    st = rec["state"]
+    for name in ("points_aligned_rel", "grids_aligned_abs", "pose_rotation_aligned_abs", "pose_translation_aligned_rel"):
+        check(case, f"converged state after gauge alignment: {name} (target 1e-7, BASELINE.md section 2)", st[name], 1e-7,
+              note="observed 2e-12 ... 3e-9")
+    check(case, "converged state WITHOUT gauge alignment (max of points / grids / poses)", rec["achieved_tolerance"]["state_raw"], 1e-6,
+          note="observed 3.7e-9: the two sides stay in the same gauge because they take the same steps; bound is loose on purpose, "
+               "the gauge directions are held by the LM damping only")

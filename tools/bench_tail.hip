@@ -87,81 +87,7 @@ __device__ __forceinline__ void tail_mma_regstaged(v4f64 (&acc)[2][2], const dou
 }
 
 }  // namespace cba
-// Experiment: the LDS-DMA K loop for TWO adjacent column blocks (64 x 128 tile, slabs of 16 rows so that two workgroups per CU
-// still fit): acc (4 waves x 32 x 64) += sum_k (d_k A[k][m]) B[k][n], B 128 columns wide.
-namespace cba {
-constexpr int kT2 = 16;                                   // slab height
-constexpr int kA2Slab = (kT2 / 2) * kDmaPair;             // 1152 doubles: pairs of 64-column rows
-constexpr int kB2Row = 2 * kInner + 16;                   // 144
-constexpr int kB2Slab = kT2 * kB2Row;                     // 2304 doubles
-constexpr int kStage2 = kA2Slab + kB2Slab;
-__device__ __forceinline__ void tail_mma_dma2(v4f64 (&acc)[2][4], const double* A_, const double* B_, int ld_, const double* dk_, int K,
-                                              double* sm) {
-  const double* A = tail_uniform(A_);
-  const double* B = tail_uniform(B_);
-  const double* dk = tail_uniform(dk_);
-  const int ld = __builtin_amdgcn_readfirstlane(ld_);
-  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 64, li = lane & 15, lk = lane >> 4;
-  const int nk = K / kT2;
-  const unsigned lds0 = (unsigned)(size_t)sm;
-  const unsigned rowb = (unsigned)ld * 8u;
-  // A: wave wv moves pairs 2 wv, 2 wv + 1 (lanes 0-31 slab row p, lanes 32-63 slab row p + 8); B: rows 4 wv ... 4 wv + 3, one per instruction
-  const unsigned voa = (unsigned)(2 * wv + (lane >> 5) * 8) * rowb + (unsigned)(lane & 31) * 16u;
-  const unsigned vob = (unsigned)(4 * wv) * rowb + (unsigned)lane * 16u;
-#define X2_STAGE(buf_, k0_)                                                                                    \
-  {                                                                                                            \
-    const double* ga = A + (size_t)(k0_) * ld;                                                                 \
-    const double* gb = B + (size_t)(k0_) * ld;                                                                 \
-    const unsigned base = lds0 + (unsigned)((buf_) * kStage2) * 8u;                                            \
-    _Pragma("unroll") for (int q = 0; q < 2; ++q) tail_dma16(ga, voa + q * rowb, base + (unsigned)((2 * wv + q) * kDmaPair) * 8u); \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) tail_dma16(gb, vob + q * rowb, base + (unsigned)(kA2Slab + (4 * wv + q) * kB2Row) * 8u); \
-    if (wv == 0) tail_dma4(dk + (k0_), (unsigned)lane * 4u, lds0 + (unsigned)(2 * kStage2 + (buf_) * 32) * 8u); \
-  }
-#define X2_AOFF(j_) ((((4 * (j_)) & 7) * kDmaPair) + ((j_) >> 1) * kInner)
-#define X2_MMA(buf_)                                                                                           \
-  {                                                                                                            \
-    const double* a_s = sm + (buf_) * kStage2 + lk * kDmaPair + wm0 + li;                                      \
-    const double* b_s = sm + (buf_) * kStage2 + kA2Slab + lk * kB2Row + wn0 + li;                              \
-    const double* d_s = sm + 2 * kStage2 + (buf_) * 32 + lk;                                                   \
-    double af[2][2], bf[2][4], dv[2];                                                                          \
-    dv[0] = d_s[0];                                                                                            \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) af[0][i] = a_s[X2_AOFF(0) + i * 16];                         \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) bf[0][j] = b_s[j * 16];                                      \
-    _Pragma("unroll") for (int s = 0; s < kT2 / 4; ++s) {                                                      \
-      const int cur = s & 1, nxt = cur ^ 1;                                                                    \
-      if (s + 1 < kT2 / 4) {                                                                                   \
-        dv[nxt] = d_s[4 * (s + 1)];                                                                            \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) af[nxt][i] = a_s[X2_AOFF(s + 1) + i * 16];               \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) bf[nxt][j] = b_s[4 * (s + 1) * kB2Row + j * 16];         \
-      }                                                                                                        \
-      af[cur][0] *= dv[cur]; af[cur][1] *= dv[cur];                                                            \
-      __builtin_amdgcn_sched_barrier(0);                                                                       \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                          \
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);        \
-      __builtin_amdgcn_sched_barrier(0);                                                                       \
-    }                                                                                                          \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                           \
-    __syncthreads();                                                                                           \
-  }
-  X2_STAGE(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-#pragma nounroll
-  for (int kb = 0; kb < nk; kb += 2) {
-    if (kb + 1 < nk) X2_STAGE(1, (kb + 1) * kT2);
-    X2_MMA(0)
-    if (kb + 1 < nk) {
-      if (kb + 2 < nk) X2_STAGE(0, (kb + 2) * kT2);
-      X2_MMA(1)
-    }
-  }
-#undef X2_MMA
-#undef X2_AOFF
-#undef X2_STAGE
-}
-}  // namespace cba
+// (the 64 x 128 LDS-DMA K loop, tail_mma_dma2, moved into the product in round 5: REG2 tasks of k_ldlt_tail)
 __global__ void __launch_bounds__(256, 2) k_mma2_only(const double* S, int ld, const double* dvec, int K, int ntc, double* out) {
   __shared__ double smem[2 * cba::kInner * cba::TS];
   const int c = blockIdx.x % ntc, r = (blockIdx.x / ntc) % ntc;
@@ -373,10 +299,15 @@ int main(int argc, char** argv) {
     };
     std::vector<double> xr, Sr, dr;
     double ms_ref, tms;
+    if (getenv("PAIRS")) setenv("CBA_TAIL_PAIR", "0", 1);          // reference = single-tile tasks
     int st = run(tails.back(), &xr, n <= 4096 ? &Sr : nullptr, &dr, &ms_ref, &tms);
     printf("reference (tail %d): %.3f ms  status %d   [128x128 GEMM launches: %d at %.1f TFLOP/s per launch]\n", tails.back(), ms_ref, st, g_launches, g_rate);
     double xmax = 0; for (double v : xr) xmax = std::max(xmax, std::fabs(v));
-    for (int tail : tails) {
+    { double s1 = 0, s2 = 0; for (size_t i = 0; i < xr.size(); ++i) { s1 += xr[i] * (1.0 + (i % 7)); s2 += xr[i] * xr[i]; } printf("checksum of x (compare across builds): %.17g %.17g\n", s1, s2); }
+    std::vector<int> pair_modes = {-1};
+    if (const char* e = getenv("PAIRS")) { pair_modes.clear(); for (const char* c = e; *c;) { pair_modes.push_back(atoi(c)); while (*c && *c != ',') ++c; if (*c) ++c; } }
+    for (int tail : tails) for (int pm : pair_modes) {
+      if (pm >= 0) { setenv("CBA_TAIL_PAIR", pm ? "1" : "0", 1); printf("-- CBA_TAIL_PAIR=%d\n", pm); }
       std::vector<double> xt, St, dt;
       double ms_t;
       st = run(tail, &xt, n <= 4096 ? &St : nullptr, &dt, &ms_t, &tms);
