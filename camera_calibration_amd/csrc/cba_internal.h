@@ -85,9 +85,10 @@ int launch_base_project(const PassArgs& a, int model_mask, double* cost_vec, dou
 int launch_base_project_slow(const PassArgs& a, int model_mask, double* cost_vec, double* pixels, uint8_t* flags, hipStream_t s);
 // redo / redo_count: device work list (redo_cap entries / one int) for the tasks that leave their staged patch; tasks that find
 // the list full are counted in *redo_overflow
+// schedule: 0 = pooled (workgroup task pool, one LM attempt per trip), 1 = one task per lane; same results bit for bit
 int launch_fd_tasks(const PassArgs& a, int model_mask, int tasks_per_obs, int localize_only, const double* pixels,
                     const uint8_t* flags, double* fd_out, uint8_t* fd_ok, int64_t* redo, int* redo_count, int redo_cap, int* redo_overflow,
-                    hipStream_t s);
+                    hipStream_t s, int schedule = 0);
 int launch_assemble(const PassArgs& a, const Layout& L, const DevState& st, int tasks_per_obs, int rec_doubles,
                     const double* pixels, uint8_t* flags, const double* fd_out, const uint8_t* fd_ok, double* jrec,
                     int* cells, uint8_t* fd_slow, hipStream_t s);

@@ -662,7 +662,6 @@ int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const doubl
 constexpr int kInner = 64;
 constexpr int kPanel = 256;
 constexpr int kSuperMax = 4096;              // widest super-panel (rows factored by one dataflow launch in front of a bulk update)
-constexpr int kTailPairDefault = 0;          // 1: REG tasks of a dataflow launch take two column blocks at a time (tail_task_pair)
 constexpr int kTailMaxBlockRows = 192;      // the persistent tail launch covers at most this many 64-row blocks (flag storage)
 // Reciprocal of a pivot: v_rcp_f64 refined by two Newton steps (the IEEE division expands to ~3x as
 // many dependent instructions, and 1/d sits on the critical path of every elimination step).
@@ -825,6 +824,7 @@ __device__ __forceinline__ int tail_wait_rows(const TailArgs& t, int k, int kend
   return n;
 }
 
+#ifdef CBA_DEV_SWITCHES
 // The same for a REG2 task: rows k ... kend - 1 of column blocks ca, cb AND cb + 1 (21 rows x 3 flags per polling round).
 __device__ __forceinline__ int tail_wait_rows3(const TailArgs& t, int k, int kend, int ca, int cb, volatile int* slot) {
   if (threadIdx.x < 64) {
@@ -854,6 +854,8 @@ __device__ __forceinline__ int tail_wait_rows3(const TailArgs& t, int k, int ken
   const int n = *slot;
   return n;
 }
+
+#endif
 
 // acc (64 x 64, 4 waves x 32 x 32) += sum_{k < K} (dk[k] A[k][m]) B[k][n]; A, B: K rows of `ld` doubles, written by other workgroups
 // of this launch (agent-scope loads).  SYM: B == A (loaded once).  Slabs of kTailKT = 32 rows, the next one in flight while the
@@ -960,6 +962,9 @@ __device__ __forceinline__ void tail_mma_dma(v4f64 (&acc)[2][2], const double* A
 }
 
 
+#ifdef CBA_DEV_SWITCHES
+// ---- round-5 variants of the helpers' K loop, measured in situ and NOT adopted (profiles/r05_pair_tasks_in_situ.txt, r05_ring_kloop_in_situ.txt); compiled into the
+// ---- bench harness only (tools/bench_tail.hip), the product library does not contain them
 // Ring variant of the 64 x 64 loop (round 5): slabs of 16 K rows in FOUR stages, three slabs in flight.  In situ the operands come
 // over the fabric (L2 hit rate 27 % in the final launch, profiles/r05_tail_traffic.txt) with a latency that one slab of look-ahead
 // (~1.8 us of MFMAs at two workgroups per CU) does not cover: SQ_WAIT_ANY is 24 % of the wave cycles of the final launch against 10 %
@@ -1128,6 +1133,8 @@ __device__ __forceinline__ void tail_mma_dma2(v4f64 (&acc)[2][4], const double* 
 #undef CBA_X2_STAGE
 }
 
+#endif  // CBA_DEV_SWITCHES
+
 // ticket of list x -> task.  kind 0 = PRE(r), 1 = PART(r + 1), 2 = REG(r, c).  List x (of `nl` lists) holds the tasks whose column
 // block c has c % nl == x, rows in increasing order -- a task only waits for tiles of earlier rows, so every list is in
 // dependency order and the launch makes progress as long as each list's pending head is held by a running workgroup or nobody
@@ -1140,6 +1147,7 @@ __device__ __forceinline__ int tail_row_count(const TailArgs& t, int r, int x, i
   if (r + 1 < t.nr && (r + 1) % nl == x) cnt += 1;
   return cnt;
 }
+#ifdef CBA_DEV_SWITCHES
 // Pair mode (t.pair, one list): row r hands out PRE(r), PART(r + 1), the REG tasks of the first kTailNearSingles columns right of
 // them one tile at a time (they feed the chain's next steps: latency matters), then REG2 tasks (kind 3) of two adjacent column blocks
 // each, and a last single tile when the count is odd.  The last block row (nothing below it) keeps single tiles.
@@ -1171,8 +1179,11 @@ __device__ __forceinline__ void tail_task_pair(const TailArgs& t, int ticket, in
   if (q < rem / 2) { *kind = 3; *c_out = r + 2 + s1 + 2 * q; return; }
   *kind = 2; *c_out = t.ntc - 1;
 }
+#endif
 __device__ __forceinline__ void tail_task(const TailArgs& t, int ticket, int x, int nl, int* kind, int* r_out, int* c_out) {
+#ifdef CBA_DEV_SWITCHES
   if (t.pair) { tail_task_pair(t, ticket, kind, r_out, c_out); return; }
+#endif
   int r = t.rt0;
   for (; r < t.nr; ++r) {
     const int cnt = tail_row_count(t, r, x, nl);
@@ -1609,6 +1620,7 @@ __device__ __forceinline__ void tail_chain(const TailArgs& t, double* sV, double
 }
 
 // ---- helper workgroups ----
+#ifdef CBA_DEV_SWITCHES
 // REG2 task (round 5): tiles (r, c) and (r, c + 1) in one go -- the K loop on the 64 x 128 tile (tail_mma_dma2: the A strip is
 // fetched once for both), then the 64 x 64 epilogue of a REG task twice with ONE load of invL_r.  false = the launch was aborted.
 __device__ __forceinline__ bool tail_helper_pair(const TailArgs& t, double* sV, double* sAB, int r, int c, volatile int* slot) {
@@ -1721,13 +1733,17 @@ __device__ __forceinline__ bool tail_helper_pair(const TailArgs& t, double* sV, 
   return true;
 }
 
+#endif
+
 __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, double* sAB) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
   // K-loop staging (LDS-DMA): kDmaDoubles from the start of sV, running over into sAB (the two tiles are one array); the slots
   // sit behind it, in the padding of sAB's last row
   static_assert(kDmaDoubles <= kInner * TS + (kInner - 1) * TS + kInner, "the K-loop staging overruns the slots");
+#ifdef CBA_DEV_SWITCHES
   static_assert(kRingDoubles <= kInner * TS + (kInner - 1) * TS + kInner, "the ring K-loop staging overruns the slots");
+#endif
   volatile int* slot = reinterpret_cast<volatile int*>(sAB + (kInner - 1) * TS + kInner);
   volatile int* slot2 = reinterpret_cast<volatile int*>(sAB + (kInner - 1) * TS + kInner + 2);
   volatile int* slot3 = reinterpret_cast<volatile int*>(sAB + (kInner - 1) * TS + kInner + 4);
@@ -1756,10 +1772,12 @@ __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, doubl
     int kind, r, c;
     tail_task(t, tk, *slot3, nl, &kind, &r, &c);
     if (kind >= 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3);
+#ifdef CBA_DEV_SWITCHES
     if (kind == 3) {
       if (!tail_helper_pair(t, sV, sAB, r, c, slot)) return;
       continue;
     }
+#endif
     const int ca = (kind == 1) ? c : r;          // column block of the A operand: PART is L_{k,r+1}^T d L_{k,r+1}
     v4f64 acc[2][2];
 #pragma unroll
@@ -2099,12 +2117,16 @@ static int ldlt_tail(double* S, int n_fact, int ld, int t0, LdltWorkspace& w, hi
   t.part_flag = t.upre_flag + t.ntc;
   t.ctrl = w.tail_ctrl;
   t.epoch = ++w.tail_epoch;
-  const char* pair_env = CBA_GETENV("CBA_TAIL_PAIR");                      // developer switch (bench harness only; read per call)
-  static const bool one_list_sw = CBA_GETENV("CBA_TAIL_XCD_LISTS") == nullptr;
-  t.pair = (pair_env ? atoi(pair_env) : kTailPairDefault) && one_list_sw ? 1 : 0;
   long long ntasks = 0;
-  for (int r = t.rt0; r < t.nr; ++r)
-    ntasks += t.pair ? tail_pair_row_count(t.rt0, t.nr, t.ntc, r) : ((r + 1 < t.nr) ? t.ntc - r : t.ntc - t.nr);
+  t.pair = 0;
+#ifdef CBA_DEV_SWITCHES
+  {
+    const char* pair_env = getenv("CBA_TAIL_PAIR");                        // bench harness only; read per call
+    t.pair = (pair_env && atoi(pair_env)) && getenv("CBA_TAIL_XCD_LISTS") == nullptr ? 1 : 0;
+  }
+  if (t.pair) for (int r = t.rt0; r < t.nr; ++r) ntasks += tail_pair_row_count(t.rt0, t.nr, t.ntc, r);
+#endif
+  if (!t.pair) for (int r = t.rt0; r < t.nr; ++r) ntasks += (r + 1 < t.nr) ? t.ntc - r : t.ntc - t.nr;
   t.ntasks = (int)ntasks;
   static const bool no_evict = CBA_GETENV("CBA_TAIL_NO_EVICT") != nullptr;     // developer switches (bench harness only)
   static const bool one_list = CBA_GETENV("CBA_TAIL_XCD_LISTS") == nullptr;   // per-XCD lists measured: no gain (the helpers are not operand-bandwidth bound)
@@ -2127,12 +2149,17 @@ static int ldlt_tail(double* S, int n_fact, int ld, int t0, LdltWorkspace& w, hi
   // a helper that finds itself on the chain's CU leaves (the chain needs the CU's LDS bandwidth and matrix pipes); with a grid this
   // small the only helpers could all sit there and nobody would run the chain's PRE / PART tasks
   if (grid <= 3) t.evict = 0;
+  // (the span of the launch itself is a harness statistic: two event records per launch are two bubbles on the critical stream)
+#ifdef CBA_DEV_SWITCHES
   if (st) CBA_HIP(hipEventRecord(w.tail_e0, s));
+#endif
   hipLaunchKernelGGL(k_ldlt_tail, dim3((unsigned)grid), dim3(256), 0, s, t);
   CBA_HIP(hipGetLastError());
   if (st) {
+#ifdef CBA_DEV_SWITCHES
     CBA_HIP(hipEventRecord(w.tail_e1, s));
     w.tail_timed = true;
+#endif
     const double R = (double)(n_fact - t0), C = (double)(ld - n_fact);
     st->flops += R * R * R / 3.0 + R * R * C;
   }
@@ -2151,12 +2178,9 @@ static int ldlt_tail(double* S, int n_fact, int ld, int t0, LdltWorkspace& w, hi
 // product with the explicit inverse of the super-panel's unit factor.)
 int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, GemmStats* st) {
   const int n_pad = ld;
-  // the side streams (users: the distributed variant, the Jacobian pass) may start once everything queued on the main stream so
-  // far (assembly of S) is done
-  CBA_HIP(hipEventRecord(w.ev_strip, s));
-  CBA_HIP(hipStreamWaitEvent(w.panel_stream, w.ev_strip, 0));
-  CBA_HIP(hipStreamWaitEvent(w.far_stream, w.ev_strip, 0));
-  CBA_HIP(hipStreamWaitEvent(w.mid_stream, w.ev_strip, 0));
+  // (one stream: nothing here runs on the side streams -- their next users, the Jacobian pass and the distributed variant, order
+  // themselves against the main stream with their own events; round 4 recorded an event and three stream waits here, a bubble in
+  // front of the first dataflow launch)
   const int sw = super_width(), tail_rows = ldlt_tail_rows(w);
   int k0 = 0, rc;
   while (n_fact - k0 > tail_rows + sw / 2 && n_pad - (k0 + sw) >= 1024) {

@@ -387,57 +387,53 @@ constexpr int kFdMaxObsPerBlock = 10;
 // (cba_fd_redo_overflow) and loses its Jacobian like a failed projection -- visible, never silent.
 
 // One finite-difference task: (observation o, task k) -> fd_out / fd_ok at index t = o * tasks_per_obs + k.
-// STG: spline evaluated on the staged patch `st`; returns false if an iterate left that patch (nothing is written then).
+// fd_task_setup: the perturbed input of the task (local point or substituted control point) and the finite-difference step;
+// false = the control point lies outside the grid (CHECK() in the reference; cannot happen inside the rectangle): fd_ok[t] = 0.
 template <int MODEL, bool STG>
-__device__ __forceinline__ bool fd_task(const PassArgs& a, const CamDev& c, int cam, int64_t o, int k, int64_t t, const double* __restrict__ pixels,
-                                        double* __restrict__ fd_out, uint8_t* __restrict__ fd_ok, StagedPatch<MODEL>* st, double* sub_slot) {
+__device__ __forceinline__ bool fd_task_setup(const PassArgs& a, const CamDev& c, int cam, int64_t o, int k, double bx, double by,
+                                              double* local, double& delta, Subst& sub, double* sub_slot) {
   constexpr int PER = (MODEL == kCentral) ? 2 : 5;
-  double local[3];
   local_point_of(a, o, cam, local);
-  const double bx = pixels[2 * o], by = pixels[2 * o + 1];
-  double px = bx, py = by;
-  double delta;
-  Subst sub; sub.index = -1;
+  sub.index = -1;
   if (k < 3) {
     delta = a.fd_delta * (MODEL == kCentral ? sqrt(local[0] * local[0] + local[1] * local[1] + local[2] * local[2]) : 0.1);
     local[k] += delta;
-  } else {
-    delta = a.fd_delta;
-    int g = k - 3;
-    int cell = g / PER, d = g - cell * PER;
-    double gx, gy;
-    pixel_to_grid(c, bx, by, gx, gy);
-    int ix = (int)floor(gx), iy = (int)floor(gy);
-    int cx = ix + (cell & 3) - 1, cy = iy + (cell >> 2) - 1;
-    if (cx < 0 || cy < 0 || cx >= c.gw || cy >= c.gh) {  // CHECK() in the reference; cannot happen inside the rectangle
-      fd_ok[t] = 0;
-      return true;
-    }
-    int seq = cx + cy * c.gw;
-    sub.index = seq;
-    const double* gd = c.grid + 3 * (size_t)seq;
-    const double* tg = c.tangents + 6 * (size_t)seq;
-    double o1 = (d == 0) ? delta : 0.0, o2 = (d == 1) ? delta : 0.0;
-    // ApplyLocalUpdateToDirection / ApplyLocalUpdateToLine (direction_parametrization.h:45-55,
-    // line_parametrization.h:107-120): always renormalises the direction
-    double nd[3] = {gd[0] + o1 * tg[0] + o2 * tg[3], gd[1] + o1 * tg[1] + o2 * tg[4], gd[2] + o1 * tg[2] + o2 * tg[5]};
-    normalize3(nd[0], nd[1], nd[2]);
-    sub.d[0] = nd[0]; sub.d[1] = nd[1]; sub.d[2] = nd[2];
-    if (MODEL == kNoncentral) {
-      const double* go = c.grid + 3 * (size_t)c.gw * c.gh + 3 * (size_t)seq;
-      double o3 = (d == 2) ? delta : 0.0, o4 = (d == 3) ? delta : 0.0, o5 = (d == 4) ? delta : 0.0;
-      sub.o[0] = go[0] + o3 * tg[0] + o4 * tg[3] + o5 * gd[0];
-      sub.o[1] = go[1] + o3 * tg[1] + o4 * tg[4] + o5 * gd[1];
-      sub.o[2] = go[2] + o3 * tg[2] + o4 * tg[5] + o5 * gd[2];
-    }
-    if (STG) {
-      sub_slot[0] = sub.d[0]; sub_slot[1] = sub.d[1]; sub_slot[2] = sub.d[2];
-      if (MODEL == kNoncentral) { sub_slot[3] = sub.o[0]; sub_slot[4] = sub.o[1]; sub_slot[5] = sub.o[2]; }
-    }
+    return true;
   }
-  bool miss = false;
-  const bool ok = project_point<MODEL, STG>(c, sub, local, px, py, st, &miss);
-  if (STG && miss) return false;
+  delta = a.fd_delta;
+  int g = k - 3;
+  int cell = g / PER, d = g - cell * PER;
+  double gx, gy;
+  pixel_to_grid(c, bx, by, gx, gy);
+  int ix = (int)floor(gx), iy = (int)floor(gy);
+  int cx = ix + (cell & 3) - 1, cy = iy + (cell >> 2) - 1;
+  if (cx < 0 || cy < 0 || cx >= c.gw || cy >= c.gh) return false;
+  int seq = cx + cy * c.gw;
+  sub.index = seq;
+  const double* gd = c.grid + 3 * (size_t)seq;
+  const double* tg = c.tangents + 6 * (size_t)seq;
+  double o1 = (d == 0) ? delta : 0.0, o2 = (d == 1) ? delta : 0.0;
+  // ApplyLocalUpdateToDirection / ApplyLocalUpdateToLine (direction_parametrization.h:45-55,
+  // line_parametrization.h:107-120): always renormalises the direction
+  double nd[3] = {gd[0] + o1 * tg[0] + o2 * tg[3], gd[1] + o1 * tg[1] + o2 * tg[4], gd[2] + o1 * tg[2] + o2 * tg[5]};
+  normalize3(nd[0], nd[1], nd[2]);
+  sub.d[0] = nd[0]; sub.d[1] = nd[1]; sub.d[2] = nd[2];
+  if (MODEL == kNoncentral) {
+    const double* go = c.grid + 3 * (size_t)c.gw * c.gh + 3 * (size_t)seq;
+    double o3 = (d == 2) ? delta : 0.0, o4 = (d == 3) ? delta : 0.0, o5 = (d == 4) ? delta : 0.0;
+    sub.o[0] = go[0] + o3 * tg[0] + o4 * tg[3] + o5 * gd[0];
+    sub.o[1] = go[1] + o3 * tg[1] + o4 * tg[4] + o5 * gd[1];
+    sub.o[2] = go[2] + o3 * tg[2] + o4 * tg[5] + o5 * gd[2];
+  }
+  if (STG) {
+    sub_slot[0] = sub.d[0]; sub_slot[1] = sub.d[1]; sub_slot[2] = sub.d[2];
+    if (MODEL == kNoncentral) { sub_slot[3] = sub.o[0]; sub_slot[4] = sub.o[1]; sub_slot[5] = sub.o[2]; }
+  }
+  return true;
+}
+// fd_task_store: the difference quotient of the task
+__device__ __forceinline__ void fd_task_store(const PassArgs& a, const CamDev& c, int64_t o, int k, int64_t t, bool ok, double px, double py,
+                                              double bx, double by, double delta, double* __restrict__ fd_out, uint8_t* __restrict__ fd_ok) {
   if (k >= 3 && a.jrec) {          // grid parameter: straight into the record (rows 0 / 1 of the 2 x K_g block)
     double* g = a.jrec + (size_t)o * a.rec_doubles + kRecHeader;
     const int Kg = c.params_per_point * 16;
@@ -448,6 +444,21 @@ __device__ __forceinline__ bool fd_task(const PassArgs& a, const CamDev& c, int 
     fd_out[2 * t + 1] = (py - by) / delta;
   }
   fd_ok[t] = ok ? 1 : 0;
+}
+// STG: spline evaluated on the staged patch `st`; returns false if an iterate left that patch (nothing is written then).
+template <int MODEL, bool STG>
+__device__ __forceinline__ bool fd_task(const PassArgs& a, const CamDev& c, int cam, int64_t o, int k, int64_t t, const double* __restrict__ pixels,
+                                        double* __restrict__ fd_out, uint8_t* __restrict__ fd_ok, StagedPatch<MODEL>* st, double* sub_slot) {
+  double local[3];
+  const double bx = pixels[2 * o], by = pixels[2 * o + 1];
+  double px = bx, py = by;
+  double delta;
+  Subst sub;
+  if (!fd_task_setup<MODEL, STG>(a, c, cam, o, k, bx, by, local, delta, sub, sub_slot)) { fd_ok[t] = 0; return true; }
+  bool miss = false;
+  const bool ok = project_point<MODEL, STG>(c, sub, local, px, py, st, &miss);
+  if (STG && miss) return false;
+  fd_task_store(a, c, o, k, t, ok, px, py, bx, by, delta, fd_out, fd_ok);
   return true;
 }
 
@@ -533,6 +544,162 @@ k_fd_tasks(PassArgs a, int tasks_per_obs, int localize_only, const double* __res
     else { fd_ok[t] = 0; atomicAdd(redo_overflow, 1); }     // list full: dropped Jacobian, as a failed projection, and counted
   }
 }
+// ---- pooled schedule (round 5): lanes take tasks from a workgroup pool, one LM attempt per trip ----
+// With one task per lane (k_fd_tasks above) a wavefront runs as long as its SLOWEST lane: projections need 1-3 outer iterations, and
+// about one in a hundred ends with ten rejected damping attempts (the iterate is converged to rounding and no candidate improves
+// it: ten Unproject evaluations, ten 2 x 2 solves) -- almost every second wavefront has such a lane and pays for it 64-fold
+// (SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU), profiles/r05_fd_lane_utilisation.txt).  Here a workgroup owns a POOL of
+// consecutive tasks (eight per lane), stages the control patches of all their observations once, and every lane runs a small state
+// machine: take the next task of the pool -> [UnprojectWithJacobian + normal equations when an outer iteration starts] -> ONE damping
+// attempt (candidate, Unproject, accept / reject) per trip of the loop -> store -> next task.  A lane stuck in rejected attempts
+// just takes fewer tasks.  Every task evaluates exactly the expressions of project_target (model.hip.h) in the same order --
+// the same device functions on the same inputs -- so results are bit-identical to the one-task-per-lane kernel
+// (tests/test_gpu_stragglers.py: cba_set_fd_schedule).
+constexpr int kFdPoolFactor = 8;
+template <int MODEL> struct FdPool { static constexpr int kMaxObs = (MODEL == kCentral) ? 64 : 32; };    // patches staged per workgroup (24.6 KB)
+template <int MODEL>
+__global__ void __launch_bounds__(256, MODEL == kCentral ? CBA_FD_WAVES_CENTRAL : CBA_FD_WAVES_NONCENTRAL)
+k_fd_pool(PassArgs a, int tasks_per_obs, int pool, const double* __restrict__ pixels, const uint8_t* __restrict__ flags,
+          double* __restrict__ fd_out, uint8_t* __restrict__ fd_ok, int64_t* __restrict__ redo, int* __restrict__ redo_count, int redo_cap,
+          int* __restrict__ redo_overflow) {
+  constexpr int PER = (MODEL == kCentral) ? 2 : 5;
+  constexpr int DIM = (MODEL == kCentral) ? 3 : 6;
+  constexpr int kMaxObs = FdPool<MODEL>::kMaxObs;
+  constexpr double kEpsilon = 1e-12;
+  __shared__ double sPatch[kMaxObs][16 * DIM];
+  __shared__ double sSub[256][DIM];             // per lane: the substituted control point of its current task
+  __shared__ int sOrigin[kMaxObs][2];
+  __shared__ int sNext;
+  const int64_t n_slots_all = a.obs_list ? (int64_t)min(*a.obs_count, a.obs_list_cap) : a.n_obs;
+  const int64_t total = n_slots_all * tasks_per_obs;
+  const int64_t t0 = (int64_t)blockIdx.x * pool;
+  if (t0 >= total) return;                                      // (uniform) list launches are sized by the list's capacity
+  const int n_pool = (int)((total - t0 < pool) ? total - t0 : pool);
+  const int64_t slot_first = t0 / tasks_per_obs;
+  {
+    // ---- stage the patches of every observation the pool touches ----
+    const int n_slots = (int)((t0 + n_pool - 1) / tasks_per_obs - slot_first) + 1;      // <= kMaxObs (launch_fd_tasks sizes the pool)
+    for (int e = threadIdx.x; e < n_slots * 16; e += blockDim.x) {
+      const int j = e >> 4, pt = e & 15;
+      const int64_t slot = slot_first + j;
+      const int64_t o = a.obs_list ? (int64_t)a.obs_list[slot] : slot;
+      bool live = (flags[o] & 1) != 0;
+      int fx = -(1 << 20), fy = -(1 << 20);
+      if (live) {
+        const CamDev c = a.cams[a.obs_camera[o]];
+        if (c.model_type == MODEL) {
+          double gx, gy;
+          pixel_to_grid(c, pixels[2 * o], pixels[2 * o + 1], gx, gy);
+          fx = (int)floor(gx + 2) - 3; fy = (int)floor(gy + 2) - 3;      // as unproject_jac places its patch
+          const int cx = fx + (pt & 3), cy = fy + (pt >> 2);
+          if (cx >= 0 && cy >= 0 && cx < c.gw && cy < c.gh) {
+            const double* g = c.grid + 3 * ((size_t)cx + (size_t)cy * c.gw);
+            sPatch[j][pt * DIM + 0] = g[0]; sPatch[j][pt * DIM + 1] = g[1]; sPatch[j][pt * DIM + 2] = g[2];
+            if (MODEL == kNoncentral) {
+              const double* p = g + 3 * (size_t)c.gw * c.gh;
+              sPatch[j][pt * DIM + 3] = p[0]; sPatch[j][pt * DIM + 4] = p[1]; sPatch[j][pt * DIM + 5] = p[2];
+            }
+          } else {
+            fx = -(1 << 20);                                             // never matches: such a patch is never evaluated
+          }
+        }
+      }
+      if (pt == 0) { sOrigin[j][0] = fx; sOrigin[j][1] = fy; }
+    }
+    if (threadIdx.x == 0) sNext = 0;
+    __syncthreads();
+  }
+  const int n_tasks = 3 + PER * 16;
+  const int first_k = (int)(t0 - slot_first * tasks_per_obs);          // task index of the pool's first task inside its observation
+  // ---- per-lane state machine ----
+  enum { kIdle = 0, kIterate = 1, kAttempt = 2, kStore = 3 };
+  int state = kIdle, k = 0, it = 0, lm = 0;
+  bool exhausted = false, ok = false;
+  int64_t o = 0, t = 0;
+  CamDev c = a.cams[0];
+  Subst sub; sub.index = -1;
+  StagedPatch<MODEL> st;
+  st.sub = (lds_cdouble_ptr)&sSub[threadIdx.x][0];
+  st.p = (lds_cdouble_ptr)&sPatch[0][0]; st.fx = st.fy = -(1 << 20);
+  double target[3] = {0, 0, 0}, bx = 0, by = 0, px = 0, py = 0, delta = 1, lambda = -1;
+  double cost = 0, H00 = 0, H01 = 0, H11 = 0, b0 = 0, b1 = 0;
+  auto to_redo = [&]() {                     // an iterate left the staged patch: the whole task is repeated on the gather path
+    const int slot = atomicAdd(redo_count, 1);
+    if (slot < redo_cap) redo[slot] = t;
+    else { fd_ok[t] = 0; atomicAdd(redo_overflow, 1); }     // list full: dropped Jacobian, as a failed projection, and counted
+    state = kIdle;
+  };
+  for (;;) {
+    if (state == kIdle && !exhausted) {
+      for (int tries = 0; tries < 8; ++tries) {              // (invalid observations / other cameras: skip their task slots quickly)
+        const int idx = atomicAdd(&sNext, 1);
+        if (idx >= n_pool) { exhausted = true; break; }
+        const int loc = idx + first_k;                       // 32-bit decode inside the pool (a 64-bit division per task is ~100 instructions)
+        const int js = loc / tasks_per_obs;
+        k = loc - js * tasks_per_obs;
+        const int64_t slot = slot_first + js;
+        o = a.obs_list ? (int64_t)a.obs_list[slot] : slot;
+        if (!a.obs_list && a.skip && a.skip[o]) continue;
+        if (!(flags[o] & 1) || k >= n_tasks) continue;
+        const int cam = a.obs_camera[o];
+        c = a.cams[cam];
+        if (c.model_type != MODEL) continue;
+        t = o * tasks_per_obs + k;            // results are indexed by (observation, task)
+        const int j = js;
+        st.p = (lds_cdouble_ptr)&sPatch[j][0];
+        st.fx = sOrigin[j][0]; st.fy = sOrigin[j][1];
+        bx = pixels[2 * o]; by = pixels[2 * o + 1];
+        px = bx; py = by;
+        if (!fd_task_setup<MODEL, true>(a, c, cam, o, k, bx, by, target, delta, sub, &sSub[threadIdx.x][0])) { fd_ok[t] = 0; continue; }
+        if (MODEL == kCentral) normalize3(target[0], target[1], target[2]);      // project_point: the central model projects directions
+        lambda = -1.0; it = 0;
+        state = kIterate;
+        break;
+      }
+    }
+    if (__all(state == kIdle && exhausted)) break;
+    if (state == kIterate) {                 // project_target: top of an outer iteration
+      double dir[3], org[3], jd[6], jo[6];
+      bool miss = false;
+      const bool inside = unproject_jac_staged<MODEL>(c, sub, st, px, py, dir, org, jd, jo, miss);
+      if (miss) to_redo();
+      else if (!inside) { ok = false; state = kStore; }                 // CHECK() in the reference
+      else {
+        projection_normal_equations<MODEL>(dir, org, jd, jo, target, cost, H00, H01, H11, b0, b1);
+        if (lambda < 0) lambda = 0.01 * 0.5 * (H00 + H11);
+        lm = 0;
+        state = kAttempt;
+      }
+    }
+    if (state == kAttempt) {                 // one damping attempt
+      double tx, ty;
+      projection_candidate(c, H00, H01, H11, b0, b1, lambda, px, py, tx, ty);
+      double test_cost = INFINITY;
+      double td[3], to[3];
+      bool miss = false;
+      const bool tin = unproject_staged<MODEL>(c, sub, st, tx, ty, td, to, miss);
+      if (miss) to_redo();
+      else {
+        if (tin) test_cost = projection_test_cost<MODEL>(td, to, target);
+        if (test_cost < cost) {
+          lambda *= 0.5;
+          px = tx; py = ty;
+          if (cost < kEpsilon) { ok = true; state = kStore; }
+          else if (++it >= 100) { ok = false; state = kStore; }         // not converged after 100 outer iterations
+          else state = kIterate;
+        } else {
+          lambda *= 2.0;
+          if (++lm >= 10) { ok = cost < kEpsilon; state = kStore; }     // no candidate accepted
+        }
+      }
+    }
+    if (state == kStore) {
+      fd_task_store(a, c, o, k, t, ok, px, py, bx, by, delta, fd_out, fd_ok);
+      state = kIdle;
+    }
+  }
+}
+
 // localize_only (3 tasks per observation, no grid tasks): a workgroup would cover 86 observations -- nothing to share, the
 // plain lane-per-task gather kernel
 template <int MODEL>
@@ -573,7 +740,7 @@ __global__ void __launch_bounds__(256) k_fd_redo(PassArgs a, int tasks_per_obs, 
 }
 int launch_fd_tasks(const PassArgs& a, int model_mask, int tasks_per_obs, int localize_only, const double* pixels,
                     const uint8_t* flags, double* fd_out, uint8_t* fd_ok, int64_t* redo, int* redo_count, int redo_cap, int* redo_overflow,
-                    hipStream_t s) {
+                    hipStream_t s, int schedule) {
   if (a.n_obs == 0) return CBA_OK;
   int64_t total = (a.obs_list ? (int64_t)a.obs_list_cap : a.n_obs) * tasks_per_obs;
   dim3 grid((unsigned)((total + 255) / 256)), block(256);
@@ -584,11 +751,24 @@ int launch_fd_tasks(const PassArgs& a, int model_mask, int tasks_per_obs, int lo
     return CBA_OK;
   }
   CBA_HIP(hipMemsetAsync(redo_count, 0, sizeof(int), s));
-  if (model_mask & 1)
-    hipLaunchKernelGGL(k_fd_tasks<kCentral>, grid, block, 0, s, a, tasks_per_obs, localize_only, pixels, flags, fd_out, fd_ok, redo, redo_count, redo_cap, redo_overflow);
-  if (model_mask & 2)
-    hipLaunchKernelGGL(k_fd_tasks<kNoncentral>, grid, block, 0, s, a, tasks_per_obs, localize_only, pixels, flags, fd_out, fd_ok, redo, redo_count, redo_cap,
-                       redo_overflow);
+  if (schedule == 0) {
+    // pooled schedule (default): a workgroup takes `pool` consecutive tasks; the pool is capped by the patches a workgroup can stage
+    auto launch_pool = [&](auto kernel, int max_obs) {
+      int pool = kFdPoolFactor * 256;
+      const int cap = (max_obs - 2) * tasks_per_obs;
+      if (pool > cap) pool = cap;
+      const dim3 pgrid((unsigned)((total + pool - 1) / pool));
+      hipLaunchKernelGGL(kernel, pgrid, block, 0, s, a, tasks_per_obs, pool, pixels, flags, fd_out, fd_ok, redo, redo_count, redo_cap, redo_overflow);
+    };
+    if (model_mask & 1) launch_pool(k_fd_pool<kCentral>, FdPool<kCentral>::kMaxObs);
+    if (model_mask & 2) launch_pool(k_fd_pool<kNoncentral>, FdPool<kNoncentral>::kMaxObs);
+  } else {
+    if (model_mask & 1)
+      hipLaunchKernelGGL(k_fd_tasks<kCentral>, grid, block, 0, s, a, tasks_per_obs, localize_only, pixels, flags, fd_out, fd_ok, redo, redo_count, redo_cap, redo_overflow);
+    if (model_mask & 2)
+      hipLaunchKernelGGL(k_fd_tasks<kNoncentral>, grid, block, 0, s, a, tasks_per_obs, localize_only, pixels, flags, fd_out, fd_ok, redo, redo_count, redo_cap,
+                         redo_overflow);
+  }
   // gather-path follow-up for the (rare) tasks that left their staged patch: fixed grid over the list capacity, the count
   // stays on the device (workgroups past it exit at once)
   const dim3 rgrid((unsigned)((redo_cap + 255) / 256));

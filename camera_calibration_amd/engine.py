@@ -77,7 +77,7 @@ EXPORTED_SYMBOLS = [
     "cba_total_dof", "cba_dense_dof", "cba_jacobian_record_doubles", "cba_reduce_buffer_doubles",
     "cba_kernel_stats", "cba_fit_grid_to_directions", "cba_prepare_device",
     "cba_model_create", "cba_model_destroy", "cba_model_set_grid", "cba_model_project", "cba_model_unproject",
-    "cba_fd_redo_overflow", "cba_debug_fd_redo_counts", "cba_schur_solve_opt",
+    "cba_fd_redo_overflow", "cba_debug_fd_redo_counts", "cba_schur_solve_opt", "cba_set_fd_schedule",
 ]
 
 DUMP_COST_VECTOR, DUMP_PIXELS, DUMP_FLAGS, DUMP_JACOBIANS = 1, 2, 3, 4
@@ -127,6 +127,7 @@ def load() -> C.CDLL:
     L.cba_debug_dump.argtypes = [vp, C.c_int32, vp, C.c_size_t]
     L.cba_debug_accumulate.argtypes = [vp, dp]
     L.cba_set_straggler_threshold.argtypes = [vp, C.c_int32]
+    L.cba_set_fd_schedule.argtypes = [vp, C.c_int32]
     L.cba_debug_solve.argtypes = [vp, C.c_double]
     L.cba_debug_apply_update.argtypes = [vp, dp]
     L.cba_total_dof.argtypes = [vp]
@@ -301,6 +302,10 @@ class Engine:
         return dict(seconds=s.value, flops=f.value, bytes=b.value, launches=n.value)
 
     # -- parity / debug ----------------------------------------------------------------------------
+    def set_fd_schedule(self, schedule: int) -> None:
+        """cba_set_fd_schedule: 0 = pooled finite-difference tasks (default), 1 = one task per lane."""
+        _check(self.L.cba_set_fd_schedule(self._h, int(schedule)), "cba_set_fd_schedule")
+
     def set_straggler_threshold(self, outer_iterations: int) -> None:
         """cba_set_straggler_threshold: outer projection iterations before an observation goes to the straggler kernel."""
         _check(self.L.cba_set_straggler_threshold(self._h, int(outer_iterations)), "cba_set_straggler_threshold")

@@ -267,6 +267,14 @@ int cba_debug_dump(cba_problem* p, int32_t what, void* out, size_t bytes);
  * observation there (the tests use it to compare the two kernels), >= 100 disables the hand-over.  Results do not depend
  * on the value. */
 int cba_set_straggler_threshold(cba_problem* p, int32_t outer_iterations);
+/* Scheduling knob of the finite-difference re-projections (joint_optimization.cc:357-372, APP/models/central_grid.h:187-245,
+ * noncentral_generic.h:224-283): 0 (default) = a workgroup takes a pool of tasks and every lane runs ONE damping attempt of its
+ * current projection per loop trip, fetching the next task when it is done (a wavefront does not wait for its slowest projection:
+ * 9 - 14 % faster at BASELINE configs[1] / [2] / [3]); 1 = one task per lane (the rounds 2-4 kernel; the tests compare the two).
+ * Both evaluate the same expressions in the same order for every task; validity / has-Jacobian flags are identical, Jacobian
+ * entries agree to ~1e-12 of a record's largest entry (the compiler fuses a multiply-add differently in the two kernels: 0.004 %
+ * of the entries differ, by an ulp of a pixel in one projection). */
+int cba_set_fd_schedule(cba_problem* p, int32_t schedule);
 /* Runs only the residual+Jacobian pass + accumulation on the current state (no solve). */
 int cba_debug_accumulate(cba_problem* p, double* cost);
 /* Solves the accumulated system for the given lambda (no state update); x via CBA_DUMP_X. */
