@@ -39,6 +39,7 @@ def parse_args():
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config id (1-5)")
     ap.add_argument("--factor-tail-rows", type=int, default=0, help="cba_solver_options.factor_tail_rows (0 = the library default); schedule sweeps only")
     ap.add_argument("--imagesets", type=int, default=0, help="imagesets per GPU (0 = the config's count)")
+    ap.add_argument("--fd-schedule", type=int, default=-1, help="cba_set_fd_schedule (0 pooled, 1 one task per lane); -1 = the library default; A/B runs only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-allreduce", action="store_true",
                     help="exercise the multi-GPU all-reduce path even with one rank (1-GPU validation of the N>1 code)")
@@ -297,6 +298,8 @@ def main():
         e = eng.Engine(pb, device=local_rank, allreduce=allreduce, n_images_global=n_img * world,
                        reduce_buffer_ptr=reduce_ptr, reduce_buffer_doubles=reduce_n, distributed_solve=dist_solve, rank=rank, world_size=world, factor_tail_rows=args.factor_tail_rows,
                        collective=make_collective(local_rank) if dist_solve else None)
+        if args.fd_schedule >= 0:
+            e.set_fd_schedule(args.fd_schedule)
         return e, keep
 
     def run_leg(dist_solve: bool) -> dict:

@@ -143,7 +143,7 @@ struct cba_problem {
   uint8_t* slow_skip = nullptr; uint8_t* fd_slow = nullptr; int* slow_list = nullptr; int* slow_count = nullptr;
   int slow_cap = kSlowCapMin;
   int straggler_threshold = 8;    // outer projection iterations before an observation goes to the straggler kernel
-  int fd_schedule = 0;            // finite-difference kernel: 0 = pooled tasks (default), 1 = one task per lane (cba_set_fd_schedule)
+  int fd_schedule = -1;           // finite-difference kernel: -1 = automatic (default), 0 = pooled tasks, 1 = one task per lane (cba_set_fd_schedule)
   int64_t* img_start = nullptr;          // first observation of every imageset (+ end), for the strip accumulation
   unsigned long long* band_mask = nullptr;   // per observation: column bands of B it touches
   // the side stream is the factorisation's far stream (idle during the Jacobian pass): the process must stay
@@ -293,6 +293,15 @@ static int upload_camdevs(cba_problem* p, int which) {
   return CBA_OK;
 }
 
+// -1 (default): pooled wherever the projections of one wavefront differ in length -- the non-central model (83 tasks per observation) and
+// rigs: 9 - 11 % faster in the bench trajectories of BASELINE configs[3] / [2] -- and one task per lane for a single central-generic
+// camera, where after the first iteration every task of an observation takes the same two outer iterations and the pool's bookkeeping
+// costs 4 % (configs[1]; in the FIRST iteration from the perturbed state the pool wins there too, 1.46 -> 1.29 ms).
+// profiles/r05_fd_schedules.txt, r05_fd_schedules_bench.txt
+static int fd_schedule_of(const cba_problem* p) {
+  if (p->fd_schedule >= 0) return p->fd_schedule;
+  return (p->L.n_cameras == 1 && p->model_mask == 1) ? 1 : 0;
+}
 static PassArgs pass_args(cba_problem* p, int which) {
   PassArgs a;
   a.n_obs = p->n_obs; a.n_cameras = p->L.n_cameras;
@@ -357,11 +366,11 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   CBA_HIP(hipStreamWaitEvent(aux, p->ev_aux2, 0));
   CBA_TRY(launch_base_project_slow(as, p->model_mask, p->cost_ref, p->pixels, p->flags, aux));
   CBA_TRY(launch_fd_tasks(as, p->model_mask, p->tasks_per_obs, L.localize_only, p->pixels, p->flags, p->fd_out, p->fd_ok, p->fd_redo[1], p->fd_redo_count + 1, p->fd_redo_cap,
-                          p->fd_redo_count + 2, aux, p->fd_schedule));
+                          p->fd_redo_count + 2, aux, fd_schedule_of(p)));
   CBA_HIP(hipEventRecord(p->ev_aux1, aux));
   CBA_TRY(timer_begin(p, 3));
   CBA_TRY(launch_fd_tasks(a, p->model_mask, p->tasks_per_obs, L.localize_only, p->pixels, p->flags, p->fd_out, p->fd_ok, p->fd_redo[0], p->fd_redo_count, p->fd_redo_cap,
-                          p->fd_redo_count + 2, p->stream, p->fd_schedule));
+                          p->fd_redo_count + 2, p->stream, fd_schedule_of(p)));
   CBA_TRY(timer_end(p, 3, 0, 0, 1));
   // Third stream: the accumulation targets are cleared (1.3 GB for H_dd at cfg 2) underneath the finite-difference launch.  Round 3
   // issued the memsets first, on the side stream: the 0.2 ms fill of H_dd then held the chip before the base projection of the pass
@@ -930,7 +939,7 @@ int cba_cost(cba_problem* p, double* cost, int64_t* n_valid, double* cost_vector
 }
 
 int cba_set_fd_schedule(cba_problem* p, int32_t schedule) {
-  if (!p || schedule < 0 || schedule > 1) { set_error("cba_set_fd_schedule: bad argument"); return CBA_ERR_ARG; }
+  if (!p || schedule < -1 || schedule > 1) { set_error("cba_set_fd_schedule: bad argument"); return CBA_ERR_ARG; }
   p->fd_schedule = schedule;
   return CBA_OK;
 }

@@ -303,7 +303,7 @@ class Engine:
 
     # -- parity / debug ----------------------------------------------------------------------------
     def set_fd_schedule(self, schedule: int) -> None:
-        """cba_set_fd_schedule: 0 = pooled finite-difference tasks (default), 1 = one task per lane."""
+        """cba_set_fd_schedule: -1 = automatic (default), 0 = pooled finite-difference tasks, 1 = one task per lane."""
         _check(self.L.cba_set_fd_schedule(self._h, int(schedule)), "cba_set_fd_schedule")
 
     def set_straggler_threshold(self, outer_iterations: int) -> None:

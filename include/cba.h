@@ -268,9 +268,10 @@ int cba_debug_dump(cba_problem* p, int32_t what, void* out, size_t bytes);
  * on the value. */
 int cba_set_straggler_threshold(cba_problem* p, int32_t outer_iterations);
 /* Scheduling knob of the finite-difference re-projections (joint_optimization.cc:357-372, APP/models/central_grid.h:187-245,
- * noncentral_generic.h:224-283): 0 (default) = a workgroup takes a pool of tasks and every lane runs ONE damping attempt of its
- * current projection per loop trip, fetching the next task when it is done (a wavefront does not wait for its slowest projection:
- * 9 - 14 % faster at BASELINE configs[1] / [2] / [3]); 1 = one task per lane (the rounds 2-4 kernel; the tests compare the two).
+ * noncentral_generic.h:224-283): 0 = a workgroup takes a pool of tasks and every lane runs ONE damping attempt of its current
+ * projection per loop trip, fetching the next task when it is done (a wavefront does not wait for its slowest projection);
+ * 1 = one task per lane (the rounds 2-4 kernel); -1 (default) = automatic: pooled for the non-central model and for rigs (9 - 11 %
+ * faster at BASELINE configs[3] / [2]), one task per lane for a single central-generic camera (4 % faster at configs[1]).
  * Both evaluate the same expressions in the same order for every task; validity / has-Jacobian flags are identical, Jacobian
  * entries agree to ~1e-12 of a record's largest entry (the compiler fuses a multiply-add differently in the two kernels: 0.004 %
  * of the entries differ, by an ulp of a pixel in one projection). */

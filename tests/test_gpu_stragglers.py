@@ -64,7 +64,7 @@ def test_straggler_kernel_is_bit_identical_to_the_one_lane_kernel(config, n_imag
 @pytest.mark.parametrize("config,n_imagesets,grid_wh", [(2, 16, (20, 16)), (4, 10, (16, 12)), (3, 8, (20, 16)), (2, 40, None)])
 def test_pooled_finite_difference_schedule_agrees_with_one_task_per_lane(config, n_imagesets, grid_wh):
     """The finite-difference re-projections (3 + K_cell per observation) run either one task per lane (rounds 2-4) or from a
-    workgroup's task pool with one damping attempt per loop trip (round 5, the default: cba_set_fd_schedule).
+    workgroup's task pool with one damping attempt per loop trip (round 5: cba_set_fd_schedule; the default picks per configuration).
     Both evaluate project_target's expressions in the same order for every task, from the same device functions -- but they are
     two kernels, and the compiler fuses a multiply-add of the 2 x 2 damped solve differently in the two instantiations: a
     projection whose last step lands within an ulp of a rounding boundary then ends one ulp of a pixel apart (observed: 45 of
