@@ -1296,6 +1296,9 @@ __device__ __forceinline__ bool chain_panel(double* sW, double* sV, double* s_rd
     const double l = a[c] * inv;
     if (c + 1 < 16) {
       const double v = readlane_f64(a[c], base + c + 1);
+      // (round 5 measured the alternative -- the next pivot as d' = W(c+1, c+1) - v^2 / d on a dependency chain of its own, one fused
+      // multiply-add behind 1 / d: panels 1.64-1.73 -> 1.79-1.90 us; with ONE wavefront issuing, the extra instructions cost more than the
+      // shorter dependency chain saves: profiles/r05_pivot_chain.txt)
       a[c + 1] = __builtin_fma(-l, v, a[c + 1]);
       slo = __builtin_amdgcn_readlane(__double2loint(a[c + 1]), base + c + 1);
       shi = __builtin_amdgcn_readlane(__double2hiint(a[c + 1]), base + c + 1);
