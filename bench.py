@@ -516,7 +516,9 @@ def main():
             fd_tflops = fd_flops / (fd_s / fd_launches) / 1e12
             out["roofline"] = {
                 "bound": "valu_fp64", "achieved": fd_tflops, "peak": 78.6, "unit": "TFLOP/s", "frac": fd_tflops / 78.6, "traffic": None,
-                "kernel": f"k_fd_tasks<{'1' if cam0.model_type == 1 else '0'}> (finite-difference re-projections, lane per (observation, task))",
+                "kernel": (f"{'k_fd_tasks' if (args.fd_schedule == 1 or (args.fd_schedule < 0 and pb.n_cameras == 1 and cam0.model_type == 0)) else 'k_fd_pool'}"
+                           f"<{'1' if cam0.model_type == 1 else '0'}> (finite-difference re-projections; k_fd_pool: workgroup task pool, one LM attempt per "
+                           "loop trip; k_fd_tasks: one task per lane -- cba_set_fd_schedule)"),
                 "launches": agg[3]["launches"], "avg_launch_ms": fd_s / fd_launches * 1e3, "flops_per_launch": fd_flops,
                 "model": "algorithmic flops = observations x (3 + K_cell) projections x 3.5 spline evaluations x 0.6 kflop "
                          "(DESIGN.md section 3); peak = MI355X fp64 vector peak"}
