@@ -350,12 +350,21 @@ static _Thread_local long g_eval_count = 0;
 static int32_t* g_eval_trace = NULL;            /* per observation: evaluations of its base projection */
 void orc_debug_set_eval_trace(int32_t* per_observation) { g_eval_trace = per_observation; }
 
+/* debug (tools/projection_orbits.py): the loop state (pixel, lambda) at the top of every outer iteration of ONE projection */
+static double* g_state_trace = NULL;
+static int g_state_trace_n = 0;
+void orc_debug_set_state_trace(double* buf300) { g_state_trace = buf300; g_state_trace_n = 0; }
+int orc_debug_state_trace_count(void) { return g_state_trace_n; }
 static int project_target(const orc_camera* cam, const double* grid, const double* target, double* result) {
   const double kEpsilon = 1e-12;
   double lambda = -1;
   for (int it = 0; it < 100; ++it) {
     double line[6], J[12];
     ++g_eval_count;
+    if (g_state_trace && g_state_trace_n < 100) {
+      g_state_trace[3 * g_state_trace_n] = result[0]; g_state_trace[3 * g_state_trace_n + 1] = result[1];
+      g_state_trace[3 * g_state_trace_n + 2] = lambda; ++g_state_trace_n;
+    }
     if (!orc_unproject_with_jacobian(cam, grid, result[0], result[1], line, J)) return -1;
     double cost, H00, H01, H11, b0, b1;
     if (cam->model_type == ORC_CENTRAL_GENERIC) {

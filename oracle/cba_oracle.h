@@ -101,6 +101,8 @@ void orc_set_num_threads(int n);
 /* developer aid: per-observation count of B-spline evaluations of the base projection in the following passes (NULL = off) */
 void orc_debug_set_eval_trace(int32_t* per_observation);
 int orc_get_num_threads(void);
+void orc_debug_set_state_trace(double* buf300);   /* single-threaded debugging only */
+int orc_debug_state_trace_count(void);
 int orc_hardware_threads(void);
 
 /* ---- model level ---- */
