@@ -26,7 +26,8 @@ case ${1:-help} in
     for b in bench_tail bench_tail_ring; do echo "==== $b"; TAILLOG=1 TAILS=6144,8192 REPS=4 timeout 300 tools/bin/$b 12672 12544 | grep -v "back substitution"; done ;;
   converged)         # profiles/r05_converged_parity*.json (the cfg-2 grid takes ~9 minutes of all-core oracle)
     timeout 600 python tools/converged_parity.py --config 1 --imagesets 0 --out $O/r05_converged_parity_cfg1.json | tail -30
-    timeout 1500 python tools/converged_parity.py --config 2 --imagesets 60 --out $O/r05_converged_parity.json | tail -30 ;;
+    timeout 1500 python tools/converged_parity.py --config 2 --imagesets 60 --out $O/r05_converged_parity.json | tail -30
+    timeout 1500 python tools/converged_parity.py --config 2 --imagesets 0 --out $O/r05_converged_parity_cfg2_full.json | tail -30 ;;   # the bench workload itself: ~6 minutes of oracle
   fd-schedules)      # profiles/r05_fd_schedules_bench.txt: pooled vs one task per lane inside the bench trajectories, alternating
     for c in 2 4 3; do for sch in 1 0 1 0; do
       timeout 600 python bench.py --config $c --steps 8 --warmup 2 --no-cpu-baseline --no-convergence --fd-schedule $sch 2>/dev/null | tail -1 | python -c "
@@ -35,7 +36,7 @@ d=json.loads(sys.stdin.read()); print('cfg $c schedule $sch: step %.3f ms, t_fd_
     done; done ;;
   fd-lanes)          # profiles/r05_fd_lane_utilisation.txt
     for c in 2 4; do ( cd /tmp; rm -rf /tmp/pmc_v$c
-      timeout 300 rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES -d /tmp/pmc_v$c -o pmc -- python $R/bench.py --config $c --steps 2 --warmup 0 --no-cpu-baseline --no-convergence --fd-schedule 1 > $O/r05_pmc_valu_cfg$c.log 2>&1
+      timeout 300 rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES -d /tmp/pmc_v$c -o pmc -- python $R/bench.py --config $c --steps 2 --warmup 0 --no-cpu-baseline --no-convergence --fd-schedule ${FD_SCHEDULE:-1} > $O/r05_pmc_valu_cfg$c.log 2>&1
       db=$(find /tmp/pmc_v$c -name "*.db" | head -1); [ -n "$db" ] && python $R/tools/rocprof_pmc_generic.py $db fd_tasks,fd_pool ); done ;;
   *) sed -n 2,4p $0 ;;
 esac
