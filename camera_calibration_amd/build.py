@@ -36,10 +36,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     objs = []
     procs = []
+    extra = os.environ.get("CBA_BUILD_EXTRA_FLAGS", "").split()      # developer A/B builds only (e.g. -DCBA_FD_POOL_WAVES_CENTRAL=3)
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc, *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *extra, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

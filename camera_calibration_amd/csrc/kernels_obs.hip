@@ -555,10 +555,13 @@ k_fd_tasks(PassArgs a, int tasks_per_obs, int localize_only, const double* __res
 // just takes fewer tasks.  Every task evaluates exactly the expressions of project_target (model.hip.h) in the same order --
 // the same device functions on the same inputs -- so results are bit-identical to the one-task-per-lane kernel
 // (tests/test_gpu_stragglers.py: cba_set_fd_schedule).
+#ifndef CBA_FD_POOL_WAVES_CENTRAL
+#define CBA_FD_POOL_WAVES_CENTRAL 3     // 4 (128 VGPRs, 16 spilled) measured: cfg 2 the same, cfg 3 4 % slower
+#endif
 constexpr int kFdPoolFactor = 8;
 template <int MODEL> struct FdPool { static constexpr int kMaxObs = (MODEL == kCentral) ? 64 : 32; };    // patches staged per workgroup (24.6 KB)
 template <int MODEL>
-__global__ void __launch_bounds__(256, MODEL == kCentral ? CBA_FD_WAVES_CENTRAL : CBA_FD_WAVES_NONCENTRAL)
+__global__ void __launch_bounds__(256, MODEL == kCentral ? CBA_FD_POOL_WAVES_CENTRAL : CBA_FD_WAVES_NONCENTRAL)
 k_fd_pool(PassArgs a, int tasks_per_obs, int pool, const double* __restrict__ pixels, const uint8_t* __restrict__ flags,
           double* __restrict__ fd_out, uint8_t* __restrict__ fd_ok, int64_t* __restrict__ redo, int* __restrict__ redo_count, int redo_cap,
           int* __restrict__ redo_overflow) {
