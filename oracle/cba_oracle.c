@@ -462,6 +462,11 @@ int orc_project_with_initial_estimate(const orc_camera* cam, const double* grid,
   }
   return r > 0;
 }
+/* CentralGenericModel::ProjectDirectionWithInitialEstimate (APP/models/central_generic.cc:137-224): the direction is taken as given
+ * (CentralGridModel::Project normalises before the call; a second normalisation could move it by an ulp) */
+int orc_project_direction_with_initial_estimate(const orc_camera* cam, const double* grid, const double* direction, double* pixel) {
+  return project_target(cam, grid, direction, pixel) > 0;
+}
 /* CameraModel::Project: start from the centre of the calibrated area (central_grid.h:79-97) */
 int orc_project(const orc_camera* cam, const double* grid, const double* local_point, double* pixel) {
   center_of_calibrated_area(cam, pixel);

@@ -113,6 +113,7 @@ int orc_unproject_with_jacobian(const orc_camera* cam, const double* grid, doubl
                                 double* line6, double* jac12);
 int orc_project_with_initial_estimate(const orc_camera* cam, const double* grid,
                                       const double* local_point, double* pixel);
+int orc_project_direction_with_initial_estimate(const orc_camera* cam, const double* grid, const double* direction, double* pixel);
 int orc_project(const orc_camera* cam, const double* grid, const double* local_point, double* pixel);
 void orc_grid_point_to_pixel(const orc_camera* cam, double gx, double gy, double* px);
 void orc_pixel_to_grid_point(const orc_camera* cam, double x, double y, double* gp);

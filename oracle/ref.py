@@ -339,3 +339,138 @@ def lmopt_optimize_jointly(oracle_problem, st, max_iteration_count: int = 1, ini
     cost = lm_lib().ref_lmopt_optimize_jointly(C.byref(oracle_problem.c), C.byref(oracle_problem._state(st)), max_iteration_count,
                                                init_lambda, C.byref(lam), C.byref(performed), _dp(trace))
     return dict(cost=cost, final_lambda=lam.value, performed=bool(performed.value), trace=trace)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the reference's outer-loop and report FUNCTIONS (oracle/_ref/libcalibref_f14.so; see ref_f14_glue.cc and the
+# rule in oracle/Makefile that pipes their line ranges from /root/reference into the compiler)
+# ---------------------------------------------------------------------------------------------------
+F14_LIB_PATH = os.path.join(_HERE, "_ref", "libcalibref_f14.so")
+_f14_lib: Optional[C.CDLL] = None
+
+
+def f14_available() -> bool:
+    build()
+    return os.path.exists(F14_LIB_PATH)
+
+
+def f14_lib() -> C.CDLL:
+    global _f14_lib
+    if _f14_lib is None:
+        build()
+        if not os.path.exists(F14_LIB_PATH):
+            raise RuntimeError("oracle/_ref/libcalibref_f14.so is missing and /root/reference is not present")
+        from oracle import oracle as orc
+        orc.lib()
+        L = C.CDLL(F14_LIB_PATH)
+        dp, fp, ip, bp = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_uint8)
+        dpp = C.POINTER(dp)
+        packed = [C.c_int, C.c_int, C.c_int, ip, C.c_int64, fp, ip, ip, ip]       # n_cameras n_images n_points cam8 n_obs xy point image camera
+        L.ref_f1_choose_nice_camera_orientation.argtypes = [ip, dp, dp]
+        L.ref_f1_scale_to_metric.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, dp, C.c_float, C.c_int, ip, ip, ip, ip, C.c_int]
+        L.ref_f1_scale_to_metric.restype = C.c_double
+        L.ref_f1_delete_outlier_features.argtypes = [C.c_int] + packed + [dp, dp, dp, dpp, C.c_float, bp, bp]
+        L.ref_f4_compute_all_reprojection_errors.argtypes = [C.c_int] + packed + [dp, dp, dp, dpp, bp, dp, fp, dp]
+        L.ref_f4_compute_all_reprojection_errors.restype = C.c_int64
+        L.ref_f4_reprojection_error_histogram.argtypes = [C.c_int, C.c_double, C.c_int64, dp, dp]
+        L.ref_f4_reprojection_error_median.argtypes = [C.c_int64, dp]
+        L.ref_f4_reprojection_error_median.restype = C.c_double
+        L.ref_f1_run_bundle_adjustment.argtypes = [C.c_int, C.c_double, C.c_int] + packed + [dp, dp, dp, dpp, dp]
+        _f14_lib = L
+    return _f14_lib
+
+
+class _Packed:
+    """ctypes views of a camera_calibration_amd.problem.Problem / State pair (central cameras only; keeps the arrays alive)."""
+
+    def __init__(self, pb, st):
+        assert all(c.model_type == 0 for c in pb.cameras), "the reference-side model of ref_f14_model.h is the central-generic one"
+        self.cam8 = np.concatenate([_cam_params8(c) for c in pb.cameras]).astype(np.int32)
+        self.xy = np.ascontiguousarray(pb.obs_xy, dtype=np.float32)
+        self.point = np.ascontiguousarray(pb.obs_point, dtype=np.int32)
+        self.image = np.ascontiguousarray(pb.obs_image, dtype=np.int32)
+        self.camera = np.ascontiguousarray(pb.obs_camera, dtype=np.int32)
+        self.rig = np.ascontiguousarray(st.rig_tr_global, dtype=np.float64).copy()
+        self.ctr = np.ascontiguousarray(st.camera_tr_rig, dtype=np.float64).copy()
+        self.points = np.ascontiguousarray(st.points, dtype=np.float64).copy()
+        self.grids = [np.ascontiguousarray(g, dtype=np.float64).copy() for g in st.grids]
+        self.grid_ptrs = (C.POINTER(C.c_double) * len(self.grids))(*[_dp(g) for g in self.grids])
+        self.head = [pb.n_cameras, pb.n_images, pb.n_points, _ip(self.cam8), int(pb.n_obs),
+                     self.xy.ctypes.data_as(C.POINTER(C.c_float)), _ip(self.point), _ip(self.image), _ip(self.camera)]
+        self.state = [_dp(self.rig), _dp(self.ctr), _dp(self.points), self.grid_ptrs]
+
+
+def _bp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def f1_choose_nice_camera_orientation(cam, grid):
+    """CentralGenericModel::ChooseNiceCameraOrientation (APP/models/central_generic.cc:570-621), the reference's text compiled on the
+    reference's CentralGridModel.  Returns (rotation 3x3, rotated grid (G, 3))."""
+    g = np.ascontiguousarray(grid, dtype=np.float64).reshape(-1, 3).copy()
+    R = np.zeros(9)
+    f14_lib().ref_f1_choose_nice_camera_orientation(_ip(_cam_params8(cam)), _dp(g), _dp(R))
+    return R.reshape(3, 3), g
+
+
+def f1_scale_to_metric(cell_length: float, feature_id_to_position, feature_id_to_points_index, points, rig_tr_global, camera_tr_rig):
+    """ScaleToMetric (APP/calibration.cc:307-370) + BAState::ScaleState (ba_state.cc).  Returns (factor, points, rig_tr_global,
+    camera_tr_rig) after scaling."""
+    pts = np.ascontiguousarray(points, dtype=np.float64).copy()
+    rig = np.ascontiguousarray(rig_tr_global, dtype=np.float64).copy()
+    ctr = np.ascontiguousarray(camera_tr_rig, dtype=np.float64).copy()
+    ids = np.array(list(feature_id_to_position.keys()), dtype=np.int32)
+    pos = np.array([feature_id_to_position[int(i)] for i in ids], dtype=np.int32).reshape(-1, 2)
+    mids = np.array(list(feature_id_to_points_index.keys()), dtype=np.int32)
+    midx = np.array([feature_id_to_points_index[int(i)] for i in mids], dtype=np.int32)
+    f = f14_lib().ref_f1_scale_to_metric(len(pts), _dp(pts), len(rig), _dp(rig), len(ctr), _dp(ctr), float(cell_length), len(ids), _ip(ids),
+                                         _ip(pos), _ip(mids), _ip(midx), len(mids))
+    return f, pts, rig, ctr
+
+
+def f1_delete_outlier_features(camera_index: int, pb, st, outlier_removal_factor: float, image_used=None):
+    """DeleteOutlierFeatures (APP/calibration.cc:62-184).  Returns (keep mask over the problem's observations, image_used)."""
+    pk = _Packed(pb, st)
+    used = (np.ones(pb.n_images, dtype=np.uint8) if image_used is None else np.asarray(image_used).astype(np.uint8).copy())
+    keep = np.zeros(pb.n_obs, dtype=np.uint8)
+    f14_lib().ref_f1_delete_outlier_features(camera_index, *pk.head, *pk.state, float(outlier_removal_factor), _bp(used), _bp(keep))
+    return keep.astype(bool), used.astype(bool)
+
+
+def f4_compute_all_reprojection_errors(camera_index: int, pb, st, image_used=None):
+    """ComputeAllReprojectionErrors (APP/calibration_report.cc:101-148)."""
+    pk = _Packed(pb, st)
+    used = (np.ones(pb.n_images, dtype=np.uint8) if image_used is None else np.asarray(image_used).astype(np.uint8).copy())
+    errors = np.zeros((pb.n_obs, 2)); feats = np.zeros((pb.n_obs, 2), dtype=np.float32); sm = np.zeros(2)
+    n = f14_lib().ref_f4_compute_all_reprojection_errors(camera_index, *pk.head, *pk.state, _bp(used), _dp(errors),
+                                                         feats.ctypes.data_as(C.POINTER(C.c_float)), _dp(sm))
+    return dict(count=int(n), sum=float(sm[0]), max=float(sm[1]), errors=errors[:n].copy(), features=feats[:n].copy())
+
+
+def f4_reprojection_error_histogram(resolution: int, extent_in_px: float, errors):
+    """ComputeReprojectionErrorHistogram (APP/calibration_report.cc:151-168); hist[hy, hx]."""
+    e = np.ascontiguousarray(errors, dtype=np.float64).reshape(-1, 2)
+    hist = np.zeros((resolution, resolution))
+    f14_lib().ref_f4_reprojection_error_histogram(resolution, float(extent_in_px), len(e), _dp(e), _dp(hist))
+    return hist
+
+
+def f4_reprojection_error_median(errors) -> float:
+    """The reprojection_error_median line of WriteReportInfoFile (APP/calibration_report.cc:686-692), printed with 17 digits."""
+    e = np.ascontiguousarray(errors, dtype=np.float64).reshape(-1, 2)
+    return float(f14_lib().ref_f4_reprojection_error_median(len(e), _dp(e)))
+
+
+def f1_run_bundle_adjustment(pb, st, max_iteration_count: int, cost_reduction_threshold: float, localize_only: bool = False):
+    """RunBundleAdjustment (APP/calibration.cc:187-304, CPU branch) around the oracle's OptimizeJointly.  Returns (State, number of
+    OptimizeJointly calls made, numerical_diff_delta the loop passed)."""
+    pk = _Packed(pb, st)
+    trace = np.zeros(4)
+    f14_lib().ref_f1_run_bundle_adjustment(max_iteration_count, float(cost_reduction_threshold), int(localize_only), *pk.head, *pk.state,
+                                           _dp(trace))
+    out = st.copy()
+    out.rig_tr_global[...] = pk.rig; out.camera_tr_rig[...] = pk.ctr; out.points[...] = pk.points
+    for g, h in zip(out.grids, pk.grids):
+        g[...] = h.reshape(g.shape)
+    return out, int(trace[0]), float(trace[1])
+

@@ -1,0 +1,256 @@
+// oracle/_ref, part 5 (glue) -- TEST INFRASTRUCTURE ONLY.
+//
+// C entry points over the reference's OWN outer-loop and report functions, which rounds 1-4 could only
+// restate (oracle/oracle.py) because their files need Qt / boost:
+//   APP/calibration.cc:62-184            DeleteOutlierFeatures
+//   APP/calibration.cc:187-304           RunBundleAdjustment (stopping rule :298, lambda carried across calls, orientation beautification
+//                                        :248-254 applied to camera_tr_rig)
+//   APP/calibration.cc:305-370           ScaleToMetric (+ BAState::ScaleState, APP/bundle_adjustment/ba_state.cc:58-74, compiled whole)
+//   APP/models/central_generic.cc:570-621  CentralGenericModel::ChooseNiceCameraOrientation
+//   APP/calibration_report.cc:101-168    ComputeAllReprojectionErrors, ComputeReprojectionErrorHistogram
+//   APP/calibration_report.cc:683-691    the reprojection_error_median rule (a fragment: compiled as the body of RefMedianRule)
+// (APP = /root/reference/applications/camera_calibration/src/camera_calibration.)  None of that text is in this repository: the rule of
+// _ref/libcalibref_f14.so in oracle/Makefile pipes exactly those line ranges out of /root/reference into the compiler, between
+// ref_f14_prelude.h (real Dataset / BAState / CameraModel headers + no-op stand-ins for the Qt window, key input and visualisation
+// calls) and this file; APP/dataset.cc and APP/bundle_adjustment/ba_state.cc are compiled whole from where they lie.
+//
+// This file adds (a) the marshalling between packed arrays (the layout of camera_calibration_amd.problem / oracle.oracle) and the
+// reference's Dataset / BAState, and (b) vis::OptimizeJointly for RunBundleAdjustment to call: the oracle's orc_optimize_jointly on
+// the marshalled problem (the LM driver behind it is pinned separately, ref_lmopt.cc) -- what is under test here is the loop AROUND it.
+#include "../cba_oracle.h"
+
+using namespace vis;
+
+namespace {
+
+struct Packed {                       // one problem in the packed layout
+  int n_cameras, n_images, n_points;
+  const int* cam8;                    // per camera: width height min_x min_y max_x max_y gw gh
+  int64_t n_obs;
+  const float* obs_xy; const int* obs_point; const int* obs_image; const int* obs_camera;
+};
+
+std::shared_ptr<RefOrientedModel> make_model(const int* p8, const double* grid) {
+  auto m = std::make_shared<RefOrientedModel>(p8[6], p8[7], p8[2], p8[3], p8[4], p8[5], p8[0], p8[1]);
+  for (int y = 0; y < p8[7]; ++y)
+    for (int x = 0; x < p8[6]; ++x) {
+      const double* g = grid + 3 * (x + (size_t)y * p8[6]);
+      m->grid()(x, y) = Vec3d(g[0], g[1], g[2]);
+    }
+  return m;
+}
+void store_grid(const CameraModel* cm, double* grid) {
+  const RefOrientedModel* m = static_cast<const RefOrientedModel*>(cm);
+  const int gw = m->grid().width(), gh = m->grid().height();
+  for (int y = 0; y < gh; ++y)
+    for (int x = 0; x < gw; ++x)
+      for (int k = 0; k < 3; ++k) grid[3 * (x + (size_t)y * gw) + k] = m->grid()(x, y)(k);
+}
+SE3d pose_of(const double* p7) { return SE3d(Eigen::Quaterniond(p7[0], p7[1], p7[2], p7[3]), Vec3d(p7[4], p7[5], p7[6])); }
+void store_pose(const SE3d& T, double* p7) {
+  p7[0] = T.unit_quaternion().w(); p7[1] = T.unit_quaternion().x(); p7[2] = T.unit_quaternion().y(); p7[3] = T.unit_quaternion().z();
+  p7[4] = T.translation()(0); p7[5] = T.translation()(1); p7[6] = T.translation()(2);
+}
+
+// Dataset with one imageset per image (all cameras), features in the packed order; feature ids = point indices
+void build(const Packed& pk, const double* rig_tr_global, const double* camera_tr_rig, const double* points, const double* const* grids,
+           const uint8_t* image_used, Dataset* ds, BAState* st) {
+  ds->Reset(pk.n_cameras);
+  for (int c = 0; c < pk.n_cameras; ++c) ds->SetImageSize(c, Vec2i(pk.cam8[8 * c], pk.cam8[8 * c + 1]));
+  for (int i = 0; i < pk.n_images; ++i) ds->NewImageset();
+  for (int64_t o = 0; o < pk.n_obs; ++o) {
+    PointFeature f(Vec2f(pk.obs_xy[2 * o], pk.obs_xy[2 * o + 1]), pk.obs_point[o]);
+    f.index = pk.obs_point[o];
+    ds->GetImageset(pk.obs_image[o])->FeaturesOfCamera(pk.obs_camera[o]).push_back(f);
+  }
+  st->image_used.assign(pk.n_images, true);
+  if (image_used) for (int i = 0; i < pk.n_images; ++i) st->image_used[i] = image_used[i] != 0;
+  st->camera_tr_rig.clear(); st->rig_tr_global.clear(); st->points.clear(); st->intrinsics.clear();
+  for (int c = 0; c < pk.n_cameras; ++c) st->camera_tr_rig.push_back(pose_of(camera_tr_rig + 7 * c));
+  for (int i = 0; i < pk.n_images; ++i) st->rig_tr_global.push_back(pose_of(rig_tr_global + 7 * i));
+  for (int p = 0; p < pk.n_points; ++p) {
+    st->points.push_back(Vec3d(points[3 * p], points[3 * p + 1], points[3 * p + 2]));
+    st->feature_id_to_points_index[p] = p;
+  }
+  for (int c = 0; c < pk.n_cameras; ++c) st->intrinsics.push_back(make_model(pk.cam8 + 8 * c, grids[c]));
+}
+
+// what vis::OptimizeJointly (below) needs to hand the problem to the oracle
+int g_optimize_calls = 0;
+double g_fd_delta_seen = 0;
+
+}  // namespace
+
+namespace vis {
+// The hot path as RunBundleAdjustment calls it (APP/bundle_adjustment/joint_optimization.h:53-70): here the oracle's restatement on the
+// marshalled problem.  Observations are walked image-major, camera, feature order -- the loop order of the reference's cost function.
+double OptimizeJointly(Dataset& dataset, BAState* state, int max_iteration_count, double init_lambda, double numerical_diff_delta,
+                       double /*regularization_weight*/, bool localize_only, bool eliminate_points, SchurMode /*schur_mode*/,
+                       double* final_lambda, bool* performed_an_iteration, bool, bool, bool, bool, bool, bool) {
+  ++g_optimize_calls;
+  g_fd_delta_seen = numerical_diff_delta;
+  const int C = dataset.num_cameras();
+  std::vector<int> seq(dataset.ImagesetCount(), -1);
+  int N = 0;
+  for (int i = 0; i < dataset.ImagesetCount(); ++i) if (state->image_used[i]) seq[i] = N++;
+  std::vector<orc_camera> cams(C);
+  std::vector<std::vector<double>> grids(C);
+  std::vector<double*> grid_ptrs(C);
+  for (int c = 0; c < C; ++c) {
+    const RefOrientedModel* m = static_cast<const RefOrientedModel*>(state->intrinsics[c].get());
+    cams[c] = orc_camera{ORC_CENTRAL_GENERIC, m->width(), m->height(), m->calibration_min_x(), m->calibration_min_y(),
+                         m->calibration_max_x(), m->calibration_max_y(), (int)m->grid().width(), (int)m->grid().height()};
+    grids[c].resize(3 * (size_t)m->grid().width() * m->grid().height());
+    store_grid(m, grids[c].data());
+    grid_ptrs[c] = grids[c].data();
+  }
+  std::vector<float> xy; std::vector<int32_t> op, oi, oc; std::vector<double> lp;
+  std::vector<PointFeature*> feats;
+  for (int i = 0; i < dataset.ImagesetCount(); ++i) {
+    if (!state->image_used[i]) continue;
+    for (int c = 0; c < C; ++c)
+      for (PointFeature& f : dataset.GetImageset(i)->FeaturesOfCamera(c)) {
+        xy.push_back(f.xy.x()); xy.push_back(f.xy.y()); op.push_back(f.index); oi.push_back(seq[i]); oc.push_back(c);
+        lp.push_back(f.last_projection.x()); lp.push_back(f.last_projection.y());
+        feats.push_back(&f);
+      }
+  }
+  std::vector<double> rig(7 * (size_t)N), cam(7 * (size_t)C), pts(3 * state->points.size());
+  for (int i = 0; i < dataset.ImagesetCount(); ++i) if (seq[i] >= 0) store_pose(state->rig_tr_global[i], rig.data() + 7 * seq[i]);
+  for (int c = 0; c < C; ++c) store_pose(state->camera_tr_rig[c], cam.data() + 7 * c);
+  for (size_t p = 0; p < state->points.size(); ++p) for (int k = 0; k < 3; ++k) pts[3 * p + k] = state->points[p](k);
+  orc_problem pb{C, N, (int32_t)state->points.size(), (int64_t)op.size(), cams.data(), xy.data(), op.data(), oi.data(), oc.data(), lp.data(),
+                 numerical_diff_delta, localize_only ? 1 : 0, eliminate_points ? 1 : 0};
+  orc_state os{rig.data(), cam.data(), pts.data(), grid_ptrs.data()};
+  double lam = 0; int32_t performed = 0;
+  const double cost = orc_optimize_jointly(&pb, &os, max_iteration_count, init_lambda, &lam, &performed, nullptr, nullptr);
+  if (final_lambda) *final_lambda = lam;
+  if (performed_an_iteration) *performed_an_iteration = performed != 0;
+  // read back (joint_optimization.cc:943-950) incl. the warm-start cache
+  for (int i = 0; i < dataset.ImagesetCount(); ++i) if (seq[i] >= 0) state->rig_tr_global[i] = pose_of(rig.data() + 7 * seq[i]);
+  for (int c = 0; c < C; ++c) state->camera_tr_rig[c] = pose_of(cam.data() + 7 * c);
+  for (size_t p = 0; p < state->points.size(); ++p) state->points[p] = Vec3d(pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]);
+  for (int c = 0; c < C; ++c) {
+    RefOrientedModel* m = static_cast<RefOrientedModel*>(state->intrinsics[c].get());
+    const int gw = m->grid().width(), gh = m->grid().height();
+    for (int y = 0; y < gh; ++y) for (int x = 0; x < gw; ++x) { const double* g = grids[c].data() + 3 * (x + (size_t)y * gw); m->grid()(x, y) = Vec3d(g[0], g[1], g[2]); }
+  }
+  for (size_t k = 0; k < feats.size(); ++k) feats[k]->last_projection = Vec2d(lp[2 * k], lp[2 * k + 1]);
+  return cost;
+}
+}  // namespace vis
+
+#define CBA_EXPORT extern "C" __attribute__((visibility("default")))
+
+// CentralGenericModel::ChooseNiceCameraOrientation: rotation (9, row-major) out, grid rotated in place
+CBA_EXPORT void ref_f1_choose_nice_camera_orientation(const int* cam8, double* grid, double* rotation9) {
+  auto m = make_model(cam8, grid);
+  const Mat3d R = m->ChooseNiceCameraOrientation();
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) rotation9[3 * r + c] = R(r, c);
+  store_grid(m.get(), grid);
+}
+
+// ScaleToMetric on a state with one known geometry (feature id -> integer pattern position): points / poses scaled in place, returns
+// the factor applied (read off the first point that moved; 1 if none)
+CBA_EXPORT double ref_f1_scale_to_metric(int n_points, double* points, int n_poses, double* rig_tr_global, int n_cam, double* camera_tr_rig,
+                                         float cell_length, int n_ids, const int* feature_ids, const int* positions_xy,
+                                         const int* id_to_point_ids, const int* id_to_point_index, int n_id_to_point) {
+  Dataset ds(n_cam);
+  ds.SetKnownGeometriesCount(1);
+  KnownGeometry& kg = ds.GetKnownGeometry(0);
+  kg.cell_length_in_meters = cell_length;
+  for (int i = 0; i < n_ids; ++i) kg.feature_id_to_position[feature_ids[i]] = Vec2i(positions_xy[2 * i], positions_xy[2 * i + 1]);
+  BAState st;
+  for (int p = 0; p < n_points; ++p) st.points.push_back(Vec3d(points[3 * p], points[3 * p + 1], points[3 * p + 2]));
+  for (int i = 0; i < n_poses; ++i) { st.rig_tr_global.push_back(pose_of(rig_tr_global + 7 * i)); st.image_used.push_back(true); }
+  for (int c = 0; c < n_cam; ++c) st.camera_tr_rig.push_back(pose_of(camera_tr_rig + 7 * c));
+  for (int i = 0; i < n_id_to_point; ++i) st.feature_id_to_points_index[id_to_point_ids[i]] = id_to_point_index[i];
+  const int cam8[8] = {64, 48, 0, 0, 63, 47, 5, 5};
+  std::vector<double> g(75, 0.0);
+  for (int i = 0; i < 25; ++i) g[3 * i + 2] = 1.0;
+  for (int c = 0; c < n_cam; ++c) st.intrinsics.push_back(make_model(cam8, g.data()));        // (Scale() of a central model: no-op)
+  ScaleToMetric(&ds, &st);
+  double factor = 1.0;
+  for (int p = 0; p < n_points && factor == 1.0; ++p)
+    for (int k = 0; k < 3; ++k) if (points[3 * p + k] != 0.0 && st.points[p](k) != points[3 * p + k]) { factor = st.points[p](k) / points[3 * p + k]; break; }
+  for (int p = 0; p < n_points; ++p) for (int k = 0; k < 3; ++k) points[3 * p + k] = st.points[p](k);
+  for (int i = 0; i < n_poses; ++i) store_pose(st.rig_tr_global[i], rig_tr_global + 7 * i);
+  for (int c = 0; c < n_cam; ++c) store_pose(st.camera_tr_rig[c], camera_tr_rig + 7 * c);
+  return factor;
+}
+
+// DeleteOutlierFeatures for one camera: keep[o] (packed observation order), image_used in / out
+CBA_EXPORT void ref_f1_delete_outlier_features(int camera_index, int n_cameras, int n_images, int n_points, const int* cam8, int64_t n_obs,
+                                               const float* obs_xy, const int* obs_point, const int* obs_image, const int* obs_camera,
+                                               const double* rig_tr_global, const double* camera_tr_rig, const double* points,
+                                               const double* const* grids, float outlier_removal_factor, uint8_t* image_used, uint8_t* keep) {
+  Packed pk{n_cameras, n_images, n_points, cam8, n_obs, obs_xy, obs_point, obs_image, obs_camera};
+  Dataset ds; BAState st;
+  build(pk, rig_tr_global, camera_tr_rig, points, grids, image_used, &ds, &st);
+  // tag every feature with its packed index (PointFeature::id is free for that here: DeleteOutlierFeatures does not read it)
+  std::vector<size_t> cursor((size_t)n_images * n_cameras, 0);
+  for (int64_t o = 0; o < n_obs; ++o) {
+    auto& feats = ds.GetImageset(obs_image[o])->FeaturesOfCamera(obs_camera[o]);
+    feats[cursor[(size_t)obs_image[o] * n_cameras + obs_camera[o]]++].id = (int)o;
+  }
+  DeleteOutlierFeatures(camera_index, &ds, &st, outlier_removal_factor, nullptr, false, nullptr);
+  for (int64_t o = 0; o < n_obs; ++o) keep[o] = obs_camera[o] == camera_index ? 0 : 1;
+  for (int i = 0; i < n_images; ++i)
+    for (const PointFeature& f : ds.GetImageset(i)->FeaturesOfCamera(camera_index)) keep[f.id] = 1;
+  for (int i = 0; i < n_images; ++i) image_used[i] = st.image_used[i] ? 1 : 0;
+}
+
+// ComputeAllReprojectionErrors for one camera: errors / features (2 per entry, capacity n_obs), returns the count; sum_max[2]
+CBA_EXPORT int64_t ref_f4_compute_all_reprojection_errors(int camera_index, int n_cameras, int n_images, int n_points, const int* cam8, int64_t n_obs,
+                                                          const float* obs_xy, const int* obs_point, const int* obs_image, const int* obs_camera,
+                                                          const double* rig_tr_global, const double* camera_tr_rig, const double* points,
+                                                          const double* const* grids, const uint8_t* image_used, double* errors, float* features,
+                                                          double* sum_max) {
+  Packed pk{n_cameras, n_images, n_points, cam8, n_obs, obs_xy, obs_point, obs_image, obs_camera};
+  Dataset ds; BAState st;
+  build(pk, rig_tr_global, camera_tr_rig, points, grids, image_used, &ds, &st);
+  usize count = 0; double sum = 0, mx = 0;
+  vector<Vec2d> errs; vector<Vec2f> feats;
+  ComputeAllReprojectionErrors(camera_index, ds, st, &count, &sum, &mx, &errs, &feats);
+  for (size_t i = 0; i < errs.size(); ++i) { errors[2 * i] = errs[i].x(); errors[2 * i + 1] = errs[i].y(); features[2 * i] = feats[i].x(); features[2 * i + 1] = feats[i].y(); }
+  sum_max[0] = sum; sum_max[1] = mx;
+  return (int64_t)count;
+}
+
+// ComputeReprojectionErrorHistogram: hist[resolution * resolution], row-major (y, x)
+CBA_EXPORT void ref_f4_reprojection_error_histogram(int resolution, double extent_in_px, int64_t n, const double* errors, double* hist) {
+  vector<Vec2d> errs;
+  for (int64_t i = 0; i < n; ++i) errs.push_back(Vec2d(errors[2 * i], errors[2 * i + 1]));
+  Image<double> img;
+  ComputeReprojectionErrorHistogram(resolution, extent_in_px, errs, &img);
+  for (int y = 0; y < resolution; ++y) for (int x = 0; x < resolution; ++x) hist[(size_t)y * resolution + x] = img(x, y);
+}
+
+// the reprojection_error_median line of the report (calibration_report.cc:683-691): the value it prints
+CBA_EXPORT double ref_f4_reprojection_error_median(int64_t n, const double* errors) {
+  vector<Vec2d> errs;
+  for (int64_t i = 0; i < n; ++i) errs.push_back(Vec2d(errors[2 * i], errors[2 * i + 1]));
+  std::ostringstream stream;
+  stream.precision(17);
+  RefMedianRule(errs, stream);
+  const std::string s = stream.str();
+  return std::stod(s.substr(s.find(':') + 1));
+}
+
+// RunBundleAdjustment (CPU branch, SchurMode::Dense) on a packed problem; state in / out; trace[0] = OptimizeJointly calls made
+CBA_EXPORT void ref_f1_run_bundle_adjustment(int max_iteration_count, double cost_reduction_threshold, int localize_only, int n_cameras,
+                                             int n_images, int n_points, const int* cam8, int64_t n_obs, const float* obs_xy, const int* obs_point,
+                                             const int* obs_image, const int* obs_camera, double* rig_tr_global, double* camera_tr_rig,
+                                             double* points, double* const* grids, double* trace) {
+  Packed pk{n_cameras, n_images, n_points, cam8, n_obs, obs_xy, obs_point, obs_image, obs_camera};
+  Dataset ds; BAState st;
+  build(pk, rig_tr_global, camera_tr_rig, points, grids, nullptr, &ds, &st);
+  g_optimize_calls = 0;
+  RunBundleAdjustment(/*use_cuda*/ false, SchurMode::Dense, max_iteration_count, cost_reduction_threshold, &ds, &st, /*regularization_weight*/ 0.0,
+                      localize_only != 0, nullptr, false, nullptr);
+  for (int i = 0; i < n_images; ++i) store_pose(st.rig_tr_global[i], rig_tr_global + 7 * i);
+  for (int c = 0; c < n_cameras; ++c) store_pose(st.camera_tr_rig[c], camera_tr_rig + 7 * c);
+  for (int p = 0; p < n_points; ++p) for (int k = 0; k < 3; ++k) points[3 * p + k] = st.points[p](k);
+  for (int c = 0; c < n_cameras; ++c) store_grid(st.intrinsics[c].get(), grids[c]);
+  trace[0] = g_optimize_calls; trace[1] = g_fd_delta_seen;
+}

@@ -1,0 +1,29 @@
+// Stand-in for <libvis/image.h> -- TEST INFRASTRUCTURE ONLY (oracle/_ref build): storage, element access, SetTo; Write() writes nothing
+#ifndef CBA_REF_SHIM_LM_LIBVIS_IMAGE_
+#define CBA_REF_SHIM_LM_LIBVIS_IMAGE_
+#include <string>
+#include <vector>
+#include "libvis/libvis.h"
+namespace vis {
+template <class T>
+class Image {
+ public:
+  Image() : w_(0), h_(0) {}
+  Image(int w, int h) : w_(w), h_(h), d_((std::size_t)w * h) {}
+  void SetSize(int w, int h) { w_ = w; h_ = h; d_.assign((std::size_t)w * h, T()); }
+  template <class V> void SetTo(const V& v) { for (auto& e : d_) e = T(v); }
+  bool Write(const std::string&) const { return true; }
+  const T* data() const { return d_.data(); }
+  T* data() { return d_.data(); }
+  unsigned width() const { return w_; }
+  unsigned height() const { return h_; }
+  const T& at(int x, int y) const { return d_[x + (std::size_t)y * w_]; }
+  T& at(int x, int y) { return d_[x + (std::size_t)y * w_]; }
+  const T& operator()(int x, int y) const { return d_[x + (std::size_t)y * w_]; }
+  T& operator()(int x, int y) { return d_[x + (std::size_t)y * w_]; }
+ private:
+  int w_, h_;
+  std::vector<T> d_;
+};
+}
+#endif
