@@ -288,12 +288,12 @@ def se3_exp(t):
 # ---------------------------------------------------------------------------------------------------
 # calibration report statistics -- restated per observation, scalar loops
 #
-# PARITY UNPINNED for everything below this line except the projection itself: the reference holds no golden vector or
-# known-answer test for ComputeAllReprojectionErrors / the histogram / DeleteOutlierFeatures / ChooseNiceCameraOrientation /
-# ScaleToMetric, and their sources (APP/calibration.cc, calibration_report.cc, central_generic.cc:570-621) need Qt and the
-# real Eigen (Quaterniond::FromTwoVectors, AngleAxisd) and cannot be compiled here (oracle/_ref covers only files that
-# build from their own sources).  These restatements are pinned only through the model-level Project / Unproject they
-# call, which IS pinned against the reference's compiled code (tests/test_oracle_vs_ref.py).
+# Pinned since round 5 to the reference's own code: ComputeAllReprojectionErrors / the histogram / the median rule /
+# DeleteOutlierFeatures / ChooseNiceCameraOrientation / ScaleToMetric / RunBundleAdjustment are compiled FROM /root/reference (their
+# files need Qt as a whole, so oracle/Makefile pipes the functions' line ranges into the compiler behind oracle/ref_f14_prelude.h;
+# Quaterniond::FromTwoVectors / AngleAxisd come from the stand-in oracle/ref_shim_lm/Eigen/Geometry, restated from Eigen 3.3.7's
+# published algorithm) and compared with these restatements in tests/test_oracle_vs_ref_outer_loop.py: decisions identical,
+# values to 1e-14 (rotations) ... 1e-10 px (reprojection errors).
 # ---------------------------------------------------------------------------------------------------
 def all_reprojection_errors(camera_index: int, pb, st):
     """ComputeAllReprojectionErrors, APP/calibration_report.cc:101-148: per feature of one camera
