@@ -474,3 +474,90 @@ def f1_run_bundle_adjustment(pb, st, max_iteration_count: int, cost_reduction_th
         g[...] = h.reshape(g.shape)
     return out, int(trace[0]), float(trace[1])
 
+
+# ---------------------------------------------------------------------------------------------------
+# The reference's ENTIRE CPU bundle-adjustment path (oracle/_ref/libcalibref_ba.so; see ref_ba_glue.cc): joint_optimization.cc, both
+# generic models and lm_optimizer.h compiled whole, plus the F1 / F4 functions on the reference's real models
+# ---------------------------------------------------------------------------------------------------
+BA_LIB_PATH = os.path.join(_HERE, "_ref", "libcalibref_ba.so")
+_ba_lib: Optional[C.CDLL] = None
+
+
+def ba_available() -> bool:
+    build()
+    return os.path.exists(BA_LIB_PATH)
+
+
+def ba_lib() -> C.CDLL:
+    global _ba_lib
+    if _ba_lib is None:
+        build()
+        if not os.path.exists(BA_LIB_PATH):
+            raise RuntimeError("oracle/_ref/libcalibref_ba.so is missing and /root/reference is not present")
+        from oracle import oracle as orc
+        orc.lib()
+        L = C.CDLL(BA_LIB_PATH)
+        dp, fp, ip = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int)
+        dpp = C.POINTER(dp)
+        L.ref_ba_optimize_jointly.argtypes = [C.c_int, C.c_int, C.c_int, ip, C.c_int64, fp, ip, ip, ip, dp, dp, dp, dpp, dp,
+                                              C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, dp, ip]
+        L.ref_ba_optimize_jointly.restype = C.c_double
+        L.ref_ba_system.argtypes = [C.c_int, C.c_int, C.c_int, ip, C.c_int64, fp, ip, ip, ip, dp, dp, dp, dpp, dp, C.c_double, C.c_int, C.c_int,
+                                    dp, dp, dp, dp, dp, dp, C.POINTER(C.c_int64)]
+        L.ref_ba_system.restype = C.c_double
+        packed = [C.c_int, C.c_int, C.c_int, ip, C.c_int64, fp, ip, ip, ip]
+        L.ref_f1_run_bundle_adjustment.argtypes = [C.c_int, C.c_double, C.c_int] + packed + [dp, dp, dp, dpp, dp]
+        L.ref_f1_choose_nice_camera_orientation.argtypes = [ip, dp, dp]
+        _ba_lib = L
+    return _ba_lib
+
+
+def ba_optimize_jointly(pb, st, last_projection=None, max_iteration_count: int = 1, init_lambda: float = -1.0):
+    """The reference's own vis::OptimizeJointly (APP/bundle_adjustment/joint_optimization.cc:757-953, SchurMode::Dense, CPU) on a
+    camera_calibration_amd.problem.Problem / State.  In place on `st` and on `last_projection` ((n_obs, 2) warm-start cache, zeros when
+    None).  Returns dict(cost, final_lambda, performed, last_projection)."""
+    cam9 = np.concatenate([np.concatenate([[c.model_type], _cam_params8(c)]) for c in pb.cameras]).astype(np.int32)
+    xy = np.ascontiguousarray(pb.obs_xy, dtype=np.float32)
+    lp = np.zeros((pb.n_obs, 2)) if last_projection is None else last_projection
+    assert lp.dtype == np.float64 and lp.flags.c_contiguous and lp.shape == (pb.n_obs, 2)
+    grids = (C.POINTER(C.c_double) * len(st.grids))(*[_dp(g) for g in st.grids])
+    lam = C.c_double(0); performed = C.c_int(0)
+    cost = ba_lib().ref_ba_optimize_jointly(pb.n_cameras, pb.n_images, pb.n_points, _ip(cam9), int(pb.n_obs),
+                                            xy.ctypes.data_as(C.POINTER(C.c_float)), _ip(pb.obs_point), _ip(pb.obs_image), _ip(pb.obs_camera),
+                                            _dp(st.rig_tr_global), _dp(st.camera_tr_rig), _dp(st.points), grids, _dp(lp),
+                                            max_iteration_count, float(init_lambda), float(pb.fd_delta), int(pb.localize_only),
+                                            int(pb.eliminate_points), C.byref(lam), C.byref(performed))
+    return dict(cost=float(cost), final_lambda=lam.value, performed=bool(performed.value), last_projection=lp)
+
+
+def ba_system(pb, st, last_projection=None):
+    """One JointOptimizationCostFunction::Compute<true> of the reference (APP/bundle_adjustment/joint_optimization.cc:240-593) into the
+    reference's UpdateEquationAccumulator: returns dict(cost, system (an oracle.System, upper triangles), cost_vector, last_projection)."""
+    from oracle import oracle as orc
+    cam9 = np.concatenate([np.concatenate([[c.model_type], _cam_params8(c)]) for c in pb.cameras]).astype(np.int32)
+    xy = np.ascontiguousarray(pb.obs_xy, dtype=np.float32)
+    lp = np.zeros((pb.n_obs, 2)) if last_projection is None else last_projection
+    grids = (C.POINTER(C.c_double) * len(st.grids))(*[_dp(g) for g in st.grids])
+    system = orc.System(pb.block_size, pb.n_blocks, pb.dense_dof)
+    cost_vector = np.zeros(pb.n_obs); n_costs = C.c_int64(0)
+    cost = ba_lib().ref_ba_system(pb.n_cameras, pb.n_images, pb.n_points, _ip(cam9), int(pb.n_obs), xy.ctypes.data_as(C.POINTER(C.c_float)),
+                                  _ip(pb.obs_point), _ip(pb.obs_image), _ip(pb.obs_camera), _dp(st.rig_tr_global), _dp(st.camera_tr_rig),
+                                  _dp(st.points), grids, _dp(lp), float(pb.fd_delta), int(pb.localize_only), int(pb.eliminate_points),
+                                  _dp(system.block_diag_H), _dp(system.off_diag_H), _dp(system.dense_H), _dp(system.block_diag_b),
+                                  _dp(system.dense_b), _dp(cost_vector), C.byref(n_costs))
+    return dict(cost=float(cost), system=system, cost_vector=cost_vector, n_costs=int(n_costs.value), last_projection=lp)
+
+
+def ba_run_bundle_adjustment(pb, st, max_iteration_count: int, cost_reduction_threshold: float, localize_only: bool = False):
+    """RunBundleAdjustment (APP/calibration.cc:187-304) around the reference's own OptimizeJointly, on the reference's own
+    CentralGenericModel: the reference's whole CPU calibration loop.  Returns (State, OptimizeJointly calls, numerical_diff_delta)."""
+    pk = _Packed(pb, st)
+    trace = np.zeros(4)
+    ba_lib().ref_f1_run_bundle_adjustment(max_iteration_count, float(cost_reduction_threshold), int(localize_only), *pk.head, *pk.state,
+                                          _dp(trace))
+    out = st.copy()
+    out.rig_tr_global[...] = pk.rig; out.camera_tr_rig[...] = pk.ctr; out.points[...] = pk.points
+    for g, h in zip(out.grids, pk.grids):
+        g[...] = h.reshape(g.shape)
+    return out, int(trace[0]), float(trace[1])
+

@@ -1,0 +1,154 @@
+// oracle/_ref, part 6 (glue of libcalibref_ba.so) -- TEST INFRASTRUCTURE ONLY.
+//
+// The reference's ENTIRE CPU bundle-adjustment path, compiled whole from where it lies:
+//   APP/bundle_adjustment/joint_optimization.cc   JointOptimizationState, JointOptimizationCostFunction (the per-observation driver
+//                                                 :240-593 that rounds 1-4 could only restate), OptimizeJointly :757-953
+//   APP/models/central_generic.cc (+ the generated central_generic_jacobians.cc), APP/models/central_grid.h
+//                                                 projection LM, finite-difference Jacobians w.r.t. the grid, FitToPixelDirections
+//   APP/models/noncentral_generic.cc (+ generated Jacobians)
+//   LV/lm_optimizer.h, lm_optimizer_update_accumulator.h, APP/dataset.cc, APP/bundle_adjustment/ba_state.cc
+// against the stand-ins of oracle/ref_shim_lm (Eigen incl. Geometry, Sophus::SE3, Image, no-op CUDA / display headers) and a stand-in
+// all_models.h that dispatches over the two generic models only.  Eigen's LDLT is the one numerical piece that is not the reference's or
+// Eigen's code: the stand-in's LDLT::solve hands the system to the oracle's term-by-term restatement (orc_ldlt_solve_upper_unblocked).
+// Nothing of the reference is copied into this repository.
+//
+// This file is appended to ref_f14_glue.cc's translation unit (CBA_REF_REAL_BA defined): the F1 / F4 entry points of that file run here
+// on the reference's real CentralGenericModel and around the reference's real OptimizeJointly; ref_ba_optimize_jointly below is the
+// hot path itself on packed arrays.
+namespace vis {
+int g_ref_ba_optimize_calls = 0;
+double g_ref_ba_fd_delta_seen = 0;
+}
+
+namespace {
+// cam9 per camera: model_type (0 central, 1 non-central), width height min_x min_y max_x max_y gw gh
+std::shared_ptr<CameraModel> make_any_model(const int* p9, const double* grid) {
+  const int gw = p9[7], gh = p9[8];
+  if (p9[0] == 0) return make_model(p9 + 1, grid);
+  auto m = std::make_shared<NoncentralGenericModel>(gw, gh, p9[3], p9[4], p9[5], p9[6], p9[1], p9[2]);
+  Image<Vec3d> dir(gw, gh), pt(gw, gh);
+  const size_t G = (size_t)gw * gh;
+  for (int y = 0; y < gh; ++y)
+    for (int x = 0; x < gw; ++x) {
+      const double* d = grid + 3 * (x + (size_t)y * gw);
+      dir(x, y) = Vec3d(d[0], d[1], d[2]);
+      pt(x, y) = Vec3d(d[3 * G], d[3 * G + 1], d[3 * G + 2]);
+    }
+  m->SetDirectionGrid(dir);
+  m->SetPointGrid(pt);
+  return m;
+}
+void store_any_grid(const CameraModel* cm, double* grid) {
+  if (cm->type() == CameraModel::Type::CentralGeneric) { store_grid(cm, grid); return; }
+  const NoncentralGenericModel* m = static_cast<const NoncentralGenericModel*>(cm);
+  const int gw = m->direction_grid().width(), gh = m->direction_grid().height();
+  const size_t G = (size_t)gw * gh;
+  for (int y = 0; y < gh; ++y)
+    for (int x = 0; x < gw; ++x)
+      for (int k = 0; k < 3; ++k) {
+        grid[3 * (x + (size_t)y * gw) + k] = m->direction_grid()(x, y)(k);
+        grid[3 * G + 3 * (x + (size_t)y * gw) + k] = m->point_grid()(x, y)(k);
+      }
+}
+}  // namespace
+
+namespace {
+struct Marshalled {
+  Dataset ds; BAState st; std::vector<PointFeature*> feats;
+};
+void marshal(int n_cameras, int n_images, int n_points, const int* cam9, int64_t n_obs, const float* obs_xy, const int* obs_point,
+             const int* obs_image, const int* obs_camera, const double* rig_tr_global, const double* camera_tr_rig, const double* points,
+             double* const* grids, const double* last_projection, Marshalled* m) {
+  Dataset& ds = m->ds; BAState& st = m->st;
+  ds.Reset(n_cameras);
+  for (int c = 0; c < n_cameras; ++c) ds.SetImageSize(c, Vec2i(cam9[9 * c + 1], cam9[9 * c + 2]));
+  for (int i = 0; i < n_images; ++i) ds.NewImageset();
+  for (int64_t o = 0; o < n_obs; ++o) {
+    PointFeature f(Vec2f(obs_xy[2 * o], obs_xy[2 * o + 1]), obs_point[o]);
+    f.index = obs_point[o];
+    f.last_projection = Vec2d(last_projection[2 * o], last_projection[2 * o + 1]);
+    ds.GetImageset(obs_image[o])->FeaturesOfCamera(obs_camera[o]).push_back(f);
+  }
+  // pointers after all push_backs: the packed order is image-major, camera, feature order
+  std::vector<size_t> cursor((size_t)n_images * n_cameras, 0);
+  for (int64_t o = 0; o < n_obs; ++o) {
+    auto& v = ds.GetImageset(obs_image[o])->FeaturesOfCamera(obs_camera[o]);
+    m->feats.push_back(&v[cursor[(size_t)obs_image[o] * n_cameras + obs_camera[o]]++]);
+  }
+  st.image_used.assign(n_images, true);
+  for (int c = 0; c < n_cameras; ++c) st.camera_tr_rig.push_back(pose_of(camera_tr_rig + 7 * c));
+  for (int i = 0; i < n_images; ++i) st.rig_tr_global.push_back(pose_of(rig_tr_global + 7 * i));
+  for (int p = 0; p < n_points; ++p) { st.points.push_back(Vec3d(points[3 * p], points[3 * p + 1], points[3 * p + 2])); st.feature_id_to_points_index[p] = p; }
+  for (int c = 0; c < n_cameras; ++c) st.intrinsics.push_back(make_any_model(cam9 + 9 * c, grids[c]));
+}
+}  // namespace
+
+// vis::OptimizeJointly (APP/bundle_adjustment/joint_optimization.cc:757-953), SchurMode::Dense, on a packed problem.  State and the
+// warm-start cache (PointFeature::last_projection, packed observation order) in / out.  Returns the final cost.
+CBA_EXPORT double ref_ba_optimize_jointly(int n_cameras, int n_images, int n_points, const int* cam9, int64_t n_obs, const float* obs_xy,
+                                          const int* obs_point, const int* obs_image, const int* obs_camera, double* rig_tr_global,
+                                          double* camera_tr_rig, double* points, double* const* grids, double* last_projection,
+                                          int max_iteration_count, double init_lambda, double numerical_diff_delta, int localize_only,
+                                          int eliminate_points, double* final_lambda, int* performed_an_iteration) {
+  Marshalled m;
+  marshal(n_cameras, n_images, n_points, cam9, n_obs, obs_xy, obs_point, obs_image, obs_camera, rig_tr_global, camera_tr_rig, points, grids,
+          last_projection, &m);
+  BAState& st = m.st;
+  double lam = 0; bool performed = false;
+  const double cost = OptimizeJointly(m.ds, &st, max_iteration_count, init_lambda, numerical_diff_delta, /*regularization_weight*/ 0.0,
+                                      localize_only != 0, eliminate_points != 0, SchurMode::Dense, &lam, &performed, false, false, false, false,
+                                      false, /*print_progress*/ false);
+  if (final_lambda) *final_lambda = lam;
+  if (performed_an_iteration) *performed_an_iteration = performed ? 1 : 0;
+  for (int i = 0; i < n_images; ++i) store_pose(st.rig_tr_global[i], rig_tr_global + 7 * i);
+  for (int c = 0; c < n_cameras; ++c) store_pose(st.camera_tr_rig[c], camera_tr_rig + 7 * c);
+  for (int p = 0; p < n_points; ++p) for (int k = 0; k < 3; ++k) points[3 * p + k] = st.points[p](k);
+  for (int c = 0; c < n_cameras; ++c) store_any_grid(st.intrinsics[c].get(), grids[c]);
+  for (int64_t o = 0; o < n_obs; ++o) { last_projection[2 * o] = m.feats[o]->last_projection.x(); last_projection[2 * o + 1] = m.feats[o]->last_projection.y(); }
+  return cost;
+}
+
+// One JointOptimizationCostFunction::Compute<true> (joint_optimization.cc:240-593: THE per-observation driver) into the reference's own
+// UpdateEquationAccumulator, set up as LMOptimizer::OptimizeImpl sets it up for SchurMode::Dense (LV/lm_optimizer.h:668-720, lambda 0):
+// the normal equations of one Jacobian pass in the layout of orc_system (upper triangles, row-major), the per-residual cost vector
+// (n_obs entries expected; -1 marks an invalid residual as the accumulator stores it) and the warm-start cache after the pass.
+// Returns the cost.
+CBA_EXPORT double ref_ba_system(int n_cameras, int n_images, int n_points, const int* cam9, int64_t n_obs, const float* obs_xy,
+                                const int* obs_point, const int* obs_image, const int* obs_camera, const double* rig_tr_global,
+                                const double* camera_tr_rig, const double* points, double* const* grids, double* last_projection,
+                                double numerical_diff_delta, int localize_only, int eliminate_points, double* block_diag_H, double* off_diag_H,
+                                double* dense_H, double* block_diag_b, double* dense_b, double* cost_vector, int64_t* n_costs) {
+  Marshalled m;
+  marshal(n_cameras, n_images, n_points, cam9, n_obs, obs_xy, obs_point, obs_image, obs_camera, rig_tr_global, camera_tr_rig, points, grids,
+          last_projection, &m);
+  JointOptimizationCostFunction cost_function;                       // as OptimizeJointly, :776-782
+  cost_function.dataset = &m.ds;
+  cost_function.numerical_diff_delta = numerical_diff_delta;
+  cost_function.regularization_weight = 0.0;
+  cost_function.localize_only = localize_only != 0;
+  cost_function.eliminate_points = eliminate_points != 0;
+  cost_function.on_the_fly_block_processing = false;
+  std::vector<int> original_to_seq_index;
+  JointOptimizationState opt_state(m.st, &original_to_seq_index, &cost_function.seq_to_original_index, localize_only != 0, eliminate_points != 0);
+  const int bs = eliminate_points ? 3 : SE3d::DoF;
+  const int nb = eliminate_points ? (int)opt_state.points.size() : (int)opt_state.rig_tr_global.size();
+  const int block_dof = bs * nb, dd = opt_state.degrees_of_freedom() - block_dof;
+  Eigen::Matrix<double, Eigen::Dynamic, Eigen::Dynamic> H_dense, H_off;
+  std::vector<Eigen::Matrix<double, Eigen::Dynamic, Eigen::Dynamic>> H_blocks(nb);
+  Eigen::Matrix<double, Eigen::Dynamic, 1> b_dense, b_block;
+  H_dense.resize(dd, dd); H_off.resize(block_dof, dd); b_dense.resize(dd); b_block.resize(block_dof);
+  for (auto& B : H_blocks) B.resize(bs, bs);
+  std::vector<double> costs;
+  UpdateEquationAccumulator<double> update_eq(block_dof, &H_dense, &H_off, nullptr, &H_blocks, &b_dense, &b_block, &costs, 0, 0.0);
+  cost_function.template Compute<true>(opt_state, &update_eq);
+  update_eq.AccumulateFinishedBlocks();
+  for (int b = 0; b < nb; ++b) for (int r = 0; r < bs; ++r) for (int c = 0; c < bs; ++c) block_diag_H[((size_t)b * bs + r) * bs + c] = H_blocks[b](r, c);
+  for (int r = 0; r < block_dof; ++r) for (int c = 0; c < dd; ++c) off_diag_H[(size_t)r * dd + c] = H_off(r, c);
+  for (int r = 0; r < dd; ++r) for (int c = 0; c < dd; ++c) dense_H[(size_t)r * dd + c] = H_dense(r, c);
+  for (int r = 0; r < block_dof; ++r) block_diag_b[r] = b_block(r);
+  for (int r = 0; r < dd; ++r) dense_b[r] = b_dense(r);
+  *n_costs = (int64_t)costs.size();
+  for (size_t i = 0; i < costs.size() && (int64_t)i < n_obs; ++i) cost_vector[i] = costs[i];
+  for (int64_t o = 0; o < n_obs; ++o) { last_projection[2 * o] = m.feats[o]->last_projection.x(); last_projection[2 * o + 1] = m.feats[o]->last_projection.y(); }
+  return update_eq.cost();
+}

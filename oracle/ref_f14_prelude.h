@@ -14,13 +14,7 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
-namespace cba_ref_shim {
-struct NullLog {
-  template <class T> NullLog& operator<<(const T&) { return *this; }
-  NullLog& operator<<(std::ostream& (*)(std::ostream&)) { return *this; }
-};
-}
-#define LOG(severity) ::cba_ref_shim::NullLog()
+#include "cba_quiet_log.h"
 
 #include <libvis/eigen.h>
 #include <libvis/image.h>
@@ -34,10 +28,15 @@ struct NullLog {
 #include "camera_calibration/models/camera_model.h"
 #include "camera_calibration/bundle_adjustment/ba_state.h"                 // APP/bundle_adjustment/ba_state.h:46-97
 #include "camera_calibration/bundle_adjustment/joint_optimization.h"       // SchurMode, OptimizeJointly (defined by ref_f14_glue.cc)
+#ifdef CBA_REF_REAL_BA
+#include <libvis/lm_optimizer.h>                                           // libcalibref_ba.so: the real OptimizationReport
+#endif
 
 namespace vis {
+#ifndef CBA_REF_REAL_BA
 // LV/lm_optimizer.h:55-77 (only final_cost is read by RunBundleAdjustment's CUDA branch, which the tests never take)
 struct OptimizationReport { double initial_cost, final_cost; int num_iterations_performed; double cost_and_jacobian_evaluation_time, solve_time; };
+#endif
 inline OptimizationReport CudaOptimizeJointly(Dataset&, BAState*, int, int, double, double, double, double*) { std::abort(); }
 inline bool SaveBAState(const char*, const BAState&) { return true; }
 // the Qt window of the application: every call is a no-op here (the tests pass a null pointer anyway)
@@ -50,8 +49,8 @@ class CalibrationWindow {
   void UpdateReprojectionErrors(int, const Image<Vec3u8>&, Dataset*, BAState*) {}
   void UpdateErrorDirections(int, const Image<Vec3u8>&) {}
 };
-inline int GetKeyInput() { return 0; }
-inline int PollKeyInput() { return 0; }
+char GetKeyInput();              // APP/util.h:42, :45 -- defined by ref_f14_glue.cc: no key is ever pressed
+int PollKeyInput();
 inline void VisualizeModelDirections(const CameraModel&, Image<Vec3u8>*) {}
 inline void CreateReprojectionErrorHistogram(int, const Dataset&, const BAState&, Image<u8>*) {}
 inline void CreateReprojectionErrorMagnitudeVisualization(const Dataset&, int, const BAState&, float, Image<Vec3u8>*) {}

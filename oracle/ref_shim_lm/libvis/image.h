@@ -3,6 +3,7 @@
 #define CBA_REF_SHIM_LM_LIBVIS_IMAGE_
 #include <string>
 #include <vector>
+#include <Eigen/Core>
 #include "libvis/libvis.h"
 namespace vis {
 template <class T>
@@ -10,7 +11,12 @@ class Image {
  public:
   Image() : w_(0), h_(0) {}
   Image(int w, int h) : w_(w), h_(h), d_((std::size_t)w * h) {}
+  template <class D> explicit Image(const Eigen::MatrixBase<D>& size) : w_(size(0)), h_(size(1)), d_((std::size_t)w_ * h_) {}
   void SetSize(int w, int h) { w_ = w; h_ = h; d_.assign((std::size_t)w * h, T()); }
+  template <class D> void SetSize(const Eigen::MatrixBase<D>& size) { SetSize((int)size(0), (int)size(1)); }
+  Eigen::Matrix<unsigned, 2, 1> size() const { return Eigen::Matrix<unsigned, 2, 1>(w_, h_); }
+  template <class D> const T& operator()(const Eigen::MatrixBase<D>& p) const { return d_[p(0) + (std::size_t)p(1) * w_]; }
+  template <class D> T& operator()(const Eigen::MatrixBase<D>& p) { return d_[p(0) + (std::size_t)p(1) * w_]; }
   template <class V> void SetTo(const V& v) { for (auto& e : d_) e = T(v); }
   bool Write(const std::string&) const { return true; }
   const T* data() const { return d_.data(); }
