@@ -16,8 +16,12 @@
  * models, the reference's self-test and its 17 x 13 calibrated camera), the generated Jacobian code
  * (joint_optimization_jacobians.h, *_generic_jacobians.cc), the local parametrisations, b_spline.h and HuberLoss;
  * tests/test_oracle_vs_ref.py holds the comparison (1e-14 class) and tests/golden/ref_vectors.npz the reference-computed
- * vectors.  Not compilable here and therefore pinned only through the tests above: joint_optimization.cc (the
- * per-observation chain and the accumulation order), lm_optimizer.h (LM loop, Schur complement) and Eigen's LDLT --
+ * vectors.  Round 5: the reference's ENTIRE CPU path -- joint_optimization.cc (state, per-observation driver, OptimizeJointly),
+ * central_generic.cc / noncentral_generic.cc, lm_optimizer.h and the outer-loop / report functions -- compiles whole against the
+ * run-time-sized Eigen / Sophus stand-ins of oracle/ref_shim_lm (oracle/_ref/libcalibref_ba.so, libcalibref_lm.so,
+ * libcalibref_f14.so) and runs next to this restatement: normal equations 1e-10, lambda 1e-11, identical decisions
+ * (tests/test_oracle_vs_ref_whole_path.py).  Not the reference's or Eigen's code in those builds: Eigen's LDLT (this file's
+ * term-by-term restatement) and the small fixed-size Eigen / Sophus operations of the stand-ins --
  * see DESIGN.md "Oracle".
  *
  * Citations are relative to /root/reference:

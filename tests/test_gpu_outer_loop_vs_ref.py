@@ -49,11 +49,64 @@ def test_run_bundle_adjustment_on_the_engine_stops_where_the_references_loop_sto
     dev = cp.gauge_aligned_deviation(pb, st_eng, st_ref)
     for name in ("points_aligned_rel", "grids_aligned_abs", "pose_rotation_aligned_abs", "pose_translation_aligned_rel"):
         check(case, f"converged state after gauge alignment: {name}", dev[name], 1e-7)
+    if ref.ba_available():
+        # the same loop run by reference code ONLY (libcalibref_ba.so: RunBundleAdjustment + OptimizeJointly + CentralGenericModel +
+        # LMOptimizer compiled from the reference's sources; ~40 s of host time)
+        st_all, calls_all, _ = ref.ba_run_bundle_adjustment(pb, st0, 100, 1e-4)
+        case2 = "RunBundleAdjustment run by reference code only (compiled from its sources) vs run_bundle_adjustment (HIP engine), BASELINE configs[0]"
+        check_equal(case2, "OptimizeJointly calls until cost >= last_cost - 1e-4 (engine - reference)", abs(len(costs) - calls_all))
+        dev = cp.gauge_aligned_deviation(pb, st_eng, st_all)
+        for name in ("points_aligned_rel", "grids_aligned_abs", "pose_rotation_aligned_abs", "pose_translation_aligned_rel"):
+            check(case2, f"converged state after gauge alignment: {name}", dev[name], 1e-7)
+        c_all = op.cost_pass(st_all)[0]
+        check(case2, "cost of the converged state rel (evaluated by the oracle on both)", abs(c_eng - c_all) / c_all, 1e-6,
+              note="fresh cost passes; see the note of the row above")
     # both sides leave the loop in the beautified orientation: image centre along +z
     cam = pb.cameras[0]
     for st in (st_ref, st_eng):
         centre = orc.unproject(cam, st.grids[0], np.array([[0.5 * cam.width, 0.5 * cam.height]]))[0][0, :3]
         np.testing.assert_allclose(centre, [0, 0, 1], atol=1e-9)
+
+
+@pytest.mark.skipif(not ref.ba_available(), reason="oracle/_ref/libcalibref_ba.so not shipped with this snapshot")
+@pytest.mark.parametrize("case", ["1cam", "rig", "noncentral", "eliminate_points"])
+def test_engine_against_the_references_own_optimize_jointly(case):
+    """The HIP engine next to the reference's ENTIRE CPU path compiled from the reference's sources (libcalibref_ba.so:
+    joint_optimization.cc, the generic models, lm_optimizer.h; see tests/test_oracle_vs_ref_whole_path.py) -- no restatement between
+    them except Eigen's LDLT: five OptimizeJointly(1) calls from the same start, lambda carried as RunBundleAdjustment carries it."""
+    import dataclasses
+    from camera_calibration_amd import engine as eng
+    from camera_calibration_amd.problem import NONCENTRAL_GENERIC
+    kw = dict(model_type=NONCENTRAL_GENERIC) if case == "noncentral" else {}
+    pb, st0, _ = syn.reference_test_problem(2 if case == "rig" else 1, orc.project, seed=7, num_points=40, num_poses=8, **kw)
+    if case == "eliminate_points":
+        pb = dataclasses.replace(pb, eliminate_points=True)
+    a = st0.copy()
+    lp = np.zeros((pb.n_obs, 2))
+    e = eng.Engine(pb)
+    name = f"HIP engine vs the reference's own OptimizeJointly (compiled from its sources), {case}"
+    try:
+        e.set_state(st0)
+        lam_a = lam_e = -1.0
+        worst = dict(cost=0.0, lam=0.0)
+        for _ in range(5):
+            ra = ref.ba_optimize_jointly(pb, a, lp, 1, lam_a)
+            re = e.step(lam_e)
+            assert bool(re.accepted) == ra["performed"]
+            worst["lam"] = max(worst["lam"], abs(re.final_lambda - ra["final_lambda"]) / ra["final_lambda"])
+            worst["cost"] = max(worst["cost"], abs(re.final_cost - ra["cost"]) / ra["cost"])
+            lam_a, lam_e = ra["final_lambda"], re.final_lambda
+        b = e.get_state(st0)
+    finally:
+        e.close()
+    state = max(np.abs(a.points - b.points).max(), np.abs(a.rig_tr_global - b.rig_tr_global).max(),
+                max(np.abs(x - y).max() for x, y in zip(a.grids, b.grids)))
+    print(name, worst, state)
+    check(name, "lambda rel, max over five calls (equal lambdas = equal accept / reject decisions)", worst["lam"], 1e-6 if case == "noncentral" else 1e-8,
+          note="the first lambda is 0.001 * mean(diag H); H carries the finite-difference noise of tests/test_oracle_vs_ref_whole_path.py")
+    check(name, "cost rel, max over five calls", worst["cost"], 1e-4,
+          note="the late costs are ~1e-5 absolute on these noiseless problems, where 1e-11 absolute is 1e-6 relative")
+    check(name, "state after five calls, raw max abs", state, 1e-6, note="no gauge alignment; both sides take the same steps")
 
 
 def test_outlier_removal_and_reprojection_statistics_on_the_gpu_are_the_references():

@@ -155,3 +155,32 @@ def test_the_references_whole_calibration_loop():
     R_f14, g_f14 = ref.f1_choose_nice_camera_orientation(pb.cameras[0], g)
     np.testing.assert_allclose(R.reshape(3, 3), R_f14, rtol=0, atol=1e-15)
     np.testing.assert_allclose(g2, g_f14, rtol=0, atol=1e-15)
+
+
+def test_the_references_whole_calibration_loop_at_baseline_config_1():
+    """BASELINE configs[0] (30 imagesets, 16 x 12 grid, 10 008 observations, D = 1 413 -- the reference's own CPU-runnable case) run to
+    convergence by reference code only (RunBundleAdjustment + OptimizeJointly + CentralGenericModel + LMOptimizer, ~40 s on the
+    stand-in Eigen) and by the same loop text around the oracle: the stopping rule fires after the same number of calls and the
+    converged calibrations agree to 1e-7 after gauge alignment (observed 5e-13 ... 9e-10) -- the converged-parity statement of
+    BASELINE.json's north_star between the oracle and the reference itself."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import converged_parity as cp
+    pb, st0, _ = syn.baseline_config(1, _proj)
+    assert pb.n_images == 30 and pb.dense_dof == 1413
+    st_all, calls_all, _ = ref.ba_run_bundle_adjustment(pb, st0, 100, 1e-4)
+    orc.set_num_threads(0)
+    try:
+        st_orc, calls_orc, _ = ref.f1_run_bundle_adjustment(pb, st0, 100, 1e-4)
+    finally:
+        orc.set_num_threads(1)
+    print("OptimizeJointly calls until the stopping rule fires:", calls_all, calls_orc)
+    assert calls_all == calls_orc >= 5
+    dev = cp.gauge_aligned_deviation(pb, st_orc, st_all)
+    print({k: v for k, v in dev.items() if k != "gauge"})
+    for name in ("points_aligned_rel", "grids_aligned_abs", "pose_rotation_aligned_abs", "pose_translation_aligned_rel"):
+        assert dev[name] <= 1e-7, (name, dev[name])
+    op = orc.OracleProblem(pb)
+    c_all, c_orc = op.cost_pass(st_all)[0], op.cost_pass(st_orc)[0]
+    assert abs(c_all - c_orc) <= 1e-6 * c_all
