@@ -376,6 +376,18 @@ int launch_base_project_slow(const PassArgs& a, int model_mask, double* cost_vec
 // wavefronts per SIMD instead of 2 / 1 (the gathers of the whole patch in flight cost ~100 / ~190 VGPRs).  A lane whose
 // pixel crosses into a neighbouring cell repeats its projection on the gather path after the staged attempt.
 constexpr int kFdMaxObsPerBlock = 10;
+// Row stride of a staged control patch in LDS: 16 control points + 2 doubles of padding.  Without the padding a row is 96 (central) /
+// 192 (non-central) dwords, i.e. every observation's patch starts on the same bank, and the compiler reads a control point with
+// ds_read2_b64 / ds_read_b128 (bank modulus 32 / 64 dwords, lane groups of 16): whenever the lanes of a group belong to different
+// observations -- every group that straddles an observation boundary in k_fd_tasks, most groups in k_fd_pool once the lanes have
+// drifted apart -- their reads collide (SQ_LDS_BANK_CONFLICT 18 % of the LDS cycles of k_fd_tasks, profiles/r04_pmc_valu_lds.txt).
+// Four dwords of padding move neighbouring observations onto neighbouring 16-byte slots.  Layout only: same values, same arithmetic.
+// Measured (profiles/r05_fd_patch_padding.txt): non-central cfg 4 FD kernel 8.0 -> 7.4 ms; cfg 2 / cfg 3 unchanged; 1 double of padding
+// instead of 2: the same; padding the per-lane substitution slots (sSub) to 7 doubles: 7.7 ms (the 16-byte reads split).
+#ifndef CBA_FD_PATCH_PAD
+#define CBA_FD_PATCH_PAD 2
+#endif
+template <int DIM> struct FdPatchRow { static constexpr int kStride = 16 * DIM + CBA_FD_PATCH_PAD; };
 #ifndef CBA_FD_WAVES_CENTRAL
 #define CBA_FD_WAVES_CENTRAL 3      // wavefronts per SIMD the kernel is register-allocated for
 #endif
@@ -475,7 +487,7 @@ k_fd_tasks(PassArgs a, int tasks_per_obs, int localize_only, const double* __res
            int* __restrict__ redo_overflow) {
   constexpr int PER = (MODEL == kCentral) ? 2 : 5;
   constexpr int DIM = (MODEL == kCentral) ? 3 : 6;
-  __shared__ double sPatch[kFdMaxObsPerBlock][16 * DIM];
+  __shared__ double sPatch[kFdMaxObsPerBlock][FdPatchRow<DIM>::kStride];
   __shared__ double sSub[256][DIM];             // per lane: its substituted control point
   __shared__ int sOrigin[kFdMaxObsPerBlock][2];
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x;
@@ -569,7 +581,7 @@ k_fd_pool(PassArgs a, int tasks_per_obs, int pool, const double* __restrict__ pi
   constexpr int DIM = (MODEL == kCentral) ? 3 : 6;
   constexpr int kMaxObs = FdPool<MODEL>::kMaxObs;
   constexpr double kEpsilon = 1e-12;
-  __shared__ double sPatch[kMaxObs][16 * DIM];
+  __shared__ double sPatch[kMaxObs][FdPatchRow<DIM>::kStride];
   __shared__ double sSub[256][DIM];             // per lane: the substituted control point of its current task
   __shared__ int sOrigin[kMaxObs][2];
   __shared__ int sNext;
