@@ -109,6 +109,45 @@ def test_engine_against_the_references_own_optimize_jointly(case):
     check(name, "state after five calls, raw max abs", state, 1e-6, note="no gauge alignment; both sides take the same steps")
 
 
+@pytest.mark.skipif(not ref.ba_available(), reason="oracle/_ref/libcalibref_ba.so not shipped with this snapshot")
+@pytest.mark.parametrize("case", ["central 40x30 grid", "rig 20x16 grids", "non-central 16x12 grid"])
+def test_normal_equations_on_the_gpu_against_the_references_own_driver(case):
+    """One Jacobian pass of the HIP engine (k_base_project, k_fd_*, k_assemble, k_accumulate*) against ONE
+    JointOptimizationCostFunction::Compute<true> of the reference into the reference's own UpdateEquationAccumulator, compiled from the
+    reference's sources (ref_ba_system) -- every entry of H and b, every residual's cost, the warm-start cache; no restatement between
+    the two sides.  Sizes the stand-in Eigen finishes in seconds: BASELINE-style problems with 12 imagesets."""
+    from camera_calibration_amd import engine as eng
+    cfg, grid = {"central 40x30 grid": (2, (40, 30)), "rig 20x16 grids": (3, (20, 16)), "non-central 16x12 grid": (4, (16, 12))}[case]
+    pb, st, _ = syn.baseline_config(cfg, lambda cam, g, pts: orc.project(cam, g, pts), n_imagesets=12, grid_wh=grid)
+    r = ref.ba_system(pb, st)
+    S = r["system"]
+    e = eng.Engine(pb)
+    try:
+        e.set_state(st)
+        cost = e.debug_accumulate()
+        vec = e.dump(eng.DUMP_COST_VECTOR)
+        got = dict(block_diag_H=e.dump(eng.DUMP_BLOCK_DIAG_H), block_diag_b=e.dump(eng.DUMP_BLOCK_DIAG_B), off_diag_H=e.dump(eng.DUMP_OFF_DIAG_H),
+                   dense_H=np.triu(e.dump(eng.DUMP_DENSE_H)), dense_b=e.dump(eng.DUMP_DENSE_B))
+        lp = e.get_last_projection()
+    finally:
+        e.close()
+    name = f"Jacobian pass on the GPU vs the reference's own driver (compiled from its sources), {case}: {pb.n_obs} observations, D = {pb.dense_dof}"
+    want = dict(block_diag_H=np.stack([np.triu(b) for b in S.block_diag_H]), block_diag_b=S.block_diag_b, off_diag_H=S.off_diag_H,
+                dense_H=np.triu(S.dense_H), dense_b=S.dense_b)
+    got["block_diag_H"] = np.stack([np.triu(b) for b in got["block_diag_H"]])
+    assert r["n_costs"] == pb.n_obs
+    check_equal(name, "residuals valid on one side and invalid on the other", int(((vec < 0) != (r["cost_vector"] < 0)).sum()))
+    check(name, "cost rel", abs(cost - r["cost"]) / r["cost"], 1e-11)
+    check(name, "per-residual cost, max abs", float(np.abs(vec - r["cost_vector"]).max()), 1e-10, note="observed 2e-12")
+    check(name, "warm-start cache (last_projection), max abs px", float(np.abs(lp - r["last_projection"]).max()), 1e-10, note="observed 2e-12")
+    tol = 1e-9                                # observed 7e-14 ... 8e-12 (the GPU contracts to FMAs as g++ does in the reference code)
+    for k in want:
+        dev = float(np.abs(got[k] - want[k]).max() / np.abs(want[k]).max())
+        check(name, f"{k}: max deviation relative to the largest entry", dev, tol,
+              note="finite-difference Jacobians of projections that differ in the last bits (FMA contraction, summation order): "
+                   "see tests/test_oracle_vs_ref_whole_path.py")
+
+
 def test_outlier_removal_and_reprojection_statistics_on_the_gpu_are_the_references():
     pb, st, _ = syn.reference_test_problem(2, orc.project, seed=3, num_points=60, num_poses=12)
     case = "DeleteOutlierFeatures / ComputeAllReprojectionErrors, projections on the GPU, vs the reference's functions"
