@@ -30,6 +30,7 @@ int schur_gemm(const double* A, const double* B, int Kpad, int ldab, const doubl
 int schur_chunk_count(int n_pad);
 void schur_chunk_order(const unsigned long long* mask_host, int n_pad, int Kpad, int* order);
 int schur_mask_words(int Kpad);
+int schur_slab_rows();
 int launch_touch_mask(const double* B, int Kpad, int n_pad, int ld, unsigned long long* mask, hipStream_t s);
 int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWorkspace& w, double* x, hipStream_t s);
 int launch_finish_diag(double* S, int ld, int n_real, int n_pad, double lambda, hipStream_t s);
@@ -555,8 +556,8 @@ static int solve_finish(cba_problem* p) {
       schur_chunk_order(p->kmask_host, p->n_pad, p->Kpad, p->chunk_order_host);
       p->chunk_order_valid = true;
     }
-    p->timers[0].flops += slabs * 2.0 * 128 * 128 * 16;
-    p->timers[0].bytes += tiles * 2.0 * 128 * 128 * 8 + slabs * 2.0 * 16 * 128 * 8;
+    p->timers[0].flops += slabs * 2.0 * 128 * 128 * schur_slab_rows();
+    p->timers[0].bytes += tiles * 2.0 * 128 * 128 * 8 + slabs * 2.0 * schur_slab_rows() * 128 * 8;
   }
   if (st[1] == 3) { set_error("reduced solve: a dataflow launch timed out waiting for another workgroup"); return CBA_ERR_TIMEOUT; }
   if (st[0] || st[1]) return CBA_ERR_NUMERIC;
@@ -690,7 +691,7 @@ int cba_create(const cba_config* config, cba_problem** out) {
   CBA_TRY(dev_alloc(&p->red8, 16));
   // normal equations
   padded_dims(L.dense_dof, &p->n_pad, &p->n_fact);
-  p->Kpad = round_up(L.block_dof > 0 ? L.block_dof : 1, 16);
+  p->Kpad = round_up(L.block_dof > 0 ? L.block_dof : 1, 48);      // a multiple of the dense K slab (16) and of the block-sparse one (12)
   const size_t bs = L.block_size, nb = L.n_blocks;
   CBA_TRY(dev_alloc(&p->Dblk, nb * bs * bs));
   CBA_TRY(dev_alloc(&p->bblk, nb * bs));

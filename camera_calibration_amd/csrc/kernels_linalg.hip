@@ -228,12 +228,18 @@ int launch_gemv_n(const double* M, int K, int n, int ld, const double* v, const 
 // tiles of the same tile row and share its A panel in that XCD's L2.
 // ------------------------------------------------------------------------------------------------
 constexpr int KT = 16;
+// K slab of the block-sparse Schur launch: 12 rows = the pose blocks of exactly TWO imagesets (6 rows each), so a slab never straddles
+// a third or fourth imageset as a 16-row slab (2.7 imagesets) does -- the product skips a slab only if ALL its rows are zero in one of
+// the two column tiles, and the imagesets are ordered so that neighbours have similar footprints (cba_set_observations).  Modelled
+// from the observation lists: 0.88 of the 16-row slabs' work at cfg 2 (0.76 against the Z-order of round 4); 48 instead of 64 MFMAs
+// per wavefront and barrier.  The dense launches (super-panel updates) keep KT = 16.
+constexpr int kSchurSlab = 12;
 constexpr int kSchurChunk = 64;   // tiles per XCD chunk of a block-sparse launch
 
 struct GemmArgs {
   const double* A; int lda;     // K x lda, column offset already applied for m_begin = 0 of this call
   const double* B; int ldb;
-  int K;                        // multiple of KT
+  int K;                        // multiple of the launch's slab (KT dense, kSchurSlab block-sparse)
   double* C; int ldc;
   const double* Cin; int ldcin; // may alias C
   int m_tiles, n_tiles;         // tile counts of this call
@@ -245,7 +251,7 @@ struct GemmArgs {
   double diag_add;              // host scalar used when diag_add_ptr == null
   long long total_tiles;
   int chunk;                    // tiles per XCD chunk (set by launch_gemm)
-  const unsigned long long* kmask;  // optional block-sparsity mask [column tile][kmask_words], bit = K slab of 16 rows
+  const unsigned long long* kmask;  // optional block-sparsity mask [column tile][kmask_words], bit = K slab of kSchurSlab rows
   int kmask_words;
   const int* chunk_order;           // block-sparse launches: permutation of the 64-tile chunks, heaviest first (null = as enumerated)
   int n_chunks;
@@ -290,8 +296,9 @@ __host__ __device__ inline int colgroup_strip_rows(const GemmArgs& g, int tn_las
 }
 // One output tile.  `b` is the linear slot of the tile (= blockIdx.x: workgroup b runs on XCD b % 8, observed dispatch
 // order; only speed depends on it).  Returns false when the slot is past the last tile.
-template <int TM, int TN, int WM, int WN, bool SUB>
+template <int TM, int TN, int WM, int WN, bool SUB, int KTT>
 __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
+  static_assert(KTT % 4 == 0 && KTT >= 4 && KTT <= 16, "a stage is KTT / 4 MFMA k-steps; every wavefront moves KTT / 4 rows of each operand");
   constexpr int LDA_S = TM + 16, LDB_S = TN + 16;
   constexpr int WAVES_N = TN / WN;
   constexpr int MI = WM / 16, NJ = WN / 16;
@@ -401,7 +408,7 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
 
   const double* Ag = g.A + m0;
   const double* Bg = g.B + n0;
-  const int nk = g.K / KT;
+  const int nk = g.K / KTT;
   static_assert(TM == 128 && TN == 128, "only the 128 x 128 LDS-DMA tile is built (the register-staged panel variants went with the blocked schedule)");
   {
     // Stage pipeline with LDS-DMA (global_load_lds_dwordx4): each wavefront-instruction moves one
@@ -414,11 +421,11 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
     // only lets an LDS read run ahead of an LDS-DMA in flight when it can prove that the two touch different LDS
     // variables; with sA[buf] / sA[buf ^ 1] it put an s_waitcnt vmcnt(0) between the DMA issue and the first
     // ds_read of EVERY stage, i.e. the next slab was never in flight during the MFMAs of the current one.
-    __shared__ double dA0[KT * LDA_S], dA1[KT * LDA_S], dB0[KT * LDB_S], dB1[KT * LDB_S];
+    __shared__ double dA0[KTT * LDA_S], dA1[KTT * LDA_S], dB0[KTT * LDB_S], dB1[KTT * LDB_S];
 #define CBA_DMA_STAGE(SA_, SB_, k0_)                                                                               \
   {                                                                                                                \
-    _Pragma("unroll") for (int j = 0; j < KT / 4; ++j) {                                                           \
-      const int row = wv * (KT / 4) + j;                                                                           \
+    _Pragma("unroll") for (int j = 0; j < KTT / 4; ++j) {                                                           \
+      const int row = wv * (KTT / 4) + j;                                                                           \
       __builtin_amdgcn_global_load_lds((gbl_ptr)(Ag + (size_t)((k0_) + row) * g.lda + 2 * lane),                   \
                                        (lds_ptr)&SA_[row * LDA_S], 16, 0, 0);                                      \
       __builtin_amdgcn_global_load_lds((gbl_ptr)(Bg + (size_t)((k0_) + row) * g.ldb + 2 * lane),                   \
@@ -427,7 +434,7 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
   }
 #define CBA_MMA_STAGE(SA_, SB_)                                                                                    \
   {                                                                                                                \
-    _Pragma("unroll") for (int kk = 0; kk < KT; kk += 4) {                                                         \
+    _Pragma("unroll") for (int kk = 0; kk < KTT; kk += 4) {                                                         \
       double af[MI], bf[NJ];                                                                                       \
       _Pragma("unroll") for (int i = 0; i < MI; ++i) af[i] = SA_[(kk + lk) * LDA_S + wm0 + i * 16 + li];           \
       _Pragma("unroll") for (int j = 0; j < NJ; ++j) bf[j] = SB_[(kk + lk) * LDB_S + wn0 + j * 16 + li];           \
@@ -459,18 +466,18 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
       return nk;
     };
     int kb = next_slab(-1);
-    if (kb < nk) CBA_DMA_STAGE(dA0, dB0, kb * KT);
+    if (kb < nk) CBA_DMA_STAGE(dA0, dB0, kb * KTT);
     preload_c();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     while (kb < nk) {
       int nxt = next_slab(kb);                       // slab kb is in dA0 / dB0
-      if (nxt < nk) CBA_DMA_STAGE(dA1, dB1, nxt * KT);
+      if (nxt < nk) CBA_DMA_STAGE(dA1, dB1, nxt * KTT);
       CBA_MMA_STAGE(dA0, dB0);
       kb = nxt;
       if (kb >= nk) break;
       nxt = next_slab(kb);                           // slab kb is in dA1 / dB1
-      if (nxt < nk) CBA_DMA_STAGE(dA0, dB0, nxt * KT);
+      if (nxt < nk) CBA_DMA_STAGE(dA0, dB0, nxt * KTT);
       CBA_MMA_STAGE(dA1, dB1);
       kb = nxt;
     }
@@ -495,9 +502,9 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
 }
 
 // One tile per workgroup.
-template <int TM, int TN, int WM, int WN, bool SUB>
+template <int TM, int TN, int WM, int WN, bool SUB, int KTT = KT>
 __global__ void __launch_bounds__(256) k_gemm_atb(GemmArgs g) {
-  gemm_tile<TM, TN, WM, WN, SUB>(g, blockIdx.x);
+  gemm_tile<TM, TN, WM, WN, SUB, KTT>(g, blockIdx.x);
 }
 
 static long long count_upper_tiles(int m_off, int n_off, int m_tiles, int n_tiles, int TM, int TN) {
@@ -535,7 +542,8 @@ static int launch_gemm(GemmArgs g, hipStream_t s) {
   g.n_chunks = (int)chunks;
   if (g.chunk != kSchurChunk) g.chunk_order = nullptr;            // the order was built for chunks of kSchurChunk tiles
   long long blocks = ((chunks + 7) / 8) * 8 * g.chunk;
-  hipLaunchKernelGGL((k_gemm_atb<TM, TN, WM, WN, SUB>), dim3((unsigned)blocks), dim3(256), 0, s, g);
+  if (g.kmask) hipLaunchKernelGGL((k_gemm_atb<TM, TN, WM, WN, SUB, kSchurSlab>), dim3((unsigned)blocks), dim3(256), 0, s, g);   // block-sparse: slabs of two pose blocks
+  else hipLaunchKernelGGL((k_gemm_atb<TM, TN, WM, WN, SUB, KT>), dim3((unsigned)blocks), dim3(256), 0, s, g);
   CBA_HIP(hipGetLastError());
   return CBA_OK;
 }
@@ -596,13 +604,13 @@ int launch_gemv_t_final(int n, const double* base, double* y, int ystride, const
 int gemv_t_workspace_doubles(int n) { return kGemvChunks * n; }
 
 // S = Hdd + lambda I - A^T B on the upper tiles (n_pad x n_pad, all leading dims = ld, multiples of 128)
-// bit (tile t, slab k) = any non-zero in B[16k .. 16k+15][128t .. 128t+127]
+// bit (tile t, slab k) = any non-zero in B[kSchurSlab k .. kSchurSlab k + kSchurSlab - 1][128t .. 128t+127]
 __global__ void __launch_bounds__(256) k_touch_mask(const double* __restrict__ B, int ld, unsigned long long* __restrict__ mask,
                                                     int words) {
   const int slab = blockIdx.x, tile = blockIdx.y;
-  const double* p = B + (size_t)slab * 16 * ld + (size_t)tile * 128;
+  const double* p = B + (size_t)slab * kSchurSlab * ld + (size_t)tile * 128;
   bool nz = false;
-  for (int e = threadIdx.x; e < 16 * 128; e += 256) nz = nz || (p[(size_t)(e >> 7) * ld + (e & 127)] != 0.0);
+  for (int e = threadIdx.x; e < kSchurSlab * 128; e += 256) nz = nz || (p[(size_t)(e >> 7) * ld + (e & 127)] != 0.0);
   __shared__ int any;
   if (threadIdx.x == 0) any = 0;
   __syncthreads();
@@ -610,7 +618,8 @@ __global__ void __launch_bounds__(256) k_touch_mask(const double* __restrict__ B
   __syncthreads();
   if (threadIdx.x == 0 && any) atomicOr(mask + (size_t)tile * words + (slab >> 6), 1ull << (slab & 63));
 }
-int schur_mask_words(int Kpad) { return (Kpad / 16 + 63) / 64; }
+int schur_mask_words(int Kpad) { return (Kpad / kSchurSlab + 63) / 64; }
+int schur_slab_rows() { return kSchurSlab; }
 // Chunks of the block-sparse Schur launch (kSchurChunk consecutive upper tiles in row-major order) sorted by the K slabs they
 // execute, heaviest first; `order` gets schur_chunk_count(n_pad) entries, or is left alone when the launch would not use chunks
 int schur_chunk_count(int n_pad) {
@@ -635,7 +644,7 @@ void schur_chunk_order(const unsigned long long* mask_host, int n_pad, int Kpad,
 int launch_touch_mask(const double* B, int Kpad, int n_pad, int ld, unsigned long long* mask, hipStream_t s) {
   const int words = schur_mask_words(Kpad);
   CBA_HIP(hipMemsetAsync(mask, 0, sizeof(unsigned long long) * (size_t)(n_pad / 128) * words, s));
-  hipLaunchKernelGGL(k_touch_mask, dim3(Kpad / 16, n_pad / 128), dim3(256), 0, s, B, ld, mask, words);
+  hipLaunchKernelGGL(k_touch_mask, dim3(Kpad / kSchurSlab, n_pad / 128), dim3(256), 0, s, B, ld, mask, words);
   CBA_HIP(hipGetLastError());
   return CBA_OK;
 }
