@@ -6,21 +6,28 @@ import hashlib, json, os, sys
 
 
 def per_call(path, counter):
+    """(launches, bytes per launch, per-instantiation rows) over ALL instantiations of k_gemm_atb<128,128,...>: since round 5 the
+    block-sparse Schur launch (12-row K slabs) and the dense super-panel updates (16-row) are two instantiations of the one kernel."""
+    calls, kib, parts = 0, 0.0, []
     for line in open(path):
         if "k_gemm_atb<128" in line.replace(" ", "") or "k_gemm_atbILi128" in line or "k_gemm_atb<128, 128" in line:
             f = line.split()
             # ... counter calls sum_KiB per_call_MiB
             i = f.index(counter)
-            return int(f[i + 1]), float(f[i + 2]) * 1024.0 / int(f[i + 1])
-    raise SystemExit(f"{path}: no k_gemm_atb row")
+            calls += int(f[i + 1]); kib += float(f[i + 2])
+            parts.append({"symbol": f[0][:80], "launches": int(f[i + 1]), "bytes_per_launch_raw": float(f[i + 2]) * 1024.0 / int(f[i + 1])})
+    if not calls:
+        raise SystemExit(f"{path}: no k_gemm_atb row")
+    return calls, kib * 1024.0 / calls, parts
 
 
-n_f, fetch = per_call(sys.argv[1], "FETCH_SIZE")
-n_w, write = per_call(sys.argv[2], "WRITE_SIZE")
+n_f, fetch, parts_f = per_call(sys.argv[1], "FETCH_SIZE")
+n_w, write, parts_w = per_call(sys.argv[2], "WRITE_SIZE")
 tag = sys.argv[4] if len(sys.argv) > 4 else "r04"
 out = {"kernel": "cba::k_gemm_atb<128,128,64,64,true>", "launches": n_f,
        "fetch_size_raw_bytes_per_launch": fetch, "fetch_bytes_per_launch": 2.0 * fetch, "write_bytes_per_launch": write,
        "traffic_bytes_per_launch": 2.0 * fetch + write,
+       "instantiations_fetch_raw": parts_f, "instantiations_write": parts_w,
        "source": f"profiles/{tag}_pmc_FETCH_SIZE.txt + {tag}_pmc_WRITE_SIZE.txt: two separate `rocprofv3 --kernel-trace --pmc <counter>` passes over "
                  "`bench.py --steps 2 --warmup 0`; FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section), WRITE_SIZE as "
                  f"reported; average over all launches of the kernel ({n_f // 2} per step: the Schur product and the super-panel updates of the two-level factorisation)"}
