@@ -459,7 +459,7 @@ def main():
                                          "shape of a super-panel update; the library computes the full square, the kernel its upper triangle), best of 5",
                          "traffic": pmc_traffic.get("traffic_bytes_per_launch"),
                          "traffic_unit": "bytes/launch", "traffic_source": pmc_traffic.get("source"), "traffic_stale": traffic_stale,
-                         "kernel": "k_gemm_atb<128,128,64,64> (Schur product B^T D^-1 B + the super-panel updates of the LDL^T, K = the super-panel width, ~2048), kernel time",
+                         "kernel": "k_gemm_atb<128,128,64,64> (two instantiations: the block-sparse Schur product B^T D^-1 B in 12-row K slabs, and the dense super-panel updates of the LDL^T in 16-row stages, K = the super-panel width, ~2048), kernel time",
                          "launches": dom_n, "avg_launch_ms": dom_s / max(1, dom_n) * 1e3,
                          "flops_per_launch": dom_f / max(1, dom_n),
                          "factorisation_span": {"tflops": (agg[1]["flops"] / agg[1]["seconds"] / 1e12) if agg[1]["seconds"] > 0 else 0.0,
