@@ -640,6 +640,10 @@ void schur_chunk_order(const unsigned long long* mask_host, int n_pad, int Kpad,
     }
   std::stable_sort(work.begin(), work.end(), [](const std::pair<long long, int>& a, const std::pair<long long, int>& b) { return a.first > b.first; });
   for (int c = 0; c < nc; ++c) order[c] = work[c].second;
+  // XCD x walks order[x], order[8 + x], order[16 + x], ... (gemm_slot_tile; the dispatcher deals workgroups to the XCDs round-robin): with
+  // the list sorted, XCD 0 would get the heaviest chunk of EVERY octet and XCD 7 the lightest -- differences that add up to about one
+  // heavy chunk (~ 18 % of an XCD's share at cfg 2).  Every other octet is dealt in reverse (boustrophedon): the totals even out.
+  for (int r = 1; 8 * r + 8 <= nc; r += 2) std::reverse(order + 8 * r, order + 8 * r + 8);
 }
 int launch_touch_mask(const double* B, int Kpad, int n_pad, int ld, unsigned long long* mask, hipStream_t s) {
   const int words = schur_mask_words(Kpad);
