@@ -10,7 +10,8 @@
 //   APP/models/noncentral_generic.h           NoncentralGenericModel::ProjectionJacobianWrtIntrinsics, SubtractDelta row  N3
 // The headers are #included from where they lie (nothing is copied) and compiled against the Eigen / libvis stand-ins of
 // oracle/ref_shim.  What this file itself adds is (a) the call sequence of AccumulateModelJacobian
-// (APP/bundle_adjustment/joint_optimization.cc:479-590, which cannot be compiled here: Sophus, cublasXt), restated call by call
+// (APP/bundle_adjustment/joint_optimization.cc:479-590; round 3 could not compile that file -- Sophus, cublasXt -- and since round 5 it
+// compiles whole against the run-time-sized stand-ins, libcalibref_ba.so / ref_ba_glue.cc, where the reference's own call sequence runs), restated call by call
 // below, and (b) a CentralGridModel subclass whose projection is the reference authors' stand-alone implementation
 // (generic_models/src/central_generic.h, pinned in ref_generic_models.cc) evaluated on the grid the base class mutates in place.
 #include <cuda_runtime.h>
