@@ -508,6 +508,9 @@ def ba_lib() -> C.CDLL:
         packed = [C.c_int, C.c_int, C.c_int, ip, C.c_int64, fp, ip, ip, ip]
         L.ref_f1_run_bundle_adjustment.argtypes = [C.c_int, C.c_double, C.c_int] + packed + [dp, dp, dp, dpp, dp]
         L.ref_f1_choose_nice_camera_orientation.argtypes = [ip, dp, dp]
+        L.ref_f3_fit_to_pixel_directions.argtypes = [ip, dp, C.c_int64, dp, dp, C.c_int]
+        L.ref_f3_fit_to_dense_model.argtypes = [ip, C.c_int, C.c_int, dp, C.c_int, C.c_int, dp]
+        L.ref_f3_fit_to_dense_model.restype = C.c_int
         _ba_lib = L
     return _ba_lib
 
@@ -560,4 +563,23 @@ def ba_run_bundle_adjustment(pb, st, max_iteration_count: int, cost_reduction_th
     for g, h in zip(out.grids, pk.grids):
         g[...] = h.reshape(g.shape)
     return out, int(trace[0]), float(trace[1])
+
+
+def f3_fit_to_pixel_directions(cam, grid, pixels, directions, max_iteration_count: int):
+    """CentralGenericModel::FitToPixelDirections (APP/models/central_generic.cc:419-431 and the LM behind it), the reference's own code."""
+    g = np.ascontiguousarray(grid, dtype=np.float64).reshape(-1, 3).copy()
+    px = np.ascontiguousarray(pixels, dtype=np.float64).reshape(-1, 2)
+    d = np.ascontiguousarray(directions, dtype=np.float64).reshape(-1, 3)
+    ba_lib().ref_f3_fit_to_pixel_directions(_ip(_cam_params8(cam)), _dp(g), len(px), _dp(px), _dp(d), int(max_iteration_count))
+    return g
+
+
+def f3_fit_to_dense_model(cam, dense_model, subsample_step: int, max_iteration_count: int = 10):
+    """CentralGenericModel::FitToDenseModel (APP/models/central_generic.cc:267-417), the reference's own code.  dense_model: (H, W, 3)
+    with NaN for invalid pixels.  Returns the (G, 3) grid or None when the reference returns false."""
+    dm = np.ascontiguousarray(dense_model, dtype=np.float64)
+    g = np.zeros((cam.grid_w * cam.grid_h, 3))
+    ok = ba_lib().ref_f3_fit_to_dense_model(_ip(_cam_params8(cam)), dm.shape[1], dm.shape[0], _dp(dm), int(subsample_step),
+                                            int(max_iteration_count), _dp(g))
+    return g if ok else None
 

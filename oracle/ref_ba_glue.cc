@@ -152,3 +152,35 @@ CBA_EXPORT double ref_ba_system(int n_cameras, int n_images, int n_points, const
   for (int64_t o = 0; o < n_obs; ++o) { last_projection[2 * o] = m.feats[o]->last_projection.x(); last_projection[2 * o + 1] = m.feats[o]->last_projection.y(); }
   return update_eq.cost();
 }
+
+// ---- the grid-only LM of the central-generic model, the reference's own (APP/models/central_generic.cc compiled whole) ----
+// CentralGenericModel::FitToPixelDirections (:419-431 -> FitToPixelDirectionsImpl: LMOptimizer on DirectionGridFit...): grid in / out.
+CBA_EXPORT void ref_f3_fit_to_pixel_directions(const int* cam8, double* grid, int64_t n, const double* pixels, const double* directions,
+                                               int max_iteration_count) {
+  auto m = make_model(cam8, grid);
+  std::vector<Vec2d> px; std::vector<Vec3d> dirs;
+  px.reserve(n); dirs.reserve(n);
+  for (int64_t i = 0; i < n; ++i) {
+    px.push_back(Vec2d(pixels[2 * i], pixels[2 * i + 1]));
+    dirs.push_back(Vec3d(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2]));
+  }
+  m->FitToPixelDirections(px, dirs, max_iteration_count);
+  store_grid(m.get(), grid);
+}
+// CentralGenericModel::FitToDenseModel (:267-417): dense_model is (height, width, 3) row-major with NaN for invalid pixels.  Returns 1 and
+// the fitted grid, or 0 when the initialisation left grid points undefined (the reference returns false).  max_iteration_count = 0 stops
+// after the initialisation + sample selection (the LM loop runs zero iterations): the initial grid.
+CBA_EXPORT int ref_f3_fit_to_dense_model(const int* cam8, int dense_width, int dense_height, const double* dense_model, int subsample_step,
+                                         int max_iteration_count, double* grid_out) {
+  std::vector<double> zeros(3 * (size_t)cam8[6] * cam8[7], 0.0);
+  auto m = make_model(cam8, zeros.data());
+  Image<Vec3d> dense(dense_width, dense_height);
+  for (int y = 0; y < dense_height; ++y)
+    for (int x = 0; x < dense_width; ++x) {
+      const double* d = dense_model + 3 * (x + (size_t)y * dense_width);
+      dense(x, y) = Vec3d(d[0], d[1], d[2]);
+    }
+  const bool ok = m->FitToDenseModel(dense, subsample_step, max_iteration_count);
+  store_grid(m.get(), grid_out);
+  return ok ? 1 : 0;
+}
