@@ -138,6 +138,16 @@ def save_poses(path: str, image_used, poses: np.ndarray) -> None:
             f.write(f"  - index: {i}\n")
             for k, v in (("tx", tx), ("ty", ty), ("tz", tz), ("qx", qx), ("qy", qy), ("qz", qz), ("qw", qw)):
                 f.write(f"    {k}: {_g14(v)}\n")
+    # "For convenience, we always also save an .obj file that can be used to visualize the pose positions.  All vertices are colored
+    # red." (:817-836): the camera centre  -R^T t  of every used pose
+    from .se3 import quat_to_matrix
+    with open(path + ".obj", "w") as f:
+        for i, used in enumerate(image_used):
+            if not used:
+                continue
+            R = quat_to_matrix(np.asarray(poses[i][:4], dtype=np.float64))
+            c = R.T @ (-np.asarray(poses[i][4:], dtype=np.float64))
+            f.write(f"v {_g14(c[0])} {_g14(c[1])} {_g14(c[2])} 1 0 0\n")
 
 
 def load_poses(path: str):
@@ -224,6 +234,10 @@ def save_points(path: str, points: np.ndarray, feature_id_to_points_index: Dict[
         f.write("feature_id_to_point_index:\n")
         for fid, idx in feature_id_to_points_index.items():
             f.write(f"  - feature_id: {fid}\n    point_index: {idx}\n")
+    # the pattern points as blue vertices (:923-935)
+    with open(path + ".obj", "w") as f:
+        for p in np.asarray(points, dtype=np.float64).reshape(-1, 3):
+            f.write(f"v {_g14(p[0])} {_g14(p[1])} {_g14(p[2])} 0 0 1\n")
 
 
 def load_points(path: str):

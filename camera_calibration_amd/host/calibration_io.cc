@@ -225,6 +225,15 @@ bool SavePoses(const std::vector<bool>& image_used, const std::vector<SE3d>& ima
     stream << "    qz: " << pose.unit_quaternion().z() << std::endl;
     stream << "    qw: " << pose.unit_quaternion().w() << std::endl;
   }
+  // the reference's convenience file next to it: the camera centres of the used poses as red vertices (:817-836)
+  std::ofstream obj_stream((std::string(path) + ".obj").c_str(), std::ios::out);
+  if (!obj_stream) return false;
+  obj_stream << std::setprecision(14);
+  for (usize i = 0; i < image_used.size(); ++i) {
+    if (!image_used[i]) continue;
+    const Vec3d camera_position = image_tr_pattern[i].inverse().translation();
+    obj_stream << "v " << camera_position.x() << " " << camera_position.y() << " " << camera_position.z() << " 1 0 0" << std::endl;
+  }
   return true;
 }
 
@@ -326,6 +335,15 @@ bool SavePointsAndIndexMapping(const BAState& calibration, const char* path) {
   for (const auto& item : calibration.feature_id_to_points_index) {
     stream << "  - feature_id: " << item.first << std::endl;
     stream << "    point_index: " << item.second << std::endl;
+  }
+  stream.close();
+  // the pattern points as blue vertices (:923-935)
+  std::ofstream obj_stream((std::string(path) + ".obj").c_str(), std::ios::out);
+  if (!obj_stream) return false;
+  obj_stream << std::setprecision(14);
+  for (usize i = 0; i < calibration.points.size(); ++i) {
+    const Vec3d& p = calibration.points[i];
+    obj_stream << "v " << p.x() << " " << p.y() << " " << p.z() << " 0 0 1" << std::endl;
   }
   return true;
 }

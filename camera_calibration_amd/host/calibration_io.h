@@ -2,7 +2,8 @@
 // APP/io/calibration_io.h / calibration_io.cc:51-247, 432-985 (APP = applications/camera_calibration/src/
 // camera_calibration).  dataset.bin is byte-compatible; the YAML files are written in the reference's line
 // format (std::setprecision(14)) and read with a small parser for exactly that subset (the reference links
-// yaml-cpp, which this image does not have).  The reference's convenience .obj side files are not written.
+// yaml-cpp, which this image does not have).  The reference's convenience .obj side files (camera centres, pattern points) are written
+// next to the pose and point files as the reference does.
 #pragma once
 #include <memory>
 #include <vector>

@@ -85,6 +85,13 @@ class SE3d {
     return r;
   }
   Vec3d operator*(const Vec3d& p) const { return q_.rotate(p) + t_; }
+  // se3.hpp: (R^-1, R^-1 * (t * -1)); the inverse of a unit quaternion is its conjugate
+  SE3d inverse() const {
+    SE3d r;
+    r.q_ = Quaterniond(q_.w(), -q_.x(), -q_.y(), -q_.z());
+    r.t_ = r.q_.rotate(Vec3d(-t_.x(), -t_.y(), -t_.z()));
+    return r;
+  }
  private:
   Quaterniond q_;
   Vec3d t_;

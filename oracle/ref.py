@@ -511,6 +511,10 @@ def ba_lib() -> C.CDLL:
         L.ref_f3_fit_to_pixel_directions.argtypes = [ip, dp, C.c_int64, dp, dp, C.c_int]
         L.ref_f3_fit_to_dense_model.argtypes = [ip, C.c_int, C.c_int, dp, C.c_int, C.c_int, dp]
         L.ref_f3_fit_to_dense_model.restype = C.c_int
+        L.ref_f2_dataset_load_and_save.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int64)]
+        L.ref_f2_save_camera_model.argtypes = [ip, dp, C.c_char_p]
+        L.ref_f2_save_poses.argtypes = [C.c_int, C.POINTER(C.c_uint8), dp, C.c_char_p]
+        L.ref_f2_save_points.argtypes = [C.c_int, dp, C.c_int, ip, ip, C.c_char_p]
         _ba_lib = L
     return _ba_lib
 
@@ -582,4 +586,36 @@ def f3_fit_to_dense_model(cam, dense_model, subsample_step: int, max_iteration_c
     ok = ba_lib().ref_f3_fit_to_dense_model(_ip(_cam_params8(cam)), dm.shape[1], dm.shape[0], _dp(dm), int(subsample_step),
                                             int(max_iteration_count), _dp(g))
     return g if ok else None
+
+
+
+
+def f2_dataset_load_and_save(path_in: str, path_out: str):
+    """The reference's own LoadDataset then SaveDataset (APP/io/calibration_io.cc:51-246).  Returns None if either fails, else
+    dict(cameras, imagesets, features, known_geometries) of what was loaded."""
+    counts = (C.c_int64 * 4)()
+    ok = ba_lib().ref_f2_dataset_load_and_save(path_in.encode(), path_out.encode(), counts)
+    return dict(cameras=counts[0], imagesets=counts[1], features=counts[2], known_geometries=counts[3]) if ok else None
+
+
+def f2_save_camera_model(cam, grid, path: str) -> bool:
+    """The reference's own SaveCameraModel (:526-647).  grid: (G, 3) central; (2, G, 3) = direction, point for the non-central model."""
+    cam9 = np.concatenate([[cam.model_type], _cam_params8(cam)]).astype(np.int32)
+    g = np.ascontiguousarray(grid, dtype=np.float64).reshape(-1)
+    return bool(ba_lib().ref_f2_save_camera_model(_ip(cam9), _dp(g), path.encode()))
+
+
+def f2_save_poses(image_used, poses, path: str) -> bool:
+    """The reference's own SavePoses (:785-839), incl. the .obj file next to it."""
+    used = np.asarray(image_used).astype(np.uint8)
+    p = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 7)
+    return bool(ba_lib().ref_f2_save_poses(len(used), used.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(p), path.encode()))
+
+
+def f2_save_points(points, feature_id_to_points_index, path: str) -> bool:
+    """The reference's own SavePointsAndIndexMapping (:890-937), incl. the .obj file next to it."""
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    ids = np.array(list(feature_id_to_points_index.keys()), dtype=np.int32)
+    idx = np.array([feature_id_to_points_index[int(i)] for i in ids], dtype=np.int32)
+    return bool(ba_lib().ref_f2_save_points(len(pts), _dp(pts), len(ids), _ip(ids), _ip(idx), path.encode()))
 

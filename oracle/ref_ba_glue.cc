@@ -184,3 +184,30 @@ CBA_EXPORT int ref_f3_fit_to_dense_model(const int* cam8, int dense_width, int d
   store_grid(m.get(), grid_out);
   return ok ? 1 : 0;
 }
+
+// ---- the reference's own on-disk writers and its dataset reader (APP/io/calibration_io.cc, piped by oracle/Makefile) ----
+// LoadDataset(path_in) followed by SaveDataset(path_out): a file in the reference's format is a fixed point of this.  Returns 0 on failure,
+// else 1; counts[0..3] = cameras, imagesets, features, known geometries of what was loaded.
+CBA_EXPORT int ref_f2_dataset_load_and_save(const char* path_in, const char* path_out, int64_t* counts) {
+  Dataset ds;
+  if (!LoadDataset(path_in, &ds)) return 0;
+  int64_t features = 0;
+  for (int i = 0; i < ds.ImagesetCount(); ++i)
+    for (int c = 0; c < ds.num_cameras(); ++c) features += (int64_t)ds.GetImageset(i)->FeaturesOfCamera(c).size();
+  counts[0] = ds.num_cameras(); counts[1] = ds.ImagesetCount(); counts[2] = features; counts[3] = ds.KnownGeometriesCount();
+  return SaveDataset(path_out, ds) ? 1 : 0;
+}
+CBA_EXPORT int ref_f2_save_camera_model(const int* cam9, const double* grid, const char* path) {
+  return SaveCameraModel(*make_any_model(cam9, grid), path) ? 1 : 0;
+}
+CBA_EXPORT int ref_f2_save_poses(int n, const uint8_t* image_used, const double* poses7, const char* path) {
+  std::vector<bool> used(n); std::vector<SE3d> poses;
+  for (int i = 0; i < n; ++i) { used[i] = image_used[i] != 0; poses.push_back(pose_of(poses7 + 7 * i)); }
+  return SavePoses(used, poses, path) ? 1 : 0;
+}
+CBA_EXPORT int ref_f2_save_points(int n_points, const double* points, int n_map, const int* feature_ids, const int* point_index, const char* path) {
+  BAState st;
+  for (int p = 0; p < n_points; ++p) st.points.push_back(Vec3d(points[3 * p], points[3 * p + 1], points[3 * p + 2]));
+  for (int i = 0; i < n_map; ++i) st.feature_id_to_points_index[feature_ids[i]] = point_index[i];
+  return SavePointsAndIndexMapping(st, path) ? 1 : 0;
+}

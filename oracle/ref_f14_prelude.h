@@ -56,5 +56,20 @@ inline void CreateReprojectionErrorHistogram(int, const Dataset&, const BAState&
 inline void CreateReprojectionErrorMagnitudeVisualization(const Dataset&, int, const BAState&, float, Image<Vec3u8>*) {}
 inline void CreateReprojectionErrorDirectionVisualization(const Dataset&, int, const BAState&, Image<Vec3u8>*) {}
 }  // namespace vis
-struct QDir { bool mkpath(const char*) { return true; } };
-struct QFileInfo { explicit QFileInfo(const char*) {} QDir dir() const { return QDir(); } };
+// QFileInfo(path).dir().mkpath(".") / QDir(path).mkpath("."): "create the containing folder" -- done with mkdir(2), component by component
+#include <sys/stat.h>
+struct QDir {
+  std::string d;
+  QDir() {}
+  explicit QDir(const char* p) : d(p) {}
+  bool mkpath(const char*) {
+    for (size_t i = 1; i <= d.size(); ++i)
+      if (i == d.size() || d[i] == '/') ::mkdir(d.substr(0, i).c_str(), 0777);
+    return true;
+  }
+};
+struct QFileInfo {
+  std::string p;
+  explicit QFileInfo(const char* path) : p(path) {}
+  QDir dir() const { const size_t k = p.rfind('/'); return QDir(k == std::string::npos ? "." : p.substr(0, k).c_str()); }
+};

@@ -5,13 +5,22 @@
 // for the two generic models, and declares the parametric classes as never-instantiated types so that the dynamic_casts which pick a
 // regularisation branch (APP/bundle_adjustment/joint_optimization.cc:842-848) still compile.
 #pragma once
+#include <cstdlib>
 #include <libvis/libvis.h>
 #include "camera_calibration/models/central_generic.h"
 #include "camera_calibration/models/noncentral_generic.h"
 namespace vis {
-class CentralOpenCVModel : public CameraModel { CentralOpenCVModel() = delete; };
-class CentralRadialModel : public CameraModel { CentralRadialModel() = delete; };
-class CentralThinPrismFisheyeModel : public CameraModel { CentralThinPrismFisheyeModel() = delete; };
+// (parameters() / use_equidistant_projection(): named by SaveCameraModel's branches for these models, APP/io/calibration_io.cc:565-608, which
+// no test can reach because no object of these classes can exist)
+struct CbaNoParameters { double operator[](int) const { std::abort(); } int size() const { std::abort(); } };
+class CentralOpenCVModel : public CameraModel { CentralOpenCVModel() = delete; public: CbaNoParameters parameters() const { std::abort(); } };
+class CentralRadialModel : public CameraModel { CentralRadialModel() = delete; public: CbaNoParameters parameters() const { std::abort(); } };
+class CentralThinPrismFisheyeModel : public CameraModel {
+  CentralThinPrismFisheyeModel() = delete;
+ public:
+  CbaNoParameters parameters() const { std::abort(); }
+  bool use_equidistant_projection() const { std::abort(); }
+};
 
 #define CBA_REF_MODEL_BRANCH(object, qualifier, Model, ...)                                                         \
   {                                                                                                                 \

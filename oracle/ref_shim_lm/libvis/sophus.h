@@ -21,6 +21,12 @@ class SE3 {
   Vec3& translation() { return t_; }
   Mat3 rotationMatrix() const { return q_.toRotationMatrix(); }
   Vec3 operator*(const Vec3& p) const { return Vec3(rotationMatrix() * p + t_); }
+  // se3.hpp: inverse = (R^-1, R^-1 * (t * -1)); so3.hpp: the inverse of a unit quaternion is its conjugate
+  SE3 inverse() const {
+    SE3 r; r.q_ = Quat(q_.w(), -q_.x(), -q_.y(), -q_.z());
+    r.t_ = Vec3(r.q_.toRotationMatrix() * Vec3(t_ * T(-1)));
+    return r;
+  }
   // so3.hpp:215-232: quaternion product, renormalised by the first-order rule when the squared norm left 1
   SE3 operator*(const SE3& b) const {
     Quat q = q_ * b.q_;

@@ -170,5 +170,11 @@ def test_cpp_mirror_reads_and_rewrites_the_files(tmp_path):
     np.testing.assert_allclose(st2.rig_tr_global[used], st.rig_tr_global[used], atol=1e-13)
     for g2, g in zip(st2.grids, st.grids):
         np.testing.assert_allclose(g2, g, atol=1e-13)
+    # the reference's convenience .obj files next to poses and points (calibration_io.cc:817-836, 923-935): written by both mirrors
+    for name in ("rig_tr_global.yaml.obj", "camera_tr_rig.yaml.obj", "points.yaml.obj"):
+        a = np.loadtxt(os.path.join(sin_, name), usecols=(1, 2, 3, 4, 5, 6), ndmin=2)
+        b = np.loadtxt(os.path.join(sout, name), usecols=(1, 2, 3, 4, 5, 6), ndmin=2)
+        assert a.shape == b.shape and a.shape[0] > 0
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
     # values that are not re-normalised pass through both writers unchanged: identical text
     assert open(os.path.join(sin_, "points.yaml")).read().split("\n")[1] == open(os.path.join(sout, "points.yaml")).read().split("\n")[1]
