@@ -511,6 +511,8 @@ def ba_lib() -> C.CDLL:
         L.ref_f3_fit_to_pixel_directions.argtypes = [ip, dp, C.c_int64, dp, dp, C.c_int]
         L.ref_f3_fit_to_dense_model.argtypes = [ip, C.c_int, C.c_int, dp, C.c_int, C.c_int, dp]
         L.ref_f3_fit_to_dense_model.restype = C.c_int
+        L.ref_f3_resample_model.argtypes = [ip, dp, C.c_int, C.c_int, C.c_int, dp]
+        L.ref_f3_resample_model.restype = C.c_int
         L.ref_f2_dataset_load_and_save.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int64)]
         L.ref_f2_save_camera_model.argtypes = [ip, dp, C.c_char_p]
         L.ref_f2_save_poses.argtypes = [C.c_int, C.POINTER(C.c_uint8), dp, C.c_char_p]
@@ -618,4 +620,18 @@ def f2_save_points(points, feature_id_to_points_index, path: str) -> bool:
     ids = np.array(list(feature_id_to_points_index.keys()), dtype=np.int32)
     idx = np.array([feature_id_to_points_index[int(i)] for i in ids], dtype=np.int32)
     return bool(ba_lib().ref_f2_save_points(len(pts), _dp(pts), len(ids), _ip(ids), _ip(idx), path.encode()))
+
+
+
+
+def f3_resample_model(cam, grid, target_type: int, target_gw: int, target_gh: int):
+    """ResampleModel (APP/calibration.cc:373-528) between generic models, the reference's own code.  grid: (G, 3) central or (2, G, 3) =
+    direction, point.  Returns the new grid in the same convention ((2, G', 3) for a non-central target) or None."""
+    cam9 = np.concatenate([[cam.model_type], _cam_params8(cam)]).astype(np.int32)
+    g = np.ascontiguousarray(grid, dtype=np.float64).reshape(-1)
+    out = np.zeros((2 if target_type else 1) * target_gw * target_gh * 3)
+    ok = ba_lib().ref_f3_resample_model(_ip(cam9), _dp(g), int(target_type), int(target_gw), int(target_gh), _dp(out))
+    if not ok:
+        return None
+    return out.reshape(2, -1, 3) if target_type else out.reshape(-1, 3)
 

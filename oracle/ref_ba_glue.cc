@@ -211,3 +211,16 @@ CBA_EXPORT int ref_f2_save_points(int n_points, const double* points, int n_map,
   for (int i = 0; i < n_map; ++i) st.feature_id_to_points_index[feature_ids[i]] = point_index[i];
   return SavePointsAndIndexMapping(st, path) ? 1 : 0;
 }
+
+// ResampleModel (APP/calibration.cc:373-528), generic source and target models: cam9 / grid of the model to resample, the target type
+// (0 central, 1 non-central) and resolution.  Returns 1 and the new grid(s) in the layout of make_any_model (central: G x 3; non-central:
+// directions then points), or 0 where the reference returns false.
+CBA_EXPORT int ref_f3_resample_model(const int* cam9, const double* grid, int target_type, int target_gw, int target_gh, double* grid_out) {
+  std::shared_ptr<CameraModel> model = make_any_model(cam9, grid);
+  SE3d camera_tr_rig;
+  const bool ok = ResampleModel(model, &camera_tr_rig, cam9[3], cam9[4], cam9[5], cam9[6],
+                                target_type == 0 ? CameraModel::Type::CentralGeneric : CameraModel::Type::NoncentralGeneric, target_gw, target_gh);
+  if (!ok) return 0;
+  store_any_grid(model.get(), grid_out);
+  return 1;
+}

@@ -2,23 +2,42 @@
 // The reference's header pulls in the three parametric models (OpenCV, radial, thin-prism fisheye), which are out of this project's
 // scope (the generic models only) and whose sources need the real Sophus.  This stand-in keeps the dispatch macros' names and
 // calling convention (a statement block that sees `_<object>` as a reference to the concrete model and `_<object>_type` as its type)
-// for the two generic models, and declares the parametric classes as never-instantiated types so that the dynamic_casts which pick a
-// regularisation branch (APP/bundle_adjustment/joint_optimization.cc:842-848) still compile.
+// for the two generic models, and declares the parametric classes as aborting stand-ins so that the code which names them (the dynamic_casts
+// that pick a regularisation branch, APP/bundle_adjustment/joint_optimization.cc:842-848; SaveCameraModel; ResampleModel) still compiles.
 #pragma once
 #include <cstdlib>
 #include <libvis/libvis.h>
 #include "camera_calibration/models/central_generic.h"
 #include "camera_calibration/models/noncentral_generic.h"
 namespace vis {
-// (parameters() / use_equidistant_projection(): named by SaveCameraModel's branches for these models, APP/io/calibration_io.cc:565-608, which
-// no test can reach because no object of these classes can exist)
+// The parametric classes: what SaveCameraModel's and ResampleModel's branches for them name (APP/io/calibration_io.cc:565-608,
+// APP/calibration.cc:477-527) -- constructors, parameters(), FitToDenseModel -- declared so that those functions compile WHOLE; every
+// member aborts: no test takes those branches (the generic models only).
 struct CbaNoParameters { double operator[](int) const { std::abort(); } int size() const { std::abort(); } };
-class CentralOpenCVModel : public CameraModel { CentralOpenCVModel() = delete; public: CbaNoParameters parameters() const { std::abort(); } };
-class CentralRadialModel : public CameraModel { CentralRadialModel() = delete; public: CbaNoParameters parameters() const { std::abort(); } };
-class CentralThinPrismFisheyeModel : public CameraModel {
-  CentralThinPrismFisheyeModel() = delete;
+class CbaUnbuiltModel : public CameraModel {
  public:
+  CbaUnbuiltModel(int width, int height, Type type) : CameraModel(width, height, 0, 0, width - 1, height - 1, type) {}
+  CameraModel* duplicate() override { std::abort(); }
+  bool Project(const Vec3d&, Vec2d*) const override { std::abort(); }
+  bool ProjectWithInitialEstimate(const Vec3d&, Vec2d*) const override { std::abort(); }
+  bool Unproject(double, double, Line3d*) const override { std::abort(); }
+  int update_parameter_count() const override { std::abort(); }
   CbaNoParameters parameters() const { std::abort(); }
+};
+class CentralOpenCVModel : public CbaUnbuiltModel {
+ public:
+  CentralOpenCVModel(int width, int height) : CbaUnbuiltModel(width, height, Type::CentralOpenCV) {}
+  bool FitToDenseModel(const Image<Vec3d>&, Mat3d*, int, int) { std::abort(); }
+};
+class CentralRadialModel : public CbaUnbuiltModel {
+ public:
+  CentralRadialModel(int width, int height, int) : CbaUnbuiltModel(width, height, Type::CentralRadial) {}
+  bool FitToDenseModel(const Image<Vec3d>&, int, int) { std::abort(); }
+};
+class CentralThinPrismFisheyeModel : public CbaUnbuiltModel {
+ public:
+  CentralThinPrismFisheyeModel(int width, int height, bool) : CbaUnbuiltModel(width, height, Type::CentralThinPrismFisheye) {}
+  bool FitToDenseModel(const Image<Vec3d>&, Mat3d*, int, int) { std::abort(); }
   bool use_equidistant_projection() const { std::abort(); }
 };
 

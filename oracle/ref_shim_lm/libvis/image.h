@@ -23,6 +23,16 @@ class Image {
   T* data() { return d_.data(); }
   unsigned width() const { return w_; }
   unsigned height() const { return h_; }
+  // libvis image.h:129-149 (InterpolateImageBilinear): integer part by truncation, the fractions held in FLOAT, four products summed in
+  // the order top-left, top-right, bottom-left, bottom-right
+  template <class R, class D> R InterpolateBilinear(const Eigen::MatrixBase<D>& position) const {
+    const int ix = static_cast<int>(position(0)), iy = static_cast<int>(position(1));
+    const float fx = position(0) - ix, fy = position(1) - iy;
+    const float fx_inv = 1.f - fx, fy_inv = 1.f - fy;
+    const T& tl = d_[ix + (std::size_t)iy * w_]; const T& tr = d_[ix + 1 + (std::size_t)iy * w_];
+    const T& bl = d_[ix + (std::size_t)(iy + 1) * w_]; const T& br = d_[ix + 1 + (std::size_t)(iy + 1) * w_];
+    return R(R(R((double)(fx_inv * fy_inv) * R(tl) + (double)(fx * fy_inv) * R(tr)) + (double)(fx_inv * fy) * R(bl)) + (double)(fx * fy) * R(br));
+  }
   const T& at(int x, int y) const { return d_[x + (std::size_t)y * w_]; }
   T& at(int x, int y) { return d_[x + (std::size_t)y * w_]; }
   const T& operator()(int x, int y) const { return d_[x + (std::size_t)y * w_]; }

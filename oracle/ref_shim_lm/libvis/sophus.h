@@ -16,6 +16,7 @@ class SE3 {
   SE3() : q_(1, 0, 0, 0) {}
   SE3(const Quat& q, const Vec3& t) : q_(q), t_(t) { q_.normalize(); }
   SE3(const Mat3& R, const Vec3& t) : q_(R), t_(t) {}
+  void setRotationMatrix(const Mat3& R) { q_ = Quat(R); }
   const Quat& unit_quaternion() const { return q_; }
   const Vec3& translation() const { return t_; }
   Vec3& translation() { return t_; }

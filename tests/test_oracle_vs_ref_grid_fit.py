@@ -73,3 +73,55 @@ def test_fit_to_dense_model_failure_is_the_references():
     dense[:20, :20] = _dense(140, 140, 160, 120)[:20, :20]
     assert ref.f3_fit_to_dense_model(cam, dense, 4, 1) is None
     assert grid_fit.fit_to_dense_model(cam, dense, 4, 1, fit_fn=_oracle_fit)[0] is None
+
+
+# ---- ResampleModel (APP/calibration.cc:373-528), piped into the same library ----
+def _oracle_unproject(cam, grid, px):
+    return orc.unproject(cam, grid, px)
+
+
+def test_resample_model_central_to_central_is_the_references():
+    """Dense direction image from the old model (pixel centres; NaN outside its calibrated area), the subsample step
+    max(1, min(round(int / 300), round(int / 300))), FitToDenseModel(.., 3) on the target grid."""
+    cam = Camera(0, W, H, 12, 8, W - 15, H - 11, 8, 6)
+    grid0 = grid_fit.initialize_grid_from_dense_model(cam, _dense(150, 149, 158, 121, k1=-0.05))
+    g_ref = ref.f3_resample_model(cam, grid0, 0, 13, 10)
+    new_cam, g_host, _ = grid_fit.resample_model(cam, grid0, 13, 10, fit_fn=_oracle_fit, unproject_fn=_oracle_unproject)
+    assert g_ref is not None and (new_cam.grid_w, new_cam.grid_h) == (13, 10)
+    np.testing.assert_allclose(np.asarray(g_host).reshape(-1, 3), g_ref, rtol=0, atol=1e-11)
+
+
+def test_resample_model_central_to_noncentral_is_the_references():
+    """Central source, non-central target: the fitted central grid becomes the direction grid, the point grid is zero
+    (InitializeFromCentralGenericModel, noncentral_generic.cc:136-146)."""
+    cam = Camera(0, W, H, 0, 0, W - 1, H - 1, 8, 6)
+    grid0 = grid_fit.initialize_grid_from_dense_model(cam, _dense(150, 150, 160, 120))
+    g_ref = ref.f3_resample_model(cam, grid0, 1, 10, 8)
+    new_cam, g_c, _ = grid_fit.resample_model(cam, grid0, 10, 8, fit_fn=_oracle_fit, unproject_fn=_oracle_unproject)
+    nc, g_host = grid_fit.initialize_noncentral_from_central(new_cam, g_c)
+    assert g_ref is not None and nc.model_type == 1
+    np.testing.assert_allclose(g_host[0], g_ref[0], rtol=0, atol=1e-11)
+    np.testing.assert_array_equal(g_ref[1], 0.0)
+    np.testing.assert_array_equal(g_host[1], 0.0)
+
+
+def test_resample_model_noncentral_to_noncentral_is_the_references():
+    """Bilinear resampling of both grids (float fractions, clamped to the old grid, directions not re-normalised; calibration.cc:386-425)."""
+    from camera_calibration_amd.problem import NONCENTRAL_GENERIC
+    cam = Camera(NONCENTRAL_GENERIC, W, H, 5, 3, W - 7, H - 4, 8, 6)
+    rng = np.random.default_rng(4)
+    d = grid_fit.initialize_grid_from_dense_model(Camera(0, W, H, 5, 3, W - 7, H - 4, 8, 6), _dense(150, 150, 160, 120))
+    grids = np.stack([d, rng.normal(0, 1e-3, d.shape)])
+    for (gw, gh) in ((12, 9), (5, 4), (8, 6)):
+        g_ref = ref.f3_resample_model(cam, grids, 1, gw, gh)
+        new_cam, g_host = grid_fit.resample_noncentral_model(cam, grids, gw, gh)
+        assert g_ref is not None and (new_cam.grid_w, new_cam.grid_h) == (gw, gh)
+        # Equal to 1e-15 when the reference code is compiled with -ffp-contract=off (checked).  With g++'s default (and the reference's own
+        # -O2 -march=native build) the FLOAT expression of the static GridPointToPixelCornerConv, min + ((x - 1.f) / (gw - 3.f)) * span
+        # (central_grid.h:132-140), becomes one fused multiply-add: one float ulp in the pixel of some grid columns, 3e-8 in their
+        # interpolated values (observed: column 0 only) -- an initial state for the optimisation that follows, as the reference notes.
+        np.testing.assert_allclose(g_host, g_ref, rtol=0, atol=1e-7)
+        assert (np.abs(g_host - g_ref).reshape(2, gh, gw, 3).max(axis=(0, 3)) > 1e-14).sum() <= gh            # at most one column
+    # a non-central source cannot be resampled into a central target: the reference returns false
+    assert ref.f3_resample_model(cam, grids, 0, 8, 6) is None
+
