@@ -10,6 +10,9 @@ Mirrors (APP = applications/camera_calibration/src/camera_calibration):
 * ``run_bundle_adjustment``          -- RunBundleAdjustment, APP/calibration.cc:187-304: OptimizeJointly(1) per iteration with the
   state device-resident, camera orientations beautified after every iteration, stop when
   ``cost >= last_cost - cost_reduction_threshold``.
+* ``compute_grid_resolution`` / ``calc_grid_resolution_for_level`` -- the grid-resolution rules of the pyramid, APP/calibration.cc:531-568.
+* ``calibrate_refinement_stage``     -- the refinement stage of Calibrate(), APP/calibration.cc:1030-1142: the pyramid levels (two
+  RunBundleAdjustment runs and a ResampleModel per level), the optional outlier stage, the main bundle adjustment and ScaleToMetric.
 """
 from __future__ import annotations
 
@@ -157,3 +160,114 @@ def run_bundle_adjustment(problem: Problem, state: State, max_iteration_count: i
     finally:
         e.close()
     return st, costs
+
+
+# ---------------------------------------------------------------------------------------------------
+# the pyramid's grid-resolution rules and the refinement stage of Calibrate()
+# ---------------------------------------------------------------------------------------------------
+def compute_grid_resolution(cam: Camera, approx_pixels_per_cell: int):
+    """ComputeGridResolution, APP/calibration.cc:531-559: area / pixels-per-cell in INTEGER division, + 0.5f + 2 * exterior cells, truncated;
+    both generic models have one exterior cell per side (central_generic.h:123, noncentral_generic.h:146)."""
+    aw = cam.calib_max_x - cam.calib_min_x + 1; ah = cam.calib_max_y - cam.calib_min_y + 1
+    f = np.float32
+    return (int(f(aw // approx_pixels_per_cell) + f(0.5) + f(2)), int(f(ah // approx_pixels_per_cell) + f(0.5) + f(2)))
+
+
+def calc_grid_resolution_for_level(pyramid_level: int, full_resolution_x: int, full_resolution_y: int):
+    """CalcGridResolutionForLevel, APP/calibration.cc:565-568: full * 1.333^-level + 0.5, truncated."""
+    s = 1.333 ** (-pyramid_level)
+    return int(full_resolution_x * s + 0.5), int(full_resolution_y * s + 0.5)
+
+
+def _default_resample(cam: Camera, grid: np.ndarray, target_x: int, target_y: int):
+    """ResampleModel between generic models of the SAME type (what the pyramid does; APP/calibration.cc:373-528)."""
+    from . import grid_fit
+    if cam.model_type == CENTRAL_GENERIC:
+        new_cam, new_grid, _ = grid_fit.resample_model(cam, grid, target_x, target_y)
+        if new_grid is None:
+            raise RuntimeError("ResampleModel failed: the dense model could not initialise every grid point")
+        return new_cam, np.asarray(new_grid).reshape(-1, 3)
+    return grid_fit.resample_noncentral_model(cam, grid, target_x, target_y)
+
+
+def _restrict(problem: Problem, state: State, keep: np.ndarray, image_used: np.ndarray):
+    """The problem OptimizeJointly sees: surviving features of the used imagesets, imagesets renumbered (joint_optimization.cc:60-110)."""
+    seq = -np.ones(problem.n_images, dtype=np.int64)
+    seq[image_used] = np.arange(int(image_used.sum()))
+    m = keep & image_used[problem.obs_image]
+    sub = Problem(problem.cameras, int(image_used.sum()), problem.n_points, problem.obs_xy[m], problem.obs_point[m],
+                  seq[problem.obs_image[m]].astype(np.int32), problem.obs_camera[m], problem.fd_delta, problem.localize_only,
+                  problem.eliminate_points)
+    return sub, State(state.rig_tr_global[image_used], state.camera_tr_rig, state.points, state.grids)
+
+
+def calibrate_refinement_stage(problem: Problem, state: State, dataset: DatasetData, feature_id_to_points_index: Dict[int, int],
+                               num_pyramid_levels: int, approx_pixels_per_cell: int, outlier_removal_factor: float = 0.0,
+                               localize_only: bool = False, run_ba_fn: Optional[Callable] = None, resample_fn: Optional[Callable] = None,
+                               delete_outliers_fn: Optional[Callable] = None):
+    """The refinement stage of Calibrate() (APP/calibration.cc:1030-1142) on a packed problem whose cameras are at the COARSEST pyramid level.
+
+    Pyramid levels L-1 ... 1 (skipped when localising only): RunBundleAdjustment(10 iterations, threshold 1e-4), RunBundleAdjustment(50, 1), then
+    every camera resampled to the next level's resolution; outlier stage when ``outlier_removal_factor`` > 0: RunBundleAdjustment(100 if L == 1
+    else 10, 1e-4) and DeleteOutlierFeatures camera by camera (an imageset that drops below three features of a camera is unused from then on);
+    main RunBundleAdjustment(100, 1e-4); ScaleToMetric unless localising only.
+
+    The functions that touch the GPU are injectable (tests run the stage on the CPU oracle): ``run_ba_fn(problem, state, max_iterations,
+    threshold, localize_only) -> (State, costs)``, ``resample_fn(cam, grid, target_x, target_y) -> (Camera, grid)``,
+    ``delete_outliers_fn(camera_index, problem, state, factor, image_used) -> (keep, image_used, threshold)``.
+    Returns dict(problem (full-resolution cameras, all observations), state, keep, image_used, scale, ba_runs)."""
+    from . import report as _report
+    run_ba_fn = run_ba_fn or (lambda pb, st, it, thr, loc: run_bundle_adjustment(pb, st, it, thr, localize_only=loc))
+    resample_fn = resample_fn or _default_resample
+    delete_outliers_fn = delete_outliers_fn or (lambda c, pb, st, f, used: _report.delete_outlier_features(c, pb, st, f, used))
+    cameras = list(problem.cameras)
+    full = [compute_grid_resolution(cam, approx_pixels_per_cell) for cam in cameras]
+    keep = np.ones(problem.n_obs, dtype=bool)
+    used = np.ones(problem.n_images, dtype=bool)
+    st = state.copy()
+    ba_runs = []
+
+    def with_cameras(cams):
+        return Problem(cams, problem.n_images, problem.n_points, problem.obs_xy, problem.obs_point, problem.obs_image, problem.obs_camera,
+                       problem.fd_delta, localize_only, problem.eliminate_points)
+
+    def run(pb_full, st_full, iterations, threshold):
+        sub, st_sub = _restrict(pb_full, st_full, keep, used)
+        out, costs = run_ba_fn(sub, st_sub, iterations, threshold, localize_only)
+        ba_runs.append(dict(max_iteration_count=iterations, threshold=threshold, iterations=len(costs), final_cost=costs[-1] if costs else None))
+        rig = st_full.rig_tr_global.copy(); rig[used] = out.rig_tr_global
+        return State(rig, out.camera_tr_rig, out.points, out.grids)
+
+    pb = with_cameras(cameras)
+    if not localize_only:
+        for level in range(num_pyramid_levels - 1, 0, -1):
+            for c, cam in enumerate(cameras):          # the reference CHECKs this (:1063-1066)
+                want = calc_grid_resolution_for_level(level, *full[c])
+                if (cam.grid_w, cam.grid_h) != want:
+                    raise ValueError(f"camera {c}: grid {cam.grid_w} x {cam.grid_h} on pyramid level {level}, expected {want[0]} x {want[1]}")
+            st = run(pb, st, 10, 0.0001)
+            st = run(pb, st, 50, 1.0)
+            grids = []
+            for c, cam in enumerate(cameras):
+                tx, ty = calc_grid_resolution_for_level(level - 1, *full[c])
+                cameras[c], g = resample_fn(cam, st.grids[c], tx, ty)
+                grids.append(np.ascontiguousarray(g, dtype=np.float64))
+            st = State(st.rig_tr_global, st.camera_tr_rig, st.points, grids)
+            pb = with_cameras(cameras)
+    if outlier_removal_factor > 0:
+        st = run(pb, st, 100 if num_pyramid_levels == 1 else 10, 0.0001)
+        for c in range(len(cameras)):
+            k, used_after, _ = delete_outliers_fn(c, _subset_observations(pb, keep), st, outlier_removal_factor, used)
+            keep[np.flatnonzero(keep)[~np.asarray(k, dtype=bool)]] = False
+            used = np.asarray(used_after, dtype=bool).copy()
+    st = run(pb, st, 100, 0.0001)
+    scale = None
+    if not localize_only:
+        scale, st = scale_to_metric(dataset, st, feature_id_to_points_index)
+    return dict(problem=pb, state=st, keep=keep, image_used=used, scale=scale, ba_runs=ba_runs)
+
+
+def _subset_observations(problem: Problem, keep: np.ndarray) -> Problem:
+    return Problem(problem.cameras, problem.n_images, problem.n_points, problem.obs_xy[keep], problem.obs_point[keep], problem.obs_image[keep],
+                   problem.obs_camera[keep], problem.fd_delta, problem.localize_only, problem.eliminate_points)
+

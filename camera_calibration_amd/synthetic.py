@@ -129,6 +129,15 @@ def pattern_points(lattice_x: int, lattice_y: int, pitch: float, rng: np.random.
     return pts
 
 
+def pattern_positions(lattice_x: int, lattice_y: int) -> np.ndarray:
+    """Integer lattice position of every point of ``pattern_points`` (same order): the known geometry of the synthetic pattern
+    (KnownGeometry::feature_id_to_position, APP/dataset.h:49-56, with feature id = point index)."""
+    ys, xs = np.meshgrid(np.arange(lattice_y), np.arange(lattice_x), indexing="ij")
+    hole_x0, hole_y0 = lattice_x // 2 - 2, lattice_y // 2 - 2
+    hole = (xs >= hole_x0) & (xs < hole_x0 + 5) & (ys >= hole_y0) & (ys < hole_y0 + 5)
+    return np.stack([xs[~hole], ys[~hole]], axis=-1).astype(np.int32)
+
+
 def _rig_layout(n_cams: int) -> np.ndarray:
     if n_cams == 1:
         return se3_identity(1)
@@ -145,7 +154,8 @@ def _rig_layout(n_cams: int) -> np.ndarray:
 
 def baseline_config(cfg: int, project_fn: ProjectFn, n_imagesets: int | None = None, noise_px: float = 0.03,
                     seed: int | None = None, grid_perturbation: float = 0.1, pose_perturbation: float = 0.01,
-                    point_perturbation: float = 0.002, image_offset: int = 0, grid_wh: Tuple[int, int] | None = None):
+                    point_perturbation: float = 0.002, image_offset: int = 0, grid_wh: Tuple[int, int] | None = None,
+                    lattice_xy: Tuple[int, int] | None = None):
     """Build BASELINE.json config ``cfg`` (optionally with fewer imagesets). Returns (problem, state, gt).
 
     Perturbations: points +-``point_perturbation`` m, poses exp(``pose_perturbation``*U^6), grid directions
@@ -157,6 +167,8 @@ def baseline_config(cfg: int, project_fn: ProjectFn, n_imagesets: int | None = N
     n_cams, model, W, H, gw, gh, lx, ly, n_default, fd = BASELINE_CONFIGS[cfg]
     if grid_wh is not None:      # coarser grid for memory-bound test hosts (the configuration's own grid is the default)
         gw, gh = grid_wh
+    if lattice_xy is not None:   # a smaller pattern (fewer points) for tests whose checker is slow
+        lx, ly = lattice_xy
     N = n_default if n_imagesets is None else n_imagesets
     seed = 1000 + cfg if seed is None else seed
     rng = np.random.default_rng(seed)

@@ -224,3 +224,52 @@ CBA_EXPORT int ref_f3_resample_model(const int* cam9, const double* grid, int ta
   store_any_grid(model.get(), grid_out);
   return 1;
 }
+
+// ---- The refinement stage of Calibrate() (APP/calibration.cc:1030-1142, compiled as the body of RefCalibrateRefinementStage): feature -> point
+// indexing, full grid resolutions, the pyramid levels (RunBundleAdjustment(10, 1e-4), RunBundleAdjustment(50, 1), ResampleModel to the next
+// level), the optional outlier stage (RunBundleAdjustment, DeleteOutlierFeatures per camera), the main RunBundleAdjustment(100, 1e-4) and
+// ScaleToMetric -- reference code all the way down (libcalibref_ba.so).  The known geometry: one pattern with cell_length and integer positions
+// (2 per point, feature id = point index).  cam9 / grids in: the models of the coarsest pyramid level; out: the models of the full resolution
+// (cam9_out receives their grid sizes; grids_out must hold the full-resolution grids).  keep[o] / image_used[i]: what the outlier stage left.
+// trace[0] = OptimizeJointly calls made.  Returns 0 where the reference returns false.
+CBA_EXPORT int ref_f1_calibrate_refinement_stage(int num_pyramid_levels, int approx_pixels_per_cell, float outlier_removal_factor, int localize_only,
+                                                 float cell_length, const int* positions_xy, int n_cameras, int n_images, int n_points,
+                                                 const int* cam9, int64_t n_obs, const float* obs_xy, const int* obs_point, const int* obs_image,
+                                                 const int* obs_camera, double* rig_tr_global, double* camera_tr_rig, double* points,
+                                                 double* const* grids_in, int* cam9_out, double* const* grids_out, uint8_t* image_used,
+                                                 uint8_t* keep, double* trace) {
+  std::vector<double> lp(2 * (size_t)n_obs, 0.0);
+  Marshalled m;
+  marshal(n_cameras, n_images, n_points, cam9, n_obs, obs_xy, obs_point, obs_image, obs_camera, rig_tr_global, camera_tr_rig, points, grids_in,
+          lp.data(), &m);
+  m.ds.SetKnownGeometriesCount(1);
+  m.ds.GetKnownGeometry(0).cell_length_in_meters = cell_length;
+  for (int p = 0; p < n_points; ++p) m.ds.GetKnownGeometry(0).feature_id_to_position[p] = Vec2i(positions_xy[2 * p], positions_xy[2 * p + 1]);
+  // tag the features with their packed index: PointFeature::last_projection.x is free for that BEFORE the first OptimizeJointly call only, so
+  // the tags live in a side table keyed by (imageset, camera, feature id) instead -- a point is seen at most once per image and camera
+  std::vector<std::unordered_map<int, int64_t>> tag((size_t)n_images * n_cameras);
+  for (int64_t o = 0; o < n_obs; ++o) tag[(size_t)obs_image[o] * n_cameras + obs_camera[o]][obs_point[o]] = o;
+  g_ref_ba_optimize_calls = 0;
+  const CameraModel::Type type = cam9[0] == 0 ? CameraModel::Type::CentralGeneric : CameraModel::Type::NoncentralGeneric;
+  const bool ok = RefCalibrateRefinementStage(&m.ds, nullptr, /*use_cuda*/ false, SchurMode::Dense, num_pyramid_levels, type, approx_pixels_per_cell,
+                                              /*regularization_weight*/ 0.0, outlier_removal_factor, localize_only != 0, nullptr, &m.st, nullptr, nullptr);
+  trace[0] = g_ref_ba_optimize_calls;
+  if (!ok) return 0;
+  BAState& st = m.st;
+  for (int i = 0; i < n_images; ++i) { store_pose(st.rig_tr_global[i], rig_tr_global + 7 * i); image_used[i] = st.image_used[i] ? 1 : 0; }
+  for (int c = 0; c < n_cameras; ++c) store_pose(st.camera_tr_rig[c], camera_tr_rig + 7 * c);
+  for (int p = 0; p < n_points; ++p) for (int k = 0; k < 3; ++k) points[3 * p + k] = st.points[p](k);
+  for (int c = 0; c < n_cameras; ++c) {
+    int gw = 0, gh = 0;
+    st.intrinsics[c]->GetGridResolution(&gw, &gh);
+    for (int k = 0; k < 9; ++k) cam9_out[9 * c + k] = cam9[9 * c + k];
+    cam9_out[9 * c] = st.intrinsics[c]->type() == CameraModel::Type::CentralGeneric ? 0 : 1;
+    cam9_out[9 * c + 7] = gw; cam9_out[9 * c + 8] = gh;
+    store_any_grid(st.intrinsics[c].get(), grids_out[c]);
+  }
+  for (int64_t o = 0; o < n_obs; ++o) keep[o] = 0;
+  for (int i = 0; i < n_images; ++i)
+    for (int c = 0; c < n_cameras; ++c)
+      for (const PointFeature& f : m.ds.GetImageset(i)->FeaturesOfCamera(c)) keep[tag[(size_t)i * n_cameras + c][f.id]] = 1;
+  return 1;
+}
