@@ -168,3 +168,33 @@ def test_outlier_removal_and_reprojection_statistics_on_the_gpu_are_the_referenc
             check_equal(case, f"camera {c}, factor {factor}: keep-mask entries that differ", int((k != k_ref).sum()))
             check_equal(case, f"camera {c}, factor {factor}: image_used entries that differ", int((u != u_ref).sum()))
             assert (~k_ref).sum() >= 1
+
+
+def test_calibrate_refinement_stage_on_the_gpu_follows_the_oracle_run_stage():
+    """camera_calibration_amd.calibration.calibrate_refinement_stage (APP/calibration.cc:1030-1142: pyramid level, ResampleModel, outlier stage, main
+    bundle adjustment, ScaleToMetric) with its GPU defaults -- HIP engine, cba_fit_grid_to_directions, cba_unproject, cba_project -- against the
+    same orchestration on the CPU oracle (which tests/test_oracle_vs_ref_calibrate_stage.py compares with the reference's own stage): every
+    RunBundleAdjustment run stops after the same number of iterations, the outlier masks are the same, the costs agree."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_oracle_vs_ref_calibrate_stage as stage
+    from camera_calibration_amd import calibration_io as cio
+    pb, st0, _ = syn.baseline_config(1, lambda cam, g, pts: orc.project(cam, g, pts), n_imagesets=8, grid_wh=(8, 6), lattice_xy=(8, 9))
+    positions = syn.pattern_positions(8, 9)
+    ds = cio.DatasetData(image_sizes=[(640, 480)], known_geometries=[cio.KnownGeometry(0.01188, {i: tuple(int(v) for v in p) for i, p in enumerate(positions)})])
+    mapping = {i: i for i in range(pb.n_points)}
+    g = cal.calibrate_refinement_stage(pb, st0, ds, mapping, 2, 80, 1.5, False)
+    orc.set_num_threads(0)
+    try:
+        o = cal.calibrate_refinement_stage(pb, st0, ds, mapping, 2, 80, 1.5, False, run_ba_fn=stage._oracle_run_ba, resample_fn=stage._oracle_resample,
+                                           delete_outliers_fn=lambda c, p, s, f, u: rp.delete_outlier_features(c, p, s, f, u, project_fn=stage._project))
+    finally:
+        orc.set_num_threads(1)
+    case = "calibrate_refinement_stage (2 pyramid levels, outlier factor 1.5): HIP engine vs the oracle-run stage"
+    print(case, [b["iterations"] for b in g["ba_runs"]], [b["iterations"] for b in o["ba_runs"]], int((~g["keep"]).sum()))
+    assert [(c.grid_w, c.grid_h) for c in g["problem"].cameras] == [(10, 8)] and len(g["ba_runs"]) == 4
+    check_equal(case, "RunBundleAdjustment runs whose iteration count differs", sum(a["iterations"] != b["iterations"] for a, b in zip(g["ba_runs"], o["ba_runs"])))
+    check_equal(case, "outlier mask entries that differ", int((g["keep"] != o["keep"]).sum()))
+    check_equal(case, "image_used entries that differ", int((g["image_used"] != o["image_used"]).sum()))
+    check(case, "final cost of the last run, rel", abs(g["ba_runs"][-1]["final_cost"] - o["ba_runs"][-1]["final_cost"]) / o["ba_runs"][-1]["final_cost"], 1e-3,
+          note="two trajectories that end on an absolute cost threshold of 1e-4; see tests/test_oracle_vs_ref_calibrate_stage.py")
+    check(case, "metric scale factor, rel", abs(g["scale"] - o["scale"]) / o["scale"], 1e-4)
