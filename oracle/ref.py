@@ -28,7 +28,27 @@ def build(force: bool = False) -> Optional[str]:
     if reference_present():
         args = ["make", "-C", _HERE, "-s", "ref"] + (["-B"] if force else [])
         subprocess.check_call(args)
+        _build_patched(force)
     return LIB_PATH if os.path.exists(LIB_PATH) else None
+
+
+PATCHED_LIB_PATH = os.path.join(_HERE, "_ref", "patched", "libcalibref_ba.so")
+
+
+def _build_patched(force: bool = False) -> None:
+    """oracle/_ref/patched/libcalibref_ba.so: the reference with integration/reference.patch applied (SchurMode::HIP + the adapter), compiled
+    by the same recipe and LINKED with camera_calibration_amd/libcalib_ba_hip.so (`make patched`).  Rebuilt when the patch, the glue or the
+    HIP library's header changed; skipped where patch(1) or the HIP library is missing."""
+    import shutil
+    root = os.path.dirname(_HERE)
+    hip = os.path.join(root, "camera_calibration_amd", "libcalib_ba_hip.so")
+    if shutil.which("patch") is None or not os.path.exists(hip):
+        return
+    deps = [os.path.join(root, "integration", "reference.patch"), os.path.join(_HERE, "ref_ba_glue.cc"), os.path.join(_HERE, "ref_f14_glue.cc"),
+            os.path.join(_HERE, "Makefile"), os.path.join(root, "include", "cba.h"), os.path.join(_HERE, "_ref", "libcalibref_ba.so")]
+    if not force and os.path.exists(PATCHED_LIB_PATH) and all(os.path.getmtime(PATCHED_LIB_PATH) >= os.path.getmtime(d) for d in deps if os.path.exists(d)):
+        return
+    subprocess.check_call(["make", "-C", _HERE, "-s", "patched"])
 
 
 def available() -> bool:
@@ -522,6 +542,49 @@ def ba_lib() -> C.CDLL:
         L.ref_f2_save_points.argtypes = [C.c_int, dp, C.c_int, ip, ip, C.c_char_p]
         _ba_lib = L
     return _ba_lib
+
+
+def patched_available() -> bool:
+    build()
+    return os.path.exists(PATCHED_LIB_PATH)
+
+
+_patched_lib: Optional[C.CDLL] = None
+
+
+def patched_lib() -> C.CDLL:
+    """The PATCHED reference (integration/reference.patch) as a library: the reference's own OptimizeJointly, generic models and LMOptimizer plus
+    the adapter the patch adds, linked with camera_calibration_amd/libcalib_ba_hip.so.  schur_mode 0 = Dense (CPU), 5 = SchurMode::HIP."""
+    global _patched_lib
+    if _patched_lib is None:
+        build()
+        if not os.path.exists(PATCHED_LIB_PATH):
+            raise RuntimeError("oracle/_ref/patched/libcalibref_ba.so is missing")
+        L = C.CDLL(PATCHED_LIB_PATH)
+        dp, fp, ip = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int)
+        L.ref_ba_optimize_jointly_mode.argtypes = [C.c_int, C.c_int, C.c_int, ip, C.c_int64, fp, ip, ip, ip, dp, dp, dp, C.POINTER(dp), dp,
+                                                   C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, dp, ip, C.c_int]
+        L.ref_ba_optimize_jointly_mode.restype = C.c_double
+        _patched_lib = L
+    return _patched_lib
+
+
+SCHUR_MODE_DENSE, SCHUR_MODE_HIP = 0, 5          # APP/bundle_adjustment/joint_optimization.h:45-51 + the patch's SchurMode::HIP
+
+
+def patched_optimize_jointly(pb, st, last_projection=None, max_iteration_count: int = 1, init_lambda: float = -1.0, schur_mode: int = SCHUR_MODE_DENSE):
+    """vis::OptimizeJointly of the PATCHED reference tree on a Problem / State; in place on `st` and `last_projection`."""
+    cam9 = np.concatenate([np.concatenate([[c.model_type], _cam_params8(c)]) for c in pb.cameras]).astype(np.int32)
+    xy = np.ascontiguousarray(pb.obs_xy, dtype=np.float32)
+    lp = np.zeros((pb.n_obs, 2)) if last_projection is None else last_projection
+    grids = (C.POINTER(C.c_double) * len(st.grids))(*[_dp(g) for g in st.grids])
+    lam = C.c_double(0); performed = C.c_int(0)
+    cost = patched_lib().ref_ba_optimize_jointly_mode(pb.n_cameras, pb.n_images, pb.n_points, _ip(cam9), int(pb.n_obs),
+                                                      xy.ctypes.data_as(C.POINTER(C.c_float)), _ip(pb.obs_point), _ip(pb.obs_image), _ip(pb.obs_camera),
+                                                      _dp(st.rig_tr_global), _dp(st.camera_tr_rig), _dp(st.points), grids, _dp(lp),
+                                                      max_iteration_count, float(init_lambda), float(pb.fd_delta), int(pb.localize_only),
+                                                      int(pb.eliminate_points), C.byref(lam), C.byref(performed), int(schur_mode))
+    return dict(cost=float(cost), final_lambda=lam.value, performed=bool(performed.value), last_projection=lp)
 
 
 def ba_optimize_jointly(pb, st, last_projection=None, max_iteration_count: int = 1, init_lambda: float = -1.0):

@@ -83,6 +83,9 @@ void marshal(int n_cameras, int n_images, int n_points, const int* cam9, int64_t
 }
 }  // namespace
 
+CBA_EXPORT double ref_ba_optimize_jointly_mode(int, int, int, const int*, int64_t, const float*, const int*, const int*, const int*, double*, double*, double*,
+                                               double* const*, double*, int, double, double, int, int, double*, int*, int);
+
 // vis::OptimizeJointly (APP/bundle_adjustment/joint_optimization.cc:757-953), SchurMode::Dense, on a packed problem.  State and the
 // warm-start cache (PointFeature::last_projection, packed observation order) in / out.  Returns the final cost.
 CBA_EXPORT double ref_ba_optimize_jointly(int n_cameras, int n_images, int n_points, const int* cam9, int64_t n_obs, const float* obs_xy,
@@ -90,13 +93,25 @@ CBA_EXPORT double ref_ba_optimize_jointly(int n_cameras, int n_images, int n_poi
                                           double* camera_tr_rig, double* points, double* const* grids, double* last_projection,
                                           int max_iteration_count, double init_lambda, double numerical_diff_delta, int localize_only,
                                           int eliminate_points, double* final_lambda, int* performed_an_iteration) {
+  return ref_ba_optimize_jointly_mode(n_cameras, n_images, n_points, cam9, n_obs, obs_xy, obs_point, obs_image, obs_camera, rig_tr_global, camera_tr_rig,
+                                      points, grids, last_projection, max_iteration_count, init_lambda, numerical_diff_delta, localize_only,
+                                      eliminate_points, final_lambda, performed_an_iteration, (int)SchurMode::Dense);
+}
+// The same with the SchurMode chosen by the caller: 0 = Dense (the CPU path); in the library built from the PATCHED tree (`make patched`:
+// integration/reference.patch) 5 = SchurMode::HIP, the reference's own OptimizeJointly handing the LM iteration to the MI355X through the
+// adapter the patch adds and include/cba.h.
+CBA_EXPORT double ref_ba_optimize_jointly_mode(int n_cameras, int n_images, int n_points, const int* cam9, int64_t n_obs, const float* obs_xy,
+                                               const int* obs_point, const int* obs_image, const int* obs_camera, double* rig_tr_global,
+                                               double* camera_tr_rig, double* points, double* const* grids, double* last_projection,
+                                               int max_iteration_count, double init_lambda, double numerical_diff_delta, int localize_only,
+                                               int eliminate_points, double* final_lambda, int* performed_an_iteration, int schur_mode) {
   Marshalled m;
   marshal(n_cameras, n_images, n_points, cam9, n_obs, obs_xy, obs_point, obs_image, obs_camera, rig_tr_global, camera_tr_rig, points, grids,
           last_projection, &m);
   BAState& st = m.st;
   double lam = 0; bool performed = false;
   const double cost = OptimizeJointly(m.ds, &st, max_iteration_count, init_lambda, numerical_diff_delta, /*regularization_weight*/ 0.0,
-                                      localize_only != 0, eliminate_points != 0, SchurMode::Dense, &lam, &performed, false, false, false, false,
+                                      localize_only != 0, eliminate_points != 0, static_cast<SchurMode>(schur_mode), &lam, &performed, false, false, false, false,
                                       false, /*print_progress*/ false);
   if (final_lambda) *final_lambda = lam;
   if (performed_an_iteration) *performed_an_iteration = performed ? 1 : 0;

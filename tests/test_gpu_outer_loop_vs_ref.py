@@ -198,3 +198,52 @@ def test_calibrate_refinement_stage_on_the_gpu_follows_the_oracle_run_stage():
     check(case, "final cost of the last run, rel", abs(g["ba_runs"][-1]["final_cost"] - o["ba_runs"][-1]["final_cost"]) / o["ba_runs"][-1]["final_cost"], 1e-3,
           note="two trajectories that end on an absolute cost threshold of 1e-4; see tests/test_oracle_vs_ref_calibrate_stage.py")
     check(case, "metric scale factor, rel", abs(g["scale"] - o["scale"]) / o["scale"], 1e-4)
+
+
+_PATCHED_SCRIPT = r"""
+import json, sys
+import numpy as np
+from camera_calibration_amd import synthetic as syn
+from camera_calibration_amd.problem import NONCENTRAL_GENERIC
+from oracle import oracle as orc
+from oracle import ref
+case = sys.argv[1]
+kw = dict(model_type=NONCENTRAL_GENERIC) if case == "noncentral" else {}
+pb, st0, _ = syn.reference_test_problem(2 if case == "rig" else 1, orc.project, seed=7, num_points=40, num_poses=8, **kw)
+out = {}
+for name, mode in (("dense", ref.SCHUR_MODE_DENSE), ("hip", ref.SCHUR_MODE_HIP)):
+    st = st0.copy(); lp = np.zeros((pb.n_obs, 2)); lam = -1.0; rows = []
+    for _ in range(4):
+        r = ref.patched_optimize_jointly(pb, st, lp, 1, lam, mode)
+        lam = r["final_lambda"]; rows.append([r["cost"], lam, int(r["performed"])])
+    out[name] = dict(rows=rows, points=st.points.tolist(), rig=st.rig_tr_global.tolist(), grid=np.asarray(st.grids[0]).reshape(-1).tolist())
+print("RESULT " + json.dumps(out))
+"""
+
+
+@pytest.mark.xfail(strict=False, reason="first run on hardware: the round's GPU budget ended before this test could be run once; it runs in a "
+                                        "child process because a failed CHECK in the reference's code aborts")
+@pytest.mark.parametrize("case", ["1cam", "rig", "noncentral"])
+def test_the_patched_references_own_optimize_jointly_in_schur_mode_hip(case):
+    """THE drop-in test: the reference's own vis::OptimizeJointly -- its Dataset, BAState, CentralGenericModel / NoncentralGenericModel, compiled
+    from the reference's sources with integration/reference.patch applied (oracle/_ref/patched/libcalibref_ba.so, `make -C oracle patched`) --
+    called with SchurMode::HIP (the patch's dispatch -> joint_optimization_hip.cc -> include/cba.h -> libcalib_ba_hip.so -> MI355X) and with
+    SchurMode::Dense (the reference's CPU path, same library, same inputs): four calls each, lambda carried."""
+    import json
+    import subprocess
+    if not ref.patched_available():
+        pytest.skip("oracle/_ref/patched/libcalibref_ba.so not shipped with this snapshot")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _PATCHED_SCRIPT, case], capture_output=True, text=True, timeout=240, cwd=root,
+                       env=dict(os.environ, PYTHONPATH=root))
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert r.returncode == 0 and line, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    out = json.loads(line[0][7:])
+    d, h = out["dense"], out["hip"]
+    name = f"the patched reference's own OptimizeJointly: SchurMode::HIP vs SchurMode::Dense, {case}"
+    for (cd, ld, pd), (ch, lh, ph) in zip(d["rows"], h["rows"]):
+        assert pd == ph
+        check(name, "lambda rel per call (equal lambdas = equal decisions)", abs(lh - ld) / ld, 1e-6 if case == "noncentral" else 1e-8)
+        check(name, "cost rel per call", abs(ch - cd) / cd, 1e-4)
+    state = max(float(np.abs(np.array(d[k]) - np.array(h[k])).max()) for k in ("points", "rig", "grid"))
+    check(name, "state after four calls, raw max abs", state, 1e-6)
