@@ -33,6 +33,7 @@ def build(force: bool = False) -> Optional[str]:
 
 
 PATCHED_LIB_PATH = os.path.join(_HERE, "_ref", "patched", "libcalibref_ba.so")
+PATCHED_DOUBLE_LIB_PATH = os.path.join(_HERE, "_ref", "patched_double", "libcalibref_ba.so")
 
 
 def _build_patched(force: bool = False) -> None:
@@ -46,9 +47,13 @@ def _build_patched(force: bool = False) -> None:
         return
     deps = [os.path.join(root, "integration", "reference.patch"), os.path.join(_HERE, "ref_ba_glue.cc"), os.path.join(_HERE, "ref_f14_glue.cc"),
             os.path.join(_HERE, "Makefile"), os.path.join(root, "include", "cba.h"), os.path.join(_HERE, "_ref", "libcalibref_ba.so")]
-    if not force and os.path.exists(PATCHED_LIB_PATH) and all(os.path.getmtime(PATCHED_LIB_PATH) >= os.path.getmtime(d) for d in deps if os.path.exists(d)):
-        return
-    subprocess.check_call(["make", "-C", _HERE, "-s", "patched"])
+    def fresh(path, extra=()):
+        return os.path.exists(path) and all(os.path.getmtime(path) >= os.path.getmtime(d) for d in list(deps) + list(extra) if os.path.exists(d))
+    if force or not fresh(PATCHED_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "patched"])
+    # the same patched build linked against the CPU test double of the C-ABI (oracle/cabi_test_double.c): executes the adapter without a GPU
+    if force or not fresh(PATCHED_DOUBLE_LIB_PATH, [os.path.join(_HERE, "cabi_test_double.c")]):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "patched_double"])
 
 
 def available() -> bool:
@@ -552,6 +557,32 @@ def patched_available() -> bool:
 _patched_lib: Optional[C.CDLL] = None
 
 
+def _bind_mode(L):
+    dp, fp, ip = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int)
+    L.ref_ba_optimize_jointly_mode.argtypes = [C.c_int, C.c_int, C.c_int, ip, C.c_int64, fp, ip, ip, ip, dp, dp, dp, C.POINTER(dp), dp,
+                                               C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, dp, ip, C.c_int]
+    L.ref_ba_optimize_jointly_mode.restype = C.c_double
+    return L
+
+
+_patched_double_lib: Optional[C.CDLL] = None
+
+
+def patched_double_available() -> bool:
+    build()
+    return os.path.exists(PATCHED_DOUBLE_LIB_PATH)
+
+
+def patched_double_lib() -> C.CDLL:
+    """The patched reference linked against the CPU test double of the C-ABI (never the product's library): SchurMode::HIP runs the adapter of
+    integration/reference.patch on the CPU."""
+    global _patched_double_lib
+    if _patched_double_lib is None:
+        build()
+        _patched_double_lib = _bind_mode(C.CDLL(PATCHED_DOUBLE_LIB_PATH))
+    return _patched_double_lib
+
+
 def patched_lib() -> C.CDLL:
     """The PATCHED reference (integration/reference.patch) as a library: the reference's own OptimizeJointly, generic models and LMOptimizer plus
     the adapter the patch adds, linked with camera_calibration_amd/libcalib_ba_hip.so.  schur_mode 0 = Dense (CPU), 5 = SchurMode::HIP."""
@@ -572,14 +603,16 @@ def patched_lib() -> C.CDLL:
 SCHUR_MODE_DENSE, SCHUR_MODE_HIP = 0, 5          # APP/bundle_adjustment/joint_optimization.h:45-51 + the patch's SchurMode::HIP
 
 
-def patched_optimize_jointly(pb, st, last_projection=None, max_iteration_count: int = 1, init_lambda: float = -1.0, schur_mode: int = SCHUR_MODE_DENSE):
-    """vis::OptimizeJointly of the PATCHED reference tree on a Problem / State; in place on `st` and `last_projection`."""
+def patched_optimize_jointly(pb, st, last_projection=None, max_iteration_count: int = 1, init_lambda: float = -1.0, schur_mode: int = SCHUR_MODE_DENSE,
+                             lib=None):
+    """vis::OptimizeJointly of the PATCHED reference tree on a Problem / State; in place on `st` and `last_projection`.  `lib`: patched_lib()
+    (default: linked with the HIP library) or patched_double_lib() (linked with the CPU test double of the C-ABI)."""
     cam9 = np.concatenate([np.concatenate([[c.model_type], _cam_params8(c)]) for c in pb.cameras]).astype(np.int32)
     xy = np.ascontiguousarray(pb.obs_xy, dtype=np.float32)
     lp = np.zeros((pb.n_obs, 2)) if last_projection is None else last_projection
     grids = (C.POINTER(C.c_double) * len(st.grids))(*[_dp(g) for g in st.grids])
     lam = C.c_double(0); performed = C.c_int(0)
-    cost = patched_lib().ref_ba_optimize_jointly_mode(pb.n_cameras, pb.n_images, pb.n_points, _ip(cam9), int(pb.n_obs),
+    cost = (lib or patched_lib()).ref_ba_optimize_jointly_mode(pb.n_cameras, pb.n_images, pb.n_points, _ip(cam9), int(pb.n_obs),
                                                       xy.ctypes.data_as(C.POINTER(C.c_float)), _ip(pb.obs_point), _ip(pb.obs_image), _ip(pb.obs_camera),
                                                       _dp(st.rig_tr_global), _dp(st.camera_tr_rig), _dp(st.points), grids, _dp(lp),
                                                       max_iteration_count, float(init_lambda), float(pb.fd_delta), int(pb.localize_only),

@@ -114,3 +114,41 @@ def test_patched_bundle_adjustment_path_links_with_the_hip_library_and_keeps_the
     np.testing.assert_array_equal(a.points, b.points)
     np.testing.assert_array_equal(a.grids[0], b.grids[0])
     np.testing.assert_array_equal(lpa, lpb)
+
+
+@pytest.mark.parametrize("case", ["1cam", "rig", "noncentral", "rig_eliminate_points", "rig_localize_only"])
+def test_the_adapter_of_the_patch_executes_on_the_cpu_against_a_test_double_of_the_c_abi(case):
+    """The adapter integration/reference.patch adds (bundle_adjustment/joint_optimization_hip.cc) had only ever been type-checked.  Here it
+    RUNS: `make -C oracle patched_double` links the patched reference (its own OptimizeJointly with the SchurMode::HIP dispatch, Dataset, BAState,
+    generic models with the packing hooks, the adapter) against oracle/cabi_test_double.c -- the nine C-ABI entry points the adapter calls,
+    backed by the CPU oracle; test infrastructure, a different library name, nothing to do with the product -- and the reference's own
+    OptimizeJointly is called with SchurMode::HIP and with SchurMode::Dense on the same inputs, four calls each with lambda carried.  What
+    this exercises is the marshalling: observation order and sequential imageset indices, pose packing, GetGridForHIP / SetGridFromHIP, the
+    read-back of state, warm-start cache, lambda and the accepted flag.  (Against the real engine: tests/test_gpu_outer_loop_vs_ref.py.)"""
+    import dataclasses
+    import numpy as np
+    from camera_calibration_amd import synthetic as syn
+    from camera_calibration_amd.problem import NONCENTRAL_GENERIC
+    from oracle import oracle as orc
+    from oracle import ref
+    if not ref.patched_double_available():
+        pytest.skip("oracle/_ref/patched_double/libcalibref_ba.so not built (needs /root/reference and patch(1))")
+    kw = dict(model_type=NONCENTRAL_GENERIC) if case == "noncentral" else {}
+    pb, st0, _ = syn.reference_test_problem(1 if case in ("1cam", "noncentral") else 2, orc.project, seed=7, num_points=40, num_poses=8, **kw)
+    pb = dataclasses.replace(pb, eliminate_points=case == "rig_eliminate_points", localize_only=case == "rig_localize_only")
+    L = ref.patched_double_lib()
+    a, b = st0.copy(), st0.copy()
+    lpa, lpb = np.zeros((pb.n_obs, 2)), np.zeros((pb.n_obs, 2))
+    la = lb = -1.0
+    for _ in range(4):
+        ra = ref.patched_optimize_jointly(pb, a, lpa, 1, la, ref.SCHUR_MODE_DENSE, lib=L)
+        rb = ref.patched_optimize_jointly(pb, b, lpb, 1, lb, ref.SCHUR_MODE_HIP, lib=L)
+        la, lb = ra["final_lambda"], rb["final_lambda"]
+        assert ra["performed"] == rb["performed"]
+        assert abs(la - lb) <= (1e-8 if case == "noncentral" else 1e-9) * la          # observed 3e-12 ... 3e-10: the oracle against the reference's CPU path
+        assert abs(ra["cost"] - rb["cost"]) <= 1e-4 * ra["cost"]
+    state = max(np.abs(a.points - b.points).max(), np.abs(a.rig_tr_global - b.rig_tr_global).max(), np.abs(a.camera_tr_rig - b.camera_tr_rig).max(),
+                max(np.abs(x - y).max() for x, y in zip(a.grids, b.grids)), np.abs(lpa - lpb).max())
+    assert state <= 1e-6                                                   # observed 3e-9 ... 3e-8
+    if case == "rig_localize_only":
+        np.testing.assert_array_equal(b.grids[0], st0.grids[0])           # intrinsics untouched through the hooks as well
