@@ -1,13 +1,14 @@
 /* oracle/cabi_test_double.c -- TEST INFRASTRUCTURE ONLY: a CPU test double of the part of include/cba.h that the reference-side adapter calls
  * (integration/reference.patch: joint_optimization_hip.cc), backed by the oracle (cba_oracle.c).
  *
- * Purpose: to EXECUTE the adapter's marshalling on a machine without a GPU.  `make -C oracle patched_double` links the PATCHED reference's
- * bundle-adjustment path (the reference's own OptimizeJointly with SchurMode::HIP, its Dataset / BAState / generic models, the adapter) against
- * this library instead of camera_calibration_amd/libcalib_ba_hip.so; tests/test_integration_patch.py then compares SchurMode::HIP with
+ * Purpose: to EXECUTE the adapter's marshalling on a machine without a GPU.  `make -C oracle patched_double` builds the PATCHED reference's
+ * bundle-adjustment path (the reference's own OptimizeJointly with SchurMode::HIP, its Dataset / BAState / generic models, the adapter) with
+ * this file in place of camera_calibration_amd/libcalib_ba_hip.so; tests/test_integration_patch.py then compares SchurMode::HIP with
  * SchurMode::Dense of that library.  What is under test is the adapter (observation order, sequential imageset indices, pose packing, the
  * GetGridForHIP / SetGridFromHIP hooks, the read-back incl. the warm-start cache, lambda and the accepted flag) -- NOT the engine: nothing here is
- * HIP code, and nothing in the product (camera_calibration_amd/, include/) links, loads or knows this file.  The library is built as
- * oracle/_ref/patched_double/libcba_cabi_double.so -- a different name from the product's library on purpose.
+ * HIP code, and nothing in the product (camera_calibration_amd/, include/) links, loads or knows this file.  The object is compiled with hidden
+ * visibility INTO oracle/_ref/patched_double/libcalibref_ba.so: its cba_* functions exist inside that one test library only and can neither
+ * shadow nor be shadowed by the product's library when both are loaded into one process.
  */
 #include <stdlib.h>
 #include <string.h>

@@ -51,7 +51,7 @@ def _build_patched(force: bool = False) -> None:
         return os.path.exists(path) and all(os.path.getmtime(path) >= os.path.getmtime(d) for d in list(deps) + list(extra) if os.path.exists(d))
     if force or not fresh(PATCHED_LIB_PATH):
         subprocess.check_call(["make", "-C", _HERE, "-s", "patched"])
-    # the same patched build linked against the CPU test double of the C-ABI (oracle/cabi_test_double.c): executes the adapter without a GPU
+    # the same patched build with the CPU test double of the C-ABI compiled in (oracle/cabi_test_double.c): executes the adapter without a GPU
     if force or not fresh(PATCHED_DOUBLE_LIB_PATH, [os.path.join(_HERE, "cabi_test_double.c")]):
         subprocess.check_call(["make", "-C", _HERE, "-s", "patched_double"])
 
@@ -574,7 +574,7 @@ def patched_double_available() -> bool:
 
 
 def patched_double_lib() -> C.CDLL:
-    """The patched reference linked against the CPU test double of the C-ABI (never the product's library): SchurMode::HIP runs the adapter of
+    """The patched reference with the CPU test double of the C-ABI compiled in (hidden symbols; never the product's library): SchurMode::HIP runs the adapter of
     integration/reference.patch on the CPU."""
     global _patched_double_lib
     if _patched_double_lib is None:
@@ -606,7 +606,7 @@ SCHUR_MODE_DENSE, SCHUR_MODE_HIP = 0, 5          # APP/bundle_adjustment/joint_o
 def patched_optimize_jointly(pb, st, last_projection=None, max_iteration_count: int = 1, init_lambda: float = -1.0, schur_mode: int = SCHUR_MODE_DENSE,
                              lib=None):
     """vis::OptimizeJointly of the PATCHED reference tree on a Problem / State; in place on `st` and `last_projection`.  `lib`: patched_lib()
-    (default: linked with the HIP library) or patched_double_lib() (linked with the CPU test double of the C-ABI)."""
+    (default: linked with the HIP library) or patched_double_lib() (the CPU test double of the C-ABI compiled in)."""
     cam9 = np.concatenate([np.concatenate([[c.model_type], _cam_params8(c)]) for c in pb.cameras]).astype(np.int32)
     xy = np.ascontiguousarray(pb.obs_xy, dtype=np.float32)
     lp = np.zeros((pb.n_obs, 2)) if last_projection is None else last_projection

@@ -119,9 +119,9 @@ def test_patched_bundle_adjustment_path_links_with_the_hip_library_and_keeps_the
 @pytest.mark.parametrize("case", ["1cam", "rig", "noncentral", "rig_eliminate_points", "rig_localize_only"])
 def test_the_adapter_of_the_patch_executes_on_the_cpu_against_a_test_double_of_the_c_abi(case):
     """The adapter integration/reference.patch adds (bundle_adjustment/joint_optimization_hip.cc) had only ever been type-checked.  Here it
-    RUNS: `make -C oracle patched_double` links the patched reference (its own OptimizeJointly with the SchurMode::HIP dispatch, Dataset, BAState,
-    generic models with the packing hooks, the adapter) against oracle/cabi_test_double.c -- the nine C-ABI entry points the adapter calls,
-    backed by the CPU oracle; test infrastructure, a different library name, nothing to do with the product -- and the reference's own
+    RUNS: `make -C oracle patched_double` builds the patched reference (its own OptimizeJointly with the SchurMode::HIP dispatch, Dataset, BAState,
+    generic models with the packing hooks, the adapter) with oracle/cabi_test_double.c compiled in -- the nine C-ABI entry points the adapter
+    calls, backed by the CPU oracle; hidden visibility (they exist in that one test library only), nothing to do with the product -- and the reference's own
     OptimizeJointly is called with SchurMode::HIP and with SchurMode::Dense on the same inputs, four calls each with lambda carried.  What
     this exercises is the marshalling: observation order and sequential imageset indices, pose packing, GetGridForHIP / SetGridFromHIP, the
     read-back of state, warm-start cache, lambda and the accepted flag.  (Against the real engine: tests/test_gpu_outer_loop_vs_ref.py.)"""
