@@ -9,8 +9,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcalib_ba_hip.so")
-SOURCES = ["cba_api.hip", "kernels_obs.hip", "kernels_linalg.hip", "kernels_fit.hip"]
-HEADERS = ["cba_internal.h", "model.hip.h", os.path.join("..", "..", "include", "cba.h")]
+SOURCES = ["cba_api.hip", "kernels_obs.hip", "kernels_linalg.hip", "kernels_fit.hip", "gridfirst_plan.hip"]
+HEADERS = ["cba_internal.h", "model.hip.h", "gridfirst_plan.h", os.path.join("..", "..", "include", "cba.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
          "-mllvm", "-amdgpu-mfma-vgpr-form"]  # keep MFMA accumulators in VGPRs: no AGPR<->VGPR copies in the K loop
 

@@ -11,6 +11,7 @@
 #include <mutex>
 
 #include "cba_internal.h"
+#include "gridfirst_plan.h"
 
 namespace cba {
 
@@ -1454,6 +1455,34 @@ int cba_schur_solve_opt(int32_t block_size, int32_t n_blocks, int32_t dense_dof,
   if (st[1] == 3) { set_error("cba_schur_solve: a dataflow launch of the factorisation timed out"); return CBA_ERR_TIMEOUT; }
   if (st[0] || st[1]) { set_error("cba_schur_solve: zero pivot"); return CBA_ERR_NUMERIC; }
   return CBA_OK;
+}
+
+int64_t cba_gridfirst_plan_query(const cba_camera* cameras, int32_t n_cameras, int32_t n_images, int32_t n_points, int32_t strips,
+                                 int32_t what, void* out, int64_t capacity_bytes) {
+  GfPlan pl;
+  int rc = gf_build_plan(cameras, n_cameras, n_images, n_points, strips, &pl);
+  if (rc != CBA_OK) { set_error("cba_gridfirst_plan_query: bad argument"); return rc; }
+  auto give = [&](const void* src, size_t bytes) -> int64_t {
+    if (out && capacity_bytes >= (int64_t)bytes && bytes) std::memcpy(out, src, bytes);
+    return (int64_t)bytes;
+  };
+  switch (what) {
+    case 0: {
+      const int32_t h[16] = {pl.G, pl.Gf, pl.n_rp, pl.n_border, pl.n_fact, pl.n_pad, pl.nbg, pl.nbf, pl.ntc, (int32_t)pl.chains.size(),
+                             (int32_t)pl.tasks.size(), pl.n_tasks0, (int32_t)pl.ivals.size(), pl.mask_words, pl.half_bandwidth, pl.strips[0]};
+      return give(h, sizeof(h));
+    }
+    case 1: return give(pl.f_of_grid.data(), pl.f_of_grid.size() * sizeof(int));
+    case 2: return give(pl.chains.data(), pl.chains.size() * sizeof(GfChain));
+    case 3: return give(pl.tasks.data(), pl.tasks.size() * sizeof(GfTask));
+    case 4: return give(pl.ivals.data(), pl.ivals.size() * sizeof(GfIval));
+    case 5: return give(pl.rowmask.data(), pl.rowmask.size() * sizeof(uint64_t));
+    case 6: { const double f[3] = {pl.flops_grid, pl.flops_update, pl.flops_border}; return give(f, sizeof(f)); }
+    default:
+      if (what >= 16 && what < 16 + n_cameras) return give(pl.gperm[what - 16].data(), pl.gperm[what - 16].size() * sizeof(int));
+      set_error("cba_gridfirst_plan_query: unknown item");
+      return CBA_ERR_ARG;
+  }
 }
 
 int cba_fit_grid_to_directions(const cba_camera* camera, double* grid, int64_t n, const double* grid_points,

@@ -78,6 +78,7 @@ EXPORTED_SYMBOLS = [
     "cba_kernel_stats", "cba_fit_grid_to_directions", "cba_prepare_device",
     "cba_model_create", "cba_model_destroy", "cba_model_set_grid", "cba_model_project", "cba_model_unproject",
     "cba_fd_redo_overflow", "cba_debug_fd_redo_counts", "cba_schur_solve_opt", "cba_set_fd_schedule",
+    "cba_gridfirst_plan_query",
 ]
 
 DUMP_COST_VECTOR, DUMP_PIXELS, DUMP_FLAGS, DUMP_JACOBIANS = 1, 2, 3, 4
@@ -143,8 +144,42 @@ def load() -> C.CDLL:
     L.cba_model_set_grid.argtypes = [vp, dp]
     L.cba_model_project.argtypes = [vp, C.c_int64, dp, dp, dp, C.POINTER(C.c_uint8)]
     L.cba_model_unproject.argtypes = [vp, C.c_int64, dp, dp, dp, C.POINTER(C.c_uint8)]
+    L.cba_gridfirst_plan_query.argtypes = [C.POINTER(CbaCamera), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int64]
+    L.cba_gridfirst_plan_query.restype = C.c_int64
     _lib = L
     return L
+
+
+def gridfirst_plan(cameras: Sequence[Camera], n_images: int, n_points: int, strips: int = 0) -> dict:
+    """cba_gridfirst_plan_query: the static plan of the grid-first elimination order (host only, no device).
+
+    Keys: the header fields (G, Gf, n_rp, n_border, n_fact, n_pad, nbg, nbf, ntc, n_tasks0, mask_words, half_bandwidth, strips0),
+    f_of_grid (G,), chains (n, 4), tasks (n, 4: kind | intervals << 8, r, c, first interval), ivals (n, 2), rowmask (nbf, words),
+    flops (3,), gperm (list per camera)."""
+    L = load()
+    cams = (CbaCamera * len(cameras))(*[_cam_struct(c) for c in cameras])
+
+    def q(what, dtype):
+        n = L.cba_gridfirst_plan_query(cams, len(cameras), n_images, n_points, strips, what, None, 0)
+        if n < 0:
+            _check(int(n), "cba_gridfirst_plan_query")
+        out = np.zeros(int(n) // np.dtype(dtype).itemsize, dtype=dtype)
+        if n:
+            L.cba_gridfirst_plan_query(cams, len(cameras), n_images, n_points, strips, what, out.ctypes.data_as(C.c_void_p), int(n))
+        return out
+
+    h = q(0, np.int32)
+    names = ["G", "Gf", "n_rp", "n_border", "n_fact", "n_pad", "nbg", "nbf", "ntc", "n_chains", "n_tasks", "n_tasks0", "n_ivals",
+             "mask_words", "half_bandwidth", "strips0"]
+    plan = {k: int(v) for k, v in zip(names, h)}
+    plan["f_of_grid"] = q(1, np.int32)
+    plan["chains"] = q(2, np.int32).reshape(-1, 4)
+    plan["tasks"] = q(3, np.int32).reshape(-1, 4)
+    plan["ivals"] = q(4, np.int32).reshape(-1, 2)
+    plan["rowmask"] = q(5, np.uint64).reshape(plan["nbf"], plan["mask_words"])
+    plan["flops"] = q(6, np.float64)
+    plan["gperm"] = [q(16 + c, np.int32) for c in range(len(cameras))]
+    return plan
 
 
 def prepare(device: int = 0) -> None:

@@ -284,6 +284,17 @@ int cba_debug_solve(cba_problem* p, double lambda);
  * the result becomes the current state. */
 int cba_debug_apply_update(cba_problem* p, const double* x);
 
+/* Host-only view of the static plan of the GRID-FIRST elimination order (cba_solver_options.elimination; camera_calibration_amd/csrc/
+ * gridfirst_plan.h): no device is touched, the CPU tests replay the task list with numpy.  `what`: 0 = header (int32: G, Gf, n_rp,
+ * n_border, n_fact, n_pad, nbg, nbf, ntc, chains, tasks, tasks of list 0, intervals, mask words, half-bandwidth, strips of camera 0),
+ * 1 = row of F of every grid unknown in the engine's order (int32 x G), 2 = chains (int32 x 4: r0, r1, dep, 0), 3 = tasks (int32 x 4:
+ * kind | intervals << 8, r, c, first interval), 4 = K intervals (int32 x 2), 5 = row masks (uint64 x nbf x mask words), 6 = flop model
+ * (double x 3: dataflow launch of the grid rows, border update, border factorisation), 16 + c = control point -> elimination rank of
+ * camera c (int32 x grid_w grid_h).  Returns the number of bytes of the item (written if capacity_bytes suffices) or a negative
+ * error code.  (No reference counterpart: LV/lm_optimizer.h:1247-1369 has one elimination order.) */
+int64_t cba_gridfirst_plan_query(const cba_camera* cameras, int32_t n_cameras, int32_t n_images, int32_t n_points, int32_t strips,
+                                 int32_t what, void* out, int64_t capacity_bytes);
+
 int32_t cba_total_dof(const cba_problem* p);
 int32_t cba_dense_dof(const cba_problem* p);
 /* layout of one CBA_DUMP_JACOBIANS record: [res 2][weight 1][pose 2x6][rig 2x6][point 2x3][grid 2xK] */
