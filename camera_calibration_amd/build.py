@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcalib_ba_hip.so")
-SOURCES = ["cba_api.hip", "kernels_obs.hip", "kernels_linalg.hip", "kernels_fit.hip", "gridfirst_plan.hip"]
+SOURCES = ["cba_api.hip", "kernels_obs.hip", "kernels_linalg.hip", "kernels_fit.hip", "gridfirst_plan.hip", "kernels_gridfirst.hip"]
 HEADERS = ["cba_internal.h", "model.hip.h", "gridfirst_plan.h", os.path.join("..", "..", "include", "cba.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
          "-mllvm", "-amdgpu-mfma-vgpr-form"]  # keep MFMA accumulators in VGPRs: no AGPR<->VGPR copies in the K loop
@@ -95,26 +95,38 @@ def check_tail_m0(obj: str) -> int:
     DMA sites checked."""
     import re
     asm = disassemble_device_code(obj)
-    m = re.search(r"^[0-9a-f]+ <[^>]*k_ldlt_tail[^>]*>:\n(.*?)(?=^[0-9a-f]+ <[^>]*>:|\Z)", asm, flags=re.S | re.M)
+    sites = 0
+    for kernel in TAIL_KERNELS:
+        sites += _check_kernel_m0(asm, kernel, obj)
+    return sites
+
+
+# every kernel that inlines tail_dma16 / tail_dma4 (the dense dataflow launch and the block-sparse one of the grid-first order)
+TAIL_KERNELS = ("k_ldlt_tail", "k_ldlt_sparse")
+
+
+def _check_kernel_m0(asm: str, kernel: str, obj: str) -> int:
+    import re
+    m = re.search(r"^[0-9a-f]+ <[^>]*" + kernel + r"[^>]*>:\n(.*?)(?=^[0-9a-f]+ <[^>]*>:|\Z)", asm, flags=re.S | re.M)
     if not m:
-        raise RuntimeError("check_tail_m0: k_ldlt_tail not found in " + obj)
+        raise RuntimeError("check_tail_m0: " + kernel + " not found in " + obj)
     ins = [ln.split("//")[0].strip() for ln in m.group(1).splitlines() if ln.strip()]
     sites = 0
     for i, text in enumerate(ins):
         mnem = text.split()[0] if text else ""
         if any(mnem.startswith(x) for x in _IMPLICIT_M0):
-            raise RuntimeError(f"check_tail_m0: k_ldlt_tail contains `{text}` (implicit M0 operand) next to the inline-asm LDS-DMA")
+            raise RuntimeError(f"check_tail_m0: {kernel} contains `{text}` (implicit M0 operand) next to the inline-asm LDS-DMA")
         if mnem.startswith("global_load_lds") or (mnem.startswith("buffer_load") and " lds" in text):
             if i < 2 or not re.fullmatch(r"s_mov_b32 m0, s\d+", ins[i - 2]) or ins[i - 1] != "s_nop 0":
-                raise RuntimeError(f"check_tail_m0: LDS-DMA `{text}` in k_ldlt_tail is not preceded by the helper's own `s_mov_b32 m0` / `s_nop 0`")
+                raise RuntimeError(f"check_tail_m0: LDS-DMA `{text}` in {kernel} is not preceded by the helper's own `s_mov_b32 m0` / `s_nop 0`")
             sites += 1
         elif re.search(r"\bm0\b", text):
             ok = re.fullmatch(r"s_mov_b32 m0, s\d+", text) and i + 2 < len(ins) and ins[i + 1] == "s_nop 0" and ins[i + 2].startswith("global_load_lds")
             if not ok:
-                raise RuntimeError(f"check_tail_m0: k_ldlt_tail uses M0 outside tail_dma16 / tail_dma4: `{text}` -- the inline asm there "
+                raise RuntimeError(f"check_tail_m0: {kernel} uses M0 outside tail_dma16 / tail_dma4: `{text}` -- the inline asm there "
                                    "writes M0 without a clobber; route that use around M0 or move the DMA to the builtin")
     if sites == 0:
-        raise RuntimeError("check_tail_m0: no LDS-DMA found in k_ldlt_tail (did the helper loop change? update this check)")
+        raise RuntimeError(f"check_tail_m0: no LDS-DMA found in {kernel} (did the helper loop change? update this check)")
     return sites
 
 

@@ -33,13 +33,16 @@ void schur_chunk_order(const unsigned long long* mask_host, int n_pad, int Kpad,
 int schur_mask_words(int Kpad);
 int schur_slab_rows();
 int launch_touch_mask(const double* B, int Kpad, int n_pad, int ld, unsigned long long* mask, hipStream_t s);
-int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWorkspace& w, double* x, hipStream_t s);
 int launch_finish_diag(double* S, int ld, int n_real, int n_pad, double lambda, hipStream_t s);
 int launch_diag_sum(const double* Dblk, int bs, int nb, const double* Hdd, int ld, int dd, double* out, hipStream_t s);
 int make_main_stream(hipStream_t* s);
 int prepare_device_streams();
 int64_t packed_upper_doubles(int n_pad);
 int launch_pack_upper(const double* S, int n_pad, double* P, int unpack, hipStream_t s);
+
+int launch_gf_form(double* F, int ldf, int Gf, int n_rp, int n_border, const int* grid_of_f, const double* Hdd, int ldh, const double* bd,
+                   const double* B, const double* Dblk, const double* bblk, double lambda, const int* tiles, int n_tiles, hipStream_t s);
+int launch_gf_scatter(const double* xF, int Gf, int n_rp, int block_dof, int G, const int* f_of_grid, double* x, hipStream_t s);
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static double now_s() {
@@ -179,6 +182,16 @@ struct cba_problem {
   double* pin_status = nullptr;   // pinned host memory: {status, ldlt status, x[0]} of the last solve
   double* pin_cost = nullptr;     // pinned host memory: the 8 reduced scalars of the Jacobian pass when their read is deferred
   double last_x0 = 0;     // x[0] of the last solve (read back with the status words: the NaN test of lm_optimizer.h:905 needs no second wait)
+  // grid-first elimination order (cba_solver_options.elimination; gridfirst_plan.h): the full normal matrix F = [grid | rig | points |
+  // poses] is formed from Dblk / B / Hdd per LM attempt and factored in place; S, W, Dinv and the touch masks are not allocated
+  bool gridfirst = false;
+  GfPlan gf;
+  GfDevice gfd;
+  double* F = nullptr;            // gf.n_pad x gf.n_pad, upper triangle, row-major
+  double* Xb = nullptr;           // gf.Gf x (gf.n_pad - gf.Gf): X = D L of the border columns (B operand of the border update)
+  double* xF = nullptr;           // gf.n_fact: solution in the order of F
+  int* gf_tiles = nullptr; int n_gf_tiles = 0;        // tiles of F the forming kernel writes
+  int* gf_grid_of_f = nullptr; int* gf_f_of_grid = nullptr;
 };
 
 namespace cba {
@@ -273,6 +286,8 @@ static int build_grid_order(cba_problem* p) {
     const int tile = per == 2 ? 8 : 5;
     std::vector<int> perm((size_t)gw * gh);
     int rank = 0;
+    if (p->gridfirst) perm = p->gf.gperm[c];          // elimination order of the grid-first plan (strips, then separators)
+    else
     for (int ty = 0; ty < gh; ty += tile)
       for (int tx = 0; tx < gw; tx += tile)
         for (int y = ty; y < std::min(gh, ty + tile); ++y)
@@ -434,11 +449,13 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   if (t_acc) *t_acc += now_s() - t0;
   // The block-sparsity mask of B is only read by the Schur product: it is built on the side stream, underneath the cost reduction,
   // the block inverses and W = D^-1 B of the solve that follows (solve_system waits for that stream in front of the product).
-  CBA_HIP(hipEventRecord(p->ev_aux2, p->stream));
-  CBA_HIP(hipStreamWaitEvent(aux, p->ev_aux2, 0));
-  CBA_TRY(launch_touch_mask(p->B, p->Kpad, p->n_pad, p->n_pad, p->kmask, aux));
-  CBA_HIP(hipEventRecord(p->ev_mask, aux));
-  p->mask_pending = true;
+  if (!p->gridfirst) {
+    CBA_HIP(hipEventRecord(p->ev_aux2, p->stream));
+    CBA_HIP(hipStreamWaitEvent(aux, p->ev_aux2, 0));
+    CBA_TRY(launch_touch_mask(p->B, p->Kpad, p->n_pad, p->n_pad, p->kmask, aux));
+    CBA_HIP(hipEventRecord(p->ev_mask, aux));
+    p->mask_pending = true;
+  }
   p->have_system = true;
   return CBA_OK;
 }
@@ -463,7 +480,33 @@ static int solve_system(cba_problem* p, double lambda, cba_report* rep) {
   CBA_TRY(solve_enqueue(p, lambda, rep));
   return solve_finish(p);
 }
+// Grid-first order: F formed from the accumulated parts, block-sparse launch of the grid rows, border update, dense border,
+// masked back substitution, x back in the engine's layout.  Timers: 0 = the border update (the K = Gf product), 1 = the whole
+// factorisation, 6 = the solve.
+static int solve_enqueue_gridfirst(cba_problem* p, double lambda) {
+  const Layout& L = p->L;
+  const GfPlan& g = p->gf;
+  const int ld = g.n_pad;
+  CBA_TRY(timer_begin(p, 6));
+  CBA_HIP(hipMemsetAsync(p->status, 0, sizeof(int), p->stream));
+  CBA_HIP(hipMemsetAsync(p->ldlt.status, 0, sizeof(int), p->stream));
+  CBA_TRY(ldlt_clear_ctrl(p->ldlt, p->stream));
+  CBA_TRY(launch_gf_form(p->F, ld, g.Gf, g.n_rp, g.n_border, p->gf_grid_of_f, p->Hdd, p->n_pad, p->bd, p->B, p->Dblk, p->bblk, lambda,
+                         p->gf_tiles, p->n_gf_tiles, p->stream));
+  GemmStats gs;
+  CBA_TRY(timer_begin(p, 1));
+  CBA_TRY(ldlt_factor_gridfirst(p->F, g.n_fact, ld, p->gfd, p->Xb, ld - g.Gf, p->ldlt, p->stream, &gs, nullptr, 0, nullptr));
+  CBA_TRY(timer_end(p, 1, gs.flops, 0, gs.launches));
+  CBA_TRY(ldlt_back_solve(p->F, g.n_fact, ld, ld - 1, p->ldlt, p->xF, p->stream, p->gfd.rowmask, p->gfd.mask_words));
+  CBA_TRY(launch_gf_scatter(p->xF, g.Gf, g.n_rp, L.block_dof, g.G, p->gf_f_of_grid, p->x, p->stream));
+  if (!p->pin_status) CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->pin_status), 4 * sizeof(double)));
+  hipLaunchKernelGGL(k_solve_status, dim3(1), dim3(64), 0, p->stream, p->status, p->ldlt.status, p->x, p->pin_status, p->status + 1);
+  CBA_HIP(hipGetLastError());
+  CBA_TRY(timer_end(p, 6, 0, 0, 1));
+  return CBA_OK;
+}
 static int solve_enqueue(cba_problem* p, double lambda, cba_report* rep) {
+  if (p->gridfirst) return solve_enqueue_gridfirst(p, lambda);
   const Layout& L = p->L;
   const int bs = L.block_size, nb = L.n_blocks, dd = L.dense_dof, ld = p->n_pad;
   const bool multi = p->cfg.allreduce != nullptr;
@@ -545,7 +588,7 @@ static int solve_finish(cba_problem* p) {
   CBA_HIP(hipStreamSynchronize(p->stream));
   const int st[2] = {(int)p->pin_status[0], (int)p->pin_status[1]};
   p->last_x0 = p->pin_status[2];
-  {
+  if (!p->gridfirst) {
     double slabs = 0;
     for (int tm = 0; tm < mask_tiles; ++tm)
       for (int tn = tm; tn < mask_tiles; ++tn)
@@ -642,6 +685,25 @@ int cba_create(const cba_config* config, cba_problem** out) {
   CBA_TRY(alloc_state(p, p->st[1]));
   CBA_TRY(dev_alloc(&p->itg, 16 * (size_t)L.n_images * L.n_cameras));
   for (int c = 0; c < L.n_cameras; ++c) CBA_TRY(dev_alloc(&p->tangents[c], 6 * (size_t)p->cams[c].grid_w * p->cams[c].grid_h));
+  {
+    // elimination order (cba_solver_options.elimination)
+    const bool eligible = !L.eliminate_points && !L.localize_only && !config->allreduce && L.n_images > 0;
+    const int want = config->solver.elimination;
+    if (want == 2 && !eligible) { set_error("cba_create: the grid-first elimination order needs eliminate_points = 0, localize_only = 0 and one rank"); return CBA_ERR_UNSUPPORTED; }
+    if (want < 0 || want > 2 || config->solver.grid_strips < 0) { set_error("cba_create: bad solver options"); return CBA_ERR_ARG; }
+    bool use = want == 2;
+    if (want == 0 && eligible) {
+      double pf = 0, gfl = 0;
+      gf_flop_model(p->cams.data(), L.n_cameras, L.n_images, L.n_points, &pf, &gfl);
+      int G = 0;
+      for (int c = 0; c < L.n_cameras; ++c) G += (p->cams[c].model_type == CBA_CENTRAL_GENERIC ? 2 : 5) * p->cams[c].grid_w * p->cams[c].grid_h;
+      use = G >= 2048 && gfl < 0.85 * pf;
+    }
+    if (use) {
+      if (gf_build_plan(p->cams.data(), L.n_cameras, L.n_images, L.n_points, config->solver.grid_strips, &p->gf) != CBA_OK) { set_error("cba_create: grid-first plan failed"); return CBA_ERR_ARG; }
+      p->gridfirst = true;
+    }
+  }
   CBA_TRY(build_grid_order(p));
   CBA_TRY(dev_alloc(&p->cams_dev[0], L.n_cameras));
   CBA_TRY(dev_alloc(&p->cams_dev[1], L.n_cameras));
@@ -699,10 +761,45 @@ int cba_create(const cba_config* config, cba_problem** out) {
   CBA_TRY(dev_alloc(&p->Dinv, nb * bs * bs));
   CBA_TRY(dev_alloc(&p->dinvb, (size_t)p->Kpad));
   CBA_TRY(dev_alloc(&p->B, (size_t)p->Kpad * p->n_pad));
-  CBA_TRY(dev_alloc(&p->W, (size_t)p->Kpad * p->n_pad));
   CBA_TRY(dev_alloc(&p->Hdd, (size_t)p->n_pad * p->n_pad));
   CBA_TRY(dev_alloc(&p->bd, (size_t)p->n_pad));
-  CBA_TRY(dev_alloc(&p->S, (size_t)p->n_pad * p->n_pad));
+  if (p->gridfirst) {
+    const GfPlan& g = p->gf;
+    const size_t nf = (size_t)g.n_pad, wb = (size_t)(g.n_pad - g.Gf);
+    CBA_TRY(dev_alloc(&p->F, nf * nf));
+    CBA_HIP(hipMemset(p->F, 0, sizeof(double) * nf * nf));          // tiles outside the plan's structure stay zero for ever
+    CBA_TRY(dev_alloc(&p->Xb, (size_t)g.Gf * wb));
+    CBA_HIP(hipMemset(p->Xb, 0, sizeof(double) * (size_t)g.Gf * wb));
+    CBA_TRY(dev_alloc(&p->xF, nf));
+    CBA_TRY(dev_alloc(&p->gfd.tasks, g.tasks.size()));
+    CBA_TRY(dev_alloc(&p->gfd.ivals, g.ivals.size()));
+    CBA_TRY(dev_alloc(&p->gfd.chains, g.chains.size()));
+    CBA_TRY(dev_alloc(&p->gfd.rowmask, g.rowmask.size()));
+    CBA_HIP(hipMemcpy(p->gfd.tasks, g.tasks.data(), sizeof(GfTask) * g.tasks.size(), hipMemcpyHostToDevice));
+    CBA_HIP(hipMemcpy(p->gfd.ivals, g.ivals.data(), sizeof(GfIval) * g.ivals.size(), hipMemcpyHostToDevice));
+    CBA_HIP(hipMemcpy(p->gfd.chains, g.chains.data(), sizeof(GfChain) * g.chains.size(), hipMemcpyHostToDevice));
+    CBA_HIP(hipMemcpy(p->gfd.rowmask, g.rowmask.data(), sizeof(uint64_t) * g.rowmask.size(), hipMemcpyHostToDevice));
+    p->gfd.n_tasks0 = g.n_tasks0; p->gfd.n_tasks1 = (int)g.tasks.size() - g.n_tasks0; p->gfd.n_chains = (int)g.chains.size();
+    p->gfd.nbg = g.nbg; p->gfd.nbf = g.nbf; p->gfd.mask_words = g.mask_words; p->gfd.flops_grid = g.flops_grid;
+    // tiles the forming kernel writes per attempt: the structural tiles of the grid x grid part, the row strips of the grid rows
+    // (every border column block + the right-hand side's), the upper triangle of the border
+    std::vector<int> tiles(g.grid_tiles);
+    for (int r = 0; r < g.nbf; ++r) {
+      for (int c = std::max(r, g.nbg); c < g.nbf; ++c) { tiles.push_back(r); tiles.push_back(c); }
+      tiles.push_back(r); tiles.push_back(g.ntc - 1);
+    }
+    tiles.push_back(g.ntc - 1); tiles.push_back(g.ntc - 1);       // (the border update also writes the block row of the right-hand side column: reset per attempt)
+    p->n_gf_tiles = (int)(tiles.size() / 2);
+    CBA_TRY(dev_alloc(&p->gf_tiles, tiles.size()));
+    CBA_HIP(hipMemcpy(p->gf_tiles, tiles.data(), sizeof(int) * tiles.size(), hipMemcpyHostToDevice));
+    CBA_TRY(dev_alloc(&p->gf_grid_of_f, g.grid_of_f.size()));
+    CBA_HIP(hipMemcpy(p->gf_grid_of_f, g.grid_of_f.data(), sizeof(int) * g.grid_of_f.size(), hipMemcpyHostToDevice));
+    CBA_TRY(dev_alloc(&p->gf_f_of_grid, g.f_of_grid.size()));
+    CBA_HIP(hipMemcpy(p->gf_f_of_grid, g.f_of_grid.data(), sizeof(int) * g.f_of_grid.size(), hipMemcpyHostToDevice));
+  } else {
+    CBA_TRY(dev_alloc(&p->W, (size_t)p->Kpad * p->n_pad));
+    CBA_TRY(dev_alloc(&p->S, (size_t)p->n_pad * p->n_pad));
+  }
   if (config->allreduce) {
     // the reduced system crosses ranks as its upper 128-row blocks only (half the all-reduce volume)
     int64_t need = packed_upper_doubles(p->n_pad);
@@ -718,8 +815,8 @@ int cba_create(const cba_config* config, cba_problem** out) {
       CBA_TRY(dev_alloc(&p->P, (size_t)need));
     }
   }
-  CBA_HIP(hipMemset(p->S, 0, sizeof(double) * (size_t)p->n_pad * p->n_pad));
-  CBA_HIP(hipMemset(p->W, 0, sizeof(double) * (size_t)p->Kpad * p->n_pad));
+  if (p->S) CBA_HIP(hipMemset(p->S, 0, sizeof(double) * (size_t)p->n_pad * p->n_pad));
+  if (p->W) CBA_HIP(hipMemset(p->W, 0, sizeof(double) * (size_t)p->Kpad * p->n_pad));
   CBA_HIP(hipMemset(p->dinvb, 0, sizeof(double) * (size_t)p->Kpad));
   CBA_TRY(dev_alloc(&p->x, (size_t)L.block_dof + p->n_pad));
   CBA_HIP(hipMemset(p->x, 0, sizeof(double) * ((size_t)L.block_dof + p->n_pad)));
@@ -731,7 +828,8 @@ int cba_create(const cba_config* config, cba_problem** out) {
   }
   CBA_TRY(dev_alloc(&p->gemv_ws, (size_t)gemv_t_workspace_doubles(p->n_pad)));
   CBA_TRY(dev_alloc(&p->status, 2));      // [0] block-inverse status, [1] guard word of the solve (k_solve_status)
-  CBA_TRY(ldlt_workspace_alloc(p->ldlt, p->n_pad));
+  if (p->gridfirst) CBA_TRY(ldlt_workspace_alloc(p->ldlt, p->gf.n_pad, p->gf.nbg));
+  else CBA_TRY(ldlt_workspace_alloc(p->ldlt, p->n_pad));
   apply_solver_options(p->ldlt, &config->solver);
   guard.q = nullptr;
   *out = p;
@@ -759,6 +857,8 @@ void cba_destroy(cba_problem* p) {
   if (p->P_owned) F(p->P);
   F(p->P2);
   F(p->x); F(p->scal); F(p->status); F(p->gemv_ws); F(p->kmask);
+  F(p->F); F(p->Xb); F(p->xF); F(p->gf_tiles); F(p->gf_grid_of_f); F(p->gf_f_of_grid);
+  F(p->gfd.tasks); F(p->gfd.ivals); F(p->gfd.chains); F(p->gfd.rowmask);
   ldlt_workspace_free(p->ldlt);
   for (auto& t : p->timers) for (auto& sp : t.spans) { hipEventDestroy(sp.e0); hipEventDestroy(sp.e1); }
   if (p->kmask_host) hipHostFree(p->kmask_host);

@@ -170,11 +170,29 @@ struct LdltWorkspace {
   hipEvent_t tail_e0 = nullptr, tail_e1 = nullptr;   // span of the last tail launch (statistics only)
   bool tail_timed = false;
 };
-int ldlt_workspace_alloc(LdltWorkspace& w, int n);
+// flag_rows_blocks: block rows a dataflow launch may cover (0 = the dense schedule's own maximum)
+int ldlt_workspace_alloc(LdltWorkspace& w, int n, int flag_rows_blocks = 0);
 // adds the GEMM launches timed since the last call to `st` (waits for them)
 int ldlt_collect_spans(LdltWorkspace& w, GemmStats* st);
 void ldlt_workspace_free(LdltWorkspace& w);
-int ldlt_factor(double* S, int n, int ld, LdltWorkspace& w, hipStream_t s, GemmStats* trailing_stats);
+// k_begin: rows above it are factored already and their update is applied (the border of the grid-first order)
+int ldlt_factor(double* S, int n, int ld, LdltWorkspace& w, hipStream_t s, GemmStats* trailing_stats, int k_begin = 0);
+// x of L^T x = z (z = column zcol of S, forward-substituted by the factorisation); rowmask: optional block-sparsity of the factor's rows
+int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWorkspace& w, double* x, hipStream_t s,
+                    const unsigned long long* rowmask = nullptr, int mask_words = 0);
+// Grid-first elimination (gridfirst_plan.h): device copies of the plan's arrays
+struct GfTask; struct GfIval; struct GfChain;
+struct GfDevice {
+  GfTask* tasks = nullptr; GfIval* ivals = nullptr; GfChain* chains = nullptr;
+  int n_tasks0 = 0, n_tasks1 = 0, n_chains = 0;
+  int nbg = 0, nbf = 0;
+  unsigned long long* rowmask = nullptr; int mask_words = 0;
+  double flops_grid = 0;
+};
+// F = [grid | border] in the plan's order, ld = its n_pad; Xb: (rows of the grid part) x (ld - Gf) panel buffer (zero outside the
+// tiles the launch writes); kmask / chunk_order: optional block-sparsity of the border update (null = dense)
+int ldlt_factor_gridfirst(double* F, int n_fact, int ld, const GfDevice& g, double* Xb, int ldxb, LdltWorkspace& w, hipStream_t s,
+                          GemmStats* st, const unsigned long long* kmask, int kmask_words, const int* chunk_order);
 // Rows that the final dataflow launch factors (w.tail_rows clamped to the workspace's flag storage)
 int ldlt_tail_rows(const LdltWorkspace& w, int world = 1);
 int ldlt_clear_ctrl(LdltWorkspace& w, hipStream_t s);

@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "cba_internal.h"
+#include "gridfirst_plan.h"
 #include <algorithm>
 #include <map>
 #include <mutex>
@@ -258,6 +259,7 @@ struct GemmArgs {
   int strips;                   // set by launch_gemm: strip-blocked tile order (square upper dense launches)
   int col_group, col_stride;    // distributed factorisation: owned column groups (tiles per group, group stride); 0 = all columns
   int keep_col_p1;              // 1 + a column of C the launch must not write (the right-hand side kept in S's last column); 0 = none
+  int slab16;                   // block-sparse launch with 16-row K slabs (the border update of the grid-first order); 0 = slabs of kSchurSlab rows
 };
 
 // Developer switches are compiled only into the bench harness (tools/bench_tail.hip, tools/bench_diag.hip define CBA_DEV_SWITCHES): the
@@ -542,7 +544,7 @@ static int launch_gemm(GemmArgs g, hipStream_t s) {
   g.n_chunks = (int)chunks;
   if (g.chunk != kSchurChunk) g.chunk_order = nullptr;            // the order was built for chunks of kSchurChunk tiles
   long long blocks = ((chunks + 7) / 8) * 8 * g.chunk;
-  if (g.kmask) hipLaunchKernelGGL((k_gemm_atb<TM, TN, WM, WN, SUB, kSchurSlab>), dim3((unsigned)blocks), dim3(256), 0, s, g);   // block-sparse: slabs of two pose blocks
+  if (g.kmask && !g.slab16) hipLaunchKernelGGL((k_gemm_atb<TM, TN, WM, WN, SUB, kSchurSlab>), dim3((unsigned)blocks), dim3(256), 0, s, g);   // block-sparse: slabs of two pose blocks
   else hipLaunchKernelGGL((k_gemm_atb<TM, TN, WM, WN, SUB, KT>), dim3((unsigned)blocks), dim3(256), 0, s, g);
   CBA_HIP(hipGetLastError());
   return CBA_OK;
@@ -750,7 +752,16 @@ struct TailArgs {
   int ntasks_x[8];                  // tasks per list
   int pair;                         // one list only: REG tasks take TWO adjacent column blocks (64 x 128 tile, kind 3) beyond the first
                                     // kTailNearSingles columns of a row (tail_task)
+  // block-sparse launch (k_ldlt_sparse; gridfirst_plan.h): static task lists with K intervals, several pivot chains
+  const GfTask* tasks;              // list 0 (ntasks_x[0] entries), then list 1 (ntasks_x[1])
+  const GfIval* ivals;
+  const GfChain* chains;            // role i < n_chains runs chain i; ctrl[kCtrlChainCu + i] = its CU
+  int n_chains;
+  int n_critical;                   // helper workgroups (roles n_chains ... n_chains + n_critical - 1) that serve list 0 first
 };
+constexpr int kCtrlWords = 128;     // control words of a dataflow launch: [1] abort, [2] role tickets, [3] CU of the chain (dense launch),
+constexpr int kCtrlChainCu = 16;    // [8 + x] task tickets of list x, [kCtrlChainCu + i] CU of chain i (block-sparse launch)
+constexpr int kMaxChains = kCtrlWords - kCtrlChainCu;
 constexpr unsigned long long kTailTimeoutTicks = 300000000ull;   // 3 s
 
 typedef unsigned v4u32_t __attribute__((ext_vector_type(4)));
@@ -1509,7 +1520,10 @@ __device__ __forceinline__ bool chain_factor_blocked(double* sW, double* sV, dou
 // and dropped: polling / loading the next step's operands underneath the pivots from a hook in the pivot loop (per pair: pivots
 // 14.3 -> 16.6 us; between the 16-step segments: 15.5-17 us) or inside the epilogue (32 us per block) -- the extra live state
 // spills, and every spill reload waits for vmcnt(0), i.e. for the write-through acknowledgement of the stores in flight.
-__device__ __forceinline__ void tail_chain(const TailArgs& t, double* sV, double* sW) {
+// Block rows [r_begin, r_end) (the dense launch: the whole tail).  start_dep: block r_begin has predecessors in the launch -- its
+// diagonal tile arrives through a PARTFULL task (block-sparse launch: the chain of a camera's separators).
+__device__ __forceinline__ void tail_chain(const TailArgs& t, double* sV, double* sW, const int r_begin, const int r_end, const int start_dep,
+                                           unsigned* cu_word) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
   double* s_rd = sW + kInner;                     // 1 / d of the block factored last: padding columns of rows 0 .. 3 of sW
@@ -1519,12 +1533,12 @@ __device__ __forceinline__ void tail_chain(const TailArgs& t, double* sV, double
   // row-wise layout: instruction k of a wave moves rows rw + 2 k (lanes 0-31) and rw + 2 k + 1 (lanes 32-63), 16 bytes per lane
   const int rw = 16 * wv + (lane >> 5), cw = 2 * (lane & 31);
   const int u_voff = (rw * ld + cw) * 8;
-  if (tid == 0 && t.evict) tail_stflag(&t.ctrl[3], tail_cu_id());
-  for (int r = t.rt0; r < t.nr; ++r) {
+  if (tid == 0 && t.evict) tail_stflag(cu_word, tail_cu_id());
+  for (int r = r_begin; r < r_end; ++r) {
     const int j0 = kInner * r;
     const int b = r - t.rt0;
     TAIL_STAMP(b, 0);
-    if (r > t.rt0) {
+    if (r > r_begin) {
       const __amdgpu_buffer_rsrc_t ru = tail_rsrc(t.S + (size_t)(j0 - kInner) * ld + j0);
       if (!tail_wait(t, &t.upre_flag[b - 1], &t.part_flag[b], slot)) return;
       TAIL_STAMP(b, 1);
@@ -1592,10 +1606,12 @@ __device__ __forceinline__ void tail_chain(const TailArgs& t, double* sV, double
       tail_publish(&t.tile_flag[(size_t)(b - 1) * t.ntc + r], t.epoch);       // L_{r-1,r}; its barrier also covers the tile in sW
       TAIL_STAMP(b, 6);
     } else {
-      // first block of the tail: nothing to subtract
+      // first block of the chain: nothing to subtract, or (start_dep) everything subtracted by a PARTFULL task of this launch
+      if (start_dep && !tail_wait(t, &t.part_flag[b], nullptr, slot)) return;
       for (int e = tid; e < kInner * kInner; e += 256) {
         const int m = e >> 6, n = e & 63;
-        sW[m * TS + n] = t.S[(size_t)(j0 + m) * ld + j0 + n];
+        const double* src = t.S + (size_t)(j0 + m) * ld + j0 + n;
+        sW[m * TS + n] = start_dep ? tail_ld(src) : *src;
       }
       __syncthreads();
     }
@@ -1631,7 +1647,7 @@ __device__ __forceinline__ void tail_chain(const TailArgs& t, double* sV, double
     }
     TAIL_STAMP(b, 9);
     // published by the next step (after its loads) -- or here, for the last block
-    if (r + 1 == t.nr) tail_publish(&t.diag_flag[b], t.epoch);
+    if (r + 1 == r_end) tail_publish(&t.diag_flag[b], t.epoch);
   }
 }
 
@@ -1751,7 +1767,10 @@ __device__ __forceinline__ bool tail_helper_pair(const TailArgs& t, double* sV, 
 
 #endif
 
-__device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, double* sAB) {
+// SPARSE (k_ldlt_sparse): tasks come from the plan's two lists (list 0 = what the chains wait for; the first n_critical helper roles
+// serve it first, everybody else list 1 first), every task carries its K intervals, several chains own a CU each.
+template <bool SPARSE>
+__device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, double* sAB, const int role) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm0 = (wv >> 1) * 32, wn0 = (wv & 1) * 32, li = lane & 15, lk = lane >> 4;
   // K-loop staging (LDS-DMA): kDmaDoubles from the start of sV, running over into sAB (the two tiles are one array); the slots
@@ -1765,13 +1784,20 @@ __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, doubl
   volatile int* slot3 = reinterpret_cast<volatile int*>(sAB + (kInner - 1) * TS + kInner + 4);
   const int ld = t.ld;
   const unsigned my_cu = tail_cu_id();
-  const int nl = t.xcd_lists ? 8 : 1;
-  const int my_list = t.xcd_lists ? (int)((my_cu >> 8) & 7u) : 0;
+  const int nl = SPARSE ? 2 : (t.xcd_lists ? 8 : 1);
+  const int my_list = SPARSE ? (role - t.n_chains < t.n_critical ? 0 : 1) : (t.xcd_lists ? (int)((my_cu >> 8) & 7u) : 0);
   for (;;) {
     __syncthreads();                             // the previous task is done with sV / sAB / the slots
+    if (SPARSE && t.evict && tid < 64) {
+      // a helper that shares a CU with one of the chains leaves (one flag per chain, polled by one wavefront)
+      const bool hit = tid < t.n_chains && tail_ldflag(&t.ctrl[kCtrlChainCu + tid]) == my_cu;
+      const unsigned long long any = __ballot(hit);
+      if (tid == 0) *slot = any != 0ull ? 1 : 0;
+    }
+    if (SPARSE) __syncthreads();
     if (tid == 0) {
       int tk = -1, lst = 0;
-      const bool evicted = t.evict && tail_ldflag(&t.ctrl[3]) == my_cu;
+      const bool evicted = t.evict && (SPARSE ? *slot != 0 : tail_ldflag(&t.ctrl[3]) == my_cu);
       if (!evicted && tail_ldflag(&t.ctrl[1]) == 0) {
         for (int d = 0; d < nl; ++d) {             // own list first, then the others
           const int x = (my_list + d) % nl;
@@ -1785,15 +1811,23 @@ __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, doubl
     __syncthreads();
     const int tk = *slot2;
     if (tk < 0) return;
-    int kind, r, c;
-    tail_task(t, tk, *slot3, nl, &kind, &r, &c);
-    if (kind >= 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3);
+    int kind, r, c, iv0 = 0, n_iv = 1;
+    if (SPARSE) {
+      const GfTask tsk = t.tasks[(*slot3 ? t.ntasks_x[0] : 0) + tk];
+      kind = tsk.kind_n & 255; n_iv = tsk.kind_n >> 8; r = tsk.r; c = tsk.c; iv0 = tsk.iv0;
+      kind = __builtin_amdgcn_readfirstlane(kind); n_iv = __builtin_amdgcn_readfirstlane(n_iv);
+      r = __builtin_amdgcn_readfirstlane(r); c = __builtin_amdgcn_readfirstlane(c); iv0 = __builtin_amdgcn_readfirstlane(iv0);
+    } else {
+      tail_task(t, tk, *slot3, nl, &kind, &r, &c);
+    }
+    if (kind == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3);
 #ifdef CBA_DEV_SWITCHES
-    if (kind == 3) {
+    if (!SPARSE && kind == 3) {
       if (!tail_helper_pair(t, sV, sAB, r, c, slot)) return;
       continue;
     }
 #endif
+    if (SPARSE && kind == 3) kind = 1;           // PARTFULL: a PART task whose intervals reach up to the row above the tile
     const int ca = (kind == 1) ? c : r;          // column block of the A operand: PART is L_{k,r+1}^T d L_{k,r+1}
     v4f64 acc[2][2];
 #pragma unroll
@@ -1813,22 +1847,29 @@ __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, doubl
       for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) a_rc[i][jj][r4] = tail_ld1(rt, acc_voff, ((16 * i + 4 * r4) * ld + 16 * jj) * 8);
-    for (int k = t.rt0; k < r;) {
-      const unsigned long long h0 = HELP_NOW();
-      const int nrows = tail_wait_rows(t, k, r, ca, c, slot);
-      if (nrows <= 0) return;
-      const unsigned long long h1 = HELP_NOW();
-      const double* A = t.S + (size_t)k * kInner * ld + (size_t)ca * kInner;
-      const double* B = t.S + (size_t)k * kInner * ld + (size_t)c * kInner;
+    for (int iv = 0; iv < n_iv; ++iv) {
+      int k = t.rt0, kend = r;
+      if (SPARSE) {
+        const GfIval v = t.ivals[iv0 + iv];
+        k = __builtin_amdgcn_readfirstlane(v.k0); kend = __builtin_amdgcn_readfirstlane(v.k1);
+      }
+      while (k < kend) {
+        const unsigned long long h0 = HELP_NOW();
+        const int nrows = tail_wait_rows(t, k, kend, ca, c, slot);
+        if (nrows <= 0) return;
+        const unsigned long long h1 = HELP_NOW();
+        const double* A = t.S + (size_t)k * kInner * ld + (size_t)ca * kInner;
+        const double* B = t.S + (size_t)k * kInner * ld + (size_t)c * kInner;
 #ifdef CBA_TAIL_RING
-      if (kind == 1) tail_mma_ring<true>(acc, A, A, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sV);
-      else tail_mma_ring<false>(acc, A, B, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sV);
+        if (kind == 1) tail_mma_ring<true>(acc, A, A, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sV);
+        else tail_mma_ring<false>(acc, A, B, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sV);
 #else
-      if (kind == 1) tail_mma_dma<true>(acc, A, A, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sV);
-      else tail_mma_dma<false>(acc, A, B, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sV);
+        if (kind == 1) tail_mma_dma<true>(acc, A, A, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sV);
+        else tail_mma_dma<false>(acc, A, B, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sV);
 #endif
-      k += nrows;
-      h_wait += h1 - h0; h_mma += HELP_NOW() - h1;
+        k += nrows;
+        h_wait += h1 - h0; h_mma += HELP_NOW() - h1;
+      }
     }
     const unsigned long long h_kend = HELP_NOW();
     // U = A_rc - acc
@@ -1921,9 +1962,30 @@ __global__ void __launch_bounds__(256, 2) k_ldlt_tail(TailArgs t) {
   __syncthreads();
   if (role == 0) {
     __builtin_amdgcn_s_setprio(3);
-    tail_chain(t, smem, smem + kInner * TS);
+    tail_chain(t, smem, smem + kInner * TS, t.rt0, t.nr, 0, &t.ctrl[3]);
   } else {
-    tail_helper(t, smem, smem + kInner * TS);
+    tail_helper<false>(t, smem, smem + kInner * TS, role);
+  }
+}
+
+// Block-sparse variant (grid-first elimination, gridfirst_plan.h): the block rows [0, nr) of F -- the grid unknowns of all cameras in
+// strip / separator order -- with every column to the right, as ONE launch.  Roles 0 ... n_chains - 1 are pivot chains (one per
+// strip, one per camera's separators: they run side by side), the next n_critical roles serve the chains' own tiles first, everybody
+// else the border tiles of the row strips.  Same tile arithmetic, flags and bounded waits as k_ldlt_tail.
+__global__ void __launch_bounds__(256, 2) k_ldlt_sparse(TailArgs t) {
+  __shared__ double smem[2 * kInner * TS];
+  volatile int* s_role = reinterpret_cast<volatile int*>(smem + kInner);
+  if (threadIdx.x == 0) *s_role = (int)atomicAdd(&t.ctrl[2], 1u);
+  __syncthreads();
+  const int role = *s_role;
+  __syncthreads();
+  if (role < t.n_chains) {
+    __builtin_amdgcn_s_setprio(3);
+    const GfChain ch = t.chains[role];
+    tail_chain(t, smem, smem + kInner * TS, __builtin_amdgcn_readfirstlane(ch.r0), __builtin_amdgcn_readfirstlane(ch.r1),
+               __builtin_amdgcn_readfirstlane(ch.dep), &t.ctrl[kCtrlChainCu + role]);
+  } else {
+    tail_helper<true>(t, smem, smem + kInner * TS, role);
   }
 }
 
@@ -1968,7 +2030,7 @@ int make_main_stream(hipStream_t* s) {
 }
 
 static int super_width();
-int ldlt_workspace_alloc(LdltWorkspace& w, int n_pad) {
+int ldlt_workspace_alloc(LdltWorkspace& w, int n_pad, int flag_rows_blocks) {
   ldlt_workspace_free(w);
   // X = D L of a super-panel's row strip: the K-major B operand of the bulk update.  A super-panel is at most super_width() + 512
   // rows wide (super_width_at), never wider than the matrix
@@ -1991,12 +2053,13 @@ int ldlt_workspace_alloc(LdltWorkspace& w, int n_pad) {
   CBA_HIP(hipEventCreateWithFlags(&w.ev_mid, hipEventDisableTiming | hipEventDisableSystemFence));
   {
     const int ntc = n_pad / kInner;
-    const int rows = ntc < kTailMaxBlockRows ? ntc : kTailMaxBlockRows;
+    int rows = ntc < kTailMaxBlockRows ? ntc : kTailMaxBlockRows;
+    if (flag_rows_blocks > rows) rows = flag_rows_blocks < ntc ? flag_rows_blocks : ntc;      // block-sparse launch: every grid block row has its flags
     const size_t words = (size_t)rows * ntc + 3 * (size_t)ntc;
     CBA_HIP(hipMalloc(&w.tail_flags, sizeof(unsigned) * words));
     CBA_HIP(hipMemset(w.tail_flags, 0, sizeof(unsigned) * words));
-    CBA_HIP(hipMalloc(&w.tail_ctrl, sizeof(unsigned) * 16));
-    CBA_HIP(hipMemset(w.tail_ctrl, 0, sizeof(unsigned) * 16));
+    CBA_HIP(hipMalloc(&w.tail_ctrl, sizeof(unsigned) * kCtrlWords));
+    CBA_HIP(hipMemset(w.tail_ctrl, 0, sizeof(unsigned) * kCtrlWords));
     w.tail_rows_cap = rows * kInner;
     w.tail_epoch = 0;
     CBA_HIP(hipEventCreate(&w.tail_e0));
@@ -2107,7 +2170,7 @@ int ldlt_tail_rows(const LdltWorkspace& w, int world) {
 // Clears the control words of the NEXT dataflow launch now (on stream s, which must be ordered in front of that launch): the
 // first launch of a factorisation then starts without a memset between it and the Schur product.
 int ldlt_clear_ctrl(LdltWorkspace& w, hipStream_t s) {
-  CBA_HIP(hipMemsetAsync(w.tail_ctrl, 0, sizeof(unsigned) * 16, s));
+  CBA_HIP(hipMemsetAsync(w.tail_ctrl, 0, sizeof(unsigned) * kCtrlWords, s));
   w.tail_ctrl_clean = true;
   return CBA_OK;
 }
@@ -2156,7 +2219,7 @@ static int ldlt_tail(double* S, int n_fact, int ld, int t0, LdltWorkspace& w, hi
     if (t.pair) t.ntasks_x[0] = t.ntasks;
   }
   if (w.tail_ctrl_clean) w.tail_ctrl_clean = false;            // cleared ahead of time by the caller (ldlt_clear_ctrl)
-  else CBA_HIP(hipMemsetAsync(w.tail_ctrl, 0, sizeof(unsigned) * 16, s));
+  else CBA_HIP(hipMemsetAsync(w.tail_ctrl, 0, sizeof(unsigned) * kCtrlWords, s));
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   long long grid = ntasks + 1;
@@ -2192,13 +2255,13 @@ static int ldlt_tail(double* S, int n_fact, int ld, int t0, LdltWorkspace& w, hi
 // (Round 4 built two alternatives and dropped both, DESIGN.md section 3: the next super-panel's dataflow launch NEXT TO the bulk
 // update -- its hand-offs through L2 take 5x as long under the GEMM's memory traffic -- and the far columns of a strip as one
 // product with the explicit inverse of the super-panel's unit factor.)
-int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, GemmStats* st) {
+int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, GemmStats* st, int k_begin) {
   const int n_pad = ld;
   // (one stream: nothing here runs on the side streams -- their next users, the Jacobian pass and the distributed variant, order
   // themselves against the main stream with their own events; round 4 recorded an event and three stream waits here, a bubble in
   // front of the first dataflow launch)
   const int sw = super_width(), tail_rows = ldlt_tail_rows(w);
-  int k0 = 0, rc;
+  int k0 = k_begin, rc;          // rows above k_begin are factored already and their update is applied (grid-first elimination)
   while (n_fact - k0 > tail_rows + sw / 2 && n_pad - (k0 + sw) >= 1024) {
     const int wk = super_width_at(n_pad, k0, sw);
     if ((rc = ldlt_tail(S, k0 + wk, ld, k0, w, s, st, w.X))) return rc;
@@ -2214,6 +2277,76 @@ int ldlt_factor(double* S, int n_fact, int ld, LdltWorkspace& w, hipStream_t s, 
   if ((rc = ldlt_tail(S, n_fact, ld, k0, w, s, st))) return rc;
   CBA_HIP(hipGetLastError());
   return CBA_OK;
+}
+
+// ---- grid-first elimination (gridfirst_plan.h) ----
+// Block rows [0, nbg) of F -- the grid unknowns -- with every column to the right in ONE block-sparse dataflow launch; X = D L of
+// the border columns goes to Xb (rows of the grid part x border columns, leading dimension ldxb, column 0 = column Gf of F).
+static int ldlt_sparse(double* F, int ld, const GfDevice& g, LdltWorkspace& w, hipStream_t s, GemmStats* st, double* Xb, int ldxb) {
+  TailArgs t{};
+  t.S = F; t.ld = ld;
+  t.X = Xb - (size_t)g.nbg * kInner; t.ldx = ldxb; t.x_c0 = g.nbg;
+  t.rt0 = 0; t.nr = g.nbg; t.ntc = ld / kInner;
+  t.dvec = w.dvec; t.invLt = w.invLt; t.status = w.status;
+  const int rows_cap = w.tail_rows_cap / kInner;
+  if (g.nbg > rows_cap || g.n_chains > kMaxChains) { set_error("ldlt_sparse: workspace too small for the plan"); return CBA_ERR_STATE; }
+  t.tile_flag = w.tail_flags;
+  t.diag_flag = w.tail_flags + (size_t)rows_cap * t.ntc;
+  t.upre_flag = t.diag_flag + t.ntc;
+  t.part_flag = t.upre_flag + t.ntc;
+  t.ctrl = w.tail_ctrl;
+  t.epoch = ++w.tail_epoch;
+  t.tasks = g.tasks; t.ivals = g.ivals; t.chains = g.chains; t.n_chains = g.n_chains;
+  for (int x = 0; x < 8; ++x) t.ntasks_x[x] = 0;
+  t.ntasks_x[0] = g.n_tasks0; t.ntasks_x[1] = g.n_tasks1;
+  t.ntasks = g.n_tasks0 + g.n_tasks1;
+  t.evict = 1; t.xcd_lists = 0; t.pair = 0;
+  if (w.tail_ctrl_clean) w.tail_ctrl_clean = false;
+  else CBA_HIP(hipMemsetAsync(w.tail_ctrl, 0, sizeof(unsigned) * kCtrlWords, s));
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  long long grid = (long long)t.ntasks + g.n_chains;
+  if (grid > 2LL * cus) grid = 2LL * cus;
+  // Workgroups that serve list 0 first: per chain the tasks of about two block rows (PRE, PART and the band's tiles).  The chains
+  // and these roles are the first workgroups dispatched; everything else starts with the border tiles.
+  long long crit = (long long)g.n_chains * 16;
+  if (crit > grid / 4) crit = grid / 4;
+  if (crit < 1) crit = 1;
+  if (grid < g.n_chains + crit + 1) grid = g.n_chains + crit + 1;
+  t.n_critical = (int)crit;
+  if (grid - g.n_chains <= 3) t.evict = 0;
+#ifdef CBA_DEV_SWITCHES
+  if (st) CBA_HIP(hipEventRecord(w.tail_e0, s));
+#endif
+  hipLaunchKernelGGL(k_ldlt_sparse, dim3((unsigned)grid), dim3(256), 0, s, t);
+  CBA_HIP(hipGetLastError());
+  if (st) {
+#ifdef CBA_DEV_SWITCHES
+    CBA_HIP(hipEventRecord(w.tail_e1, s));
+    w.tail_timed = true;
+#endif
+    st->flops += g.flops_grid;
+  }
+  return CBA_OK;
+}
+
+// Factors rows [0, n_fact) of F = [grid | border] (ld = n_pad of the plan): block-sparse launch of the grid rows, ONE update of
+// the border by the K = Gf product C -= L^T X on the 128 x 128 MFMA GEMM (optionally block-sparse in K: `kmask`, one bit per
+// 128-column border tile and 16-row slab), then the dense border by the two-level schedule of ldlt_factor.
+int ldlt_factor_gridfirst(double* F, int n_fact, int ld, const GfDevice& g, double* Xb, int ldxb, LdltWorkspace& w, hipStream_t s,
+                          GemmStats* st, const unsigned long long* kmask, int kmask_words, const int* chunk_order) {
+  int rc;
+  if ((rc = ldlt_sparse(F, ld, g, w, s, st, Xb, ldxb))) return rc;
+  const int Gf = g.nbg * kInner;
+  GemmArgs u{};
+  u.A = F; u.lda = ld; u.B = Xb - Gf; u.ldb = ldxb; u.K = Gf;
+  u.C = F; u.ldc = ld; u.Cin = F; u.ldcin = ld; u.diag = 0; u.upper = 1;
+  const int tl = (ld - Gf) / 128;
+  u.m_off = Gf; u.m_tiles = tl; u.n_off = Gf; u.n_tiles = tl;
+  u.kmask = kmask; u.kmask_words = kmask_words; u.slab16 = 1; u.chunk_order = chunk_order;
+  if ((rc = timed_gemm128(u, s, w, st != nullptr, (double)tl * (tl + 1) / 2))) return rc;
+  if (st) { const double rows = (double)(ld - Gf); st->flops += rows * rows * Gf; st->launches += 1; }
+  return ldlt_factor(F, n_fact, ld, w, s, st, Gf);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2527,6 +2660,8 @@ struct BackArgs {
   double* xe;                 // 2 * n_pad doubles: {value, tag} pairs
   double tag;
   int* status;
+  const unsigned long long* rowmask;   // optional [block row][mask_words]: bit c = tile (r, c) can be non-zero (grid-first order: the
+  int mask_words;                      // grid x grid part of the factor is block-sparse); null = every tile
 };
 // Round 4: (1) a lane's 16 columns of a 64-column block are 8 jj + 2 q4 + {0, 1}, jj = 0 ... 7 -- one 16-byte load per jj, the four
 // lanes of a row read 64 contiguous bytes per instruction; with 16 consecutive columns per lane a wavefront-load touched 64 cache
@@ -2568,14 +2703,27 @@ __global__ void __launch_bounds__(256) k_back_dataflow(BackArgs a) {
   double acc = 0.0;
   const __amdgpu_buffer_rsrc_t rx = tail_rsrc(a.xe);
   double l[16], ln[16];
-  {
-    const int c = nblk - 1;
-    ld16(row + (size_t)c * kInner, l, rlive && c > r, a.n_fact - c * kInner < kInner ? a.n_fact - c * kInner : kInner);
-  }
-  for (int c = nblk - 1; c > r; --c) {
+  // largest column block below c whose tile (r, .) can be non-zero (r itself when there is none)
+  const unsigned long long* mrow = a.rowmask ? a.rowmask + (size_t)r * a.mask_words : nullptr;
+  auto next_active = [&](int c) -> int {
+    if (!mrow) return c - 1;
+    int cc = c - 1;
+    while (cc > r) {
+      const unsigned long long wbits = mrow[cc >> 6] & (~0ull >> (63 - (cc & 63)));
+      if (wbits) { const int hit = (cc & ~63) + 63 - __builtin_clzll(wbits); return hit > r ? hit : r; }
+      cc = (cc & ~63) - 1;
+    }
+    return r;
+  };
+  int c = next_active(nblk);
+  if (c > r) ld16(row + (size_t)c * kInner, l, rlive, a.n_fact - c * kInner < kInner ? a.n_fact - c * kInner : kInner);
+  int par = 0;
+  while (c > r) {
     // the strip's entries do not depend on x: those of the next column block are in flight while this one's x is polled
-    ld16(row + (size_t)(c - 1) * kInner, ln, rlive && c - 1 > r, kInner);
-    double* xs = s_x[c & 1];
+    const int cn = next_active(c);
+    ld16(row + (size_t)(cn > r ? cn : c) * kInner, ln, rlive && cn > r, kInner);
+    double* xs = s_x[par];
+    par ^= 1;
     if (tid < kInner) {
       const unsigned long long t0 = wall_clock64();
       v2f64_t v;
@@ -2595,6 +2743,7 @@ __global__ void __launch_bounds__(256) k_back_dataflow(BackArgs a) {
     acc += dot16(l, xs);
 #pragma unroll
     for (int j = 0; j < 16; ++j) l[j] = ln[j];
+    c = cn;
   }
   acc += __shfl_xor(acc, 1, 64);
   acc += __shfl_xor(acc, 2, 64);
@@ -2610,11 +2759,13 @@ __global__ void __launch_bounds__(256) k_back_dataflow(BackArgs a) {
   }
 }
 
-int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWorkspace& w, double* x, hipStream_t s) {
+int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWorkspace& w, double* x, hipStream_t s,
+                    const unsigned long long* rowmask, int mask_words) {
   static const bool no_df = CBA_GETENV("CBA_BACK_PANELS") != nullptr;       // developer switch (bench harness only)
-  if (w.back_dataflow && !no_df && w.back_xe && n_fact % kInner == 0) {
+  if (((w.back_dataflow && !no_df) || rowmask) && w.back_xe && n_fact % kInner == 0) {
     BackArgs a{};
     a.S = S; a.ld = ld; a.n_fact = n_fact; a.zcol = zcol; a.invLt = w.invLt; a.x = x; a.xe = w.back_xe; a.status = w.status;
+    a.rowmask = rowmask; a.mask_words = mask_words;
     LdltWorkspace& wm = const_cast<LdltWorkspace&>(w);
     wm.back_epoch += 1;
     a.tag = (double)wm.back_epoch;

@@ -76,6 +76,19 @@ typedef struct {
                                  2-3 ranks and 4096 from 4 ranks on), clamped to what the launch has flags for.  Smaller values
                                  give small systems the super-panel structure of large ones (the tests use that) */
   int32_t back_substitution;  /* 0 = one dataflow launch (default); 1 = panels of 256 rows (98 launches at BASELINE configs[1]) */
+  int32_t elimination;        /* order in which the unknowns are eliminated.  The reference eliminates the 6 x 6 pose blocks and factors
+                                 the dense rest of D = 3 P + 6 C + (grid unknowns) rows (APP/bundle_adjustment/joint_optimization.cc:794-804,
+                                 LV/lm_optimizer.h:1247-1369); (H + lambda I) x = b has one solution, so every exact order gives the same x
+                                 up to rounding.  1 = that order (pose-first).  2 = grid-first: an observation touches a 4 x 4 window of
+                                 control points (APP/models/central_grid.h:199-209), so the grid x grid block is banded; the grid is
+                                 eliminated by a block-sparse LDL^T and the dense border [rig | points | poses] of 6 N + 3 P + 6 C rows is
+                                 factored instead (5 445 instead of 12 525 rows at BASELINE configs[1]: 0.39 instead of 0.77 TFLOP per
+                                 solve).  0 = automatic: grid-first on one GPU when a flop model of the two orders favours it (poses the
+                                 Schur blocks, intrinsics optimised, at least 2048 grid unknowns), pose-first otherwise (always with image
+                                 sharding: the reduced system that crosses the ranks is the pose-first one).  DESIGN.md section 3a */
+  int32_t grid_strips;        /* grid-first order: independent strips the long grid dimension is cut into (separated by 3-line
+                                 separators that are eliminated after the strips): one pivot chain per strip instead of one chain of
+                                 all grid unknowns.  0 = automatic (at most 4) */
 } cba_solver_options;
 
 typedef struct {

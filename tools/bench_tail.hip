@@ -108,7 +108,6 @@ __global__ void __launch_bounds__(256, 2) k_mma2_only(const double* S, int ld, c
   }
 }
 using namespace cba;
-namespace cba { int ldlt_back_solve(const double* S, int n_fact, int ld, int zcol, const LdltWorkspace& w, double* x, hipStream_t s); }
 
 static float timeit(hipEvent_t e0, hipEvent_t e1) { float ms; hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); return ms; }
 
