@@ -37,6 +37,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config id (1-5)")
+    ap.add_argument("--elimination", type=int, default=0, help="cba_solver_options.elimination: 0 = automatic (default), 1 = pose-first (the reference's order), 2 = grid-first")
+    ap.add_argument("--grid-strips", type=int, default=0, help="cba_solver_options.grid_strips (grid-first order; 0 = automatic)")
     ap.add_argument("--factor-tail-rows", type=int, default=0, help="cba_solver_options.factor_tail_rows (0 = the library default); schedule sweeps only")
     ap.add_argument("--imagesets", type=int, default=0, help="imagesets per GPU (0 = the config's count)")
     ap.add_argument("--fd-schedule", type=int, default=-1, help="cba_set_fd_schedule (0 pooled, 1 one task per lane); -1 = the library default; A/B runs only")
@@ -297,6 +299,7 @@ def main():
             allreduce = make_allreduce(keep, local_rank)
         e = eng.Engine(pb, device=local_rank, allreduce=allreduce, n_images_global=n_img * world,
                        reduce_buffer_ptr=reduce_ptr, reduce_buffer_doubles=reduce_n, distributed_solve=dist_solve, rank=rank, world_size=world, factor_tail_rows=args.factor_tail_rows,
+                       elimination=args.elimination, grid_strips=args.grid_strips,
                        collective=make_collective(local_rank) if dist_solve else None)
         if args.fd_schedule >= 0:
             e.set_fd_schedule(args.fd_schedule)

@@ -41,7 +41,12 @@ int64_t packed_upper_doubles(int n_pad);
 int launch_pack_upper(const double* S, int n_pad, double* P, int unpack, hipStream_t s);
 
 int launch_gf_form(double* F, int ldf, int Gf, int n_rp, int n_border, const int* grid_of_f, const double* Hdd, int ldh, const double* bd,
-                   const double* B, const double* Dblk, const double* bblk, double lambda, const int* tiles, int n_tiles, hipStream_t s);
+                   const double* B, const double* Dblk, const double* bblk, double lambda, const int* tiles, int n_tiles,
+                   const unsigned long long* act, int act_words, hipStream_t s);
+int launch_gf_activity(const PassArgs& pa, const uint8_t* flags, const int* cells, const int64_t* img_start, int n_images, const int* f_of_grid,
+                       int n_rp, int rig_dof, int n_tiles, int words, int nbg, int nbf, const unsigned long long* gridrow, unsigned long long* act,
+                       unsigned long long* kmask, int kwords, int tile0, const unsigned long long* rowmask_static, unsigned long long* rowmask,
+                       int mask_words, hipStream_t s);
 int launch_gf_scatter(const double* xF, int Gf, int n_rp, int block_dof, int G, const int* f_of_grid, double* x, hipStream_t s);
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -192,6 +197,8 @@ struct cba_problem {
   double* xF = nullptr;           // gf.n_fact: solution in the order of F
   int* gf_tiles = nullptr; int n_gf_tiles = 0;        // tiles of F the forming kernel writes
   int* gf_grid_of_f = nullptr; int* gf_f_of_grid = nullptr;
+  unsigned long long* gf_kmask_host = nullptr;    // pinned copy of the border update's K-slab masks (executed flops of the launch)
+  double gf_update_flops = 0;                     // executed flops of the border update with the masks of the last pass
 };
 
 namespace cba {
@@ -406,10 +413,25 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   CBA_HIP(hipStreamWaitEvent(p->stream, p->ev_aux1, 0));
   CBA_HIP(hipStreamWaitEvent(p->stream, p->ev_clear, 0));
   a.skip = nullptr;
+  const bool side = !L.localize_only;      // the per-cell accumulation runs on the side stream
   // (Running the assembly / accumulation of one chunk of imagesets next to the finite-difference launches of the
   // next chunk was measured and gained nothing: the two share the same CUs and the sum stayed the same.)
   CBA_TRY(launch_assemble(a, L, p->st[w], p->tasks_per_obs, p->rec_doubles, p->pixels, p->flags, p->fd_out, p->fd_ok,
                           p->jrec, p->cells, p->fd_slow, p->stream));
+  if (p->gridfirst) {
+    // Grid-first order: which grid block rows each 128-column tile of the border can reach in THIS pass (the control patch of an
+    // observation sits under its projected pixel), closed under the fill of the grid factor, and the masks derived from it -- on
+    // the side stream, underneath the accumulation (the per-cell kernel queued behind it there is waited for at the end of the pass)
+    const GfPlan& g = p->gf;
+    GfDevice& d = p->gfd;
+    CBA_HIP(hipEventRecord(p->ev_aux2, p->stream));
+    CBA_HIP(hipStreamWaitEvent(aux, p->ev_aux2, 0));
+    CBA_TRY(launch_gf_activity(a, p->flags, p->cells, p->img_start, L.n_images, p->gf_f_of_grid, g.n_rp, L.rig_in_state ? 6 * L.n_cameras : 0,
+                               d.n_act_tiles, d.act_words, g.nbg, g.nbf, d.gridrow, d.act, d.kmask, d.kmask_words, g.Gf / 128, d.rowmask, d.rowmask_dyn,
+                               d.mask_words, aux));
+    CBA_HIP(hipMemcpyAsync(p->gf_kmask_host, d.kmask, sizeof(unsigned long long) * (size_t)(g.n_pad / 128) * d.kmask_words, hipMemcpyDeviceToHost, aux));
+    if (!side) { CBA_HIP(hipEventRecord(p->ev_aux1, aux)); CBA_HIP(hipStreamWaitEvent(p->stream, p->ev_aux1, 0)); }
+  }
   double t0 = now_s();
   CBA_TRY(timer_begin(p, 2));
   AccumTargets T{p->Dblk, p->bblk, p->B, p->Hdd, p->bd};
@@ -422,7 +444,6 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   // stream next to the others; the per-point kernel (120 KB of LDS per workgroup, one per CU) goes FIRST on the main stream, alone:
   // next to the strips kernel its workgroups rarely find a CU with that much LDS free and the launch takes 3.9 ms instead of
   // ~0.6 at cfg 3 (measured, profiles/r03_v4_bench_cfg3_kernel_stats.txt).
-  const bool side = !L.localize_only;
   if (side) {
     CBA_HIP(hipEventRecord(p->ev_aux0, p->stream));
     CBA_HIP(hipStreamWaitEvent(aux, p->ev_aux0, 0));
@@ -491,13 +512,14 @@ static int solve_enqueue_gridfirst(cba_problem* p, double lambda) {
   CBA_HIP(hipMemsetAsync(p->status, 0, sizeof(int), p->stream));
   CBA_HIP(hipMemsetAsync(p->ldlt.status, 0, sizeof(int), p->stream));
   CBA_TRY(ldlt_clear_ctrl(p->ldlt, p->stream));
+  const GfDevice& d = p->gfd;
   CBA_TRY(launch_gf_form(p->F, ld, g.Gf, g.n_rp, g.n_border, p->gf_grid_of_f, p->Hdd, p->n_pad, p->bd, p->B, p->Dblk, p->bblk, lambda,
-                         p->gf_tiles, p->n_gf_tiles, p->stream));
+                         p->gf_tiles, p->n_gf_tiles, d.act, d.act_words, p->stream));
   GemmStats gs;
   CBA_TRY(timer_begin(p, 1));
-  CBA_TRY(ldlt_factor_gridfirst(p->F, g.n_fact, ld, p->gfd, p->Xb, ld - g.Gf, p->ldlt, p->stream, &gs, nullptr, 0, nullptr));
+  CBA_TRY(ldlt_factor_gridfirst(p->F, g.n_fact, ld, d, p->Xb, ld - g.Gf, p->ldlt, p->stream, &gs, d.kmask, d.kmask_words, nullptr));
   CBA_TRY(timer_end(p, 1, gs.flops, 0, gs.launches));
-  CBA_TRY(ldlt_back_solve(p->F, g.n_fact, ld, ld - 1, p->ldlt, p->xF, p->stream, p->gfd.rowmask, p->gfd.mask_words));
+  CBA_TRY(ldlt_back_solve(p->F, g.n_fact, ld, ld - 1, p->ldlt, p->xF, p->stream, d.rowmask_dyn, d.mask_words));
   CBA_TRY(launch_gf_scatter(p->xF, g.Gf, g.n_rp, L.block_dof, g.G, p->gf_f_of_grid, p->x, p->stream));
   if (!p->pin_status) CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->pin_status), 4 * sizeof(double)));
   hipLaunchKernelGGL(k_solve_status, dim3(1), dim3(64), 0, p->stream, p->status, p->ldlt.status, p->x, p->pin_status, p->status + 1);
@@ -588,6 +610,20 @@ static int solve_finish(cba_problem* p) {
   CBA_HIP(hipStreamSynchronize(p->stream));
   const int st[2] = {(int)p->pin_status[0], (int)p->pin_status[1]};
   p->last_x0 = p->pin_status[2];
+  if (p->gridfirst) {
+    // executed K slabs of the border update (masks of this pass, copied on the side stream during the pass): the launch's flops
+    const GfPlan& g = p->gf;
+    const int kw = p->gfd.kmask_words, t0 = g.Gf / 128, nt = (g.n_pad - g.Gf) / 128;
+    double slabs = 0;
+    for (int tm = 0; tm < nt; ++tm)
+      for (int tn = tm; tn < nt; ++tn)
+        for (int w = 0; w < kw; ++w)
+          slabs += __builtin_popcountll(p->gf_kmask_host[(size_t)(t0 + tm) * kw + w] & p->gf_kmask_host[(size_t)(t0 + tn) * kw + w]);
+    p->gf_update_flops = slabs * 2.0 * 128 * 128 * 16;
+    LdltWorkspace& w = p->ldlt;
+    for (int i = 0; i < w.spans_used; ++i)
+      if (w.spans[i].masked_update) { w.spans[i].flops = p->gf_update_flops; w.spans[i].masked_update = false; }
+  }
   if (!p->gridfirst) {
     double slabs = 0;
     for (int tm = 0; tm < mask_tiles; ++tm)
@@ -796,6 +832,25 @@ int cba_create(const cba_config* config, cba_problem** out) {
     CBA_HIP(hipMemcpy(p->gf_grid_of_f, g.grid_of_f.data(), sizeof(int) * g.grid_of_f.size(), hipMemcpyHostToDevice));
     CBA_TRY(dev_alloc(&p->gf_f_of_grid, g.f_of_grid.size()));
     CBA_HIP(hipMemcpy(p->gf_f_of_grid, g.f_of_grid.data(), sizeof(int) * g.f_of_grid.size(), hipMemcpyHostToDevice));
+    // activity of the row strips (per pass): bit sets over the grid block rows per 128-column border tile, and what is derived
+    {
+      GfDevice& d = p->gfd;
+      d.act_words = (g.nbg + 63) / 64;
+      d.n_act_tiles = (g.n_pad - g.Gf) / 128;
+      d.kmask_words = (g.Gf / 16 + 63) / 64;
+      CBA_TRY(dev_alloc(&d.act, (size_t)d.n_act_tiles * d.act_words));
+      CBA_TRY(dev_alloc(&d.kmask, (size_t)(g.n_pad / 128) * d.kmask_words));
+      CBA_HIP(hipMemset(d.kmask, 0, sizeof(unsigned long long) * (size_t)(g.n_pad / 128) * d.kmask_words));
+      CBA_TRY(dev_alloc(&d.rowmask_dyn, g.rowmask.size()));
+      std::vector<unsigned long long> gridrow((size_t)g.nbg * d.act_words, 0ull);
+      for (int r = 0; r < g.nbg; ++r)
+        for (int c = r + 1; c < g.nbg; ++c)
+          if ((g.rowmask[(size_t)r * g.mask_words + (c >> 6)] >> (c & 63)) & 1ull) gridrow[(size_t)r * d.act_words + (c >> 6)] |= 1ull << (c & 63);
+      CBA_TRY(dev_alloc(&d.gridrow, gridrow.size()));
+      CBA_HIP(hipMemcpy(d.gridrow, gridrow.data(), sizeof(unsigned long long) * gridrow.size(), hipMemcpyHostToDevice));
+      CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->gf_kmask_host), sizeof(unsigned long long) * (size_t)(g.n_pad / 128) * d.kmask_words));
+      std::memset(p->gf_kmask_host, 0, sizeof(unsigned long long) * (size_t)(g.n_pad / 128) * d.kmask_words);
+    }
   } else {
     CBA_TRY(dev_alloc(&p->W, (size_t)p->Kpad * p->n_pad));
     CBA_TRY(dev_alloc(&p->S, (size_t)p->n_pad * p->n_pad));
@@ -859,6 +914,8 @@ void cba_destroy(cba_problem* p) {
   F(p->x); F(p->scal); F(p->status); F(p->gemv_ws); F(p->kmask);
   F(p->F); F(p->Xb); F(p->xF); F(p->gf_tiles); F(p->gf_grid_of_f); F(p->gf_f_of_grid);
   F(p->gfd.tasks); F(p->gfd.ivals); F(p->gfd.chains); F(p->gfd.rowmask);
+  F(p->gfd.act); F(p->gfd.gridrow); F(p->gfd.kmask); F(p->gfd.rowmask_dyn);
+  if (p->gf_kmask_host) hipHostFree(p->gf_kmask_host);
   ldlt_workspace_free(p->ldlt);
   for (auto& t : p->timers) for (auto& sp : t.spans) { hipEventDestroy(sp.e0); hipEventDestroy(sp.e1); }
   if (p->kmask_host) hipHostFree(p->kmask_host);
@@ -981,6 +1038,31 @@ int cba_set_observations(cba_problem* p, int64_t n, const float* xy, const int32
     // Executed slabs of the product, modelled from the observation lists: x 0.86 (cfg 2), 0.85 (cfg 4), 0.83 (cfg 3) against the
     // Z-order; measured: profiles/r05_schur_row_order.txt.  The order is internal (x and the dumps are un-permuted); the sum over the
     // pose blocks is taken in another order, which moves S by rounding only.  O(N^2 T / 64): skipped above 8192 imagesets.
+    if (p->gridfirst) {
+      // Grid-first order: the pose columns of F are empty in the grid block rows the imageset does not reach (per-pass activity,
+      // k_gf_touch), per 128-column tile = ~21 imagesets.  Imagesets are ordered by the first row of F their control patches touch
+      // (under the MEASURED pixels: a heuristic, the activity itself comes from the projected ones), so that the imagesets of a tile
+      // start at about the same place of the elimination order and their union stays small.
+      const GfPlan& g = p->gf;
+      std::vector<int> first(L.n_images, 0x7fffffff);
+      for (int64_t i = 0; i < n; ++i) {
+        const int img = image_index[i], cam = camera_index[i];
+        const cba_camera& cm = p->cams[cam];
+        if (!std::isfinite(xy[2 * i]) || !std::isfinite(xy[2 * i + 1])) continue;
+        const int per = cm.model_type == CBA_CENTRAL_GENERIC ? 2 : 5;
+        const double gx = 1.0 + (cm.grid_w - 3.0) * (xy[2 * i] - cm.calib_min_x) / (cm.calib_max_x + 1.0 - cm.calib_min_x);      // central_grid.h:150-154
+        const double gy = 1.0 + (cm.grid_h - 3.0) * (xy[2 * i + 1] - cm.calib_min_y) / (cm.calib_max_y + 1.0 - cm.calib_min_y);
+        const int fx = (int)std::floor(gx + 2) - 3, fy = (int)std::floor(gy + 2) - 3;
+        for (int r = 0; r < 4; ++r)
+          for (int q = 0; q < 4; ++q) {
+            const int cx = fx + q, cy = fy + r;
+            if (cx < 0 || cy < 0 || cx >= cm.grid_w || cy >= cm.grid_h) continue;
+            const int e = L.intr_offset[cam] - g.n_rp + per * g.gperm[cam][cx + (size_t)cy * cm.grid_w];
+            first[img] = std::min(first[img], g.f_of_grid[e]);
+          }
+      }
+      std::stable_sort(order.begin(), order.end(), [&](int u, int v) { return first[u] < first[v]; });
+    } else
     if (!L.localize_only && L.n_images >= 4 && L.n_images <= 8192 && !p->dense_perm_host.empty()) {
       const int T = (L.dense_dof + 127) / 128, W = (T + 63) / 64;
       std::vector<unsigned long long> mask((size_t)L.n_images * W, 0ull);

@@ -156,7 +156,7 @@ struct LdltWorkspace {
   size_t n_alloc = 0;
   // kernel-only timing of the 128 x 128 GEMM launches of the factorisation (bulk and row-strip updates): event pairs
   // on the stream of each launch, read back by the caller after the step (ldlt_collect_spans)
-  struct Span { hipEvent_t e0 = nullptr, e1 = nullptr; double flops = 0; };
+  struct Span { hipEvent_t e0 = nullptr, e1 = nullptr; double flops = 0; bool masked_update = false; };
   std::vector<Span> spans;
   int spans_used = 0;
   // persistent tail launch (ldlt_tail): flags hold the number of the call that set them, nothing is cleared between calls
@@ -186,8 +186,13 @@ struct GfDevice {
   GfTask* tasks = nullptr; GfIval* ivals = nullptr; GfChain* chains = nullptr;
   int n_tasks0 = 0, n_tasks1 = 0, n_chains = 0;
   int nbg = 0, nbf = 0;
-  unsigned long long* rowmask = nullptr; int mask_words = 0;
+  unsigned long long* rowmask = nullptr; int mask_words = 0;      // static structure of every factored block row (the plan's)
   double flops_grid = 0;
+  // per Jacobian pass (launch_gf_activity): activity of the grid x border tiles and what is derived from it
+  unsigned long long* act = nullptr; int act_words = 0; int n_act_tiles = 0;
+  unsigned long long* gridrow = nullptr;          // [nbg][act_words]: structure of the grid x grid factor's rows (closure of the activity)
+  unsigned long long* kmask = nullptr; int kmask_words = 0;      // border update: [absolute 128-column tile][words], bit = 16-row K slab
+  unsigned long long* rowmask_dyn = nullptr;      // back substitution: rowmask with the border bits of the grid rows from `act`
 };
 // F = [grid | border] in the plan's order, ld = its n_pad; Xb: (rows of the grid part) x (ld - Gf) panel buffer (zero outside the
 // tiles the launch writes); kmask / chunk_order: optional block-sparsity of the border update (null = dense)

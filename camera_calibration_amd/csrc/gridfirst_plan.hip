@@ -20,14 +20,12 @@ struct Bits {
   bool get(int r, int c) const { return (row(r)[c >> 6] >> (c & 63)) & 1ull; }
 };
 
-// automatic number of strips: at least ~8 grid lines per strip, at most 4 strips (the separators' own chain grows with every cut:
-// at BASELINE configs[1] 2 / 3 / 4 / 5 / 6 strips give pivot chains of 82 / 60 / 52 / 50 / 50 blocks, one band gives 158)
-int auto_strips(int n_lines) {
-  int s = (n_lines + 3) / 11;
-  if (s < 1) s = 1;
-  if (s > 4) s = 4;
-  return s;
-}
+// automatic number of strips: two.  A banded factorisation is ONE chain of dependent pivots (158 blocks of 64 at BASELINE configs[1],
+// 17 us each: 2.7 ms for 52 GFLOP); two strips eliminated towards the separator between them are two chains of half the length
+// and cost nothing extra (no strip is eliminated away from a separator: 52 GFLOP).  Every further strip lies between two separators
+// and fills one of them through its whole length: 3 / 4 strips cost 68 / 78 GFLOP, and measured on MI355X the launch is then bound
+// by the tile tasks, not by the chains (4 strips: 2.5 ms).
+int auto_strips(int n_lines) { return n_lines >= 16 ? 2 : 1; }
 
 }  // namespace
 
@@ -92,18 +90,24 @@ int gf_build_plan(const cba_camera* cams, int C, int N, int P, int strips_overri
     }
     pl.gperm[c].assign((size_t)gw * gh, -1);
     int rank = 0;
-    auto place_lines = [&](int l0, int l1) {
-      for (int l = l0; l < l1; ++l)
+    auto place_lines = [&](int l0, int l1, bool backward = false) {
+      for (int li = l0; li < l1; ++li) {
+        const int l = backward ? l1 - 1 - (li - l0) : li;
         for (int t = 0; t < ns; ++t) {
           const int gx = long_is_x ? l : t, gy = long_is_x ? t : l;
           pl.gperm[c][gx + (size_t)gy * gw] = rank;
           for (int d = 0; d < ppg; ++d) pl.f_of_grid[cam_first[c] + ppg * rank + d] = f++;
           ++rank;
         }
+      }
     };
     for (int s = 0; s < S; ++s) {
       Group g{f, 0};
-      place_lines(strip_lines[s].first, strip_lines[s].second);
+      // A strip eliminated towards a separator meets it with its last band only; one eliminated AWAY from a separator fills that
+      // separator's rows of the factor through the whole strip (a "spike": at BASELINE configs[1] 23 GFLOP per spike against 43
+      // for the band itself).  The first strip runs forward, the last one backward (from the image border towards its separator):
+      // two strips have no spike at all, S strips have S - 2.
+      place_lines(strip_lines[s].first, strip_lines[s].second, S > 1 && s == S - 1);
       f = round_up_i(f, 64);
       g.f1 = f;
       groups[c].push_back(g);

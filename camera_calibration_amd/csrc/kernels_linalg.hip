@@ -758,7 +758,20 @@ struct TailArgs {
   const GfChain* chains;            // role i < n_chains runs chain i; ctrl[kCtrlChainCu + i] = its CU
   int n_chains;
   int n_critical;                   // helper workgroups (roles n_chains ... n_chains + n_critical - 1) that serve list 0 first
+  const unsigned long long* act;    // optional activity of the border tiles: [(c - x_c0) / 2][act_words], bit r = block row r of the 128-column
+  int act_words;                    // tile can be non-zero (kernels_gridfirst.hip: k_gf_touch / k_gf_close); inactive tiles are neither computed nor read
 };
+// first block row >= k (< kend) whose bit is set / clear in `bits`; kend if there is none
+__device__ __forceinline__ int bits_next(const unsigned long long* bits, int k, int kend, bool want_set) {
+  while (k < kend) {
+    unsigned long long w = bits[k >> 6];
+    if (!want_set) w = ~w;
+    w >>= (k & 63);
+    if (w) { const int hit = k + __builtin_ctzll(w); return hit < kend ? hit : kend; }
+    k = (k | 63) + 1;
+  }
+  return kend;
+}
 constexpr int kCtrlWords = 128;     // control words of a dataflow launch: [1] abort, [2] role tickets, [3] CU of the chain (dense launch),
 constexpr int kCtrlChainCu = 16;    // [8 + x] task tickets of list x, [kCtrlChainCu + i] CU of chain i (block-sparse launch)
 constexpr int kMaxChains = kCtrlWords - kCtrlChainCu;
@@ -1828,6 +1841,15 @@ __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, doubl
     }
 #endif
     if (SPARSE && kind == 3) kind = 1;           // PARTFULL: a PART task whose intervals reach up to the row above the tile
+    // border tile of the row strip: its 128-column tile's activity bits (uniform)
+    const unsigned long long* arow = nullptr;
+    if (SPARSE && t.act && kind == 2 && c >= t.x_c0) {
+      arow = t.act + (size_t)((c - t.x_c0) >> 1) * t.act_words;
+      if (!((arow[r >> 6] >> (r & 63)) & 1ull)) {          // nothing touches this tile and no fill reaches it: not computed, not read
+        tail_publish(&t.tile_flag[(size_t)(r - t.rt0) * t.ntc + c], t.epoch);
+        continue;
+      }
+    }
     const int ca = (kind == 1) ? c : r;          // column block of the A operand: PART is L_{k,r+1}^T d L_{k,r+1}
     v4f64 acc[2][2];
 #pragma unroll
@@ -1854,8 +1876,14 @@ __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, doubl
         k = __builtin_amdgcn_readfirstlane(v.k0); kend = __builtin_amdgcn_readfirstlane(v.k1);
       }
       while (k < kend) {
+        int run_end = kend;
+        if (SPARSE && arow) {                      // only the rows whose tile (k, c) exists
+          k = bits_next(arow, k, kend, true);
+          if (k >= kend) break;
+          run_end = bits_next(arow, k, kend, false);
+        }
         const unsigned long long h0 = HELP_NOW();
-        const int nrows = tail_wait_rows(t, k, kend, ca, c, slot);
+        const int nrows = tail_wait_rows(t, k, run_end, ca, c, slot);
         if (nrows <= 0) return;
         const unsigned long long h1 = HELP_NOW();
         const double* A = t.S + (size_t)k * kInner * ld + (size_t)ca * kInner;
@@ -2297,6 +2325,7 @@ static int ldlt_sparse(double* F, int ld, const GfDevice& g, LdltWorkspace& w, h
   t.ctrl = w.tail_ctrl;
   t.epoch = ++w.tail_epoch;
   t.tasks = g.tasks; t.ivals = g.ivals; t.chains = g.chains; t.n_chains = g.n_chains;
+  t.act = g.act; t.act_words = g.act_words;
   for (int x = 0; x < 8; ++x) t.ntasks_x[x] = 0;
   t.ntasks_x[0] = g.n_tasks0; t.ntasks_x[1] = g.n_tasks1;
   t.ntasks = g.n_tasks0 + g.n_tasks1;
@@ -2345,6 +2374,7 @@ int ldlt_factor_gridfirst(double* F, int n_fact, int ld, const GfDevice& g, doub
   u.m_off = Gf; u.m_tiles = tl; u.n_off = Gf; u.n_tiles = tl;
   u.kmask = kmask; u.kmask_words = kmask_words; u.slab16 = 1; u.chunk_order = chunk_order;
   if ((rc = timed_gemm128(u, s, w, st != nullptr, (double)tl * (tl + 1) / 2))) return rc;
+  if (st && kmask && w.spans_used > 0) w.spans[w.spans_used - 1].masked_update = true;      // (the caller replaces the dense flop count by the executed one)
   if (st) { const double rows = (double)(ld - Gf); st->flops += rows * rows * Gf; st->launches += 1; }
   return ldlt_factor(F, n_fact, ld, w, s, st, Gf);
 }

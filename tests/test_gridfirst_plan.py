@@ -261,11 +261,14 @@ def test_more_workers_and_other_seeds_agree():
     assert np.allclose(xs[0], xs[2], rtol=0, atol=1e-12 * np.max(np.abs(xs[0])))
 
 
-def test_strips_shorten_the_pivot_chain_at_the_headline_configuration():
+def test_two_strips_halve_the_pivot_chain_at_the_headline_configuration_for_free():
     cam = Camera(CENTRAL_GENERIC, 2048, 1456, 0, 0, 2047, 1455, 84, 60)
     one = engine.gridfirst_plan([cam], 500, 815, 1)
-    four = engine.gridfirst_plan([cam], 500, 815, 0)
+    auto = engine.gridfirst_plan([cam], 500, 815, 0)
     assert one["half_bandwidth"] == 367 and one["n_chains"] == 1 and one["chains"][0][1] - one["chains"][0][0] == 158
     longest = lambda p, dep: max([int(c[1] - c[0]) for c in p["chains"] if c[2] == dep] or [0])
-    assert four["strips0"] == 4 and longest(four, 0) + longest(four, 1) <= 60
-    assert four["n_border"] == 5445
+    assert auto["strips0"] == 2 and longest(auto, 0) + longest(auto, 1) <= 84
+    assert auto["n_border"] == 5445
+    # two strips eliminated towards their separator cost no more than one band; every further strip fills a separator
+    assert auto["flops"][0] <= 1.02 * one["flops"][0]
+    assert engine.gridfirst_plan([cam], 500, 815, 4)["flops"][0] >= 1.3 * one["flops"][0]
