@@ -418,20 +418,6 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
   // next chunk was measured and gained nothing: the two share the same CUs and the sum stayed the same.)
   CBA_TRY(launch_assemble(a, L, p->st[w], p->tasks_per_obs, p->rec_doubles, p->pixels, p->flags, p->fd_out, p->fd_ok,
                           p->jrec, p->cells, p->fd_slow, p->stream));
-  if (p->gridfirst) {
-    // Grid-first order: which grid block rows each 128-column tile of the border can reach in THIS pass (the control patch of an
-    // observation sits under its projected pixel), closed under the fill of the grid factor, and the masks derived from it -- on
-    // the side stream, underneath the accumulation (the per-cell kernel queued behind it there is waited for at the end of the pass)
-    const GfPlan& g = p->gf;
-    GfDevice& d = p->gfd;
-    CBA_HIP(hipEventRecord(p->ev_aux2, p->stream));
-    CBA_HIP(hipStreamWaitEvent(aux, p->ev_aux2, 0));
-    CBA_TRY(launch_gf_activity(a, p->flags, p->cells, p->img_start, L.n_images, p->gf_f_of_grid, g.n_rp, L.rig_in_state ? 6 * L.n_cameras : 0,
-                               d.n_act_tiles, d.act_words, g.nbg, g.nbf, d.gridrow, d.act, d.kmask, d.kmask_words, g.Gf / 128, d.rowmask, d.rowmask_dyn,
-                               d.mask_words, aux));
-    CBA_HIP(hipMemcpyAsync(p->gf_kmask_host, d.kmask, sizeof(unsigned long long) * (size_t)(g.n_pad / 128) * d.kmask_words, hipMemcpyDeviceToHost, aux));
-    if (!side) { CBA_HIP(hipEventRecord(p->ev_aux1, aux)); CBA_HIP(hipStreamWaitEvent(p->stream, p->ev_aux1, 0)); }
-  }
   double t0 = now_s();
   CBA_TRY(timer_begin(p, 2));
   AccumTargets T{p->Dblk, p->bblk, p->B, p->Hdd, p->bd};
@@ -450,6 +436,17 @@ static int jacobian_pass_and_accumulate(cba_problem* p, double* t_acc) {
     CBA_TRY(launch_accumulate_cells(a, p->cams, p->cell_base_host, p->rec_doubles, p->n_pad, p->flags, p->jrec, p->cells, p->cell_base,
                                     p->cell_count, p->cell_start, p->cell_fill, p->cell_order, p->Hdd,
                                     (!L.eliminate_points && L.rig_in_state) ? L.first_camera_tr_rig - L.block_dof : -1, det, p->bd, aux));
+    if (p->gridfirst) {
+      // Grid-first order: which grid block rows each 128-column tile of the border can reach in THIS pass (the control patch of an
+      // observation sits under its projected pixel), closed under the fill of the grid factor, and the masks derived from it -- on
+      // the side stream behind the per-cell accumulation, underneath the strips kernel of the main stream (waited for at the end of the pass)
+      const GfPlan& g = p->gf;
+      GfDevice& d = p->gfd;
+      CBA_TRY(launch_gf_activity(a, p->flags, p->cells, p->img_start, L.n_images, p->gf_f_of_grid, g.n_rp, L.rig_in_state ? 6 * L.n_cameras : 0,
+                                 d.n_act_tiles, d.act_words, g.nbg, g.nbf, d.gridrow, d.act, d.kmask, d.kmask_words, g.Gf / 128, d.rowmask, d.rowmask_dyn,
+                                 d.mask_words, aux));
+      CBA_HIP(hipMemcpyAsync(p->gf_kmask_host, d.kmask, sizeof(unsigned long long) * (size_t)(g.n_pad / 128) * d.kmask_words, hipMemcpyDeviceToHost, aux));
+    }
     CBA_HIP(hipEventRecord(p->ev_aux1, aux));
   }
   if (points_separate)
@@ -842,12 +839,8 @@ int cba_create(const cba_config* config, cba_problem** out) {
       CBA_TRY(dev_alloc(&d.kmask, (size_t)(g.n_pad / 128) * d.kmask_words));
       CBA_HIP(hipMemset(d.kmask, 0, sizeof(unsigned long long) * (size_t)(g.n_pad / 128) * d.kmask_words));
       CBA_TRY(dev_alloc(&d.rowmask_dyn, g.rowmask.size()));
-      std::vector<unsigned long long> gridrow((size_t)g.nbg * d.act_words, 0ull);
-      for (int r = 0; r < g.nbg; ++r)
-        for (int c = r + 1; c < g.nbg; ++c)
-          if ((g.rowmask[(size_t)r * g.mask_words + (c >> 6)] >> (c & 63)) & 1ull) gridrow[(size_t)r * d.act_words + (c >> 6)] |= 1ull << (c & 63);
-      CBA_TRY(dev_alloc(&d.gridrow, gridrow.size()));
-      CBA_HIP(hipMemcpy(d.gridrow, gridrow.data(), sizeof(unsigned long long) * gridrow.size(), hipMemcpyHostToDevice));
+      CBA_TRY(dev_alloc(&d.gridrow, g.gridrow.size()));
+      CBA_HIP(hipMemcpy(d.gridrow, g.gridrow.data(), sizeof(uint64_t) * g.gridrow.size(), hipMemcpyHostToDevice));
       CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->gf_kmask_host), sizeof(unsigned long long) * (size_t)(g.n_pad / 128) * d.kmask_words));
       std::memset(p->gf_kmask_host, 0, sizeof(unsigned long long) * (size_t)(g.n_pad / 128) * d.kmask_words);
     }
@@ -1044,7 +1037,8 @@ int cba_set_observations(cba_problem* p, int64_t n, const float* xy, const int32
       // (under the MEASURED pixels: a heuristic, the activity itself comes from the projected ones), so that the imagesets of a tile
       // start at about the same place of the elimination order and their union stays small.
       const GfPlan& g = p->gf;
-      std::vector<int> first(L.n_images, 0x7fffffff);
+      const int W = g.grid_words;
+      std::vector<uint64_t> touched((size_t)L.n_images * W, 0ull);
       for (int64_t i = 0; i < n; ++i) {
         const int img = image_index[i], cam = camera_index[i];
         const cba_camera& cm = p->cams[cam];
@@ -1058,10 +1052,14 @@ int cba_set_observations(cba_problem* p, int64_t n, const float* xy, const int32
             const int cx = fx + q, cy = fy + r;
             if (cx < 0 || cy < 0 || cx >= cm.grid_w || cy >= cm.grid_h) continue;
             const int e = L.intr_offset[cam] - g.n_rp + per * g.gperm[cam][cx + (size_t)cy * cm.grid_w];
-            first[img] = std::min(first[img], g.f_of_grid[e]);
+            const int r0 = g.f_of_grid[e] >> 6, r1 = g.f_of_grid[e + per - 1] >> 6;
+            touched[(size_t)img * W + (r0 >> 6)] |= 1ull << (r0 & 63);
+            touched[(size_t)img * W + (r1 >> 6)] |= 1ull << (r1 & 63);
           }
       }
-      std::stable_sort(order.begin(), order.end(), [&](int u, int v) { return first[u] < first[v]; });
+      std::vector<int> slot_of;
+      gf_order_imagesets(g, touched, L.n_images, g.n_rp, &slot_of);
+      for (int i = 0; i < L.n_images; ++i) order[slot_of[i]] = i;
     } else
     if (!L.localize_only && L.n_images >= 4 && L.n_images <= 8192 && !p->dense_perm_host.empty()) {
       const int T = (L.dense_dof + 127) / 128, W = (T + 63) / 64;

@@ -55,6 +55,9 @@ struct GfPlan {
   std::vector<GfIval> ivals;
   int mask_words = 0;
   std::vector<uint64_t> rowmask;  // [nbf][mask_words]: bit c = tile (r, c), c > r, can be non-zero in the factor
+  int grid_words = 0;
+  std::vector<uint64_t> gridrow;  // [nbg][grid_words]: the grid x grid part of rowmask (bit c, r < c < nbg): what the fill of a border
+                                  // column follows (closure of the row strips' activity, k_gf_close / gf_order_imagesets)
   // 64 x 64 tiles of the grid x grid part that hold input data (the forming kernel copies these; fill-only tiles are zeroed)
   std::vector<int> grid_tiles;    // pairs (r, c), r <= c < nbg, every tile of rowmask (+ the diagonal tiles)
   double flops_grid = 0, flops_update = 0, flops_border = 0;   // model: dataflow launch of the grid rows, border update, border factorisation
@@ -63,6 +66,14 @@ struct GfPlan {
 
 // strips_override: 0 = automatic, >= 1 = that many strips per camera (clamped to what the grid allows).  Returns CBA_OK / CBA_ERR_ARG.
 int gf_build_plan(const cba_camera* cams, int n_cameras, int n_images, int n_points, int strips_override, GfPlan* out);
+
+// Order of the imagesets' pose columns in the border (slot of every imageset).  first_rows[i]: bit set over the grid block rows
+// (plan.grid_words words) that imageset i touches -- from the measured pixels, a prediction of the per-pass activity.  The border
+// update skips, per 128-column tile (~21 imagesets) and 16-row slab, what NO column of the tile reaches, so imagesets are grouped
+// greedily: a tile is seeded with the unplaced imageset that starts earliest in the elimination order and filled with the
+// imagesets that enlarge the tile's union (closed under the fill of the grid factor) least.  first_col: border index of slot 0's
+// first column (tiles are counted in border columns).
+void gf_order_imagesets(const GfPlan& plan, const std::vector<uint64_t>& touched_rows, int n_images, int first_col, std::vector<int>* slot_of_image);
 
 // flop model of the two elimination orders (dense border columns): used by the automatic choice
 void gf_flop_model(const cba_camera* cams, int n_cameras, int n_images, int n_points, double* pose_first, double* grid_first);

@@ -49,6 +49,55 @@ void gf_flop_model(const cba_camera* cams, int C, int N, int P, double* pose_fir
   if (grid_first) *grid_first = band + strip + A * A * G + A * A * A / 3.0;
 }
 
+void gf_order_imagesets(const GfPlan& pl, const std::vector<uint64_t>& touched, int N, int first_col, std::vector<int>* slot_of_image) {
+  const int W = pl.grid_words, nbg = pl.nbg;
+  slot_of_image->assign(N, 0);
+  if (N == 0) return;
+  // closure of every imageset's rows under the fill of the grid factor
+  std::vector<uint64_t> act((size_t)N * W, 0ull);
+  std::vector<int> first(N, nbg), bits(N, 0);
+  for (int i = 0; i < N; ++i) {
+    uint64_t* a = &act[(size_t)i * W];
+    for (int w = 0; w < W; ++w) a[w] = touched[(size_t)i * W + w];
+    for (int r = 0; r < nbg; ++r)
+      if ((a[r >> 6] >> (r & 63)) & 1ull) {
+        if (first[i] == nbg) first[i] = r;
+        for (int w = r >> 6; w < W; ++w) a[w] |= pl.gridrow[(size_t)r * W + w];
+      }
+    for (int w = 0; w < W; ++w) bits[i] += __builtin_popcountll(a[w]);
+  }
+  std::vector<char> placed(N, 0);
+  std::vector<uint64_t> uni(W);
+  int slot = 0;
+  while (slot < N) {
+    // imagesets of the 128-column tile that slot's first column falls into: up to the first slot that starts in the next tile
+    const int tile = (first_col + 6 * slot) >> 7;
+    int count = 0;
+    while (slot + count < N && ((first_col + 6 * (slot + count)) >> 7) == tile) ++count;
+    int seed = -1;
+    for (int i = 0; i < N; ++i)
+      if (!placed[i] && (seed < 0 || first[i] < first[seed] || (first[i] == first[seed] && bits[i] < bits[seed]))) seed = i;
+    for (int w = 0; w < W; ++w) uni[w] = act[(size_t)seed * W + w];
+    (*slot_of_image)[seed] = slot; placed[seed] = 1;
+    for (int k = 1; k < count; ++k) {
+      int best = -1, best_grow = 0x7fffffff, best_dist = 0x7fffffff;
+      for (int i = 0; i < N; ++i) {
+        if (placed[i]) continue;
+        int grow = 0, dist = 0;
+        for (int w = 0; w < W; ++w) {
+          const uint64_t a = act[(size_t)i * W + w];
+          grow += __builtin_popcountll(a & ~uni[w]);
+          dist += __builtin_popcountll(a ^ uni[w]);
+        }
+        if (grow < best_grow || (grow == best_grow && dist < best_dist)) { best = i; best_grow = grow; best_dist = dist; }
+      }
+      for (int w = 0; w < W; ++w) uni[w] |= act[(size_t)best * W + w];
+      (*slot_of_image)[best] = slot + k; placed[best] = 1;
+    }
+    slot += count;
+  }
+}
+
 int gf_build_plan(const cba_camera* cams, int C, int N, int P, int strips_override, GfPlan* out) {
   if (!cams || !out || C < 1 || C > 16 || N < 0 || P < 0) return CBA_ERR_ARG;
   GfPlan& pl = *out;
@@ -255,6 +304,11 @@ int gf_build_plan(const cba_camera* cams, int C, int N, int P, int strips_overri
   for (int r = 0; r < nbg; ++r)
     for (int c = r; c < nbg; ++c)
       if (up.get(r, c)) { pl.grid_tiles.push_back(r); pl.grid_tiles.push_back(c); }
+  pl.grid_words = (nbg + 63) / 64;
+  pl.gridrow.assign((size_t)nbg * pl.grid_words, 0ull);
+  for (int r = 0; r < nbg; ++r)
+    for (int c = r + 1; c < nbg; ++c)
+      if (up.get(r, c)) pl.gridrow[(size_t)r * pl.grid_words + (c >> 6)] |= 1ull << (c & 63);
   {
     const double A = (double)(pl.n_pad - pl.Gf);
     pl.flops_update = A * A * (double)pl.Gf;             // upper triangle, 2 flops per multiply-add

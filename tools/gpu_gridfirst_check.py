@@ -85,10 +85,12 @@ def step_case(name, pb, st, steps, modes):
             r = e.step(lam)
             lam = r.final_lambda
             reps.append(r)
+        ks = e.kernel_stats(4)
+        upd = f"  in-factor GEMMs of the last step: {ks['launches']} launches, {ks['flops'] / 1e9:.1f} GFLOP, {ks['seconds'] * 1e3:.2f} ms" if ks["launches"] else ""
         tail = reps[1:] if len(reps) > 1 else reps
         ms = lambda f: 1e3 * np.mean([getattr(r, f) for r in tail])
         print(f"   {label:>22}: costs {[f'{r.final_cost:.6g}' for r in reps]} attempts {[r.lm_attempts for r in reps]}"
-              f"  t_jac {ms('t_jac'):.2f} t_solve {ms('t_solve'):.2f} (factor {ms('t_factor'):.2f}, gemm {ms('t_gemm'):.2f}) t_cost {ms('t_cost'):.2f} ms", flush=True)
+              f"  t_jac {ms('t_jac'):.2f} t_solve {ms('t_solve'):.2f} (factor {ms('t_factor'):.2f}, gemm {ms('t_gemm'):.2f}) t_cost {ms('t_cost'):.2f} ms{upd}", flush=True)
         e.close()
 
 
