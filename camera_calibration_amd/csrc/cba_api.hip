@@ -199,6 +199,9 @@ struct cba_problem {
   int* gf_grid_of_f = nullptr; int* gf_f_of_grid = nullptr;
   unsigned long long* gf_kmask_host = nullptr;    // pinned copy of the border update's K-slab masks (executed flops of the launch)
   double gf_update_flops = 0;                     // executed flops of the border update with the masks of the last pass
+  // order of the border update's tiles, heaviest first, from the masks of the PREVIOUS solve (a scheduling hint: any permutation is
+  // correct, and the activity hardly moves from pass to pass)
+  int* gf_tile_list = nullptr; int* gf_tile_list_host = nullptr; bool gf_tile_list_valid = false; unsigned gf_tile_list_age = 0;
 };
 
 namespace cba {
@@ -514,7 +517,13 @@ static int solve_enqueue_gridfirst(cba_problem* p, double lambda) {
                          p->gf_tiles, p->n_gf_tiles, d.act, d.act_words, p->stream));
   GemmStats gs;
   CBA_TRY(timer_begin(p, 1));
-  CBA_TRY(ldlt_factor_gridfirst(p->F, g.n_fact, ld, d, p->Xb, ld - g.Gf, p->ldlt, p->stream, &gs, d.kmask, d.kmask_words, nullptr));
+  const int* tile_list = nullptr;
+  if (p->gf_tile_list_valid) {
+    const size_t nt = (size_t)d.n_act_tiles;
+    CBA_HIP(hipMemcpyAsync(p->gf_tile_list, p->gf_tile_list_host, sizeof(int) * nt * (nt + 1), hipMemcpyHostToDevice, p->stream));
+    tile_list = p->gf_tile_list;
+  }
+  CBA_TRY(ldlt_factor_gridfirst(p->F, g.n_fact, ld, d, p->Xb, ld - g.Gf, p->ldlt, p->stream, &gs, d.kmask, d.kmask_words, tile_list));
   CBA_TRY(timer_end(p, 1, gs.flops, 0, gs.launches));
   CBA_TRY(ldlt_back_solve(p->F, g.n_fact, ld, ld - 1, p->ldlt, p->xF, p->stream, d.rowmask_dyn, d.mask_words));
   CBA_TRY(launch_gf_scatter(p->xF, g.Gf, g.n_rp, L.block_dof, g.G, p->gf_f_of_grid, p->x, p->stream));
@@ -617,6 +626,21 @@ static int solve_finish(cba_problem* p) {
         for (int w = 0; w < kw; ++w)
           slabs += __builtin_popcountll(p->gf_kmask_host[(size_t)(t0 + tm) * kw + w] & p->gf_kmask_host[(size_t)(t0 + tn) * kw + w]);
     p->gf_update_flops = slabs * 2.0 * 128 * 128 * 16;
+    // tile order of the NEXT border updates: executed slabs descending, row-major among equals (host work while the device idles:
+    // first solve, then every 8th)
+    if (!p->gf_tile_list_valid || (++p->gf_tile_list_age & 7) == 0) {
+      std::vector<std::pair<int, int>> work;
+      work.reserve((size_t)nt * (nt + 1) / 2);
+      for (int tm = 0; tm < nt; ++tm)
+        for (int tn = tm; tn < nt; ++tn) {
+          int sl = 0;
+          for (int w = 0; w < kw; ++w) sl += __builtin_popcountll(p->gf_kmask_host[(size_t)(t0 + tm) * kw + w] & p->gf_kmask_host[(size_t)(t0 + tn) * kw + w]);
+          work.push_back({sl, tm * nt + tn});
+        }
+      std::stable_sort(work.begin(), work.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
+      for (size_t i = 0; i < work.size(); ++i) { p->gf_tile_list_host[2 * i] = work[i].second / nt; p->gf_tile_list_host[2 * i + 1] = work[i].second % nt; }
+      p->gf_tile_list_valid = true;
+    }
     LdltWorkspace& w = p->ldlt;
     for (int i = 0; i < w.spans_used; ++i)
       if (w.spans[i].masked_update) { w.spans[i].flops = p->gf_update_flops; w.spans[i].masked_update = false; }
@@ -841,6 +865,11 @@ int cba_create(const cba_config* config, cba_problem** out) {
       CBA_TRY(dev_alloc(&d.rowmask_dyn, g.rowmask.size()));
       CBA_TRY(dev_alloc(&d.gridrow, g.gridrow.size()));
       CBA_HIP(hipMemcpy(d.gridrow, g.gridrow.data(), sizeof(uint64_t) * g.gridrow.size(), hipMemcpyHostToDevice));
+      {
+        const size_t nt = (size_t)d.n_act_tiles;
+        CBA_TRY(dev_alloc(&p->gf_tile_list, nt * (nt + 1)));
+        CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->gf_tile_list_host), sizeof(int) * nt * (nt + 1)));
+      }
       CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->gf_kmask_host), sizeof(unsigned long long) * (size_t)(g.n_pad / 128) * d.kmask_words));
       std::memset(p->gf_kmask_host, 0, sizeof(unsigned long long) * (size_t)(g.n_pad / 128) * d.kmask_words);
     }
@@ -909,6 +938,8 @@ void cba_destroy(cba_problem* p) {
   F(p->gfd.tasks); F(p->gfd.ivals); F(p->gfd.chains); F(p->gfd.rowmask);
   F(p->gfd.act); F(p->gfd.gridrow); F(p->gfd.kmask); F(p->gfd.rowmask_dyn);
   if (p->gf_kmask_host) hipHostFree(p->gf_kmask_host);
+  F(p->gf_tile_list);
+  if (p->gf_tile_list_host) hipHostFree(p->gf_tile_list_host);
   ldlt_workspace_free(p->ldlt);
   for (auto& t : p->timers) for (auto& sp : t.spans) { hipEventDestroy(sp.e0); hipEventDestroy(sp.e1); }
   if (p->kmask_host) hipHostFree(p->kmask_host);
