@@ -37,6 +37,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config id (1-5)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short side legs of BASELINE configs[2] and configs[3] behind the headline leg (config 2, one GPU)")
     ap.add_argument("--elimination", type=int, default=0, help="cba_solver_options.elimination: 0 = automatic (default), 1 = pose-first (the reference's order), 2 = grid-first")
     ap.add_argument("--grid-strips", type=int, default=0, help="cba_solver_options.grid_strips (grid-first order; 0 = automatic)")
     ap.add_argument("--factor-tail-rows", type=int, default=0, help="cba_solver_options.factor_tail_rows (0 = the library default); schedule sweeps only")
@@ -309,6 +310,7 @@ def main():
         """One complete measurement with its own engine: warm-up, barrier + synchronize, exactly --steps timed steps, barrier +
         synchronize, MAX over ranks.  The engine stays open in the result (the caller closes it)."""
         e, keep = open_engine(dist_solve)
+        order = e.elimination_order()
         e.set_state(st0)
         state = {"lam": -1.0, "it": 0}
         reports = []
@@ -354,7 +356,7 @@ def main():
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             ranks_consistent = bool(torch.equal(lo, hi))
         return {"engine": e, "keep": keep, "dist_solve": dist_solve, "elapsed": elapsed, "reports": reports, "agg": agg,
-                "ranks_consistent": ranks_consistent}
+                "ranks_consistent": ranks_consistent, "order": order}
 
     def leg_summary(leg: dict) -> dict:
         reps = leg["reports"]
@@ -387,6 +389,9 @@ def main():
         try:
             n_l = ((pb.dense_dof + 1 + 127) // 128) * 128
             K_l = 2048          # the K of a super-panel update (ldlt_factor), the launch shape that carries most of the flops
+            if best["order"]["order"] == "grid-first":      # the border update: n = the border, K = the grid part
+                n_l = ((best["order"]["dense_rows"] + 1 + 127) // 128) * 128
+                K_l = best["order"]["grid_rows"]
             A_l = torch.randn(K_l, n_l, dtype=torch.float64, device=f"cuda:{local_rank}")
             B_l = torch.randn(K_l, n_l, dtype=torch.float64, device=f"cuda:{local_rank}")
             torch.mm(A_l.t(), B_l)
@@ -405,6 +410,8 @@ def main():
     def build_output(leg: dict) -> dict:
         """The JSON line of one leg (rank 0)."""
         reports, agg, elapsed, dist_solve, ranks_consistent = leg["reports"], leg["agg"], leg["elapsed"], leg["dist_solve"], leg["ranks_consistent"]
+        order = leg["order"]
+        gridfirst = order["order"] == "grid-first"
         ms_per_step = elapsed / max(1, args.steps) * 1e3
         # SURVEY 8(d): n_valid / t_iter.  n_residuals_valid is the whole job's count (the 8-double scalar all-reduce of the
         # Jacobian pass sums it over the ranks); invalid residuals (projection failed, APP joint_optimization.cc:334-342) do not count
@@ -452,17 +459,26 @@ def main():
                        "parallelism": (f"image-sharded x{world}" + (", distributed factorisation" if dist_solve else ", replicated factorisation")) if world > 1 else ("single GPU (all-reduce path forced)" if use_dist else "single GPU"),
                        "lm_attempts_per_step": [r.lm_attempts for r in reports],
                        "trajectory_restart_every": RESTART,
+                       "elimination": order,
                        "cost": [reports[0].initial_cost, reports[-1].final_cost], "ranks_consistent": ranks_consistent,
                        "model_ceiling_ms": _model_ceiling(args.config, world) if world > 1 else None},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                          "library_tflops": lib_tflops, "frac_vs_library": (ach / lib_tflops) if lib_tflops else None,
                          "library_note": "rocBLAS / hipBLASLt DGEMM through torch.mm on the same device in this process, outside the "
-                                         "timed region: C[n x n] = A^T[n x K] B[K x n], n = the padded reduced system, K = 2048 (the "
-                                         "shape of a super-panel update; the library computes the full square, the kernel its upper triangle), best of 5",
+                                         "timed region: C[n x n] = A^T[n x K] B[K x n], " +
+                                         ("n = the padded border system, K = the rows of the grid part (the shape of the border update; the library "
+                                          "computes the full dense square, the kernel the upper triangle and only the K slabs its masks keep), best of 5"
+                                          if gridfirst else
+                                          "n = the padded reduced system, K = 2048 (the "
+                                          "shape of a super-panel update; the library computes the full square, the kernel its upper triangle), best of 5"),
                          "traffic": pmc_traffic.get("traffic_bytes_per_launch"),
                          "traffic_unit": "bytes/launch", "traffic_source": pmc_traffic.get("source"), "traffic_stale": traffic_stale,
-                         "kernel": "k_gemm_atb<128,128,64,64> (two instantiations: the block-sparse Schur product B^T D^-1 B in 12-row K slabs, and the dense super-panel updates of the LDL^T in 16-row stages, K = the super-panel width, ~2048), kernel time",
+                         "kernel": ("k_gemm_atb<128,128,64,64,true,16> -- grid-first elimination order: the update of the border system by the eliminated "
+                                    "grid part, C -= L^T (D L), K = the rows of the grid part, block-sparse in K (16-row slabs, per-pass activity masks of "
+                                    "the 128-column border tiles), tiles handed out heaviest first; flops = the executed slabs; kernel time"
+                                    if gridfirst else
+                                    "k_gemm_atb<128,128,64,64> (two instantiations: the block-sparse Schur product B^T D^-1 B in 12-row K slabs, and the dense super-panel updates of the LDL^T in 16-row stages, K = the super-panel width, ~2048), kernel time"),
                          "launches": dom_n, "avg_launch_ms": dom_s / max(1, dom_n) * 1e3,
                          "flops_per_launch": dom_f / max(1, dom_n),
                          "factorisation_span": {"tflops": (agg[1]["flops"] / agg[1]["seconds"] / 1e12) if agg[1]["seconds"] > 0 else 0.0,
@@ -533,6 +549,46 @@ def main():
         return out
 
     out = build_output(best) if rank == 0 else None
+
+    # ---- BASELINE configs[2] and configs[3] (stereo rig, 1000 imagesets; non-central camera, 800 imagesets) as short side legs:
+    # ---- outside the headline's timed region, their own engines, 2 warm-up + 5 timed steps each, same step definition
+    if rank == 0 and args.config == 2 and world == 1 and not use_dist and not args.no_other_configs:
+        others = {}
+        for cfg_o in (3, 4):
+            try:
+                t_o = time.time()
+                pb_o, st_o, _ = syn.baseline_config(cfg_o, proj)
+                e_o = eng.Engine(pb_o, device=local_rank, elimination=args.elimination, grid_strips=args.grid_strips)
+                e_o.set_state(st_o)
+                lam_o, reps_o, agg_o = -1.0, [], {k: 0.0 for k in (0, 3)}
+                for _ in range(2):
+                    r_o = e_o.step(lam_o); lam_o = r_o.final_lambda
+                e_o.set_state(st_o); lam_o = -1.0
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i_o in range(5):
+                    if i_o == RESTART:
+                        e_o.set_state(st_o); lam_o = -1.0
+                    r_o = e_o.step(lam_o); lam_o = r_o.final_lambda
+                    reps_o.append(r_o)
+                    for k in agg_o:
+                        agg_o[k] += e_o.kernel_stats(k)["seconds"]
+                torch.cuda.synchronize()
+                el_o = time.perf_counter() - t1
+                others[f"cfg{cfg_o}"] = {
+                    "workload": f"BASELINE configs[{cfg_o - 1}]: {pb_o.n_cameras} cam, {pb_o.n_images} imagesets, {pb_o.n_obs} observations, D={pb_o.dense_dof}",
+                    "elimination": e_o.elimination_order(), "steps": 5, "warmup": 2,
+                    "ms_per_step": el_o / 5 * 1e3, "value": sum(r.n_residuals_valid for r in reps_o) / el_o / 1e6,
+                    "lm_attempts_per_step": [r.lm_attempts for r in reps_o],
+                    "t_jac": sum(r.t_jac for r in reps_o) / 5 * 1e3, "t_solve": sum(r.t_solve for r in reps_o) / 5 * 1e3,
+                    "t_factor": sum(r.t_factor for r in reps_o) / 5 * 1e3, "t_schur_gemm": agg_o[0] / 5 * 1e3,
+                    "t_fd_kernel": agg_o[3] / 5 * 1e3, "t_accumulate": sum(r.t_accumulate for r in reps_o) / 5 * 1e3,
+                    "t_cost": sum(r.t_cost for r in reps_o) / 5 * 1e3, "setup_and_run_s": time.time() - t_o}
+                e_o.close()
+                del pb_o, st_o, e_o
+            except Exception as ex:      # a side leg never costs the headline line
+                others[f"cfg{cfg_o}"] = {"error": repr(ex)[:300]}
+        out["other_configs"] = others
 
     # ---- second leg under a watchdog ----
     import threading

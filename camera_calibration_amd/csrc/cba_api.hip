@@ -675,6 +675,16 @@ extern "C" {
 const char* cba_last_error(void) { return g_error.c_str(); }
 const char* cba_version(void) { return "camera_calibration_amd 0.1 (gfx950)"; }
 
+int32_t cba_elimination_order(const cba_problem* p, int32_t out[4]) {
+  if (!p) return 0;
+  if (out) {
+    out[0] = p->gridfirst ? p->gf.strips[0] : 0;
+    out[1] = p->gridfirst ? p->gf.n_border : p->L.dense_dof;
+    out[2] = p->gridfirst ? p->gf.Gf : 0;
+    out[3] = p->gridfirst ? (int32_t)p->gf.chains.size() : 1;
+  }
+  return p->gridfirst ? 2 : 1;
+}
 int32_t cba_total_dof(const cba_problem* p) { return p ? p->L.total_dof : 0; }
 int32_t cba_dense_dof(const cba_problem* p) { return p ? p->L.dense_dof : 0; }
 int32_t cba_jacobian_record_doubles(const cba_problem* p) { return p ? p->rec_doubles : 0; }

@@ -81,7 +81,7 @@ EXPORTED_SYMBOLS = [
     "cba_kernel_stats", "cba_fit_grid_to_directions", "cba_prepare_device",
     "cba_model_create", "cba_model_destroy", "cba_model_set_grid", "cba_model_project", "cba_model_unproject",
     "cba_fd_redo_overflow", "cba_debug_fd_redo_counts", "cba_schur_solve_opt", "cba_set_fd_schedule",
-    "cba_gridfirst_plan_query",
+    "cba_gridfirst_plan_query", "cba_elimination_order",
 ]
 
 DUMP_COST_VECTOR, DUMP_PIXELS, DUMP_FLAGS, DUMP_JACOBIANS = 1, 2, 3, 4
@@ -338,6 +338,14 @@ class Engine:
         n = C.c_int32(0)
         _check(self.L.cba_kernel_stats(self._h, which, C.byref(s), C.byref(f), C.byref(b), C.byref(n)), "cba_kernel_stats")
         return dict(seconds=s.value, flops=f.value, bytes=b.value, launches=n.value)
+
+    def elimination_order(self) -> dict:
+        """cba_elimination_order: which order this problem uses (cba_solver_options.elimination resolved) and its sizes."""
+        out = (C.c_int32 * 4)()
+        self.L.cba_elimination_order.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        self.L.cba_elimination_order.restype = C.c_int32
+        order = int(self.L.cba_elimination_order(self._h, out))
+        return dict(order={1: "pose-first", 2: "grid-first"}.get(order, "?"), strips=int(out[0]), dense_rows=int(out[1]), grid_rows=int(out[2]), chains=int(out[3]))
 
     # -- parity / debug ----------------------------------------------------------------------------
     def set_fd_schedule(self, schedule: int) -> None:

@@ -308,6 +308,9 @@ int cba_debug_apply_update(cba_problem* p, const double* x);
 int64_t cba_gridfirst_plan_query(const cba_camera* cameras, int32_t n_cameras, int32_t n_images, int32_t n_points, int32_t strips,
                                  int32_t what, void* out, int64_t capacity_bytes);
 
+/* Elimination order the problem uses (cba_solver_options.elimination resolved): 1 = pose-first, 2 = grid-first; out[0..3] (optional,
+ * may be NULL) = strips of camera 0, rows of the border system that is factored densely, rows of the grid part, pivot chains. */
+int32_t cba_elimination_order(const cba_problem* p, int32_t out[4]);
 int32_t cba_total_dof(const cba_problem* p);
 int32_t cba_dense_dof(const cba_problem* p);
 /* layout of one CBA_DUMP_JACOBIANS record: [res 2][weight 1][pose 2x6][rig 2x6][point 2x3][grid 2xK] */
