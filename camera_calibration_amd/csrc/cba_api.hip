@@ -850,12 +850,16 @@ int cba_create(const cba_config* config, cba_problem** out) {
     p->gfd.nbg = g.nbg; p->gfd.nbf = g.nbf; p->gfd.mask_words = g.mask_words; p->gfd.flops_grid = g.flops_grid;
     // tiles the forming kernel writes per attempt: the structural tiles of the grid x grid part, the row strips of the grid rows
     // (every border column block + the right-hand side's), the upper triangle of the border
+    // Rule: every tile that any launch of a solve WRITES is formed again for the next attempt (a broken solve -- zero pivot, NaN --
+    // must not leave anything behind: tests/test_gpu_gridfirst.py).  The dense border launch and the border update also write the
+    // padding-only block columns and the block rows behind the factored ones.
     std::vector<int> tiles(g.grid_tiles);
-    for (int r = 0; r < g.nbf; ++r) {
-      for (int c = std::max(r, g.nbg); c < g.nbf; ++c) { tiles.push_back(r); tiles.push_back(c); }
+    for (int r = 0; r < g.nbg; ++r) {
+      for (int c = g.nbg; c < g.nbf; ++c) { tiles.push_back(r); tiles.push_back(c); }
       tiles.push_back(r); tiles.push_back(g.ntc - 1);
     }
-    tiles.push_back(g.ntc - 1); tiles.push_back(g.ntc - 1);       // (the border update also writes the block row of the right-hand side column: reset per attempt)
+    for (int r = g.nbg; r < g.ntc; ++r)
+      for (int c = r; c < g.ntc; ++c) { tiles.push_back(r); tiles.push_back(c); }
     p->n_gf_tiles = (int)(tiles.size() / 2);
     CBA_TRY(dev_alloc(&p->gf_tiles, tiles.size()));
     CBA_HIP(hipMemcpy(p->gf_tiles, tiles.data(), sizeof(int) * tiles.size(), hipMemcpyHostToDevice));

@@ -207,6 +207,10 @@ int gf_build_plan(const cba_camera* cams, int C, int N, int P, int strips_overri
           }
       }
   }
+  // consecutive blocks of one chain: the chain reads and rewrites tile (r, r + 1) whatever the geometry says (a block of identity
+  // padding rows at the end of the grid part couples with nothing) -- part of the structure, so that it is formed for every attempt
+  for (auto& ch : pl.chains)
+    for (int r = ch.r0; r + 1 < ch.r1; ++r) up.set(r, r + 1);
   // half-bandwidth inside the strips (diagnostic)
   for (int c = 0; c < C; ++c) {
     const int ppg = cams[c].model_type == CBA_CENTRAL_GENERIC ? 2 : 5;
