@@ -202,6 +202,7 @@ struct cba_problem {
   // order of the border update's tiles, heaviest first, from the masks of the PREVIOUS solve (a scheduling hint: any permutation is
   // correct, and the activity hardly moves from pass to pass)
   int* gf_tile_list = nullptr; int* gf_tile_list_host = nullptr; bool gf_tile_list_valid = false; unsigned gf_tile_list_age = 0;
+  int gf_tile_list_entries = 0;     // slots of the launch (eight interleaved per-XCD lists, padded)
 };
 
 namespace cba {
@@ -519,11 +520,11 @@ static int solve_enqueue_gridfirst(cba_problem* p, double lambda) {
   CBA_TRY(timer_begin(p, 1));
   const int* tile_list = nullptr;
   if (p->gf_tile_list_valid) {
-    const size_t nt = (size_t)d.n_act_tiles;
-    CBA_HIP(hipMemcpyAsync(p->gf_tile_list, p->gf_tile_list_host, sizeof(int) * nt * (nt + 1), hipMemcpyHostToDevice, p->stream));
+    CBA_HIP(hipMemcpyAsync(p->gf_tile_list, p->gf_tile_list_host, sizeof(int) * 2 * (size_t)p->gf_tile_list_entries, hipMemcpyHostToDevice, p->stream));
     tile_list = p->gf_tile_list;
   }
-  CBA_TRY(ldlt_factor_gridfirst(p->F, g.n_fact, ld, d, p->Xb, ld - g.Gf, p->ldlt, p->stream, &gs, d.kmask, d.kmask_words, tile_list));
+  CBA_TRY(ldlt_factor_gridfirst(p->F, g.n_fact, ld, d, p->Xb, ld - g.Gf, p->ldlt, p->stream, &gs, d.kmask, d.kmask_words, tile_list,
+                                tile_list ? p->gf_tile_list_entries : 0));
   CBA_TRY(timer_end(p, 1, gs.flops, 0, gs.launches));
   CBA_TRY(ldlt_back_solve(p->F, g.n_fact, ld, ld - 1, p->ldlt, p->xF, p->stream, d.rowmask_dyn, d.mask_words));
   CBA_TRY(launch_gf_scatter(p->xF, g.Gf, g.n_rp, L.block_dof, g.G, p->gf_f_of_grid, p->x, p->stream));
@@ -626,24 +627,58 @@ static int solve_finish(cba_problem* p) {
         for (int w = 0; w < kw; ++w)
           slabs += __builtin_popcountll(p->gf_kmask_host[(size_t)(t0 + tm) * kw + w] & p->gf_kmask_host[(size_t)(t0 + tn) * kw + w]);
     p->gf_update_flops = slabs * 2.0 * 128 * 128 * 16;
-    // tile order of the NEXT border updates: executed slabs descending, row-major among equals (host work while the device idles:
-    // first solve, then every 8th)
+    {
+      LdltWorkspace& w = p->ldlt;
+      for (int i = 0; i < w.spans_used; ++i)
+        if (w.spans[i].masked_update) { w.spans[i].flops = p->gf_update_flops; w.spans[i].masked_update = false; }
+    }
+    // Tile order of the NEXT border updates (host work while the device idles: first solve, then every 8th).  Workgroup b of the
+    // launch runs on XCD b % 8 and the dispatcher hands workgroups out strictly in order, so (a) the list as a whole is sorted by
+    // executed K slabs, heaviest first -- list scheduling: the light tiles fill the gaps behind the heavy ones, and every XCD (every
+    // eighth entry) sees the same sequence of weights, which keeps the in-order dispatcher from waiting for one XCD -- and (b) inside
+    // a run of tiles of about the same weight (7 % buckets) the tiles are dealt so that one XCD walks a CONTIGUOUS piece of the run
+    // in row-major order: its tiles in flight share an A panel and neighbouring B panels in that XCD's L2 instead of 64 unrelated
+    // pairs (FETCH_SIZE of the launch: profiles/r06_update_tile_order.txt).  Short lists are padded with (-1, -1) (the workgroup leaves).
     if (!p->gf_tile_list_valid || (++p->gf_tile_list_age & 7) == 0) {
-      std::vector<std::pair<int, int>> work;
-      work.reserve((size_t)nt * (nt + 1) / 2);
+      struct Tile { int w, tm, tn; };
+      std::vector<Tile> all;
+      all.reserve((size_t)nt * (nt + 1) / 2);
       for (int tm = 0; tm < nt; ++tm)
         for (int tn = tm; tn < nt; ++tn) {
           int sl = 0;
           for (int w = 0; w < kw; ++w) sl += __builtin_popcountll(p->gf_kmask_host[(size_t)(t0 + tm) * kw + w] & p->gf_kmask_host[(size_t)(t0 + tn) * kw + w]);
-          work.push_back({sl, tm * nt + tn});
+          all.push_back(Tile{sl, tm, tn});
         }
-      std::stable_sort(work.begin(), work.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
-      for (size_t i = 0; i < work.size(); ++i) { p->gf_tile_list_host[2 * i] = work[i].second / nt; p->gf_tile_list_host[2 * i + 1] = work[i].second % nt; }
+      std::stable_sort(all.begin(), all.end(), [](const Tile& u, const Tile& v) { return u.w > v.w; });      // row-major among equals
+      std::vector<Tile> lists[8];
+      size_t i0 = 0;
+      while (i0 < all.size()) {
+        size_t i1 = i0 + 1;
+        while (i1 < all.size() && (double)all[i1].w >= 0.93 * all[i0].w) ++i1;                               // one bucket
+        std::stable_sort(all.begin() + i0, all.begin() + i1, [](const Tile& u, const Tile& v) { return u.tm != v.tm ? u.tm < v.tm : u.tn < v.tn; });
+        const size_t L = i1 - i0;
+        int start = 0;
+        for (int x = 1; x < 8; ++x) if (lists[x].size() < lists[start].size()) start = x;
+        size_t pos = i0;
+        for (int k = 0; k < 8; ++k) {
+          const size_t len = L / 8 + ((size_t)k < L % 8 ? 1 : 0);
+          std::vector<Tile>& dst = lists[(start + k) % 8];
+          dst.insert(dst.end(), all.begin() + pos, all.begin() + pos + len);
+          pos += len;
+        }
+        i0 = i1;
+      }
+      size_t longest = 0;
+      for (int x = 0; x < 8; ++x) longest = std::max(longest, lists[x].size());
+      p->gf_tile_list_entries = (int)(8 * longest);
+      for (size_t i = 0; i < longest; ++i)
+        for (int x = 0; x < 8; ++x) {
+          const bool have = i < lists[x].size();
+          p->gf_tile_list_host[2 * (8 * i + x)] = have ? lists[x][i].tm : -1;
+          p->gf_tile_list_host[2 * (8 * i + x) + 1] = have ? lists[x][i].tn : -1;
+        }
       p->gf_tile_list_valid = true;
     }
-    LdltWorkspace& w = p->ldlt;
-    for (int i = 0; i < w.spans_used; ++i)
-      if (w.spans[i].masked_update) { w.spans[i].flops = p->gf_update_flops; w.spans[i].masked_update = false; }
   }
   if (!p->gridfirst) {
     double slabs = 0;
@@ -881,8 +916,8 @@ int cba_create(const cba_config* config, cba_problem** out) {
       CBA_HIP(hipMemcpy(d.gridrow, g.gridrow.data(), sizeof(uint64_t) * g.gridrow.size(), hipMemcpyHostToDevice));
       {
         const size_t nt = (size_t)d.n_act_tiles;
-        CBA_TRY(dev_alloc(&p->gf_tile_list, nt * (nt + 1)));
-        CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->gf_tile_list_host), sizeof(int) * nt * (nt + 1)));
+        CBA_TRY(dev_alloc(&p->gf_tile_list, 8 * nt * (nt + 1)));      // worst case: one XCD's list holds every tile
+        CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->gf_tile_list_host), sizeof(int) * 8 * nt * (nt + 1)));
       }
       CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->gf_kmask_host), sizeof(unsigned long long) * (size_t)(g.n_pad / 128) * d.kmask_words));
       std::memset(p->gf_kmask_host, 0, sizeof(unsigned long long) * (size_t)(g.n_pad / 128) * d.kmask_words);

@@ -196,9 +196,9 @@ struct GfDevice {
 };
 // F = [grid | border] in the plan's order, ld = its n_pad; Xb: (rows of the grid part) x (ld - Gf) panel buffer (zero outside the
 // tiles the launch writes); kmask: optional block-sparsity of the border update (null = dense); tile_list: optional order of its
-// upper tiles, (tm, tn) pairs relative to the border, all of them
+// upper tiles, tile_list_entries (tm, tn) pairs relative to the border -- every upper tile once, (-1, -1) = an empty slot
 int ldlt_factor_gridfirst(double* F, int n_fact, int ld, const GfDevice& g, double* Xb, int ldxb, LdltWorkspace& w, hipStream_t s,
-                          GemmStats* st, const unsigned long long* kmask, int kmask_words, const int* tile_list);
+                          GemmStats* st, const unsigned long long* kmask, int kmask_words, const int* tile_list, int tile_list_entries);
 // Rows that the final dataflow launch factors (w.tail_rows clamped to the workspace's flag storage)
 int ldlt_tail_rows(const LdltWorkspace& w, int world = 1);
 int ldlt_clear_ctrl(LdltWorkspace& w, hipStream_t s);

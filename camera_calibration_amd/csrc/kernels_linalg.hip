@@ -260,7 +260,8 @@ struct GemmArgs {
   int col_group, col_stride;    // distributed factorisation: owned column groups (tiles per group, group stride); 0 = all columns
   int keep_col_p1;              // 1 + a column of C the launch must not write (the right-hand side kept in S's last column); 0 = none
   int slab16;                   // block-sparse launch with 16-row K slabs (the border update of the grid-first order); 0 = slabs of kSchurSlab rows
-  const int2* tile_list;        // optional explicit order of the launch's tiles (tm, tn), total_tiles entries: slot b runs tile_list[b].  The
+  int tile_list_entries;        // slots of a tile_list launch
+  const int2* tile_list;        // optional explicit order of the launch's tiles (tm, tn): slot b runs tile_list[b], (-1, -1) = no tile.  The
                                 // dispatcher hands workgroups out in slot order as slots come free, i.e. list scheduling: with the tiles
                                 // sorted by executed K slabs, heaviest first, the light tiles fill the gaps behind the heavy ones
 };
@@ -313,11 +314,12 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
   // workgroup slots of an XCD share one A panel (and neighbouring B panels) in its L2, and chunks from
   // all parts of the matrix land on every XCD, which balances the block-sparse K loops.
   const long long t = g.tile_list ? b : gemm_slot_tile(g, b);
-  if (t >= g.total_tiles) return false;
+  if (t >= (g.tile_list ? (long long)g.tile_list_entries : g.total_tiles)) return false;
   int tm, tn;
   if (g.tile_list) {
     const int2 tt = g.tile_list[t];
     tm = tt.x; tn = tt.y;
+    if (tm < 0) return true;
   } else if (g.strips) {
     // Square upper-triangular launch, dense: tiles are enumerated strip by strip (kStripW tile columns), row by
     // row inside a strip, so that the ~64 workgroups in flight on an XCD form an 8 x 8 block sharing 8 A and
@@ -550,7 +552,7 @@ static int launch_gemm(GemmArgs g, hipStream_t s) {
   g.n_chunks = (int)chunks;
   if (g.chunk != kSchurChunk) g.chunk_order = nullptr;            // the order was built for chunks of kSchurChunk tiles
   long long blocks = ((chunks + 7) / 8) * 8 * g.chunk;
-  if (g.tile_list) { blocks = g.total_tiles; g.strips = 0; }
+  if (g.tile_list) { blocks = g.tile_list_entries; g.strips = 0; }
   if (g.kmask && !g.slab16) hipLaunchKernelGGL((k_gemm_atb<TM, TN, WM, WN, SUB, kSchurSlab>), dim3((unsigned)blocks), dim3(256), 0, s, g);   // block-sparse: slabs of two pose blocks
   else hipLaunchKernelGGL((k_gemm_atb<TM, TN, WM, WN, SUB, KT>), dim3((unsigned)blocks), dim3(256), 0, s, g);
   CBA_HIP(hipGetLastError());
@@ -2372,7 +2374,7 @@ static int ldlt_sparse(double* F, int ld, const GfDevice& g, LdltWorkspace& w, h
 // heaviest first -- a scheduling hint, any permutation of the upper tiles is correct), then the dense border by the two-level
 // schedule of ldlt_factor.
 int ldlt_factor_gridfirst(double* F, int n_fact, int ld, const GfDevice& g, double* Xb, int ldxb, LdltWorkspace& w, hipStream_t s,
-                          GemmStats* st, const unsigned long long* kmask, int kmask_words, const int* tile_list) {
+                          GemmStats* st, const unsigned long long* kmask, int kmask_words, const int* tile_list, int tile_list_entries) {
   int rc;
   if ((rc = ldlt_sparse(F, ld, g, w, s, st, Xb, ldxb))) return rc;
   const int Gf = g.nbg * kInner;
@@ -2381,7 +2383,7 @@ int ldlt_factor_gridfirst(double* F, int n_fact, int ld, const GfDevice& g, doub
   u.C = F; u.ldc = ld; u.Cin = F; u.ldcin = ld; u.diag = 0; u.upper = 1;
   const int tl = (ld - Gf) / 128;
   u.m_off = Gf; u.m_tiles = tl; u.n_off = Gf; u.n_tiles = tl;
-  u.kmask = kmask; u.kmask_words = kmask_words; u.slab16 = 1; u.tile_list = reinterpret_cast<const int2*>(tile_list);
+  u.kmask = kmask; u.kmask_words = kmask_words; u.slab16 = 1; u.tile_list = reinterpret_cast<const int2*>(tile_list); u.tile_list_entries = tile_list_entries;
   if ((rc = timed_gemm128(u, s, w, st != nullptr, (double)tl * (tl + 1) / 2))) return rc;
   if (st && kmask && w.spans_used > 0) w.spans[w.spans_used - 1].masked_update = true;      // (the caller replaces the dense flop count by the executed one)
   if (st) { const double rows = (double)(ld - Gf); st->flops += rows * rows * Gf; st->launches += 1; }
