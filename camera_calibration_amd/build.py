@@ -22,8 +22,18 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+FLAGS_STAMP = os.path.join(HERE, ".build_flags")      # the extra flags the current library was built with ("" = the product build)
+
+
+def _extra_flags() -> str:
+    return " ".join(os.environ.get("CBA_BUILD_EXTRA_FLAGS", "").split())
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
+        return True
+    built_with = open(FLAGS_STAMP).read() if os.path.exists(FLAGS_STAMP) else ""
+    if built_with != _extra_flags():            # a library tuned by a leftover CBA_BUILD_EXTRA_FLAGS is never reused silently
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
@@ -56,6 +66,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError("hipcc compilation failed")
     check_tail_m0(os.path.join(CSRC, "kernels_linalg.o"))
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    with open(FLAGS_STAMP, "w") as f:
+        f.write(_extra_flags())
     return LIB
 
 

@@ -1149,6 +1149,7 @@ int cba_set_observations(cba_problem* p, int64_t n, const float* xy, const int32
         const int img = image_index[i], cam = camera_index[i];
         const int pc = L.first_points - L.block_dof + 3 * point_index[i];
         set_col(img, pc); set_col(img, pc + 2);
+        if (!std::isfinite(xy[2 * i]) || !std::isfinite(xy[2 * i + 1])) continue;      // (the cast below is undefined for a non-finite pixel)
         const cba_camera& cm = p->cams[cam];
         const int per = cm.model_type == CBA_CENTRAL_GENERIC ? 2 : 5;
         const double gx = 1.0 + (cm.grid_w - 3.0) * (xy[2 * i] - cm.calib_min_x) / (cm.calib_max_x + 1.0 - cm.calib_min_x);      // central_grid.h:150-154
@@ -1384,7 +1385,8 @@ int cba_step(cba_problem* p, double init_lambda, int32_t max_lm_attempts, double
       CBA_HIP(hipStreamSynchronize(p->stream));                // (a no-op after a completed solve; a numeric failure may return before its wait)
       for (int i = 0; i < 8; ++i) h[i] = p->pin_cost[i];
       take_pass_scalars();
-      if (last_cost == 0) {                // lm_optimizer.h:755-760 (the solve above is discarded)
+      if (last_cost == 0) {                // lm_optimizer.h:755-760 (the solve above is discarded; its queued cost pass has rewritten the warm-start
+                                           // cache from the candidate state, which for a zero cost is the same pixels: x solves H x = 0 there)
         report->lm_attempts = 0;
         report->lambda = p->last_lambda;
         CBA_TRY(timers_collect(p));

@@ -85,7 +85,9 @@ int launch_base_project(const PassArgs& a, int model_mask, double* cost_vec, dou
 int launch_base_project_slow(const PassArgs& a, int model_mask, double* cost_vec, double* pixels, uint8_t* flags, hipStream_t s);
 // redo / redo_count: device work list (redo_cap entries / one int) for the tasks that leave their staged patch; tasks that find
 // the list full are counted in *redo_overflow
-// schedule: 0 = pooled (workgroup task pool, one LM attempt per trip), 1 = one task per lane; same results bit for bit
+// schedule: 0 = pooled (workgroup task pool, one LM attempt per trip), 1 = one task per lane; same expressions in the same order,
+// flags identical, Jacobian entries agree to ~1e-12 (0.004 % of them differ: the compiler contracts one multiply-add of the damped
+// 2 x 2 solve differently in the two kernels; include/cba.h: cba_set_fd_schedule, tests/test_gpu_stragglers.py)
 int launch_fd_tasks(const PassArgs& a, int model_mask, int tasks_per_obs, int localize_only, const double* pixels,
                     const uint8_t* flags, double* fd_out, uint8_t* fd_ok, int64_t* redo, int* redo_count, int redo_cap, int* redo_overflow,
                     hipStream_t s, int schedule = 0);
@@ -142,7 +144,8 @@ int launch_gemv_n(const double* M, int K, int n, int ld, const double* v, const 
 struct GemmStats { double seconds = 0, flops = 0, bytes = 0; int launches = 0; };
 // In-place blocked LDL^T of a symmetric matrix stored "upper in row-major" (= lower in column-major).
 struct LdltWorkspace {
-  double* X = nullptr;       // X = D L of a super-panel's row strip [kSuperMax][ld]
+  double* X = nullptr;       // X = D L of a super-panel's row strip [x_rows][ld]
+  int x_rows = 0;
   double* invLt = nullptr;   // per 64-block: transposed inverse of the unit factor [kInner][kInner]
   // scheduling options (cba_solver_options): rows left to the final dataflow launch; back substitution as one dataflow launch
   int tail_rows = 0;         // rows left to the final dataflow launch; 0 = the schedule's default (ldlt_tail_rows)

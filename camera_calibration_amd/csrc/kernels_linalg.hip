@@ -2072,10 +2072,13 @@ int ldlt_workspace_alloc(LdltWorkspace& w, int n_pad, int flag_rows_blocks) {
   // X = D L of a super-panel's row strip: the K-major B operand of the bulk update.  A super-panel is at most super_width() + 512
   // rows wide (super_width_at), never wider than the matrix
   {
-    int x_rows = super_width() + 512;
+    // (the distributed schedule falls back to W = 2048 when the developer switch CBA_SUPER_W is not a multiple of its 512-column
+    // groups: the panel buffer must hold that width as well)
+    int x_rows = std::max(super_width(), (super_width() % 512) ? 2048 : 0) + 512;
     if (x_rows > kSuperMax) x_rows = kSuperMax;
     if (x_rows > n_pad) x_rows = n_pad;
     CBA_HIP(hipMalloc(&w.X, sizeof(double) * (size_t)x_rows * n_pad));
+    w.x_rows = x_rows;
   }
   CBA_HIP(hipMalloc(&w.invLt, sizeof(double) * (size_t)(n_pad / kInner) * kInner * kInner));
   CBA_HIP(hipMalloc(&w.dvec, sizeof(double) * (size_t)n_pad));
@@ -2221,6 +2224,7 @@ double ldlt_tail_last_ms(LdltWorkspace& w) {
 // on stream s.  t0 and n_fact are multiples of 64.
 static int ldlt_tail(double* S, int n_fact, int ld, int t0, LdltWorkspace& w, hipStream_t s, GemmStats* st, double* X = nullptr,
                      int reserve_wgs = 0) {
+  if (X && X == w.X && n_fact - t0 > w.x_rows) { set_error("ldlt_tail: super-panel wider than the panel buffer"); return CBA_ERR_STATE; }
   TailArgs t{};
   t.S = S; t.ld = ld;
   t.X = X; t.ldx = ld; t.x_c0 = n_fact / kInner;

@@ -565,8 +565,10 @@ k_fd_tasks(PassArgs a, int tasks_per_obs, int localize_only, const double* __res
 // machine: take the next task of the pool -> [UnprojectWithJacobian + normal equations when an outer iteration starts] -> ONE damping
 // attempt (candidate, Unproject, accept / reject) per trip of the loop -> store -> next task.  A lane stuck in rejected attempts
 // just takes fewer tasks.  Every task evaluates exactly the expressions of project_target (model.hip.h) in the same order --
-// the same device functions on the same inputs -- so results are bit-identical to the one-task-per-lane kernel
-// (tests/test_gpu_stragglers.py: cba_set_fd_schedule).
+// the same device functions on the same inputs.  Flags and decisions are identical to the one-task-per-lane kernel; 0.004 % of the
+// Jacobian entries differ by an ulp of a pixel in one projection, because the compiler contracts a multiply-add of the damped 2 x 2
+// solve differently in the two kernels (tests/test_gpu_stragglers.py allows 1e-11 relative and 5e-4 differing entries; include/cba.h:
+// cba_set_fd_schedule).  The default schedule is chosen per configuration, so runs with different camera setups are not bit-comparable.
 #ifndef CBA_FD_POOL_WAVES_CENTRAL
 #define CBA_FD_POOL_WAVES_CENTRAL 3     // 4 (128 VGPRs, 16 spilled) measured: cfg 2 the same, cfg 3 4 % slower
 #endif
