@@ -98,6 +98,112 @@ def make_allreduce_host_staged():
     return allreduce
 
 
+class GridFirstSharedLayout:
+    """FOLLOW-UP DESIGN (not used by the engine yet): what would cross the ranks per Gauss-Newton step if the
+    image-sharded path used the grid-first elimination order -- literally BASELINE.json's "shared intrinsics and pattern J^T J /
+    J^T r blocks" instead of the packed reduced system S of the pose-first order:
+
+        [ grid x grid, BANDED: unknown g of a camera (numbered along the short grid dimension) x its hb + 1 right neighbours |
+          rig / point rows x grid columns, dense | rig rows x (rig, point) columns | 3 x 3 point blocks (upper) | J^T r of all of them ]
+
+    An observation touches a 4 x 4 window of control points (APP/models/central_grid.h:199-209), so nothing else of the dense part of
+    the reference's accumulator (LV/lm_optimizer_update_accumulator.h:108-155: rig | points | intrinsics) can be non-zero.  At BASELINE
+    configs[1] this is 228 MB against the 642 MB of the packed upper triangle of S (cba_reduce_buffer_doubles).  The pose blocks D_i /
+    strips B_i stay on their owners in both designs.  pack / unpack work on the reference-order dense part (oracle.System.dense_H /
+    dense_b layout); tests/test_distributed_gloo.py sums the buffer over two ranks with gloo and compares with the single-process
+    accumulator."""
+
+    def __init__(self, cameras, n_points: int):
+        self.cameras = list(cameras)
+        C = len(self.cameras)
+        self.rig = 6 * C if C > 1 else 0
+        self.n_rp = self.rig + 3 * n_points
+        self.n_points = n_points
+        self.cam_first, self.hb, self.order = [], [], []
+        off = self.n_rp
+        for cam in self.cameras:
+            ppg = cam.params_per_grid_point
+            gw, gh = cam.grid_w, cam.grid_h
+            long_is_x = gw >= gh
+            nl, ns = (gw, gh) if long_is_x else (gh, gw)
+            # band order: along the short dimension inside a line of the long one; dense column of every unknown in that order
+            cols = np.empty(ppg * gw * gh, dtype=np.int64)
+            k = 0
+            for l in range(nl):
+                for t in range(ns):
+                    gx, gy = (l, t) if long_is_x else (t, l)
+                    for d in range(ppg):
+                        cols[k] = off + ppg * (gx + gy * gw) + d
+                        k += 1
+            self.order.append(cols)
+            self.hb.append((3 * ns + 3) * ppg + ppg - 1)
+            self.cam_first.append(off)
+            off += ppg * gw * gh
+        self.dense_dof = off
+        self.G = off - self.n_rp
+        # offsets of the parts
+        self.off_band = 0
+        n = 0
+        self.band_rows = []
+        for cols, hb in zip(self.order, self.hb):
+            self.band_rows.append((n, cols.size, hb + 1))
+            n += cols.size * (hb + 1)
+        self.off_rp_grid = n
+        n += self.n_rp * self.G
+        self.off_rig = n
+        n += self.rig * self.n_rp
+        self.off_pp = n
+        n += 6 * n_points
+        self.off_b = n
+        n += self.dense_dof
+        self.doubles = n
+
+    def pack(self, dense_H: np.ndarray, dense_b: np.ndarray) -> np.ndarray:
+        """dense_H: upper triangle in the reference order (rig | points | grids row-major)."""
+        H = np.triu(dense_H) + np.triu(dense_H, 1).T
+        buf = np.zeros(self.doubles)
+        for (o, n, w), cols in zip(self.band_rows, self.order):
+            band = np.zeros((n, w))
+            for k in range(w):
+                band[:n - k, k] = H[cols[:n - k], cols[k:]]
+            buf[o:o + n * w] = band.ravel()
+        gcols = np.concatenate(self.order)
+        buf[self.off_rp_grid:self.off_rp_grid + self.n_rp * self.G] = H[:self.n_rp][:, gcols].ravel()
+        if self.rig:
+            buf[self.off_rig:self.off_rig + self.rig * self.n_rp] = H[:self.rig, :self.n_rp].ravel()
+        iu = np.triu_indices(3)
+        for p in range(self.n_points):
+            a = self.rig + 3 * p
+            buf[self.off_pp + 6 * p:self.off_pp + 6 * p + 6] = H[a:a + 3, a:a + 3][iu]
+        buf[self.off_b:self.off_b + self.dense_dof] = dense_b
+        return buf
+
+    def unpack(self, buf: np.ndarray):
+        """(dense_H upper triangle, dense_b) in the reference order."""
+        D = self.dense_dof
+        H = np.zeros((D, D))                      # filled symmetrically by ASSIGNMENT (a band pair can sit on either side of the diagonal)
+        for (o, n, w), cols in zip(self.band_rows, self.order):
+            band = buf[o:o + n * w].reshape(n, w)
+            for k in range(w):
+                H[cols[:n - k], cols[k:]] = band[:n - k, k]
+                H[cols[k:], cols[:n - k]] = band[:n - k, k]
+        gcols = np.concatenate(self.order)
+        blk = buf[self.off_rp_grid:self.off_rp_grid + self.n_rp * self.G].reshape(self.n_rp, self.G)
+        H[np.ix_(np.arange(self.n_rp), gcols)] = blk
+        H[np.ix_(gcols, np.arange(self.n_rp))] = blk.T
+        iu = np.triu_indices(3)
+        for p in range(self.n_points):
+            a = self.rig + 3 * p
+            m = np.zeros((3, 3))
+            m[iu] = buf[self.off_pp + 6 * p:self.off_pp + 6 * p + 6]
+            H[a:a + 3, a:a + 3] = m + np.triu(m, 1).T
+        if self.rig:
+            r = buf[self.off_rig:self.off_rig + self.rig * self.n_rp].reshape(self.rig, self.n_rp)
+            H[:self.rig, :self.n_rp] = r
+            H[:self.n_rp, :self.rig] = r.T
+        return np.triu(H), buf[self.off_b:self.off_b + D].copy()
+
+
 class NativeRccl:
     """libcalib_ba_rccl.so (include/cba_rccl.h): the all-reduce callback a C++ host uses, bound for Python callers.
     `fn` / `user` go straight into cba_config.allreduce / allreduce_user -- no Python frame on the reduction path."""
