@@ -39,6 +39,7 @@ def parse_args():
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config id (1-5)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short side legs of BASELINE configs[2] and configs[3] behind the headline leg (config 2, one GPU)")
     ap.add_argument("--elimination", type=int, default=0, help="cba_solver_options.elimination: 0 = automatic (default), 1 = pose-first (the reference's order), 2 = grid-first")
+    ap.add_argument("--grid-single-tiles", action="store_true", help="cba_solver_options.grid_single_tile_tasks (grid-first order: one task per 64-column border tile)")
     ap.add_argument("--grid-strips", type=int, default=0, help="cba_solver_options.grid_strips (grid-first order; 0 = automatic)")
     ap.add_argument("--factor-tail-rows", type=int, default=0, help="cba_solver_options.factor_tail_rows (0 = the library default); schedule sweeps only")
     ap.add_argument("--imagesets", type=int, default=0, help="imagesets per GPU (0 = the config's count)")
@@ -331,7 +332,7 @@ def main():
             allreduce = make_allreduce(keep, local_rank)
         e = eng.Engine(pb, device=local_rank, allreduce=allreduce, n_images_global=n_img * world,
                        reduce_buffer_ptr=reduce_ptr, reduce_buffer_doubles=reduce_n, distributed_solve=dist_solve, rank=rank, world_size=world, factor_tail_rows=args.factor_tail_rows,
-                       elimination=args.elimination, grid_strips=args.grid_strips,
+                       elimination=args.elimination, grid_strips=args.grid_strips, grid_single_tile_tasks=args.grid_single_tiles,
                        collective=make_collective(local_rank) if dist_solve else None)
         if args.fd_schedule >= 0:
             e.set_fd_schedule(args.fd_schedule)
@@ -587,7 +588,7 @@ def main():
             try:
                 t_o = time.time()
                 pb_o, st_o, _ = syn.baseline_config(cfg_o, proj)
-                e_o = eng.Engine(pb_o, device=local_rank, elimination=args.elimination, grid_strips=args.grid_strips)
+                e_o = eng.Engine(pb_o, device=local_rank, elimination=args.elimination, grid_strips=args.grid_strips, grid_single_tile_tasks=args.grid_single_tiles)
                 e_o.set_state(st_o)
                 lam_o, reps_o, agg_o = -1.0, [], {k: 0.0 for k in (0, 3)}
                 for _ in range(2):

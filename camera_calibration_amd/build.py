@@ -93,6 +93,9 @@ def disassemble_device_code(obj: str) -> str:
         return subprocess.check_output([objdump, "-d", os.path.join(tmp, dev[0])], text=True)
 
 
+# the helper's own write of M0: the "s" operand of the inline asm is any scalar source the compiler picks (an SGPR, vcc_lo / vcc_hi, a
+# trap temporary, a literal)
+_M0_MOV = r"s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi|ttmp\d+|0x[0-9a-f]+|\d+)"
 # instructions that read M0 without naming it as an operand
 _IMPLICIT_M0 = ("s_sendmsg", "s_movrel", "v_movrel", "ds_gws", "s_ttrace", "v_interp", "ds_ordered_count")
 
@@ -129,11 +132,11 @@ def _check_kernel_m0(asm: str, kernel: str, obj: str) -> int:
         if any(mnem.startswith(x) for x in _IMPLICIT_M0):
             raise RuntimeError(f"check_tail_m0: {kernel} contains `{text}` (implicit M0 operand) next to the inline-asm LDS-DMA")
         if mnem.startswith("global_load_lds") or (mnem.startswith("buffer_load") and " lds" in text):
-            if i < 2 or not re.fullmatch(r"s_mov_b32 m0, s\d+", ins[i - 2]) or ins[i - 1] != "s_nop 0":
+            if i < 2 or not re.fullmatch(_M0_MOV, ins[i - 2]) or ins[i - 1] != "s_nop 0":
                 raise RuntimeError(f"check_tail_m0: LDS-DMA `{text}` in {kernel} is not preceded by the helper's own `s_mov_b32 m0` / `s_nop 0`")
             sites += 1
         elif re.search(r"\bm0\b", text):
-            ok = re.fullmatch(r"s_mov_b32 m0, s\d+", text) and i + 2 < len(ins) and ins[i + 1] == "s_nop 0" and ins[i + 2].startswith("global_load_lds")
+            ok = re.fullmatch(_M0_MOV, text) and i + 2 < len(ins) and ins[i + 1] == "s_nop 0" and ins[i + 2].startswith("global_load_lds")
             if not ok:
                 raise RuntimeError(f"check_tail_m0: {kernel} uses M0 outside tail_dma16 / tail_dma4: `{text}` -- the inline asm there "
                                    "writes M0 without a clobber; route that use around M0 or move the DMA to the builtin")

@@ -802,7 +802,7 @@ int cba_create(const cba_config* config, cba_problem** out) {
       use = G >= 2048 && gfl < 0.85 * pf;
     }
     if (use) {
-      if (gf_build_plan(p->cams.data(), L.n_cameras, L.n_images, L.n_points, config->solver.grid_strips, &p->gf) != CBA_OK) { set_error("cba_create: grid-first plan failed"); return CBA_ERR_ARG; }
+      if (gf_build_plan(p->cams.data(), L.n_cameras, L.n_images, L.n_points, config->solver.grid_strips, config->solver.grid_single_tile_tasks, &p->gf) != CBA_OK) { set_error("cba_create: grid-first plan failed"); return CBA_ERR_ARG; }
       p->gridfirst = true;
     }
   }
@@ -1720,9 +1720,9 @@ int cba_schur_solve_opt(int32_t block_size, int32_t n_blocks, int32_t dense_dof,
 }
 
 int64_t cba_gridfirst_plan_query(const cba_camera* cameras, int32_t n_cameras, int32_t n_images, int32_t n_points, int32_t strips,
-                                 int32_t what, void* out, int64_t capacity_bytes) {
+                                 int32_t single_tile_tasks, int32_t what, void* out, int64_t capacity_bytes) {
   GfPlan pl;
-  int rc = gf_build_plan(cameras, n_cameras, n_images, n_points, strips, &pl);
+  int rc = gf_build_plan(cameras, n_cameras, n_images, n_points, strips, single_tile_tasks, &pl);
   if (rc != CBA_OK) { set_error("cba_gridfirst_plan_query: bad argument"); return rc; }
   auto give = [&](const void* src, size_t bytes) -> int64_t {
     if (out && capacity_bytes >= (int64_t)bytes && bytes) std::memcpy(out, src, bytes);

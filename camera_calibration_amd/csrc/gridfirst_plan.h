@@ -29,7 +29,8 @@ namespace cba {
 
 struct GfChain { int r0, r1, dep, pad; };            // block rows [r0, r1); dep: block r0 has predecessors (its diagonal tile comes from a PARTFULL task)
 struct GfTask { int kind_n, r, c, iv0; };            // kind_n = kind | (number of K intervals << 8); kinds: 0 PRE(r): tile (r, r + 1); 1 PART(c): diagonal
-                                                     // tile (c, c) less the rows below c - 1; 2 REG(r, c); 3 PARTFULL(c): diagonal tile (c, c), all rows
+                                                     // tile (c, c) less the rows below c - 1; 2 REG(r, c); 3 PARTFULL(c): diagonal tile (c, c), all rows;
+                                                     // 4 REG2(r, c): the border tiles (r, c) and (r, c + 1) of one 128-column tile in one task
 struct GfIval { int k0, k1; };                       // block rows [k0, k1)
 
 struct GfPlan {
@@ -65,7 +66,9 @@ struct GfPlan {
 };
 
 // strips_override: 0 = automatic, >= 1 = that many strips per camera (clamped to what the grid allows).  Returns CBA_OK / CBA_ERR_ARG.
-int gf_build_plan(const cba_camera* cams, int n_cameras, int n_images, int n_points, int strips_override, GfPlan* out);
+// single_tile_tasks: 1 = every border tile of the row strips is a task of its own (REG); 0 (default) = the two tiles of a 128-column border
+// tile share one task (REG2: half as many workgroup slots wait at the chains' frontiers, the A strip is fetched once).
+int gf_build_plan(const cba_camera* cams, int n_cameras, int n_images, int n_points, int strips_override, int single_tile_tasks, GfPlan* out);
 
 // Order of the imagesets' pose columns in the border (slot of every imageset).  first_rows[i]: bit set over the grid block rows
 // (plan.grid_words words) that imageset i touches -- from the measured pixels, a prediction of the per-pass activity.  The border

@@ -98,7 +98,7 @@ void gf_order_imagesets(const GfPlan& pl, const std::vector<uint64_t>& touched, 
   }
 }
 
-int gf_build_plan(const cba_camera* cams, int C, int N, int P, int strips_override, GfPlan* out) {
+int gf_build_plan(const cba_camera* cams, int C, int N, int P, int strips_override, int single_tile_tasks, GfPlan* out) {
   if (!cams || !out || C < 1 || C > 16 || N < 0 || P < 0) return CBA_ERR_ARG;
   GfPlan& pl = *out;
   pl = GfPlan();
@@ -272,7 +272,7 @@ int gf_build_plan(const cba_camera* cams, int C, int N, int P, int strips_overri
     }
     t.kind_n = kind | (n << 8);
     list[which].push_back(t);
-    pl.flops_grid += 2.0 * 64 * 64 * 64 * rows + (kind == 2 ? 2.0 * 64 * 64 * 64 : 0.0);
+    pl.flops_grid += (kind == 4 ? 2.0 : 1.0) * (2.0 * 64 * 64 * 64 * rows + (kind == 2 || kind == 4 ? 2.0 * 64 * 64 * 64 : 0.0));
   };
   for (int r : row_order) {
     const GfChain& mine = pl.chains[chain_of[r]];
@@ -291,7 +291,10 @@ int gf_build_plan(const cba_camera* cams, int C, int N, int P, int strips_overri
     // border columns (dense) and the block column of the right-hand side; padding-only block columns are skipped
     for (int c = nbg; c < pl.ntc; ++c) {
       if (c >= pl.nbf && c != pl.ntc - 1) continue;
-      add_task(1, 2, r, c, col.row(r), nullptr, r);
+      // the two column blocks of a 128-column tile (the border starts at a multiple of 128) in one task, unless asked otherwise
+      const bool pair = !single_tile_tasks && ((c - nbg) & 1) == 0 && c + 1 < pl.nbf;
+      add_task(1, pair ? 4 : 2, r, c, col.row(r), nullptr, r);
+      if (pair) ++c;
     }
   }
   pl.n_tasks0 = (int)list[0].size();

@@ -870,7 +870,6 @@ __device__ __forceinline__ int tail_wait_rows(const TailArgs& t, int k, int kend
   return n;
 }
 
-#ifdef CBA_DEV_SWITCHES
 // The same for a REG2 task: rows k ... kend - 1 of column blocks ca, cb AND cb + 1 (21 rows x 3 flags per polling round).
 __device__ __forceinline__ int tail_wait_rows3(const TailArgs& t, int k, int kend, int ca, int cb, volatile int* slot) {
   if (threadIdx.x < 64) {
@@ -900,8 +899,6 @@ __device__ __forceinline__ int tail_wait_rows3(const TailArgs& t, int k, int ken
   const int n = *slot;
   return n;
 }
-
-#endif
 
 // acc (64 x 64, 4 waves x 32 x 32) += sum_{k < K} (dk[k] A[k][m]) B[k][n]; A, B: K rows of `ld` doubles, written by other workgroups
 // of this launch (agent-scope loads).  SYM: B == A (loaded once).  Slabs of kTailKT = 32 rows, the next one in flight while the
@@ -1096,6 +1093,8 @@ __device__ __forceinline__ void tail_mma_ring(v4f64 (&acc)[2][2], const double* 
 #undef CBA_RSTAGE
 }
 
+#endif  // CBA_DEV_SWITCHES (the ring variant)
+
 // The same loop for TWO adjacent column blocks (round 5): acc (64 x 128, 4 waves x 32 x 64) += sum_{k < K} (dk[k] A[k][m]) B[k][n],
 // B 128 columns wide.  Why: the final dataflow launch is bound by what its operands cost on the FABRIC, not by the matrix pipe -- per
 // dispatch PMC (profiles/r05_tail_traffic.txt): 11.1 GiB FETCH_SIZE raw = 23 GB corrected in 5.3 ms = 4.4 TB/s over the whole launch
@@ -1178,8 +1177,6 @@ __device__ __forceinline__ void tail_mma_dma2(v4f64 (&acc)[2][4], const double* 
 #undef CBA_X2_AOFF
 #undef CBA_X2_STAGE
 }
-
-#endif  // CBA_DEV_SWITCHES
 
 // ticket of list x -> task.  kind 0 = PRE(r), 1 = PART(r + 1), 2 = REG(r, c).  List x (of `nl` lists) holds the tasks whose column
 // block c has c % nl == x, rows in increasing order -- a task only waits for tiles of earlier rows, so every list is in
@@ -1674,10 +1671,15 @@ __device__ __forceinline__ void tail_chain(const TailArgs& t, double* sV, double
 }
 
 // ---- helper workgroups ----
-#ifdef CBA_DEV_SWITCHES
 // REG2 task (round 5): tiles (r, c) and (r, c + 1) in one go -- the K loop on the 64 x 128 tile (tail_mma_dma2: the A strip is
 // fetched once for both), then the 64 x 64 epilogue of a REG task twice with ONE load of invL_r.  false = the launch was aborted.
-__device__ __forceinline__ bool tail_helper_pair(const TailArgs& t, double* sV, double* sAB, int r, int c, volatile int* slot) {
+// Round 6: the border tiles of the block-sparse launch (k_ldlt_sparse) are REG2 tasks -- a 128-column pair is exactly the unit of the
+// row strips' activity, and what the launch runs out of with several pivot chains is workgroup SLOTS: at the frontier of every chain
+// one task per border column block is waiting for that chain's next diagonal block (4 chains x 133 column blocks at BASELINE
+// configs[2] against 2 x 256 slots).  ivals / n_iv: the K intervals of the task (null: [rt0, r)); arow: the activity bits of the pair's
+// 128-column tile (K rows whose tiles do not exist are skipped) or null.
+__device__ __forceinline__ bool tail_helper_pair(const TailArgs& t, double* sV, double* sAB, int r, int c, volatile int* slot,
+                                                 const GfIval* ivals, int n_iv, const unsigned long long* arow) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int ld = t.ld;
@@ -1687,13 +1689,23 @@ __device__ __forceinline__ bool tail_helper_pair(const TailArgs& t, double* sV, 
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
-  for (int k = t.rt0; k < r;) {
-    const int nrows = tail_wait_rows3(t, k, r, r, c, slot);
-    if (nrows <= 0) return false;
-    const double* A = t.S + (size_t)k * kInner * ld + (size_t)r * kInner;
-    const double* B = t.S + (size_t)k * kInner * ld + (size_t)c * kInner;
-    tail_mma_dma2(acc, A, B, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sV);
-    k += nrows;
+  for (int iv = 0; iv < n_iv; ++iv) {
+    int k = t.rt0, kend = r;
+    if (ivals) { k = __builtin_amdgcn_readfirstlane(ivals[iv].k0); kend = __builtin_amdgcn_readfirstlane(ivals[iv].k1); }
+    while (k < kend) {
+      int run_end = kend;
+      if (arow) {
+        k = bits_next(arow, k, kend, true);
+        if (k >= kend) break;
+        run_end = bits_next(arow, k, kend, false);
+      }
+      const int nrows = tail_wait_rows3(t, k, run_end, r, c, slot);
+      if (nrows <= 0) return false;
+      const double* A = t.S + (size_t)k * kInner * ld + (size_t)r * kInner;
+      const double* B = t.S + (size_t)k * kInner * ld + (size_t)c * kInner;
+      tail_mma_dma2(acc, A, B, ld, t.dvec + (size_t)k * kInner, nrows * kInner, sV);
+      k += nrows;
+    }
   }
   // accumulator layout of the 64 x 128 tile: wave wv holds rows 32 (wv >> 1) + 16 i + lk + 4 r4, columns 64 (wv & 1) + 16 j + li,
   // i.e. waves 0 / 2 hold tile (r, c) and waves 1 / 3 hold tile (r, c + 1)
@@ -1787,8 +1799,6 @@ __device__ __forceinline__ bool tail_helper_pair(const TailArgs& t, double* sV, 
   return true;
 }
 
-#endif
-
 // SPARSE (k_ldlt_sparse): tasks come from the plan's two lists (list 0 = what the chains wait for; the first n_critical helper roles
 // serve it first, everybody else list 1 first), every task carries its K intervals, several chains own a CU each.
 template <bool SPARSE>
@@ -1845,10 +1855,24 @@ __device__ __forceinline__ void tail_helper(const TailArgs& t, double* sV, doubl
     if (kind == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3);
 #ifdef CBA_DEV_SWITCHES
     if (!SPARSE && kind == 3) {
-      if (!tail_helper_pair(t, sV, sAB, r, c, slot)) return;
+      if (!tail_helper_pair(t, sV, sAB, r, c, slot, nullptr, 1, nullptr)) return;
       continue;
     }
 #endif
+    if (SPARSE && kind == 4) {                   // REG2: the two border column blocks of one 128-column tile
+      const unsigned long long* arow2 = t.act ? t.act + (size_t)((c - t.x_c0) >> 1) * t.act_words : nullptr;
+      if (arow2 && !((arow2[r >> 6] >> (r & 63)) & 1ull)) {      // nothing touches this tile and no fill reaches it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+          tail_stflag(&t.tile_flag[(size_t)(r - t.rt0) * t.ntc + c], t.epoch);
+          tail_stflag(&t.tile_flag[(size_t)(r - t.rt0) * t.ntc + c + 1], t.epoch);
+        }
+        continue;
+      }
+      if (!tail_helper_pair(t, sV, sAB, r, c, slot, t.ivals + iv0, n_iv, arow2)) return;
+      continue;
+    }
     if (SPARSE && kind == 3) kind = 1;           // PARTFULL: a PART task whose intervals reach up to the row above the tile
     // border tile of the row strip: its 128-column tile's activity bits (uniform)
     const unsigned long long* arow = nullptr;

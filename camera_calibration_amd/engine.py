@@ -38,7 +38,8 @@ COLL_ALLREDUCE_SUM, COLL_REDUCE_SCATTER_SUM, COLL_ALLGATHER = 0, 1, 2
 
 class CbaSolverOptions(C.Structure):
     """cba_solver_options: scheduling options of the reduced solve (all zero = defaults)."""
-    _fields_ = [("factor_tail_rows", C.c_int32), ("back_substitution", C.c_int32), ("elimination", C.c_int32), ("grid_strips", C.c_int32)]
+    _fields_ = [("factor_tail_rows", C.c_int32), ("back_substitution", C.c_int32), ("elimination", C.c_int32), ("grid_strips", C.c_int32),
+                ("grid_single_tile_tasks", C.c_int32)]
 
 
 ELIMINATION_AUTO, ELIMINATION_POSE_FIRST, ELIMINATION_GRID_FIRST = 0, 1, 2
@@ -147,13 +148,13 @@ def load() -> C.CDLL:
     L.cba_model_set_grid.argtypes = [vp, dp]
     L.cba_model_project.argtypes = [vp, C.c_int64, dp, dp, dp, C.POINTER(C.c_uint8)]
     L.cba_model_unproject.argtypes = [vp, C.c_int64, dp, dp, dp, C.POINTER(C.c_uint8)]
-    L.cba_gridfirst_plan_query.argtypes = [C.POINTER(CbaCamera), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int64]
+    L.cba_gridfirst_plan_query.argtypes = [C.POINTER(CbaCamera), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, C.c_int64]
     L.cba_gridfirst_plan_query.restype = C.c_int64
     _lib = L
     return L
 
 
-def gridfirst_plan(cameras: Sequence[Camera], n_images: int, n_points: int, strips: int = 0) -> dict:
+def gridfirst_plan(cameras: Sequence[Camera], n_images: int, n_points: int, strips: int = 0, single_tile_tasks: bool = False) -> dict:
     """cba_gridfirst_plan_query: the static plan of the grid-first elimination order (host only, no device).
 
     Keys: the header fields (G, Gf, n_rp, n_border, n_fact, n_pad, nbg, nbf, ntc, n_tasks0, mask_words, half_bandwidth, strips0),
@@ -163,12 +164,12 @@ def gridfirst_plan(cameras: Sequence[Camera], n_images: int, n_points: int, stri
     cams = (CbaCamera * len(cameras))(*[_cam_struct(c) for c in cameras])
 
     def q(what, dtype):
-        n = L.cba_gridfirst_plan_query(cams, len(cameras), n_images, n_points, strips, what, None, 0)
+        n = L.cba_gridfirst_plan_query(cams, len(cameras), n_images, n_points, strips, int(single_tile_tasks), what, None, 0)
         if n < 0:
             _check(int(n), "cba_gridfirst_plan_query")
         out = np.zeros(int(n) // np.dtype(dtype).itemsize, dtype=dtype)
         if n:
-            L.cba_gridfirst_plan_query(cams, len(cameras), n_images, n_points, strips, what, out.ctypes.data_as(C.c_void_p), int(n))
+            L.cba_gridfirst_plan_query(cams, len(cameras), n_images, n_points, strips, int(single_tile_tasks), what, out.ctypes.data_as(C.c_void_p), int(n))
         return out
 
     h = q(0, np.int32)
@@ -234,7 +235,8 @@ class Engine:
                  last_projection: Optional[np.ndarray] = None, deterministic: bool = False,
                  allreduce_native: Optional[tuple] = None, distributed_solve: bool = False, rank: int = 0, world_size: int = 1,
                  collective: Optional[Callable[[int, int, int, int], int]] = None, collective_native: Optional[tuple] = None,
-                 factor_tail_rows: int = 0, back_substitution_panels: bool = False, elimination: int = 0, grid_strips: int = 0):
+                 factor_tail_rows: int = 0, back_substitution_panels: bool = False, elimination: int = 0, grid_strips: int = 0,
+                 grid_single_tile_tasks: bool = False):
         self.L = load()
         self.problem = problem
         self._cams = (CbaCamera * problem.n_cameras)(*[_cam_struct(c) for c in problem.cameras])
@@ -269,7 +271,7 @@ class Engine:
                         int(problem.localize_only), int(problem.eliminate_points), device,
                         cb, user, n_images_global,
                         reduce_buffer_ptr or None, reduce_buffer_doubles, int(deterministic), int(distributed_solve), int(rank), int(world_size),
-                        ccb, cuser, CbaSolverOptions(int(factor_tail_rows), int(bool(back_substitution_panels)), int(elimination), int(grid_strips)))
+                        ccb, cuser, CbaSolverOptions(int(factor_tail_rows), int(bool(back_substitution_panels)), int(elimination), int(grid_strips), int(bool(grid_single_tile_tasks))))
         self._cfg = cfg
         self._h = C.c_void_p()
         _check(self.L.cba_create(C.byref(cfg), C.byref(self._h)), "cba_create")
@@ -286,7 +288,7 @@ class Engine:
         cams = (CbaCamera * problem.n_cameras)(*[_cam_struct(c) for c in problem.cameras])
         cfg = CbaConfig(problem.n_cameras, cams, problem.n_images, problem.n_points, problem.fd_delta,
                         int(problem.localize_only), int(problem.eliminate_points), 0, ALLREDUCE_FN(0), None, 0, None, 0, 0,
-                        int(distributed_solve), 0, int(world_size), COLLECTIVE_FN(0), None, CbaSolverOptions(0, 0, 0, 0))
+                        int(distributed_solve), 0, int(world_size), COLLECTIVE_FN(0), None, CbaSolverOptions(0, 0, 0, 0, 0))
         return int(load().cba_reduce_buffer_doubles(C.byref(cfg)))
 
     def close(self) -> None:
@@ -489,7 +491,7 @@ def schur_solve(block_diag_H: np.ndarray, off_diag_H: np.ndarray, dense_H: np.nd
     dd = dH.shape[0]
     x = np.zeros(nb * bs + dd)
     if factor_tail_rows or back_substitution_panels:
-        opt = CbaSolverOptions(int(factor_tail_rows), int(bool(back_substitution_panels)), 0, 0)
+        opt = CbaSolverOptions(int(factor_tail_rows), int(bool(back_substitution_panels)), 0, 0, 0)
         L.cba_schur_solve_opt.argtypes = [C.c_int32, C.c_int32, C.c_int32] + [C.POINTER(C.c_double)] * 6 + [C.POINTER(CbaSolverOptions), C.c_int32]
         _check(L.cba_schur_solve_opt(bs, nb, dd, _dp(bD), _dp(oH), _dp(dH), _dp(bb), _dp(db), _dp(x), C.byref(opt), device), "cba_schur_solve_opt")
     else:

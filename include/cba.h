@@ -89,6 +89,9 @@ typedef struct {
   int32_t grid_strips;        /* grid-first order: independent strips the long grid dimension is cut into (separated by 3-line
                                  separators that are eliminated after the strips): one pivot chain per strip instead of one chain of
                                  all grid unknowns.  0 = automatic (at most 4) */
+  int32_t grid_single_tile_tasks; /* grid-first order: 1 = one task per 64-column border tile in the block-sparse launch (the first version
+                                 of round 6); 0 = default: the two tiles of a 128-column border tile share a task (half as many workgroup
+                                 slots wait at the pivot chains' frontiers) */
 } cba_solver_options;
 
 typedef struct {
@@ -301,12 +304,12 @@ int cba_debug_apply_update(cba_problem* p, const double* x);
  * gridfirst_plan.h): no device is touched, the CPU tests replay the task list with numpy.  `what`: 0 = header (int32: G, Gf, n_rp,
  * n_border, n_fact, n_pad, nbg, nbf, ntc, chains, tasks, tasks of list 0, intervals, mask words, half-bandwidth, strips of camera 0),
  * 1 = row of F of every grid unknown in the engine's order (int32 x G), 2 = chains (int32 x 4: r0, r1, dep, 0), 3 = tasks (int32 x 4:
- * kind | intervals << 8, r, c, first interval), 4 = K intervals (int32 x 2), 5 = row masks (uint64 x nbf x mask words), 6 = flop model
+ * kind | intervals << 8, r, c, first interval; kinds: gridfirst_plan.h), 4 = K intervals (int32 x 2), 5 = row masks (uint64 x nbf x mask words), 6 = flop model
  * (double x 3: dataflow launch of the grid rows, border update, border factorisation), 16 + c = control point -> elimination rank of
  * camera c (int32 x grid_w grid_h).  Returns the number of bytes of the item (written if capacity_bytes suffices) or a negative
  * error code.  (No reference counterpart: LV/lm_optimizer.h:1247-1369 has one elimination order.) */
 int64_t cba_gridfirst_plan_query(const cba_camera* cameras, int32_t n_cameras, int32_t n_images, int32_t n_points, int32_t strips,
-                                 int32_t what, void* out, int64_t capacity_bytes);
+                                 int32_t single_tile_tasks, int32_t what, void* out, int64_t capacity_bytes);
 
 /* Elimination order the problem uses (cba_solver_options.elimination resolved): 1 = pose-first, 2 = grid-first; out[0..3] (optional,
  * may be NULL) = strips of camera 0, rows of the border system that is factored densely, rows of the grid part, pivot chains. */

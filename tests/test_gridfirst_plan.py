@@ -97,12 +97,21 @@ class Replay:
             for k in range(k0, k1):
                 if not (self.tile[k, ca] and self.tile[k, c]):
                     return False
-        if kind == 2 and not self.diag[r]:
+        if kind == 4:
+            for k0, k1 in self.pl["ivals"][iv0:iv0 + n_iv]:
+                for k in range(k0, k1):
+                    if not self.tile[k, c + 1]:
+                        return False
+        if kind in (2, 4) and not self.diag[r]:
             return False
         return True
 
     def run_task(self, task):
         kind = task[0] & 255; n_iv = task[0] >> 8; r, c, iv0 = int(task[1]), int(task[2]), int(task[3])
+        if kind == 4:                                    # REG2: the two tiles of one 128-column border tile, same K intervals
+            for cc in (c, c + 1):
+                self.run_task(np.array([2 | (n_iv << 8), r, cc, iv0]))
+            return
         ca = c if kind in (1, 3) else r
         row = c if kind in (1, 3) else r
         acc = np.zeros((B, B))
@@ -203,6 +212,7 @@ CASES = [
     ([_cam(NONCENTRAL_GENERIC, 16, 10)], 3, 9, 2),
     ([_cam(CENTRAL_GENERIC, 20, 10), _cam(CENTRAL_GENERIC, 26, 12)], 3, 8, 2),      # rig: two independent grids
     ([_cam(CENTRAL_GENERIC, 16, 12)], 2, 5, 0),            # automatic strip count
+    ([_cam(CENTRAL_GENERIC, 20, 12)], 16, 40, 2),          # a border of four block columns: two REG2 pairs per row
 ]
 
 
@@ -222,15 +232,19 @@ def test_layout(cams, N, P, strips):
     # no two tasks write the same tile; every tile of a row mask is produced by exactly one task or by a chain
     seen = set()
     for t in pl["tasks"]:
-        key = (int(t[0]) & 255 if (int(t[0]) & 255) != 3 else 1, int(t[1]) if (int(t[0]) & 255) in (0, 2) else int(t[2]), int(t[2]))
-        assert key not in seen
-        seen.add(key)
+        kind = int(t[0]) & 255
+        for cc in ((int(t[2]), int(t[2]) + 1) if kind == 4 else (int(t[2]),)):
+            key = ({3: 1, 4: 2}.get(kind, kind), int(t[1]) if kind in (0, 2, 4) else cc, cc)
+            assert key not in seen
+            seen.add(key)
 
 
+@pytest.mark.parametrize("single_tile_tasks", [False, True])
 @pytest.mark.parametrize("cams,N,P,strips", CASES)
-def test_replay_gives_the_dense_solution(cams, N, P, strips):
+def test_replay_gives_the_dense_solution(cams, N, P, strips, single_tile_tasks):
     rng = np.random.default_rng(11)
-    pl = engine.gridfirst_plan(cams, N, P, strips)
+    pl = engine.gridfirst_plan(cams, N, P, strips, single_tile_tasks)
+    assert (4 in set(int(k) & 255 for k in pl["tasks"][:, 0])) == (not single_tile_tasks and pl["nbf"] - pl["nbg"] >= 2)
     F, real = _build_system(cams, N, P, pl, rng)
     n_pad, n_fact = pl["n_pad"], pl["n_fact"]
     rp = Replay(pl, F)
