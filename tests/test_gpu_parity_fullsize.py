@@ -246,8 +246,12 @@ def test_full_step_at_config2_grid_size_against_oracle_optimize_jointly():
             check(case, f"iteration {it}: final cost rel", abs(rep.final_cost - r["cost"]) / r["cost"], 2e-9)
             check(case, f"iteration {it}: lambda rel", abs(lam - lam_ref) / lam_ref, 5e-13)
         st = e.get_state(st0)
-        check(case, "state after 2 iterations: points abs", np.abs(st.points - st_ref.points).max(), 1e-10)
-        check(case, "state after 2 iterations: poses abs", np.abs(st.rig_tr_global - st_ref.rig_tr_global).max(), 2e-10)
+        # round 6: this size runs the grid-first elimination order (automatic choice).  With 60 imagesets many control points have a
+        # handful of observations and the grid block is the badly conditioned part: x against LAPACK on the same system is 2e-10 of
+        # |x|max in that order (9e-12 pose-first; at the full 500 imagesets 3e-11 / 6e-12), so the state after two updates moved from
+        # 1.7e-11 / 1.5e-11 (rounds 4, 5) to 3.4e-11 (points) / 1.2e-10 (poses): bounds ~10x the new observation
+        check(case, "state after 2 iterations: points abs", np.abs(st.points - st_ref.points).max(), 3e-10)
+        check(case, "state after 2 iterations: poses abs", np.abs(st.rig_tr_global - st_ref.rig_tr_global).max(), 1e-9)
         check(case, "state after 2 iterations: grid abs", np.abs(st.grids[0] - st_ref.grids[0]).max(), 1e-9)
         e.close()
     finally:
