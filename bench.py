@@ -493,7 +493,12 @@ def main():
                        "trajectory_restart_every": RESTART,
                        "elimination": order,
                        "cost": [reports[0].initial_cost, reports[-1].final_cost], "ranks_consistent": ranks_consistent,
-                       "model_ceiling_ms": _model_ceiling(args.config, world) if world > 1 else None},
+                       "model_ceiling_ms": _model_ceiling(args.config, world) if world > 1 else None,
+                       "scaling_note": ("image-sharded runs use the pose-first elimination order (the reduced system that crosses the ranks does not grow with "
+                                        "the number of imagesets); a single rank WITHOUT the all-reduce path picks the grid-first order by its flop model and is "
+                                        "1.6x faster at configs[1] (11.7 against 19.0 ms per step, profiles/r06_v2_bench_cfg2*.json).  Scaling efficiency of the "
+                                        "sharded algorithm itself is value(N) / (N x the pose-first single-GPU value): `bench.py --gpus 1 --elimination 1`, "
+                                        "19.5 M obs/s in that record") if use_dist else None},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                          "library_tflops": lib_tflops, "frac_vs_library": (ach / lib_tflops) if lib_tflops else None,
