@@ -29,12 +29,16 @@ import converged_parity as cp  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("deterministic", [False, True])
-def test_baseline_config1_converges_like_the_oracle_under_the_reference_stopping_rule(deterministic):
+@pytest.mark.parametrize("deterministic,elimination", [(False, 0), (True, 0), (False, 2)])
+def test_baseline_config1_converges_like_the_oracle_under_the_reference_stopping_rule(deterministic, elimination):
+    """elimination = 0: the automatic choice (pose-first at this size); 2: the grid-first order of round 6 forced on the same problem --
+    the same iterations, attempt counts and accept decisions (at BASELINE configs[1] / [2] / [3] the automatic choice IS the grid-first
+    order: profiles/r06_converged_parity_cfg{2,3,4}_full.json)."""
     pb, st0, _ = syn.baseline_config(1, lambda cam, grid, pts: orc.project(cam, grid, pts))
     assert pb.dense_dof == 1413 and pb.n_images == 30
-    rec = cp.run_pair(eng, orc, pb, st0, max_iterations=100, threshold=1e-4, threads=0, deterministic=deterministic)
-    case = "converged calibration, BASELINE configs[0], " + ("deterministic accumulation" if deterministic else "default accumulation")
+    rec = cp.run_pair(eng, orc, pb, st0, max_iterations=100, threshold=1e-4, threads=0, deterministic=deterministic, elimination=elimination)
+    case = "converged calibration, BASELINE configs[0], " + ("deterministic accumulation" if deterministic else "default accumulation") + \
+        (", grid-first order" if elimination == 2 else "")
     print(case, rec["outer_iterations"], rec["lm_attempts_per_iteration"], rec["achieved_tolerance"], rec["state"])
     assert rec["outer_iterations"]["engine"] >= 5, rec["outer_iterations"]          # the case is meant to converge over several iterations
     check_equal(case, "outer iterations until the stopping rule fires (engine - oracle)",

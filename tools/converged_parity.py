@@ -102,8 +102,8 @@ def _stop(accepted: bool, cost: float, last_cost: float, threshold: float) -> bo
     return (not accepted) or cost >= last_cost - threshold
 
 
-def run_engine(eng, pb, st0, max_iterations=100, threshold=1e-4, deterministic=False, device=0):
-    e = eng.Engine(pb, device=device, deterministic=deterministic)
+def run_engine(eng, pb, st0, max_iterations=100, threshold=1e-4, deterministic=False, device=0, **engine_kwargs):
+    e = eng.Engine(pb, device=device, deterministic=deterministic, **engine_kwargs)
     try:
         e.set_state(st0)
         lam, last = -1.0, float("inf")
@@ -180,8 +180,8 @@ def compare(pb, eng_its, eng_state, orc_its, orc_state) -> dict:
     return out
 
 
-def run_pair(eng, orc, pb, st0, max_iterations=100, threshold=1e-4, threads=0, deterministic=False) -> dict:
-    e_its, e_st, e_s = run_engine(eng, pb, st0, max_iterations, threshold, deterministic)
+def run_pair(eng, orc, pb, st0, max_iterations=100, threshold=1e-4, threads=0, deterministic=False, **engine_kwargs) -> dict:
+    e_its, e_st, e_s = run_engine(eng, pb, st0, max_iterations, threshold, deterministic, **engine_kwargs)
     o_its, o_st, o_s = run_oracle(orc, pb, st0, max_iterations, threshold, threads)
     out = compare(pb, e_its, e_st, o_its, o_st)
     out["seconds"] = {"engine_wall_clock_to_convergence": e_s, "oracle": o_s}
