@@ -203,6 +203,7 @@ struct cba_problem {
   // correct, and the activity hardly moves from pass to pass)
   int* gf_tile_list = nullptr; int* gf_tile_list_host = nullptr; bool gf_tile_list_valid = false; unsigned gf_tile_list_age = 0;
   int gf_tile_list_entries = 0;     // slots of the launch (eight interleaved per-XCD lists, padded)
+  bool gf_tile_list_dirty = false;  // the host copy was rebuilt since the last upload
 };
 
 namespace cba {
@@ -520,7 +521,10 @@ static int solve_enqueue_gridfirst(cba_problem* p, double lambda) {
   CBA_TRY(timer_begin(p, 1));
   const int* tile_list = nullptr;
   if (p->gf_tile_list_valid) {
-    CBA_HIP(hipMemcpyAsync(p->gf_tile_list, p->gf_tile_list_host, sizeof(int) * 2 * (size_t)p->gf_tile_list_entries, hipMemcpyHostToDevice, p->stream));
+    if (p->gf_tile_list_dirty) {      // (rebuilt by solve_finish behind a stream wait: nothing in flight reads the device copy)
+      CBA_HIP(hipMemcpyAsync(p->gf_tile_list, p->gf_tile_list_host, sizeof(int) * 2 * (size_t)p->gf_tile_list_entries, hipMemcpyHostToDevice, p->stream));
+      p->gf_tile_list_dirty = false;
+    }
     tile_list = p->gf_tile_list;
   }
   CBA_TRY(ldlt_factor_gridfirst(p->F, g.n_fact, ld, d, p->Xb, ld - g.Gf, p->ldlt, p->stream, &gs, d.kmask, d.kmask_words, tile_list,
@@ -678,6 +682,7 @@ static int solve_finish(cba_problem* p) {
           p->gf_tile_list_host[2 * (8 * i + x) + 1] = have ? lists[x][i].tn : -1;
         }
       p->gf_tile_list_valid = true;
+      p->gf_tile_list_dirty = true;
     }
   }
   if (!p->gridfirst) {
