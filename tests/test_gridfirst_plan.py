@@ -262,6 +262,43 @@ def test_replay_gives_the_dense_solution(cams, N, P, strips, single_tile_tasks):
                 assert np.all(L[B * c:B * c + B, B * r:B * r + B] == 0.0)
 
 
+def _check_plan_by_replay(cams, N, P, strips, single_tile_tasks, seed, workers=(1, 1)):
+    pl = engine.gridfirst_plan(cams, N, P, strips, single_tile_tasks)
+    F, _ = _build_system(cams, N, P, pl, np.random.default_rng(seed))
+    n_pad, n_fact, nbg, nbf = pl["n_pad"], pl["n_fact"], pl["nbg"], pl["nbf"]
+    rp = Replay(pl, F)
+    assert rp.run(*workers), "the task lists deadlock"
+    x = _finish_solve(rp)
+    Fs = F[:n_fact, :n_fact] + np.triu(F[:n_fact, :n_fact], 1).T
+    x_ref = np.linalg.solve(Fs, F[:n_fact, n_pad - 1])
+    assert np.max(np.abs(x - x_ref)) <= 1e-9 * np.max(np.abs(x_ref))
+    L = np.linalg.cholesky(Fs)
+    for r in range(nbg):
+        for c in range(r + 1, nbf):
+            if not (int(pl["rowmask"][r, c >> 6]) >> (c & 63)) & 1:
+                assert np.all(L[B * c:B * c + B, B * r:B * r + B] == 0.0)
+
+
+def test_random_geometries_replay_to_the_dense_solution():
+    """Property test over the plan's inputs (hypothesis, derandomised: the same 60 geometries on every run): any grid from 4 x 4 up, either
+    model, one to three cameras of different sizes, any strip request, both task granularities, one or several simulated workgroups --
+    the replay never deadlocks, x is the dense solution, and the factor has nothing outside the planned tiles."""
+    hyp = pytest.importorskip("hypothesis")
+    st = hyp.strategies
+
+    cam_st = st.tuples(st.sampled_from([CENTRAL_GENERIC, NONCENTRAL_GENERIC]), st.integers(4, 26), st.integers(4, 22))
+
+    @hyp.settings(max_examples=60, deadline=None, derandomize=True, suppress_health_check=list(hyp.HealthCheck))
+    @hyp.given(cams=st.lists(cam_st, min_size=1, max_size=3), N=st.integers(1, 5), P=st.integers(3, 10), strips=st.integers(0, 5),
+               single=st.booleans(), seed=st.integers(0, 1000), many=st.booleans())
+    def run(cams, N, P, strips, single, seed, many):
+        cams = [_cam(m, gw, gh) for m, gw, gh in cams]
+        hyp.assume(sum(c.params_per_grid_point * c.grid_points for c in cams) <= 2600)      # keeps one replay around a second
+        _check_plan_by_replay(cams, N, P, strips, single, seed, workers=(3, 9) if many else (1, 1))
+
+    run()
+
+
 def test_more_workers_and_other_seeds_agree():
     cams, N, P = [_cam(CENTRAL_GENERIC, 40, 12)], 3, 10
     pl = engine.gridfirst_plan(cams, N, P, 3)
