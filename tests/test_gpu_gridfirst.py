@@ -88,6 +88,56 @@ def test_one_solve_matches_lapack_the_pose_first_order_and_the_oracle(name, cfg,
               np.abs(x - x_oracle).max() / np.abs(x_oracle).max(), 1e-6)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_geometries_give_the_x_of_the_pose_first_order(seed):
+    """Sweep over what the static plan depends on -- model, number of cameras, grid size and aspect, imagesets, requested strips, task
+    granularity -- and over lambda (1e-3 ... 1e-7 of the mean diagonal: condition numbers 6e4 ... 4e9): both orders on bit-identical
+    normal equations (deterministic accumulation), x against a reference refined in extended precision (three steps of iterative
+    refinement with long-double residuals on top of LAPACK).  The error any backward-stable solver may show is ~ cond(A) eps, so that
+    is the scale of the bound: 0.5 cond eps (observed on MI355X: grid-first <= 0.05, pose-first <= 0.05, LAPACK itself <= 0.02 cond eps;
+    at the ill-conditioned end that is 3.7e-8 / 3.4e-8 / 1.6e-8 of |x|max), and the new order may not be worse than the old one by more
+    than 4 x.  (The CPU counterpart over the plan alone: tests/test_gridfirst_plan.py::test_random_geometries_...)"""
+    rng = np.random.default_rng(1000 + seed)
+    cfg = int(rng.choice([2, 3, 4]))
+    big = 26 if cfg == 4 else 44
+    grid = (int(rng.integers(10, big)), int(rng.integers(10, big * 3 // 4)))
+    n_img = int(rng.integers(3, 14))
+    strips = int(rng.integers(0, 5))
+    single = bool(rng.integers(2))
+    lam_rel = float(rng.choice([1e-3, 1e-5, 1e-7]))
+    pb, st, _ = syn.baseline_config(cfg, oracle_project, n_imagesets=n_img, grid_wh=grid, lattice_xy=(10, 13))
+    case = f"grid-first order, random geometry {seed}: cfg {cfg}, grid {grid[0]}x{grid[1]}, {n_img} imagesets, strips {strips}, single tiles {single}, lambda {lam_rel:g}"
+    e1 = eng.Engine(pb, deterministic=True, elimination=eng.ELIMINATION_POSE_FIRST)
+    e1.set_state(st)
+    e1.debug_accumulate()
+    H, b = _dense_system(e1, pb)
+    lam = lam_rel * np.trace(H) / pb.total_dof
+    A = H + lam * np.eye(H.shape[0])
+    x_ref = np.linalg.solve(A, b)
+    Al, bl = A.astype(np.longdouble), b.astype(np.longdouble)
+    for _ in range(3):
+        res = (bl - Al @ x_ref.astype(np.longdouble)).astype(np.float64)
+        x_ref = (x_ref.astype(np.longdouble) + np.linalg.solve(A, res).astype(np.longdouble)).astype(np.float64)
+    w = np.linalg.eigvalsh(A)
+    scale = (w[-1] / w[0]) * np.finfo(np.float64).eps * np.abs(x_ref).max()
+    x_pose = e1.debug_solve(lam)
+    e1.close()
+    e2 = eng.Engine(pb, deterministic=True, elimination=eng.ELIMINATION_GRID_FIRST, grid_strips=strips, grid_single_tile_tasks=single)
+    check_equal(case, "the engine did not take the requested order", int(e2.elimination_order()["order"] != "grid-first"))
+    e2.set_state(st)
+    e2.debug_accumulate()
+    x = e2.debug_solve(lam)
+    x_again = e2.debug_solve(lam)                     # a second attempt on the same accumulated system: every tile is formed again
+    e2.close()
+    err, err_pose = np.abs(x - x_ref).max(), np.abs(x_pose - x_ref).max()
+    print(case, f"cond {w[-1] / w[0]:.1e}: grid-first {err / np.abs(x_ref).max():.1e}, pose-first {err_pose / np.abs(x_ref).max():.1e} of |x|max")
+    sweep = "grid-first order, random geometries"
+    check(sweep, "x grid-first vs the refined solution / (cond eps |x|max), max over the sweep", err / scale, 0.5)
+    check(sweep, "x pose-first vs the refined solution / (cond eps |x|max), max over the sweep", err_pose / scale, 0.5)
+    check(sweep, "error of the grid-first order / error of the pose-first order, max over the sweep", err / (err_pose + 1e-12 * np.abs(x_ref).max()), 4.0)
+    check_equal(case, "second solve of the same system differs (entries)", int(np.count_nonzero(x != x_again)))
+
+
 @pytest.mark.parametrize("name,cfg,n_img,grid", [("central 24x18", 2, 12, (24, 18)), ("rig 2 x 20x16", 3, 6, (20, 16)), ("non-central 12x10", 4, 8, (12, 10))])
 def test_lm_trajectory_matches_the_oracle(name, cfg, n_img, grid):
     """Five calls of OptimizeJointly(max_iteration_count = 1) (APP/calibration.cc:227-237): the engine in the grid-first order against
