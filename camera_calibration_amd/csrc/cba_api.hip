@@ -493,6 +493,52 @@ __global__ void k_solve_status(const int* __restrict__ s0, const int* __restrict
     *guard = (*s0 != 0 || *s1 != 0 || x0 != x0) ? 1 : 0;
   }
 }
+// Order in which the border update hands out its 128 x 128 tiles (GemmArgs::tile_list): workgroup b of the launch runs on XCD b % 8 and
+// the dispatcher hands workgroups out strictly in order, so (a) the list as a whole is sorted by executed K slabs, heaviest first --
+// list scheduling: the light tiles fill the gaps behind the heavy ones, and every XCD (every eighth entry) sees the same sequence of
+// weights, which keeps the in-order dispatcher from waiting for one XCD -- and (b) inside a run of tiles of about the same weight (7 %
+// buckets) the tiles are dealt so that one XCD walks a CONTIGUOUS piece of the run in row-major order: its tiles in flight share an A
+// panel and neighbouring B panels in that XCD's L2 instead of 64 unrelated pairs (FETCH_SIZE of the launch:
+// profiles/r06_update_tile_order.txt).  Short lists are padded with (-1, -1) (the workgroup leaves).  weight(tm, tn): executed K slabs
+// (or anything proportional) of upper tile (tm, tn), tm <= tn < nt.  Host work; the list is uploaded by the next solve.
+template <class Weight>
+static void gf_build_tile_list(cba_problem* p, int nt, Weight weight) {
+  struct Tile { int w, tm, tn; };
+  std::vector<Tile> all;
+  all.reserve((size_t)nt * (nt + 1) / 2);
+  for (int tm = 0; tm < nt; ++tm)
+    for (int tn = tm; tn < nt; ++tn) all.push_back(Tile{weight(tm, tn), tm, tn});
+  std::stable_sort(all.begin(), all.end(), [](const Tile& u, const Tile& v) { return u.w > v.w; });      // row-major among equals
+  std::vector<Tile> lists[8];
+  size_t i0 = 0;
+  while (i0 < all.size()) {
+    size_t i1 = i0 + 1;
+    while (i1 < all.size() && (double)all[i1].w >= 0.93 * all[i0].w) ++i1;                               // one bucket
+    std::stable_sort(all.begin() + i0, all.begin() + i1, [](const Tile& u, const Tile& v) { return u.tm != v.tm ? u.tm < v.tm : u.tn < v.tn; });
+    const size_t L = i1 - i0;
+    int start = 0;
+    for (int x = 1; x < 8; ++x) if (lists[x].size() < lists[start].size()) start = x;
+    size_t pos = i0;
+    for (int k = 0; k < 8; ++k) {
+      const size_t len = L / 8 + ((size_t)k < L % 8 ? 1 : 0);
+      std::vector<Tile>& dst = lists[(start + k) % 8];
+      dst.insert(dst.end(), all.begin() + pos, all.begin() + pos + len);
+      pos += len;
+    }
+    i0 = i1;
+  }
+  size_t longest = 0;
+  for (int x = 0; x < 8; ++x) longest = std::max(longest, lists[x].size());
+  p->gf_tile_list_entries = (int)(8 * longest);
+  for (size_t i = 0; i < longest; ++i)
+    for (int x = 0; x < 8; ++x) {
+      const bool have = i < lists[x].size();
+      p->gf_tile_list_host[2 * (8 * i + x)] = have ? lists[x][i].tm : -1;
+      p->gf_tile_list_host[2 * (8 * i + x) + 1] = have ? lists[x][i].tn : -1;
+    }
+  p->gf_tile_list_valid = true;
+  p->gf_tile_list_dirty = true;
+}
 // Builds S (+ right-hand side in its last column) for `lambda`, factors and solves; x (device) = full update.
 static int solve_finish(cba_problem* p);
 // solve_enqueue queues the whole solve on the stream (no host wait; the status words, x[0] and the guard word are written by its
@@ -636,54 +682,15 @@ static int solve_finish(cba_problem* p) {
       for (int i = 0; i < w.spans_used; ++i)
         if (w.spans[i].masked_update) { w.spans[i].flops = p->gf_update_flops; w.spans[i].masked_update = false; }
     }
-    // Tile order of the NEXT border updates (host work while the device idles: first solve, then every 8th).  Workgroup b of the
-    // launch runs on XCD b % 8 and the dispatcher hands workgroups out strictly in order, so (a) the list as a whole is sorted by
-    // executed K slabs, heaviest first -- list scheduling: the light tiles fill the gaps behind the heavy ones, and every XCD (every
-    // eighth entry) sees the same sequence of weights, which keeps the in-order dispatcher from waiting for one XCD -- and (b) inside
-    // a run of tiles of about the same weight (7 % buckets) the tiles are dealt so that one XCD walks a CONTIGUOUS piece of the run
-    // in row-major order: its tiles in flight share an A panel and neighbouring B panels in that XCD's L2 instead of 64 unrelated
-    // pairs (FETCH_SIZE of the launch: profiles/r06_update_tile_order.txt).  Short lists are padded with (-1, -1) (the workgroup leaves).
-    if (!p->gf_tile_list_valid || (++p->gf_tile_list_age & 7) == 0) {
-      struct Tile { int w, tm, tn; };
-      std::vector<Tile> all;
-      all.reserve((size_t)nt * (nt + 1) / 2);
-      for (int tm = 0; tm < nt; ++tm)
-        for (int tn = tm; tn < nt; ++tn) {
-          int sl = 0;
-          for (int w = 0; w < kw; ++w) sl += __builtin_popcountll(p->gf_kmask_host[(size_t)(t0 + tm) * kw + w] & p->gf_kmask_host[(size_t)(t0 + tn) * kw + w]);
-          all.push_back(Tile{sl, tm, tn});
-        }
-      std::stable_sort(all.begin(), all.end(), [](const Tile& u, const Tile& v) { return u.w > v.w; });      // row-major among equals
-      std::vector<Tile> lists[8];
-      size_t i0 = 0;
-      while (i0 < all.size()) {
-        size_t i1 = i0 + 1;
-        while (i1 < all.size() && (double)all[i1].w >= 0.93 * all[i0].w) ++i1;                               // one bucket
-        std::stable_sort(all.begin() + i0, all.begin() + i1, [](const Tile& u, const Tile& v) { return u.tm != v.tm ? u.tm < v.tm : u.tn < v.tn; });
-        const size_t L = i1 - i0;
-        int start = 0;
-        for (int x = 1; x < 8; ++x) if (lists[x].size() < lists[start].size()) start = x;
-        size_t pos = i0;
-        for (int k = 0; k < 8; ++k) {
-          const size_t len = L / 8 + ((size_t)k < L % 8 ? 1 : 0);
-          std::vector<Tile>& dst = lists[(start + k) % 8];
-          dst.insert(dst.end(), all.begin() + pos, all.begin() + pos + len);
-          pos += len;
-        }
-        i0 = i1;
-      }
-      size_t longest = 0;
-      for (int x = 0; x < 8; ++x) longest = std::max(longest, lists[x].size());
-      p->gf_tile_list_entries = (int)(8 * longest);
-      for (size_t i = 0; i < longest; ++i)
-        for (int x = 0; x < 8; ++x) {
-          const bool have = i < lists[x].size();
-          p->gf_tile_list_host[2 * (8 * i + x)] = have ? lists[x][i].tm : -1;
-          p->gf_tile_list_host[2 * (8 * i + x) + 1] = have ? lists[x][i].tn : -1;
-        }
-      p->gf_tile_list_valid = true;
-      p->gf_tile_list_dirty = true;
-    }
+    // Tile order of the NEXT border updates (gf_build_tile_list; host work while the device idles)
+    // (cba_set_observations leaves a first list predicted from the measured pixels; the first solve's masks replace it, then every 8th)
+    ++p->gf_tile_list_age;
+    if (!p->gf_tile_list_valid || p->gf_tile_list_age == 1 || (p->gf_tile_list_age & 7) == 0)
+      gf_build_tile_list(p, nt, [&](int tm, int tn) {
+        int sl = 0;
+        for (int w = 0; w < kw; ++w) sl += __builtin_popcountll(p->gf_kmask_host[(size_t)(t0 + tm) * kw + w] & p->gf_kmask_host[(size_t)(t0 + tn) * kw + w]);
+        return sl;
+      });
   }
   if (!p->gridfirst) {
     double slabs = 0;
@@ -1145,6 +1152,33 @@ int cba_set_observations(cba_problem* p, int64_t n, const float* xy, const int32
       std::vector<int> slot_of;
       gf_order_imagesets(g, touched, L.n_images, g.n_rp, &slot_of);
       for (int i = 0; i < L.n_images; ++i) order[slot_of[i]] = i;
+      // First tile order of the border update, predicted from the same rows (the first solve would otherwise run its tiles in
+      // row-major order: 4.7 instead of 3.5 ms at BASELINE configs[1]): per 128-column tile of the border the union of its imagesets'
+      // rows, closed under the fill of the grid factor; rig / point tiles and the right-hand side's tile reach every row.
+      if (p->gf_tile_list_host) {
+        const int nt = (g.n_pad - g.Gf) / 128;
+        std::vector<uint64_t> tact((size_t)nt * W, 0ull);
+        auto all_rows = [&](int t) { for (int w = 0; w < W; ++w) tact[(size_t)t * W + w] = ~0ull; };
+        for (int t = 0; t < nt && 128 * t < g.n_rp; ++t) all_rows(t);
+        all_rows(nt - 1);
+        for (int i = 0; i < L.n_images; ++i)
+          for (int t : {(g.n_rp + 6 * slot_of[i]) >> 7, (g.n_rp + 6 * slot_of[i] + 5) >> 7})
+            for (int w = 0; w < W; ++w) tact[(size_t)t * W + w] |= touched[(size_t)i * W + w];
+        for (int t = 0; t < nt; ++t) {
+          uint64_t* a = &tact[(size_t)t * W];
+          for (int r = 0; r < g.nbg; ++r)
+            if ((a[r >> 6] >> (r & 63)) & 1ull)
+              for (int w = r >> 6; w < W; ++w) a[w] |= g.gridrow[(size_t)r * W + w];
+          for (int w = 0; w < W; ++w)
+            if (64 * w + 64 > g.nbg) a[w] &= (64 * w >= g.nbg) ? 0ull : (~0ull >> (64 - (g.nbg - 64 * w)));
+        }
+        gf_build_tile_list(p, nt, [&](int tm, int tn) {
+          int rows = 0;
+          for (int w = 0; w < W; ++w) rows += __builtin_popcountll(tact[(size_t)tm * W + w] & tact[(size_t)tn * W + w]);
+          return rows;
+        });
+        p->gf_tile_list_age = 0;
+      }
     } else
     if (!L.localize_only && L.n_images >= 4 && L.n_images <= 8192 && !p->dense_perm_host.empty()) {
       const int T = (L.dense_dof + 127) / 128, W = (T + 63) / 64;
