@@ -138,6 +138,53 @@ def test_random_geometries_give_the_x_of_the_pose_first_order(seed):
     check_equal(case, "second solve of the same system differs (entries)", int(np.count_nonzero(x != x_again)))
 
 
+@pytest.mark.parametrize("name,cfg,keep", [("left third of the image only", 2, "left"), ("one imageset keeps a single observation, one camera of the rig sees a corner", 3, "thin")])
+def test_sparse_coverage_most_of_the_grid_unobserved(name, cfg, keep):
+    """Observations that cover a corner of the image only: most control points are observed by nothing (their rows of H hold lambda
+    alone), most grid x border tiles are inactive in the per-pass masks, whole strips of the grid do nothing -- the forming kernel, the
+    block-sparse launch, the border update and the back substitution must all skip the same tiles.  x against LAPACK and against the
+    pose-first order on the bit-identical system; the reference has no such case (its tests observe the whole image)."""
+    from camera_calibration_amd.problem import Problem
+    pb0, st, _ = syn.baseline_config(cfg, oracle_project, n_imagesets=10, grid_wh=(30, 22), lattice_xy=(10, 13))
+    w = pb0.cameras[0].width
+    xy = pb0.obs_xy
+    if keep == "left":
+        sel = xy[:, 0] < w / 3
+    else:
+        sel = (xy[:, 0] < w / 4) | (pb0.obs_camera == 0)
+        first_of_img3 = np.nonzero(pb0.obs_image == 3)[0][:1]
+        sel &= pb0.obs_image != 3
+        sel[first_of_img3] = True
+    pb = Problem(pb0.cameras, pb0.n_images, pb0.n_points, xy[sel], pb0.obs_point[sel], pb0.obs_image[sel], pb0.obs_camera[sel], fd_delta=pb0.fd_delta)
+    assert 0 < pb.n_obs < 0.95 * pb0.n_obs
+    case = "grid-first order, sparse coverage: " + name
+    e1 = eng.Engine(pb, deterministic=True, elimination=eng.ELIMINATION_POSE_FIRST)
+    e1.set_state(st)
+    e1.debug_accumulate()
+    H, b = _dense_system(e1, pb)
+    # unknowns nothing observes: a zero ROW of H and of b (a zero diagonal alone is not enough: the fixed-point accumulation of the
+    # deterministic mode rounds the tiny diagonal of a control point at the rim of a patch to zero while its couplings survive)
+    empty = (np.abs(H).sum(axis=1) == 0.0) & (b == 0.0)
+    unobserved = int(np.count_nonzero(empty))
+    assert unobserved > 0.15 * pb.dense_dof, unobserved                      # the case is meant to leave a large part of the grid empty
+    lam = 1e-4 * np.trace(H) / max(1, np.count_nonzero(np.diag(H)))
+    x_lapack = np.linalg.solve(H + lam * np.eye(H.shape[0]), b)
+    x_pose = e1.debug_solve(lam)
+    e1.close()
+    for S in (1, 2, 3):
+        e2 = eng.Engine(pb, deterministic=True, elimination=eng.ELIMINATION_GRID_FIRST, grid_strips=S)
+        e2.set_state(st)
+        e2.debug_accumulate()
+        x = e2.debug_solve(lam)
+        x2 = e2.debug_solve(2.0 * lam)                                      # another attempt: every tile any launch wrote is formed again
+        e2.close()
+        check(case, f"x grid-first ({S} strip(s)) vs LAPACK / |x|max", np.abs(x - x_lapack).max() / np.abs(x_lapack).max(), 5e-9)
+        check(case, f"x grid-first ({S} strip(s)) vs pose-first / |x|max", np.abs(x - x_pose).max() / np.abs(x_pose).max(), 5e-9)
+        x2_ref = np.linalg.solve(H + 2.0 * lam * np.eye(H.shape[0]), b)
+        check(case, f"x of the next attempt (2 lambda, {S} strip(s)) vs LAPACK / |x|max", np.abs(x2 - x2_ref).max() / np.abs(x2_ref).max(), 5e-9)
+        check_equal(case, f"unobserved control points must get a zero update ({S} strip(s)), entries", int(np.count_nonzero(x[empty] != 0.0)))
+
+
 @pytest.mark.parametrize("name,cfg,n_img,grid", [("central 24x18", 2, 12, (24, 18)), ("rig 2 x 20x16", 3, 6, (20, 16)), ("non-central 12x10", 4, 8, (12, 10))])
 def test_lm_trajectory_matches_the_oracle(name, cfg, n_img, grid):
     """Five calls of OptimizeJointly(max_iteration_count = 1) (APP/calibration.cc:227-237): the engine in the grid-first order against
