@@ -204,6 +204,7 @@ struct cba_problem {
   int* gf_tile_list = nullptr; int* gf_tile_list_host = nullptr; bool gf_tile_list_valid = false; unsigned gf_tile_list_age = 0;
   int gf_tile_list_entries = 0;     // slots of the launch (eight interleaved per-XCD lists, padded)
   bool gf_tile_list_dirty = false;  // the host copy was rebuilt since the last upload
+  size_t gf_tile_list_capacity = 0; // ints
 };
 
 namespace cba {
@@ -501,20 +502,49 @@ __global__ void k_solve_status(const int* __restrict__ s0, const int* __restrict
 // panel and neighbouring B panels in that XCD's L2 instead of 64 unrelated pairs (FETCH_SIZE of the launch:
 // profiles/r06_update_tile_order.txt).  Short lists are padded with (-1, -1) (the workgroup leaves).  weight(tm, tn): executed K slabs
 // (or anything proportional) of upper tile (tm, tn), tm <= tn < nt.  Host work; the list is uploaded by the next solve.
-template <class Weight>
-static void gf_build_tile_list(cba_problem* p, int nt, Weight weight) {
-  struct Tile { int w, tm, tn; };
+// A tile with all K slabs runs for most of the launch (2.7 of 3.5 ms at BASELINE configs[1]); tiles heavier than a third of the heaviest
+// are therefore handed out in PARTS (K ranges with equal shares of the executed slabs, GemmArgs::tile_list) that add to C atomically --
+// not in the deterministic mode, where the additions must keep one order.  split(tm, tn, target): the K slab in front of which
+// `target` units of the tile's weight lie; n_slabs: K slabs of the launch.
+template <class Weight, class Split>
+static void gf_build_tile_list(cba_problem* p, int nt, int n_slabs, Weight weight, Split split) {
+  struct Tile { int w, tm, tn, s0, s1; };
   std::vector<Tile> all;
-  all.reserve((size_t)nt * (nt + 1) / 2);
+  all.reserve((size_t)nt * (nt + 1));
+  int w_max = 0;
   for (int tm = 0; tm < nt; ++tm)
-    for (int tn = tm; tn < nt; ++tn) all.push_back(Tile{weight(tm, tn), tm, tn});
+    for (int tn = tm; tn < nt; ++tn) { const int w = weight(tm, tn); all.push_back(Tile{w, tm, tn, 0, 0}); w_max = std::max(w_max, w); }
+  if (!p->cfg.deterministic) {
+    // unit: a third of the heaviest tile (measured at BASELINE configs[1] / [2] / [3], launch ms with units of 1/2, 1/3, 1/4, 1/6:
+    // 3.31 / 3.31 / 3.26 / 3.26, 12.17 / 12.03 / 12.09 / 12.18, 5.40 / 5.27 / 5.37 / 5.41; whole tiles: 3.50 / 12.34 / 5.53)
+    const int unit = std::max(8, w_max / 3);
+    const size_t n0 = all.size();
+    for (size_t i = 0; i < n0; ++i) {
+      const int w = all[i].w, parts = (w + unit - 1) / unit;
+      if (parts < 2) continue;
+      int prev = 0, done = 0;
+      bool ok = true;
+      std::vector<Tile> add;
+      for (int q = 1; q < parts && ok; ++q) {
+        const int target = (int)((long long)w * q / parts);
+        const int sq = split(all[i].tm, all[i].tn, target);
+        if (sq <= prev || sq >= n_slabs) { ok = false; break; }
+        add.push_back(Tile{target - done, all[i].tm, all[i].tn, prev, sq});
+        prev = sq; done = target;
+      }
+      if (!ok) continue;
+      add.push_back(Tile{w - done, all[i].tm, all[i].tn, prev, n_slabs});
+      all[i] = add[0];
+      for (size_t q = 1; q < add.size(); ++q) all.push_back(add[q]);
+    }
+  }
   std::stable_sort(all.begin(), all.end(), [](const Tile& u, const Tile& v) { return u.w > v.w; });      // row-major among equals
   std::vector<Tile> lists[8];
   size_t i0 = 0;
   while (i0 < all.size()) {
     size_t i1 = i0 + 1;
     while (i1 < all.size() && (double)all[i1].w >= 0.93 * all[i0].w) ++i1;                               // one bucket
-    std::stable_sort(all.begin() + i0, all.begin() + i1, [](const Tile& u, const Tile& v) { return u.tm != v.tm ? u.tm < v.tm : u.tn < v.tn; });
+    std::stable_sort(all.begin() + i0, all.begin() + i1, [](const Tile& u, const Tile& v) { return u.tm != v.tm ? u.tm < v.tm : (u.tn != v.tn ? u.tn < v.tn : u.s0 < v.s0); });
     const size_t L = i1 - i0;
     int start = 0;
     for (int x = 1; x < 8; ++x) if (lists[x].size() < lists[start].size()) start = x;
@@ -529,12 +559,14 @@ static void gf_build_tile_list(cba_problem* p, int nt, Weight weight) {
   }
   size_t longest = 0;
   for (int x = 0; x < 8; ++x) longest = std::max(longest, lists[x].size());
+  if (4 * 8 * longest > p->gf_tile_list_capacity) return;      // (cannot happen with the sizing of cba_create; the previous list stays)
   p->gf_tile_list_entries = (int)(8 * longest);
   for (size_t i = 0; i < longest; ++i)
     for (int x = 0; x < 8; ++x) {
       const bool have = i < lists[x].size();
-      p->gf_tile_list_host[2 * (8 * i + x)] = have ? lists[x][i].tm : -1;
-      p->gf_tile_list_host[2 * (8 * i + x) + 1] = have ? lists[x][i].tn : -1;
+      int* e = p->gf_tile_list_host + 4 * (8 * i + x);
+      e[0] = have ? lists[x][i].tm : -1; e[1] = have ? lists[x][i].tn : -1;
+      e[2] = have ? lists[x][i].s0 : 0; e[3] = have ? lists[x][i].s1 : 0;
     }
   p->gf_tile_list_valid = true;
   p->gf_tile_list_dirty = true;
@@ -568,7 +600,7 @@ static int solve_enqueue_gridfirst(cba_problem* p, double lambda) {
   const int* tile_list = nullptr;
   if (p->gf_tile_list_valid) {
     if (p->gf_tile_list_dirty) {      // (rebuilt by solve_finish behind a stream wait: nothing in flight reads the device copy)
-      CBA_HIP(hipMemcpyAsync(p->gf_tile_list, p->gf_tile_list_host, sizeof(int) * 2 * (size_t)p->gf_tile_list_entries, hipMemcpyHostToDevice, p->stream));
+      CBA_HIP(hipMemcpyAsync(p->gf_tile_list, p->gf_tile_list_host, sizeof(int) * 4 * (size_t)p->gf_tile_list_entries, hipMemcpyHostToDevice, p->stream));
       p->gf_tile_list_dirty = false;
     }
     tile_list = p->gf_tile_list;
@@ -686,10 +718,21 @@ static int solve_finish(cba_problem* p) {
     // (cba_set_observations leaves a first list predicted from the measured pixels; the first solve's masks replace it, then every 8th)
     ++p->gf_tile_list_age;
     if (!p->gf_tile_list_valid || p->gf_tile_list_age == 1 || (p->gf_tile_list_age & 7) == 0)
-      gf_build_tile_list(p, nt, [&](int tm, int tn) {
+      gf_build_tile_list(p, nt, g.Gf / 16, [&](int tm, int tn) {
         int sl = 0;
         for (int w = 0; w < kw; ++w) sl += __builtin_popcountll(p->gf_kmask_host[(size_t)(t0 + tm) * kw + w] & p->gf_kmask_host[(size_t)(t0 + tn) * kw + w]);
         return sl;
+      }, [&](int tm, int tn, int target) {
+        int seen = 0;
+        for (int w = 0; w < kw; ++w) {
+          unsigned long long bits = p->gf_kmask_host[(size_t)(t0 + tm) * kw + w] & p->gf_kmask_host[(size_t)(t0 + tn) * kw + w];
+          const int c = __builtin_popcountll(bits);
+          if (seen + c < target) { seen += c; continue; }
+          for (int b = 0; b < 64; ++b)
+            if ((bits >> b) & 1ull) { if (seen == target) return 64 * w + b; ++seen; }
+          return 64 * (w + 1);
+        }
+        return 0;
       });
   }
   if (!p->gridfirst) {
@@ -928,8 +971,11 @@ int cba_create(const cba_config* config, cba_problem** out) {
       CBA_HIP(hipMemcpy(d.gridrow, g.gridrow.data(), sizeof(uint64_t) * g.gridrow.size(), hipMemcpyHostToDevice));
       {
         const size_t nt = (size_t)d.n_act_tiles;
-        CBA_TRY(dev_alloc(&p->gf_tile_list, 8 * nt * (nt + 1)));      // worst case: one XCD's list holds every tile
-        CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->gf_tile_list_host), sizeof(int) * 8 * nt * (nt + 1)));
+        // entries of four ints (tm, tn, K-slab range), eight interleaved per-XCD lists padded to the longest: 4 x 8 x (tiles in up to three
+        // parts each, dealt evenly) is a quarter of this
+        p->gf_tile_list_capacity = (size_t)32 * nt * (nt + 1) + 4096;
+        CBA_TRY(dev_alloc(&p->gf_tile_list, p->gf_tile_list_capacity));
+        CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->gf_tile_list_host), sizeof(int) * p->gf_tile_list_capacity));
       }
       CBA_HIP(hipHostMalloc(reinterpret_cast<void**>(&p->gf_kmask_host), sizeof(unsigned long long) * (size_t)(g.n_pad / 128) * d.kmask_words));
       std::memset(p->gf_kmask_host, 0, sizeof(unsigned long long) * (size_t)(g.n_pad / 128) * d.kmask_words);
@@ -1172,10 +1218,18 @@ int cba_set_observations(cba_problem* p, int64_t n, const float* xy, const int32
           for (int w = 0; w < W; ++w)
             if (64 * w + 64 > g.nbg) a[w] &= (64 * w >= g.nbg) ? 0ull : (~0ull >> (64 - (g.nbg - 64 * w)));
         }
-        gf_build_tile_list(p, nt, [&](int tm, int tn) {
+        gf_build_tile_list(p, nt, g.Gf / 16, [&](int tm, int tn) {
           int rows = 0;
           for (int w = 0; w < W; ++w) rows += __builtin_popcountll(tact[(size_t)tm * W + w] & tact[(size_t)tn * W + w]);
-          return rows;
+          return 4 * rows;                                   // K slabs of 16 rows: four per block row
+        }, [&](int tm, int tn, int target) {
+          int seen = 0;
+          for (int r = 0; r < g.nbg; ++r)
+            if (((tact[(size_t)tm * W + (r >> 6)] & tact[(size_t)tn * W + (r >> 6)]) >> (r & 63)) & 1ull) {
+              if (seen + 4 > target) return 4 * r;
+              seen += 4;
+            }
+          return 0;
         });
         p->gf_tile_list_age = 0;
       }

@@ -199,7 +199,8 @@ struct GfDevice {
 };
 // F = [grid | border] in the plan's order, ld = its n_pad; Xb: (rows of the grid part) x (ld - Gf) panel buffer (zero outside the
 // tiles the launch writes); kmask: optional block-sparsity of the border update (null = dense); tile_list: optional order of its
-// upper tiles, tile_list_entries (tm, tn) pairs relative to the border -- every upper tile once, (-1, -1) = an empty slot
+// upper tiles, tile_list_entries entries (tm, tn, s0, s1) relative to the border -- every upper tile once (s1 = 0) or as parts whose K-slab
+// ranges [s0, s1) cover all slabs (added atomically), tm = -1 = an empty slot
 int ldlt_factor_gridfirst(double* F, int n_fact, int ld, const GfDevice& g, double* Xb, int ldxb, LdltWorkspace& w, hipStream_t s,
                           GemmStats* st, const unsigned long long* kmask, int kmask_words, const int* tile_list, int tile_list_entries);
 // Rows that the final dataflow launch factors (w.tail_rows clamped to the workspace's flag storage)

@@ -261,9 +261,12 @@ struct GemmArgs {
   int keep_col_p1;              // 1 + a column of C the launch must not write (the right-hand side kept in S's last column); 0 = none
   int slab16;                   // block-sparse launch with 16-row K slabs (the border update of the grid-first order); 0 = slabs of kSchurSlab rows
   int tile_list_entries;        // slots of a tile_list launch
-  const int2* tile_list;        // optional explicit order of the launch's tiles (tm, tn): slot b runs tile_list[b], (-1, -1) = no tile.  The
-                                // dispatcher hands workgroups out in slot order as slots come free, i.e. list scheduling: with the tiles
-                                // sorted by executed K slabs, heaviest first, the light tiles fill the gaps behind the heavy ones
+  const int4* tile_list;        // optional explicit order of the launch's tiles (tm, tn, s0, s1): slot b runs tile_list[b], tm = -1: no tile.
+                                // The dispatcher hands workgroups out in slot order as slots come free, i.e. list scheduling: with the
+                                // tiles sorted by executed K slabs, heaviest first, the light tiles fill the gaps behind the heavy ones.
+                                // s1 > 0: a PART of the tile -- K slabs [s0, s1) only, added to C with fp64 atomics (the other part(s) of
+                                // the tile are entries of their own and run whenever: a tile with all slabs is a third of the launch's
+                                // makespan, two halves are not); s1 = 0: the whole tile, plain read-modify-write
 };
 
 // Developer switches are compiled only into the bench harness (tools/bench_tail.hip, tools/bench_diag.hip define CBA_DEV_SWITCHES): the
@@ -316,10 +319,13 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
   const long long t = g.tile_list ? b : gemm_slot_tile(g, b);
   if (t >= (g.tile_list ? (long long)g.tile_list_entries : g.total_tiles)) return false;
   int tm, tn;
+  bool part = false;            // a K range of the tile (tile_list): starts from zero, leaves through atomics
+  int s_lo = 0, s_hi = g.K / KTT;
   if (g.tile_list) {
-    const int2 tt = g.tile_list[t];
+    const int4 tt = g.tile_list[t];
     tm = tt.x; tn = tt.y;
     if (tm < 0) return true;
+    if (tt.w > 0) { part = true; s_lo = tt.z; s_hi = tt.w; }
   } else if (g.strips) {
     // Square upper-triangular launch, dense: tiles are enumerated strip by strip (kStripW tile columns), row by
     // row inside a strip, so that the ~64 workgroups in flight on an XCD form an 8 x 8 block sharing 8 A and
@@ -393,7 +399,7 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
   // SUB: the accumulators start as -(Cin + diag) (see below); in the LDS-DMA variant the tile is loaded AFTER the
   // first operand slab has been put in flight so that the two HBM round trips overlap.
   auto preload_c = [&]() {
-    if (SUB) {
+    if (SUB && !part) {
       double dadd0 = 0.0;
       if (g.diag) dadd0 = g.diag_add_ptr ? *g.diag_add_ptr : g.diag_add;
 #pragma unroll
@@ -418,7 +424,7 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
 
   const double* Ag = g.A + m0;
   const double* Bg = g.B + n0;
-  const int nk = g.K / KTT;
+  const int nk = s_hi;          // (the whole K range unless the entry is a part of a tile)
   static_assert(TM == 128 && TN == 128, "only the 128 x 128 LDS-DMA tile is built (the register-staged panel variants went with the blocked schedule)");
   {
     // Stage pipeline with LDS-DMA (global_load_lds_dwordx4): each wavefront-instruction moves one
@@ -475,7 +481,7 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
       }
       return nk;
     };
-    int kb = next_slab(-1);
+    int kb = next_slab(s_lo - 1);
     if (kb < nk) CBA_DMA_STAGE(dA0, dB0, kb * KTT);
     preload_c();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -506,7 +512,9 @@ __device__ __forceinline__ bool gemm_tile(const GemmArgs& g, long long b) {
         const int n = n0 + wn0 + j * 16 + li;
         double v = acc[i][j][r];
         if (SUB) v = -v;
-        if (n + 1 != g.keep_col_p1) g.C[(size_t)m * g.ldc + n] = v;
+        if (n + 1 == g.keep_col_p1) continue;
+        if (part) atomicAdd(&g.C[(size_t)m * g.ldc + n], v);      // C += -(A^T B over the part's slabs)
+        else g.C[(size_t)m * g.ldc + n] = v;
       }
   return true;
 }
@@ -2411,7 +2419,7 @@ int ldlt_factor_gridfirst(double* F, int n_fact, int ld, const GfDevice& g, doub
   u.C = F; u.ldc = ld; u.Cin = F; u.ldcin = ld; u.diag = 0; u.upper = 1;
   const int tl = (ld - Gf) / 128;
   u.m_off = Gf; u.m_tiles = tl; u.n_off = Gf; u.n_tiles = tl;
-  u.kmask = kmask; u.kmask_words = kmask_words; u.slab16 = 1; u.tile_list = reinterpret_cast<const int2*>(tile_list); u.tile_list_entries = tile_list_entries;
+  u.kmask = kmask; u.kmask_words = kmask_words; u.slab16 = 1; u.tile_list = reinterpret_cast<const int4*>(tile_list); u.tile_list_entries = tile_list_entries;
   if ((rc = timed_gemm128(u, s, w, st != nullptr, (double)tl * (tl + 1) / 2))) return rc;
   if (st && kmask && w.spans_used > 0) w.spans[w.spans_used - 1].masked_update = true;      // (the caller replaces the dense flop count by the executed one)
   if (st) { const double rows = (double)(ld - Gf); st->flops += rows * rows * Gf; st->launches += 1; }
